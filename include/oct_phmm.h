@@ -1,0 +1,205 @@
+/*
+ * oct_phmm.h — C ABI of the MI355X pair-HMM haplotype-likelihood engine.
+ *
+ * This is the drop-in boundary for ONE path of luntergroup/octopus (reference tree at
+ * /root/reference, v0.7.4): the batch that HaplotypeLikelihoodArray::populate computes
+ * (src/core/models/haplotype_likelihood_array.cpp:51-199) by calling
+ * HaplotypeLikelihoodModel::evaluate (src/core/models/haplotype_likelihood_model.cpp:261-320) ->
+ * hmm::PairHMM::evaluate (src/core/models/pairhmm/pair_hmm.hpp:831-841) ->
+ * simd::PairHMM::align (src/core/models/pairhmm/simd_pair_hmm.hpp:240-324, 438-509).
+ *
+ * Plain pointers and sizes only. All input pointers are HOST pointers borrowed for the duration of
+ * the call; outputs are caller-allocated. The library owns device memory and streams through the
+ * handle. One handle per calling thread (the reference copies its model per task,
+ * haplotype_likelihood_array.cpp:172); distinct handles may be used concurrently.
+ *
+ * There is no CPU fallback: without a usable HIP device every compute entry returns
+ * OCT_PHMM_ENODEVICE / OCT_PHMM_EHIP.
+ */
+#ifndef OCT_PHMM_H
+#define OCT_PHMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCT_PHMM_ABI_VERSION 1
+
+/* ---- return codes ------------------------------------------------------------------------- */
+enum {
+    OCT_PHMM_OK               = 0,
+    OCT_PHMM_EINVAL           = 1, /* malformed batch (null pointer, non-monotone offsets, a base quality or
+                                      penalty outside [0,127], read not contained in haplotype region order) */
+    OCT_PHMM_EBAND            = 2, /* simd::PairHMMWrapper::TooLargeBandSizeError, simd_pair_hmm_wrapper.hpp:45-61,229 */
+    OCT_PHMM_ESHORT_HAPLOTYPE = 3, /* HaplotypeLikelihoodModel::ShortHaplotypeError, haplotype_likelihood_model.cpp:17-33,244,252 */
+    OCT_PHMM_EHIP             = 4, /* HIP runtime error; status->hip_error holds hipError_t */
+    OCT_PHMM_ENODEVICE        = 5, /* no gfx950 device visible */
+    OCT_PHMM_EUNSUPPORTED     = 6, /* valid request this build does not cover (see DESIGN.md "limits") */
+    OCT_PHMM_EOVERFLOW        = 7  /* hmm::HMMOverflow, pair_hmm.hpp:47-64,815-817 (align path only) */
+};
+
+/* Sentinel the reference returns for a window that overruns the haplotype or a traceback that
+ * overflowed: std::numeric_limits<double>::lowest() (pair_hmm.hpp:736-738,750-752). */
+#define OCT_PHMM_LOWEST (-1.7976931348623157e308)
+
+/* ---- configuration: HaplotypeLikelihoodModel::Config (haplotype_likelihood_model.hpp:36-44) -- */
+typedef struct oct_phmm_config {
+    uint32_t struct_size;                /* sizeof(oct_phmm_config), for ABI growth */
+    int32_t  max_indel_error;            /* Config::max_indel_error; band = smallest of {8,16,32,64,128,256} >= this
+                                            (simd_pair_hmm_wrapper.hpp:219-241). CLI default 16, Config{} default 8 */
+    int32_t  use_int_scores;             /* Config::use_int_scores -> int32 lanes instead of int16 */
+    int32_t  use_mapping_quality;        /* Config::use_mapping_quality (default 1) */
+    int32_t  mapping_quality_cap;        /* Config::mapping_quality_cap (default 120) */
+    int32_t  mapping_quality_cap_trigger;/* Config::mapping_quality_cap_trigger, -1 = none */
+    int32_t  use_flank_state;            /* Config::use_flank_state (default 1): if 0 flank states passed in are ignored,
+                                            as Caller::compute_haplotype_likelihoods does (caller.cpp:1172) */
+    int32_t  nuc_prior;                  /* hmm::Parameters::nuc_prior (pair_hmm.hpp:86), product value 2 */
+    int32_t  max_mapping_positions;      /* HaplotypeLikelihoodArray::maxMappingPositions (array.hpp:104) = 10 */
+    int32_t  device_id;                  /* HIP device ordinal */
+} oct_phmm_config;
+
+/* Fill with the reference's defaults (Config{} + CLI band 16 is NOT applied: max_indel_error = 8). */
+void oct_phmm_config_default(oct_phmm_config* cfg);
+
+typedef struct oct_phmm_handle oct_phmm_handle;
+
+/* ---- batch description ---------------------------------------------------------------------- */
+
+/* AlignedRead fields the path touches (basics/aligned_read.hpp): sequence, base_qualities,
+ * mapping_quality, is_marked_reverse_mapped(), mapped_region().begin(). Reads of one template are
+ * consecutive; a likelihood "row" is a template (TemplateMap overload, array.cpp:105) or a single
+ * read (ReadMap overload, array.cpp:51). */
+typedef struct oct_phmm_reads {
+    uint32_t        n_reads;
+    const char*     bases;            /* concatenated sequences */
+    const uint8_t*  qualities;        /* concatenated phred base qualities, each <= 127 */
+    const uint32_t* offsets;          /* [n_reads+1] into bases/qualities */
+    const uint8_t*  mapping_quality;  /* [n_reads] */
+    const uint8_t*  reverse_strand;   /* [n_reads] AlignedRead::is_marked_reverse_mapped() */
+    const int64_t*  ref_begin;        /* [n_reads] mapped_region(read).begin() */
+    uint32_t        n_rows;           /* number of output rows */
+    const uint32_t* row_offsets;      /* [n_rows+1] first read of each row; NULL => one read per row (n_rows == n_reads) */
+} oct_phmm_reads;
+
+/* Haplotype plus the six per-haplotype vectors HaplotypeLikelihoodModel::reset prepares
+ * (haplotype_likelihood_model.cpp:60-78): all concatenated with the same offsets. */
+typedef struct oct_phmm_haplotypes {
+    uint32_t        n_haps;
+    const char*     bases;            /* Haplotype::sequence() */
+    const uint32_t* offsets;          /* [n_haps+1] */
+    const int64_t*  ref_begin;        /* [n_haps] mapped_region(haplotype).begin() */
+    const int8_t*   gap_open;         /* haplotype_gap_open_penalities_,  each in [0,127] */
+    const int8_t*   gap_extend;       /* haplotype_gap_extend_penalities_, each in [0,127] */
+    const char*     snv_mask_fwd;     /* haplotype_snv_forward_mask_ */
+    const int8_t*   snv_prior_fwd;    /* haplotype_snv_forward_priors_, each in [0,127] */
+    const char*     snv_mask_rev;     /* haplotype_snv_reverse_mask_ */
+    const int8_t*   snv_prior_rev;    /* haplotype_snv_reverse_priors_ */
+} oct_phmm_haplotypes;
+
+/* HaplotypeLikelihoodModel::FlankState (haplotype_likelihood_model.hpp:46-49). */
+typedef struct oct_phmm_flank_state {
+    uint32_t lhs_flank, rhs_flank;
+} oct_phmm_flank_state;
+
+/* Optional: several independent populate() calls (active regions) in one batch. Region g owns rows
+ * [row_offsets[g], row_offsets[g+1]) and haplotypes [hap_offsets[g], hap_offsets[g+1]); every row of a
+ * region is scored against every haplotype of the same region. NULL => one region. */
+typedef struct oct_phmm_regions {
+    uint32_t        n_regions;
+    const uint32_t* row_offsets;      /* [n_regions+1] */
+    const uint32_t* hap_offsets;      /* [n_regions+1] */
+    const uint8_t*  has_flank;        /* [n_regions] or NULL (= none) */
+    const oct_phmm_flank_state* flank;/* [n_regions] or NULL */
+} oct_phmm_regions;
+
+/* Optional precomputed candidate mapping positions (what map_query_to_target emits,
+ * utils/kmer_mapper.hpp:120-159), CSR over (haplotype, read-of-its-region) in output order:
+ * entry index = read_pair_offset(haplotype) + (read - first read of the region). NULL => the library
+ * runs the k-mer mapper on the device. */
+typedef struct oct_phmm_positions {
+    const uint64_t* offsets;          /* [n_read_pairs+1] */
+    const uint32_t* positions;
+} oct_phmm_positions;
+
+typedef struct oct_phmm_status {
+    int32_t  code;                    /* same as the return value */
+    int32_t  hip_error;               /* hipError_t when code == OCT_PHMM_EHIP */
+    uint32_t hap_index;               /* OCT_PHMM_ESHORT_HAPLOTYPE: first offending haplotype (iteration order of the serial reference) */
+    uint32_t read_index;              /*   ... and read */
+    uint32_t required_extension;      /* ShortHaplotypeError::required_extension() */
+    char     message[128];
+} oct_phmm_status;
+
+/* Work counters of the last run (for GCUPS accounting). */
+typedef struct oct_phmm_stats {
+    uint64_t n_pairs;                 /* (read, haplotype) pairs = log-likelihoods before template summing */
+    uint64_t n_candidates;            /* in-range (read, haplotype, position) evaluations */
+    uint64_t n_fast_path;             /* answered by try_naive_evaluate (pair_hmm.hpp:278-319) */
+    uint64_t n_dp_score_only;         /* simd align, score only */
+    uint64_t n_dp_traceback;          /* simd align + traceback + flank score */
+    uint64_t band_cells;              /* sum over DP tasks of 2*B*(T+B) */
+} oct_phmm_stats;
+
+/* ---- lifecycle -------------------------------------------------------------------------------- */
+int  oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out);
+void oct_phmm_destroy(oct_phmm_handle* h);
+/* HaplotypeLikelihoodModel::pad_requirement() == hmm band size (haplotype_likelihood_model.cpp:55-58). */
+int  oct_phmm_band_size(const oct_phmm_handle* h);
+const char* oct_phmm_strerror(int code);
+
+/* ---- the hot path ----------------------------------------------------------------------------- */
+/* HaplotypeLikelihoodArray::populate: out[out_offset(hap) + row - first row of the region] =
+ * ln p(row | haplotype); for one region that is an H x n_rows row-major matrix, haplotype-major, i.e.
+ * likelihoods_[h][*][row] flattened (array.hpp:123). `out` has sum over regions of H_g * rows_g doubles. */
+int oct_phmm_populate(oct_phmm_handle* h,
+                      const oct_phmm_reads* reads,
+                      const oct_phmm_haplotypes* haps,
+                      const oct_phmm_regions* regions,      /* NULL => one region using `flank` */
+                      const oct_phmm_flank_state* flank,    /* NULL => no flank state (single-region form only) */
+                      const oct_phmm_positions* positions,  /* NULL => device k-mer mapping */
+                      double* out,
+                      oct_phmm_status* status);
+
+/* Split form of the same call for callers that keep a batch resident in HBM and overlap transfers:
+ * upload (H2D + table building), run (enqueue every kernel of the path on the handle's stream, no
+ * host synchronisation beyond what sizing the launches needs), download (sync + D2H). bench.py times
+ * oct_phmm_batch_run + oct_phmm_batch_wait only. */
+typedef struct oct_phmm_batch oct_phmm_batch;
+int  oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads*, const oct_phmm_haplotypes*,
+                           const oct_phmm_regions*, const oct_phmm_flank_state*, const oct_phmm_positions*,
+                           oct_phmm_batch** out, oct_phmm_status* status);
+int  oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phmm_status* status);
+int  oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_phmm_status* status);
+int  oct_phmm_batch_download(oct_phmm_handle* h, oct_phmm_batch* b, double* out, oct_phmm_status* status);
+int  oct_phmm_batch_stats(const oct_phmm_batch* b, oct_phmm_stats* stats);
+size_t oct_phmm_batch_out_size(const oct_phmm_batch* b); /* number of doubles `out` must hold */
+/* Average device time (ms) of the last run's dominant DP kernel launches measured with HIP events on the
+ * handle's stream, and the number of launches; for bench.py's roofline block. */
+int  oct_phmm_batch_kernel_time(const oct_phmm_batch* b, double* dp_kernel_ms, uint32_t* dp_launches);
+void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b);
+
+/* ---- test seam: the raw band kernel ------------------------------------------------------------ */
+/* simd::PairHMM::align on explicit windows (simd_pair_hmm.hpp:438-509): what the reference's golden tests
+ * drive (test/unit/core/models/pair_hmm_tests.cpp:63-85). Window i has truth_len = target_len + 2B - 1.
+ * snv_mask == NULL selects the no-mask overload; gap_extend == NULL uses gap_extend_scalar.
+ * traceback != 0 also returns first_pos and the two gapped strings (capacity 2*(T+B)+1 each, NUL terminated)
+ * and, if lhs_flank != NULL, calculate_flank_score (simd_pair_hmm.hpp:511-549) into flank_score/mask_size. */
+int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
+                           const char* truth, const uint32_t* truth_offsets,
+                           const char* target, const uint8_t* qualities, const uint32_t* target_offsets,
+                           const int8_t* gap_open, const int8_t* gap_extend, int32_t gap_extend_scalar,
+                           const char* snv_mask, const int8_t* snv_prior,
+                           int32_t nuc_prior, int32_t traceback,
+                           int32_t* scores, int32_t* first_pos,
+                           char* align1, char* align2, const uint32_t* align_offsets,
+                           const int32_t* lhs_flank, const int32_t* rhs_flank,
+                           int32_t* flank_score, int32_t* target_mask_size,
+                           oct_phmm_status* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCT_PHMM_H */

@@ -1,0 +1,179 @@
+"""CPU ORACLE bindings — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package. It binds
+  * oracle/liboracle.so      — our plain-C restatement of the reference algorithm (phmm_oracle.c)
+  * oracle/_ref/libref_phmm.so — the reference's own SIMD pair-HMM headers compiled in place (built in the
+                                 container where /root/reference exists; travels to the GPU box as a .so)
+The product package (octopus_amd) never imports this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+from octopus_amd import abi
+
+_DIR = Path(__file__).resolve().parent
+_LIB: Optional[C.CDLL] = None
+_REF: Optional[C.CDLL] = None
+ISA = {"sse2": 0, "avx2": 1, "avx512": 2, "native": -1}
+
+
+def build(quiet: bool = True) -> None:
+    """make liboracle.so (always) and _ref/libref_phmm.so (only where /root/reference is present)."""
+    subprocess.run(["make", "-C", str(_DIR), "-j4", "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        p = _DIR / "liboracle.so"
+        if not p.exists():
+            build()
+        _LIB = C.CDLL(str(p))
+        _LIB.oracle_align.restype = C.c_int
+        _LIB.oracle_flank.restype = C.c_int
+        _LIB.oracle_evaluate.restype = C.c_double
+        _LIB.oracle_time_align_windows.restype = C.c_double
+    return _LIB
+
+
+def have_ref() -> bool:
+    return (_DIR / "_ref" / "libref_phmm.so").exists()
+
+
+def ref() -> C.CDLL:
+    global _REF
+    if _REF is None:
+        _REF = C.CDLL(str(_DIR / "_ref" / "libref_phmm.so"))
+        _REF.ref_phmm_align.restype = C.c_int
+        _REF.ref_phmm_flank.restype = C.c_int
+    return _REF
+
+
+def ref_isa_supported(isa: str) -> bool:
+    return have_ref() and bool(ref().ref_phmm_isa_supported(ISA[isa])) if isa != "native" else have_ref()
+
+
+def _p(a):
+    return None if a is None else np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+
+
+def _i8(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.int8))
+
+
+def _bytes(a):
+    if a is None:
+        return None
+    if isinstance(a, (bytes, bytearray)):
+        return np.frombuffer(bytes(a), dtype=np.uint8)
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint8))
+
+
+def align(band, score_bits, truth, target, quals, gap_open, gap_extend=None, gap_extend_scalar=1,
+          snv_mask=None, snv_prior=None, nuc_prior=2, traceback=False, backend: str = "oracle"):
+    """simd::PairHMM::align. backend: 'oracle' (restatement) or 'sse2'/'avx2'/'avx512'/'native' (reference .so).
+    Returns dict(score, status[, first_pos, align1, align2])."""
+    truth_a, target_a = _bytes(truth), _bytes(target)
+    q, go, ge = _i8(np.asarray(quals, dtype=np.uint8).view(np.int8)), _i8(gap_open), _i8(gap_extend)
+    m, pr = _bytes(snv_mask), _i8(snv_prior)
+    T = len(target_a)
+    n = 2 * (T + band) + 1
+    a1, a2 = C.create_string_buffer(n + 1), C.create_string_buffer(n + 1)
+    fp, st = C.c_int(0), C.c_int(0)
+    args = (band, score_bits, _p(truth_a), _p(target_a), _p(q), len(truth_a), T, _p(m), _p(pr), _p(go), _p(ge),
+            int(gap_extend_scalar), int(nuc_prior), 1 if traceback else 0, C.byref(fp), a1, a2, C.byref(st))
+    if backend == "oracle":
+        score = lib().oracle_align(*args)
+    else:
+        score = ref().ref_phmm_align(ISA[backend], *args)
+    out = dict(score=int(score), status=st.value)
+    if traceback:
+        out.update(first_pos=fp.value, align1=a1.value.decode("latin1"), align2=a2.value.decode("latin1"))
+    return out
+
+
+def flank(band, score_bits, truth_len, lhs, rhs, target, quals, snv_mask, snv_prior, gap_open, gap_extend, nuc_prior,
+          first_pos, aln1: str, aln2: str, backend: str = "oracle"):
+    """simd::PairHMM::calculate_flank_score (masked overload). Returns (flank_score, target_mask_size, status)."""
+    target_a = _bytes(target)
+    q = _i8(np.asarray(quals, dtype=np.uint8).view(np.int8))
+    m, pr, go, ge = _bytes(snv_mask), _i8(snv_prior), _i8(gap_open), _i8(gap_extend)
+    ms, st = C.c_int(0), C.c_int(0)
+    args = (band, score_bits, truth_len, lhs, rhs, _p(target_a), _p(q), _p(m), _p(pr), _p(go), _p(ge), int(nuc_prior),
+            int(first_pos), aln1.encode("latin1"), aln2.encode("latin1"), C.byref(ms), C.byref(st))
+    s = lib().oracle_flank(*args) if backend == "oracle" else ref().ref_phmm_flank(ISA[backend], *args)
+    return int(s), ms.value, st.value
+
+
+def set_l1_backend(name: str = "oracle") -> None:
+    """Choose the L1 kernels the oracle's L2/L3 layers drive: the restatement or the reference's SIMD kernels."""
+    L = lib()
+    L.oracle_set_l1_backend.argtypes = [C.c_void_p, C.c_void_p]
+    if name == "oracle":
+        L.oracle_set_l1_backend(None, None)
+        return
+    r = ref()
+    a = C.cast(getattr(r, f"ref_phmm_align_bound_{name}"), C.c_void_p)
+    f = C.cast(getattr(r, f"ref_phmm_flank_bound_{name}"), C.c_void_p)
+    L.oracle_set_l1_backend(a, f)
+
+
+def try_naive_evaluate(truth, target, quals, offset, gap_open, gap_extend, mask, prior, lhs=0, rhs=0):
+    truth_a, target_a = _bytes(truth), _bytes(target)
+    pen = C.c_int(0)
+    handled = lib().oracle_try_naive_evaluate(_p(truth_a), len(truth_a), _p(target_a), len(target_a),
+                                              _p(np.asarray(quals, np.uint8)), C.c_uint32(offset), _p(_i8(gap_open)),
+                                              _p(_i8(gap_extend)), _p(_bytes(mask)), _p(_i8(prior)),
+                                              C.c_uint32(lhs), C.c_uint32(rhs), C.byref(pen))
+    return bool(handled), pen.value
+
+
+def evaluate(truth, target, quals, offset, band, score_bits, gap_open, gap_extend, mask, prior, lhs=0, rhs=0, nuc_prior=2):
+    truth_a, target_a = _bytes(truth), _bytes(target)
+    kind = C.c_int(0)
+    v = lib().oracle_evaluate(_p(truth_a), len(truth_a), _p(target_a), len(target_a), _p(np.asarray(quals, np.uint8)),
+                              C.c_uint32(offset), band, score_bits, _p(_i8(gap_open)), _p(_i8(gap_extend)),
+                              _p(_bytes(mask)), _p(_i8(prior)), C.c_uint32(lhs), C.c_uint32(rhs), int(nuc_prior), C.byref(kind))
+    return float(v), kind.value
+
+
+def map_query_to_target(query, target, max_positions=10):
+    q, t = _bytes(query), _bytes(target)
+    out = np.zeros(max(max_positions, 1), dtype=np.uint32)
+    n = lib().oracle_map_query_to_target(_p(q), len(q), _p(t), len(t), int(max_positions), _p(out))
+    return out[:n].tolist()
+
+
+def populate(cfg: abi.Config, batch: abi.Batch, n_threads: int = 1):
+    """HaplotypeLikelihoodArray::populate on the CPU oracle. Returns (out ndarray, status, stats dict)."""
+    out = np.full(max(batch.out_size(), 1), np.nan, dtype=np.float64)
+    st, stats = abi.Status(), abi.Stats()
+    r, h, g, f, p = batch.c_args()
+    code = lib().oracle_populate(C.byref(cfg), r, h, g, f, p, _p(out), C.byref(st), C.byref(stats), int(n_threads))
+    assert code == st.code
+    return out[:batch.out_size()], st, stats.as_dict()
+
+
+def time_align_windows(band, score_bits, truth, truth_offsets, target, quals, target_offsets, gap_open, gap_extend,
+                       snv_mask, snv_prior, nuc_prior=2, traceback=False, reps=1, n_threads=1):
+    """Seconds to run the current L1 backend over all windows `reps` times (CPU baseline leg of bench.py)."""
+    chk = C.c_int64(0)
+    n = len(truth_offsets) - 1
+    secs = lib().oracle_time_align_windows(band, score_bits, C.c_uint32(n), _p(_bytes(truth)),
+                                           _p(np.asarray(truth_offsets, np.uint32)), _p(_bytes(target)),
+                                           _p(np.asarray(quals, np.uint8)), _p(np.asarray(target_offsets, np.uint32)),
+                                           _p(_i8(gap_open)), _p(_i8(gap_extend)), _p(_bytes(snv_mask)), _p(_i8(snv_prior)),
+                                           int(nuc_prior), 1 if traceback else 0, int(reps), int(n_threads), C.byref(chk))
+    return float(secs), int(chk.value)
+
+
+def host_cores() -> int:
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

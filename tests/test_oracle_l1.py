@@ -1,0 +1,92 @@
+"""Pin the CPU oracle's L1 restatement: (a) against every golden vector of the reference's own
+test/unit/core/models/pair_hmm_tests.cpp, (b) against the reference's own SIMD headers compiled in place
+(oracle/_ref/libref_phmm.so) on seeded random cases: score, first_pos, both gapped strings, flank score."""
+import numpy as np
+import pytest
+
+import oracle
+from l1_cases import random_case
+
+
+def _golden_call(rec, inst, traceback, backend):
+    t = rec["test"]
+    return oracle.align(inst["band"], inst["score_bits"], t["truth"].encode(), t["target"].encode(),
+                        t["base_qualities"], t["gap_open"], None, t["gap_extend"], None, None, t["nuc_prior"],
+                        traceback=traceback, backend=backend)
+
+
+def test_oracle_matches_reference_golden_vectors(golden_records):
+    n = 0
+    for rec in golden_records:
+        e = rec["expected"]
+        for inst in rec["instantiations"]:
+            assert _golden_call(rec, inst, False, "oracle")["score"] == e["score"], rec["name"]
+            r = _golden_call(rec, inst, True, "oracle")
+            assert (r["score"], r["first_pos"], r["align1"], r["align2"]) == (e["score"], e["begin"], e["align1"], e["align2"]), rec["name"]
+            n += 1
+    assert n == 39  # 15 SSE2 cases x {short,int} + 5 AVX2 + 4 speed cases
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libref_phmm.so not built")
+def test_reference_build_matches_its_own_golden_vectors(golden_records):
+    for rec in golden_records:
+        e = rec["expected"]
+        for inst in rec["instantiations"]:
+            if not oracle.ref_isa_supported(inst["isa"]):
+                continue
+            assert _golden_call(rec, inst, False, inst["isa"])["score"] == e["score"]
+            r = _golden_call(rec, inst, True, inst["isa"])
+            assert (r["score"], r["first_pos"], r["align1"], r["align2"]) == (e["score"], e["begin"], e["align1"], e["align2"])
+
+
+CONFIGS = [(8, 16, "sse2"), (16, 16, "sse2"), (16, 16, "avx2"), (32, 32, "sse2"), (32, 16, "avx512"),
+           (64, 16, "sse2"), (16, 32, "avx512"), (128, 16, "avx2"), (256, 32, "sse2")]
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libref_phmm.so not built")
+@pytest.mark.parametrize("band,bits,isa", CONFIGS)
+def test_oracle_matches_reference_kernels_on_random_cases(band, bits, isa):
+    if not oracle.ref_isa_supported(isa):
+        pytest.skip(f"{isa} not supported on this host")
+    rng = np.random.default_rng(1234 + band * 7 + bits)
+    n_cases = 150 if band <= 32 else 40
+    for it in range(n_cases):
+        T = int(rng.integers(9, 151)) if band <= 64 else int(rng.integers(60, 300))
+        c = random_case(rng, band, T)
+        for masked in (True, False):
+            kw = dict(snv_mask=c["mask"], snv_prior=c["prior"]) if masked else {}
+            ge = c["gap_extend"] if (masked or it % 2) else None
+            for tb in (False, True):
+                a = oracle.align(band, bits, c["truth"], c["target"], c["quals"], c["gap_open"], ge, 3, nuc_prior=2,
+                                 traceback=tb, backend="oracle", **kw)
+                b = oracle.align(band, bits, c["truth"], c["target"], c["quals"], c["gap_open"], ge, 3, nuc_prior=2,
+                                 traceback=tb, backend=isa, **kw)
+                assert a == b, (band, bits, isa, it, masked, tb, a, b)
+            if masked and a["first_pos"] >= 0:
+                L = len(c["truth"])
+                lhs, rhs = int(rng.integers(0, L // 2)), int(rng.integers(0, L // 2))
+                fa = oracle.flank(band, bits, L, lhs, rhs, c["target"], c["quals"], c["mask"], c["prior"], c["gap_open"],
+                                  c["gap_extend"], 2, a["first_pos"], a["align1"], a["align2"], backend="oracle")
+                fb = oracle.flank(band, bits, L, lhs, rhs, c["target"], c["quals"], c["mask"], c["prior"], c["gap_open"],
+                                  c["gap_extend"], 2, a["first_pos"], a["align1"], a["align2"], backend=isa)
+                assert fa == fb
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libref_phmm.so not built")
+def test_oracle_matches_reference_on_int16_overflow():
+    """Junk reads with maximal qualities drive int16 lanes past 15,872 phred: the restatement must wrap like the SIMD lanes."""
+    if not oracle.ref_isa_supported("sse2"):
+        pytest.skip("sse2")
+    rng = np.random.default_rng(99)
+    for it in range(30):
+        band, T = 16, 150
+        c = random_case(rng, band, T, q_max=125)
+        c["target"] = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), T))  # unrelated read
+        c["quals"] = np.full(T, 125, np.uint8)
+        c["prior"][:] = 125
+        for tb in (False, True):
+            a = oracle.align(band, 16, c["truth"], c["target"], c["quals"], c["gap_open"], c["gap_extend"], 1,
+                             snv_mask=c["mask"], snv_prior=c["prior"], traceback=tb)
+            b = oracle.align(band, 16, c["truth"], c["target"], c["quals"], c["gap_open"], c["gap_extend"], 1,
+                             snv_mask=c["mask"], snv_prior=c["prior"], traceback=tb, backend="sse2")
+            assert a == b, (it, tb, a["score"], b["score"])
