@@ -1,0 +1,624 @@
+// liboct_phmm.so — host side of the C ABI in include/oct_phmm.h: validation, HBM layout, kernel sequencing.
+// All compute happens in the HIP kernels of phmm_kernels.hpp; there is no CPU compute path here.
+#include "../../include/oct_phmm.h"
+
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "phmm_rt.hpp"
+#include "phmm_kernels.hpp"
+
+using namespace octphmm;
+
+// ---------------------------------------------------------------------------------------------------------------
+// handle / batch objects
+// ---------------------------------------------------------------------------------------------------------------
+struct oct_phmm_handle {
+    oct_phmm_config cfg;
+    int band = 0;
+    rt::Stream stream {};
+    rt::Event ev[2] {};
+    uint32_t* bp = nullptr; size_t bp_bytes = 0;          // traceback scratch, grown on demand
+    size_t bp_budget = (size_t)2 << 30;
+};
+
+struct oct_phmm_batch {
+    DevBatch d {};
+    std::vector<void*> allocs;
+    // host-side shape + small copies needed for error reporting
+    uint32_t n_reads = 0, n_haps = 0, n_rows = 0, n_regions = 0, t_cap = 0, lh_cap = 0, n_hap_bases = 0;
+    uint64_t n_pairs = 0, n_out = 0;
+    std::vector<uint32_t> h_roff, h_hoff; std::vector<int64_t> h_rbegin, h_hbegin;
+    // run state
+    uint4* d_hap_base = nullptr; uint4* d_tile_sums = nullptr; uint32_t n_tiles = 0;
+    DevTask* d_tasks = nullptr; size_t tasks_cap = 0; TraceEnd* d_ends = nullptr; size_t ends_cap = 0;
+    double* d_out = nullptr;
+    uint32_t n_tasks[kNumKinds] = {0, 0, 0, 0};
+    unsigned long long h_stats[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long h_err_key = ~0ull;
+    bool ran = false;
+    double dp_ms = 0; uint32_t dp_launches = 0;
+    std::vector<std::pair<rt::Event, rt::Event>> timers;
+    oct_phmm_handle* owner = nullptr;
+};
+
+namespace {
+
+int fail(oct_phmm_status* st, int code, const char* msg)
+{
+    if (st) {
+        memset(st, 0, sizeof(*st));
+        st->code = code;
+        if (code == OCT_PHMM_EHIP) st->hip_error = rt::last_error_code;
+        if (msg) snprintf(st->message, sizeof(st->message), "%s", msg);
+    }
+    return code;
+}
+int ok(oct_phmm_status* st) { if (st) { memset(st, 0, sizeof(*st)); } return OCT_PHMM_OK; }
+
+int band_for(int max_indel_error)   // simd_pair_hmm_wrapper.hpp:219-241
+{
+    for (int b = 8; b <= 256; b *= 2) if (max_indel_error <= b) return b;
+    return -1;
+}
+
+#define RT(expr) do { if (!(expr)) return fail(status, OCT_PHMM_EHIP, #expr); } while (0)
+
+template <class T>
+bool upload(oct_phmm_batch* b, rt::Stream s, const T* host, size_t n, const T** dev, size_t pad = 16)
+{
+    void* p = nullptr;
+    if (!rt::dev_malloc(&p, n * sizeof(T) + pad)) return false;
+    b->allocs.push_back(p);
+    if (!rt::dev_memset((char*)p + n * sizeof(T), 0, pad, s)) return false;
+    if (!rt::h2d(p, host, n * sizeof(T), s)) return false;
+    *dev = (const T*)p;
+    return true;
+}
+template <class T>
+bool dalloc(oct_phmm_batch* b, T** dev, size_t n)
+{
+    void* p = nullptr;
+    if (!rt::dev_malloc(&p, n * sizeof(T) + 16)) return false;
+    b->allocs.push_back(p);
+    *dev = (T*)p;
+    return true;
+}
+
+bool monotone(const uint32_t* off, uint32_t n) { for (uint32_t i = 0; i < n; ++i) if (off[i + 1] < off[i]) return false; return true; }
+
+// kernel dispatch over (band, traceback, generic)
+template <int B, bool TR, bool GEN>
+bool launch_dp_inst(const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
+{
+    if (!rt::allow_lds((k_dp<B, TR, GEN>), lds)) return false;
+    OCT_LAUNCH((k_dp<B, TR, GEN>), n_blocks, kBlockWaves * 64, lds, s, p);
+    return rt::launch_ok();
+}
+template <int B>
+bool launch_dp_band(bool tr, bool gen, const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
+{
+    if (tr) return gen ? launch_dp_inst<B, true, true>(p, n_blocks, lds, s) : launch_dp_inst<B, true, false>(p, n_blocks, lds, s);
+    return gen ? launch_dp_inst<B, false, true>(p, n_blocks, lds, s) : launch_dp_inst<B, false, false>(p, n_blocks, lds, s);
+}
+bool launch_dp(int band, bool tr, bool gen, const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
+{
+    switch (band) {
+        case 8:  return launch_dp_band<8>(tr, gen, p, n_blocks, lds, s);
+        case 16: return launch_dp_band<16>(tr, gen, p, n_blocks, lds, s);
+        case 32: return launch_dp_band<32>(tr, gen, p, n_blocks, lds, s);
+        case 64: return launch_dp_band<64>(tr, gen, p, n_blocks, lds, s);
+        default: return false;
+    }
+}
+bool launch_walk(int band, const WalkParams& w, rt::Stream s)
+{
+    const uint32_t blocks = (w.n_tasks + 255) / 256;
+    switch (band) {
+        case 8:  OCT_LAUNCH((k_walk<8>), blocks, 256, 0, s, w); break;
+        case 16: OCT_LAUNCH((k_walk<16>), blocks, 256, 0, s, w); break;
+        case 32: OCT_LAUNCH((k_walk<32>), blocks, 256, 0, s, w); break;
+        case 64: OCT_LAUNCH((k_walk<64>), blocks, 256, 0, s, w); break;
+        default: return false;
+    }
+    return rt::launch_ok();
+}
+
+bool ensure_bp(oct_phmm_handle* h, size_t bytes)
+{
+    if (h->bp_bytes >= bytes) return true;
+    rt::dev_free(h->bp); h->bp = nullptr; h->bp_bytes = 0;
+    void* p = nullptr;
+    if (!rt::dev_malloc(&p, bytes)) return false;
+    h->bp = (uint32_t*)p; h->bp_bytes = bytes;
+    return true;
+}
+
+// Run one kind's task list through the DP kernel (+ walk for traceback kinds), chunked so the traceback scratch fits.
+int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
+                int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status)
+{
+    if (!n_tasks) return OCT_PHMM_OK;
+    const int B = h->band;
+    const uint32_t G = 2 * (64 / B);
+    const bool tr = kind == kTraceFast || kind == kTraceGen, gen = kind == kScoreGen || kind == kTraceGen;
+    const size_t lds = dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B);
+    if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
+    DpParams p {};
+    p.rbases = b->d.rbases; p.rquals = b->d.rquals; p.roff = b->d.roff; p.rrev = b->d.rrev; p.hoff = b->d.hoff;
+    p.tabF = gen ? b->d.tabGenF : b->d.tabFastF; p.tabR = gen ? b->d.tabGenR : b->d.tabFastR;
+    p.pair_best = b->d.pair_best;
+    p.k_cap = b->t_cap + (uint32_t)B; p.t_cap = b->t_cap; p.lh_cap = b->lh_cap;
+    const uint32_t n4 = ((uint32_t)(int8_t)nuc_prior << 2) & 0xffffu;       // vectorise_left_shift_bits(int8_t), simd_pair_hmm.hpp:74-78,257
+    p.nuc4 = n4 | n4 << 16;
+    p.groups_per_block = kBlockWaves * kGroupsPerWave;
+    const uint32_t n_groups = n_tasks / G;
+    uint32_t chunk_groups = n_groups;
+    if (tr) {
+        const size_t per_group = (size_t)p.k_cap * 64 * sizeof(uint32_t);
+        const size_t fit = std::max<size_t>(1, h->bp_budget / per_group);
+        chunk_groups = (uint32_t)std::min<size_t>(n_groups, fit);
+        chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / p.groups_per_block * p.groups_per_block);
+        if (!ensure_bp(h, (size_t)std::min(chunk_groups, n_groups) * per_group)) return fail(status, OCT_PHMM_EHIP, "traceback scratch allocation");
+    }
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += chunk_groups) {
+        const uint32_t ng = std::min(chunk_groups, n_groups - g0);
+        p.tasks = tasks + (size_t)g0 * G; p.n_tasks = ng * G;
+        p.bp = h->bp; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
+        const uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
+        rt::Event e0, e1;
+        RT(rt::event_create(&e0)); RT(rt::event_create(&e1));
+        RT(rt::event_record(e0, h->stream));
+        if (!launch_dp(B, tr, gen, p, n_blocks, lds, h->stream)) return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
+        RT(rt::event_record(e1, h->stream));
+        b->timers.emplace_back(e0, e1);
+        if (tr) {
+            WalkParams w {};
+            if (seam_walk) w = *seam_walk;
+            w.tasks = p.tasks; w.n_tasks = p.n_tasks; w.ends = p.ends; w.bp = h->bp; w.k_cap = p.k_cap; w.band = B;
+            w.rbases = b->d.rbases; w.rquals = b->d.rquals; w.roff = b->d.roff; w.rrev = b->d.rrev;
+            w.hbases = b->d.hbases; w.hoff = b->d.hoff; w.go = b->d.go; w.ge = b->d.ge;
+            w.maskF = b->d.maskF; w.priorF = b->d.priorF; w.maskR = b->d.maskR; w.priorR = b->d.priorR;
+            w.hap_region = b->d.hap_region; w.reg_lhs = b->d.reg_lhs; w.reg_rhs = b->d.reg_rhs;
+            w.nuc_prior = nuc_prior; w.pair_best = b->d.pair_best;
+            if (seam_walk) {   // seam outputs are indexed by task: advance to this chunk
+                const size_t o = (size_t)g0 * G;
+                w.out_first_pos += o; w.out_align_off += o;
+                if (w.seam_lhs) { w.seam_lhs += o; w.seam_rhs += o; w.out_flank += o; w.out_mask_size += o; }
+            }
+            if (!launch_walk(B, w, h->stream)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
+        }
+    }
+    return OCT_PHMM_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// lifecycle
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" void oct_phmm_config_default(oct_phmm_config* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->struct_size = sizeof(*c);
+    c->max_indel_error = 8; c->use_int_scores = 0; c->use_mapping_quality = 1; c->mapping_quality_cap = 120;
+    c->mapping_quality_cap_trigger = -1; c->use_flank_state = 1; c->nuc_prior = 2; c->max_mapping_positions = 10; c->device_id = 0;
+}
+
+extern "C" const char* oct_phmm_strerror(int code)
+{
+    switch (code) {
+        case OCT_PHMM_OK: return "ok";
+        case OCT_PHMM_EINVAL: return "invalid batch";
+        case OCT_PHMM_EBAND: return "requested band size is too large";
+        case OCT_PHMM_ESHORT_HAPLOTYPE: return "Haplotype is too short for alignment";
+        case OCT_PHMM_EHIP: return "HIP runtime error";
+        case OCT_PHMM_ENODEVICE: return "no gfx950 device";
+        case OCT_PHMM_EUNSUPPORTED: return "unsupported configuration";
+        case OCT_PHMM_EOVERFLOW: return "Pair HMM alignment overflowed";
+        default: return "unknown";
+    }
+}
+
+extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out)
+{
+    if (!cfg || !out || cfg->struct_size != sizeof(oct_phmm_config)) return OCT_PHMM_EINVAL;
+    *out = nullptr;
+    const int band = band_for(cfg->max_indel_error);
+    if (band < 0) return OCT_PHMM_EBAND;
+    if (band > 64 || cfg->use_int_scores) return OCT_PHMM_EUNSUPPORTED;            // see DESIGN.md "limits"
+    if (cfg->max_mapping_positions < 0 || cfg->max_mapping_positions >= kMaxSlots) return OCT_PHMM_EUNSUPPORTED;
+    int n = 0;
+    if (!rt::device_count(&n) || n <= 0 || cfg->device_id < 0 || cfg->device_id >= n) return OCT_PHMM_ENODEVICE;
+    if (!rt::device_is_gfx950(cfg->device_id)) return OCT_PHMM_ENODEVICE;
+    if (!rt::set_device(cfg->device_id)) return OCT_PHMM_EHIP;
+    std::unique_ptr<oct_phmm_handle> h(new (std::nothrow) oct_phmm_handle());
+    if (!h) return OCT_PHMM_EHIP;
+    h->cfg = *cfg; h->band = band;
+    if (h->cfg.mapping_quality_cap_trigger >= 0 && h->cfg.mapping_quality_cap_trigger >= h->cfg.mapping_quality_cap)
+        h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
+    if (!rt::stream_create(&h->stream)) return OCT_PHMM_EHIP;
+    *out = h.release();
+    return OCT_PHMM_OK;
+}
+
+extern "C" void oct_phmm_destroy(oct_phmm_handle* h)
+{
+    if (!h) return;
+    rt::set_device(h->cfg.device_id);
+    rt::stream_sync(h->stream);
+    rt::dev_free(h->bp);
+    rt::stream_destroy(h->stream);
+    delete h;
+}
+
+extern "C" int oct_phmm_band_size(const oct_phmm_handle* h) { return h ? h->band : -1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// upload
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
+{
+    if (!b) return;
+    if (h) { rt::set_device(h->cfg.device_id); rt::stream_sync(h->stream); }
+    for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
+    for (void* p : b->allocs) rt::dev_free(p);
+    rt::dev_free(b->d_tasks); rt::dev_free(b->d_ends);
+    delete b;
+}
+
+extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
+                                     const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                                     const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status)
+{
+    if (!h || !R || !H || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
+    *out = nullptr;
+    if (!positions) return fail(status, OCT_PHMM_EUNSUPPORTED, "device k-mer mapping not built yet: pass mapping positions");
+    if ((R->n_reads && (!R->bases || !R->qualities || !R->offsets || !R->mapping_quality || !R->reverse_strand || !R->ref_begin))
+        || (H->n_haps && (!H->bases || !H->offsets || !H->ref_begin || !H->gap_open || !H->gap_extend || !H->snv_mask_fwd
+                          || !H->snv_prior_fwd || !H->snv_mask_rev || !H->snv_prior_rev)))
+        return fail(status, OCT_PHMM_EINVAL, "null array");
+    if (!R->offsets || !H->offsets || !monotone(R->offsets, R->n_reads) || !monotone(H->offsets, H->n_haps))
+        return fail(status, OCT_PHMM_EINVAL, "offsets not monotone");
+    const uint32_t n_rows = R->row_offsets ? R->n_rows : R->n_reads;
+    if (R->row_offsets && (!monotone(R->row_offsets, n_rows) || R->row_offsets[0] != 0 || R->row_offsets[n_rows] != R->n_reads))
+        return fail(status, OCT_PHMM_EINVAL, "row_offsets must partition the reads");
+    const uint32_t n_read_bases = R->offsets[R->n_reads], n_hap_bases = H->offsets[H->n_haps];
+    for (uint32_t i = 0; i < n_read_bases; ++i) if (R->qualities[i] > 127) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
+    for (uint32_t i = 0; i < n_hap_bases; ++i)
+        if (H->gap_open[i] < 0 || H->gap_extend[i] < 0 || H->snv_prior_fwd[i] < 0 || H->snv_prior_rev[i] < 0)
+            return fail(status, OCT_PHMM_EINVAL, "negative penalty");
+
+    // regions
+    uint32_t one_row[2] = {0, n_rows}, one_hap[2] = {0, H->n_haps};
+    uint8_t one_hf = flank ? 1 : 0; oct_phmm_flank_state one_fl = flank ? *flank : oct_phmm_flank_state {0, 0};
+    uint32_t G = 1; const uint32_t* g_row = one_row; const uint32_t* g_hap = one_hap;
+    const uint8_t* g_hf = &one_hf; const oct_phmm_flank_state* g_fl = &one_fl;
+    if (regions) {
+        G = regions->n_regions; g_row = regions->row_offsets; g_hap = regions->hap_offsets; g_hf = regions->has_flank; g_fl = regions->flank;
+        if (!g_row || !g_hap || !monotone(g_row, G) || !monotone(g_hap, G) || g_row[0] != 0 || g_hap[0] != 0
+            || g_row[G] != n_rows || g_hap[G] != H->n_haps || (g_hf && !g_fl))
+            return fail(status, OCT_PHMM_EINVAL, "region tables must partition rows and haplotypes");
+    }
+    auto first_read = [&](uint32_t row) { return R->row_offsets ? R->row_offsets[row] : row; };
+
+    std::unique_ptr<oct_phmm_batch> b(new (std::nothrow) oct_phmm_batch());
+    if (!b) return fail(status, OCT_PHMM_EHIP, "host allocation");
+    b->owner = h; b->n_reads = R->n_reads; b->n_haps = H->n_haps; b->n_rows = n_rows; b->n_regions = G; b->n_hap_bases = n_hap_bases;
+    std::vector<uint32_t> hap_region(H->n_haps + 1, 0), reg_row0(G + 1), reg_read0(G + 1), reg_lhs(G + 1, 0), reg_rhs(G + 1, 0);
+    std::vector<uint64_t> hap_out_off(H->n_haps + 1, 0), hap_pair_off(H->n_haps + 1, 0);
+    for (uint32_t g = 0; g < G; ++g) {
+        reg_row0[g] = g_row[g]; reg_read0[g] = first_read(g_row[g]);
+        const uint32_t rows = g_row[g + 1] - g_row[g], nreads = first_read(g_row[g + 1]) - first_read(g_row[g]);
+        if (h->cfg.use_flank_state && g_hf && g_hf[g]) { reg_lhs[g] = g_fl[g].lhs_flank; reg_rhs[g] = g_fl[g].rhs_flank; }   // model.cpp:276-282
+        for (uint32_t hp = g_hap[g]; hp < g_hap[g + 1]; ++hp) {
+            hap_region[hp] = g; hap_out_off[hp + 1] = hap_out_off[hp] + rows; hap_pair_off[hp + 1] = hap_pair_off[hp] + nreads;
+            for (uint32_t r = reg_read0[g]; r < reg_read0[g] + nreads; ++r)
+                if (R->ref_begin[r] < H->ref_begin[hp]) return fail(status, OCT_PHMM_EINVAL, "read begins before its haplotype (contains() violated)");
+        }
+    }
+    b->n_out = hap_out_off[H->n_haps]; b->n_pairs = hap_pair_off[H->n_haps];
+    if (b->n_pairs >= 0xffffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "more than 2^32-1 pairs in one batch");
+    for (uint32_t r = 0; r < R->n_reads; ++r) b->t_cap = std::max(b->t_cap, R->offsets[r + 1] - R->offsets[r]);
+    for (uint32_t hp = 0; hp < H->n_haps; ++hp) b->lh_cap = std::max(b->lh_cap, H->offsets[hp + 1] - H->offsets[hp]);
+    if (b->t_cap + (uint32_t)h->band >= 32768) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long for int16 diagonal indices");
+    for (uint32_t r = 0; r < R->n_reads; ++r) if (R->offsets[r + 1] == R->offsets[r]) return fail(status, OCT_PHMM_EINVAL, "empty read");
+    const uint64_t n_pos = positions->offsets ? positions->offsets[b->n_pairs] : 0;
+    if (b->n_pairs && !positions->offsets) return fail(status, OCT_PHMM_EINVAL, "positions.offsets null");
+    for (uint64_t e = 0; e < b->n_pairs; ++e) {
+        if (positions->offsets[e + 1] < positions->offsets[e] || positions->offsets[e + 1] - positions->offsets[e] > (uint64_t)h->cfg.max_mapping_positions)
+            return fail(status, OCT_PHMM_EINVAL, "more mapping positions than max_mapping_positions");
+    }
+    b->h_roff.assign(R->offsets, R->offsets + R->n_reads + 1); b->h_hoff.assign(H->offsets, H->offsets + H->n_haps + 1);
+    b->h_rbegin.assign(R->ref_begin, R->ref_begin + R->n_reads); b->h_hbegin.assign(H->ref_begin, H->ref_begin + H->n_haps);
+
+    RT(rt::set_device(h->cfg.device_id));
+    rt::Stream s = h->stream;
+    DevBatch& d = b->d;
+    d.n_reads = R->n_reads; d.n_rows = n_rows; d.n_haps = H->n_haps; d.n_regions = G; d.n_pairs = b->n_pairs;
+    d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions;
+    d.use_mapq = h->cfg.use_mapping_quality; d.mapq_cap = h->cfg.mapping_quality_cap; d.mapq_trigger = h->cfg.mapping_quality_cap_trigger;
+    oct_phmm_batch* bp = b.get();
+    RT(upload(bp, s, (const uint8_t*)R->bases, n_read_bases, &d.rbases));
+    RT(upload(bp, s, R->qualities, n_read_bases, &d.rquals));
+    RT(upload(bp, s, R->offsets, (size_t)R->n_reads + 1, &d.roff));
+    RT(upload(bp, s, R->mapping_quality, R->n_reads, &d.rmapq));
+    RT(upload(bp, s, R->reverse_strand, R->n_reads, &d.rrev));
+    RT(upload(bp, s, R->ref_begin, R->n_reads, &d.rbegin));
+    d.row_off = nullptr;
+    if (R->row_offsets) RT(upload(bp, s, R->row_offsets, (size_t)n_rows + 1, &d.row_off));
+    RT(upload(bp, s, (const uint8_t*)H->bases, n_hap_bases, &d.hbases));
+    RT(upload(bp, s, H->offsets, (size_t)H->n_haps + 1, &d.hoff));
+    RT(upload(bp, s, H->ref_begin, H->n_haps, &d.hbegin));
+    RT(upload(bp, s, H->gap_open, n_hap_bases, &d.go));
+    RT(upload(bp, s, H->gap_extend, n_hap_bases, &d.ge));
+    RT(upload(bp, s, (const uint8_t*)H->snv_mask_fwd, n_hap_bases, &d.maskF));
+    RT(upload(bp, s, H->snv_prior_fwd, n_hap_bases, &d.priorF));
+    RT(upload(bp, s, (const uint8_t*)H->snv_mask_rev, n_hap_bases, &d.maskR));
+    RT(upload(bp, s, H->snv_prior_rev, n_hap_bases, &d.priorR));
+    RT(upload(bp, s, hap_region.data(), hap_region.size(), &d.hap_region));
+    RT(upload(bp, s, hap_out_off.data(), hap_out_off.size(), &d.hap_out_off));
+    RT(upload(bp, s, hap_pair_off.data(), hap_pair_off.size(), &d.hap_pair_off));
+    RT(upload(bp, s, reg_row0.data(), reg_row0.size(), &d.reg_row0));
+    RT(upload(bp, s, reg_read0.data(), reg_read0.size(), &d.reg_read0));
+    RT(upload(bp, s, reg_lhs.data(), reg_lhs.size(), &d.reg_lhs));
+    RT(upload(bp, s, reg_rhs.data(), reg_rhs.size(), &d.reg_rhs));
+    RT(upload(bp, s, positions->offsets, (size_t)b->n_pairs + 1, &d.pos_off));
+    RT(upload(bp, s, positions->positions, (size_t)n_pos, &d.pos));
+    RT(dalloc(bp, &d.racgt, (size_t)R->n_reads));
+    RT(dalloc(bp, &d.tabFastF, (size_t)n_hap_bases)); RT(dalloc(bp, &d.tabFastR, (size_t)n_hap_bases));
+    RT(dalloc(bp, &d.tabGenF, (size_t)n_hap_bases));  RT(dalloc(bp, &d.tabGenR, (size_t)n_hap_bases));
+    RT(dalloc(bp, &d.hclean, (size_t)H->n_haps));
+    RT(dalloc(bp, &d.pair_best, (size_t)b->n_pairs)); RT(dalloc(bp, &d.pair_cls, (size_t)b->n_pairs));
+    RT(dalloc(bp, &d.pair_extra, (size_t)b->n_pairs)); RT(dalloc(bp, &d.pair_cnt, (size_t)b->n_pairs + 1));
+    RT(dalloc(bp, &d.stats, (size_t)8)); d.err_key = d.stats + 6;
+    RT(dalloc(bp, &b->d_hap_base, (size_t)H->n_haps + 1));
+    b->n_tiles = (uint32_t)((b->n_pairs + 1 + kScanTile - 1) / kScanTile);
+    RT(dalloc(bp, &b->d_tile_sums, (size_t)b->n_tiles + 1));
+    RT(dalloc(bp, &b->d_out, (size_t)b->n_out));
+    // per-read flags and per-base DP tables (once per batch; HaplotypeLikelihoodModel::reset analogue)
+    std::vector<uint32_t> ones(H->n_haps + 1, 1u);
+    RT(rt::h2d(d.hclean, ones.data(), (size_t)H->n_haps * sizeof(uint32_t), s));
+    if (R->n_reads) { OCT_LAUNCH(k_read_flags, (R->n_reads + 255) / 256, 256, 0, s, d); RT(rt::launch_ok()); }
+    if (n_hap_bases) { OCT_LAUNCH(k_hap_tables, (n_hap_bases + 255) / 256, 256, 0, s, d, n_hap_bases); RT(rt::launch_ok()); }
+    RT(rt::stream_sync(s));
+    *out = b.release();
+    return ok(status);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// run
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phmm_status* status)
+{
+    if (!h || !b || b->owner != h) return fail(status, OCT_PHMM_EINVAL, "bad handle/batch");
+    RT(rt::set_device(h->cfg.device_id));
+    rt::Stream s = h->stream;
+    DevBatch& d = b->d;
+    for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
+    b->timers.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
+    const uint32_t G = 2 * (64 / (uint32_t)h->band);
+    RT(rt::dev_memset(d.stats, 0, 6 * sizeof(unsigned long long), s));
+    RT(rt::dev_memset(d.err_key, 0xff, sizeof(unsigned long long), s));
+    for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
+    if (b->n_pairs) {
+        RT(rt::dev_memset(d.pair_cnt + b->n_pairs, 0, sizeof(uint4), s));
+        const uint32_t pair_blocks = (uint32_t)((b->n_pairs + 255) / 256);
+        OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d); RT(rt::launch_ok());
+        const uint64_t n_scan = b->n_pairs + 1;
+        OCT_LAUNCH(k_scan_tiles, b->n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, d.pair_cnt, n_scan, b->d_tile_sums, 0); RT(rt::launch_ok());
+        OCT_LAUNCH(k_scan_tile_sums, 1, 64, 0, s, b->d_tile_sums, b->n_tiles); RT(rt::launch_ok());
+        OCT_LAUNCH(k_scan_tiles, b->n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, d.pair_cnt, n_scan, b->d_tile_sums, 1); RT(rt::launch_ok());
+        OCT_LAUNCH(k_hap_bases, 1, 64, 0, s, d, b->d_hap_base, G); RT(rt::launch_ok());
+        uint4 totals;
+        RT(rt::d2h(&totals, b->d_hap_base + b->n_haps, sizeof(uint4), s));
+        RT(rt::stream_sync(s));                                  // the one host sync of the path: launch sizes
+        b->n_tasks[0] = totals.x; b->n_tasks[1] = totals.y; b->n_tasks[2] = totals.z; b->n_tasks[3] = totals.w;
+        const size_t total = (size_t)totals.x + totals.y + totals.z + totals.w;
+        if (total > b->tasks_cap) {
+            rt::dev_free(b->d_tasks); b->d_tasks = nullptr; b->tasks_cap = 0;
+            void* p = nullptr; RT(rt::dev_malloc(&p, total * sizeof(DevTask))); b->d_tasks = (DevTask*)p; b->tasks_cap = total;
+        }
+        const size_t n_trace = (size_t)std::max(totals.y, totals.w);
+        if (n_trace > b->ends_cap) {
+            rt::dev_free(b->d_ends); b->d_ends = nullptr; b->ends_cap = 0;
+            void* p = nullptr; RT(rt::dev_malloc(&p, n_trace * sizeof(TraceEnd))); b->d_ends = (TraceEnd*)p; b->ends_cap = n_trace;
+        }
+        TaskArrays ta;
+        ta.t[0] = b->d_tasks; ta.t[1] = ta.t[0] + totals.x; ta.t[2] = ta.t[1] + totals.y; ta.t[3] = ta.t[2] + totals.z;
+        if (total) {
+            OCT_LAUNCH(k_emit, pair_blocks, 256, 0, s, d, (const uint4*)b->d_hap_base, ta); RT(rt::launch_ok());
+            const uint32_t pad_threads = b->n_haps * kNumKinds * G;
+            OCT_LAUNCH(k_emit_pad, (pad_threads + 255) / 256, 256, 0, s, d, (const uint4*)b->d_hap_base, ta, G); RT(rt::launch_ok());
+            for (int k = 0; k < kNumKinds; ++k) {
+                const int rc = run_dp_kind(h, b, k, ta.t[k], b->n_tasks[k], b->d_ends, h->cfg.nuc_prior, nullptr, status);
+                if (rc != OCT_PHMM_OK) return rc;
+            }
+        }
+    }
+    if (b->n_out) { OCT_LAUNCH(k_epilogue, (uint32_t)((b->n_out + 255) / 256), 256, 0, s, d, b->d_out, b->n_out); RT(rt::launch_ok()); }
+    RT(rt::d2h(b->h_stats, d.stats, 6 * sizeof(unsigned long long), s));
+    RT(rt::d2h(&b->h_err_key, d.err_key, sizeof(unsigned long long), s));
+    b->ran = true;
+    return ok(status);
+}
+
+extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_phmm_status* status)
+{
+    if (!h || !b || b->owner != h || !b->ran) return fail(status, OCT_PHMM_EINVAL, "batch was not run");
+    RT(rt::set_device(h->cfg.device_id));
+    RT(rt::stream_sync(h->stream));
+    b->dp_ms = 0; b->dp_launches = 0;
+    for (auto& t : b->timers) { float ms = 0; RT(rt::event_elapsed_ms(&ms, t.first, t.second)); b->dp_ms += ms; ++b->dp_launches; }
+    if (b->h_err_key != ~0ull) {
+        // ShortHaplotypeError: recompute required_extension for the first offending (haplotype, read) — model.cpp:238-253
+        const uint32_t hp = (uint32_t)(b->h_err_key >> 32), r = (uint32_t)b->h_err_key;
+        fail(status, OCT_PHMM_ESHORT_HAPLOTYPE, "Haplotype is too short for alignment");
+        if (status) {
+            const uint64_t T = b->h_roff[r + 1] - b->h_roff[r], Lh = b->h_hoff[hp + 1] - b->h_hoff[hp], B = (uint64_t)h->band;
+            const uint64_t orig = (uint64_t)(b->h_rbegin[r] - b->h_hbegin[hp]);
+            int32_t min_shift;
+            if (orig < B) min_shift = (int32_t)(B - orig); else { const uint64_t e = orig + T + B; min_shift = e > Lh ? (int32_t)Lh - (int32_t)e : 0; }
+            status->hap_index = hp; status->read_index = r;
+            status->required_extension = min_shift > 0 ? (uint32_t)min_shift : (uint32_t)((uint32_t)(-min_shift) - orig);
+        }
+        return OCT_PHMM_ESHORT_HAPLOTYPE;
+    }
+    return ok(status);
+}
+
+extern "C" int oct_phmm_batch_download(oct_phmm_handle* h, oct_phmm_batch* b, double* out, oct_phmm_status* status)
+{
+    if (!out && b && b->n_out) return fail(status, OCT_PHMM_EINVAL, "null output");
+    const int rc = oct_phmm_batch_wait(h, b, status);
+    if (rc != OCT_PHMM_OK) return rc;
+    RT(rt::d2h(out, b->d_out, (size_t)b->n_out * sizeof(double), h->stream));
+    RT(rt::stream_sync(h->stream));
+    return ok(status);
+}
+
+extern "C" int oct_phmm_batch_stats(const oct_phmm_batch* b, oct_phmm_stats* st)
+{
+    if (!b || !st) return OCT_PHMM_EINVAL;
+    st->n_candidates = b->h_stats[0]; st->n_fast_path = b->h_stats[1]; st->n_dp_score_only = b->h_stats[2];
+    st->n_dp_traceback = b->h_stats[3]; st->band_cells = b->h_stats[4]; st->n_pairs = b->h_stats[5];
+    return OCT_PHMM_OK;
+}
+
+extern "C" size_t oct_phmm_batch_out_size(const oct_phmm_batch* b) { return b ? (size_t)b->n_out : 0; }
+
+extern "C" int oct_phmm_batch_kernel_time(const oct_phmm_batch* b, double* ms, uint32_t* launches)
+{
+    if (!b) return OCT_PHMM_EINVAL;
+    if (ms) *ms = b->dp_ms;
+    if (launches) *launches = b->dp_launches;
+    return OCT_PHMM_OK;
+}
+
+extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
+                                 const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                                 const oct_phmm_positions* positions, double* out, oct_phmm_status* status)
+{
+    oct_phmm_batch* b = nullptr;
+    int rc = oct_phmm_batch_upload(h, reads, haps, regions, flank, positions, &b, status);
+    if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_run(h, b, status);
+    if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_download(h, b, out, status);
+    oct_phmm_batch_free(h, b);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// test seam: raw band kernel on explicit windows
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
+                                      const char* truth, const uint32_t* truth_offsets,
+                                      const char* target, const uint8_t* qualities, const uint32_t* target_offsets,
+                                      const int8_t* gap_open, const int8_t* gap_extend, int32_t gap_extend_scalar,
+                                      const char* snv_mask, const int8_t* snv_prior,
+                                      int32_t nuc_prior, int32_t traceback,
+                                      int32_t* scores, int32_t* first_pos,
+                                      char* align1, char* align2, const uint32_t* align_offsets,
+                                      const int32_t* lhs_flank, const int32_t* rhs_flank,
+                                      int32_t* flank_score, int32_t* target_mask_size,
+                                      oct_phmm_status* status)
+{
+    if (!h || !truth || !truth_offsets || !target || !qualities || !target_offsets || !gap_open || !scores
+        || (!!snv_mask != !!snv_prior) || (traceback && (!first_pos || !align1 || !align2 || !align_offsets))
+        || (lhs_flank && (!traceback || !rhs_flank || !flank_score || !target_mask_size || !snv_mask)))
+        return fail(status, OCT_PHMM_EINVAL, "null argument");
+    if (!n) return ok(status);
+    const uint32_t B = (uint32_t)h->band, G = 2 * (64 / B);
+    const uint32_t n_truth = truth_offsets[n], n_target = target_offsets[n];
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t L = truth_offsets[i + 1] - truth_offsets[i], T = target_offsets[i + 1] - target_offsets[i];
+        if (T == 0 || L != T + 2 * B - 1) return fail(status, OCT_PHMM_EINVAL, "truth_len must equal target_len + 2*band - 1");
+        if (traceback && align_offsets[i + 1] - align_offsets[i] < 2 * (T + B) + 1) return fail(status, OCT_PHMM_EINVAL, "alignment buffer too small");
+    }
+    // the windows become one-off "haplotypes", the targets "reads", one task each at offset 0
+    std::vector<int8_t> ge_arr, prior_arr; std::vector<uint8_t> zeros8(n, 0), mapq(n, 0); std::vector<int64_t> zeros64(n, 0);
+    if (!gap_extend) { ge_arr.assign(n_truth, (int8_t)gap_extend_scalar); gap_extend = ge_arr.data(); }
+    if (!snv_mask) { snv_mask = truth; prior_arr.assign(n_truth, 0); snv_prior = prior_arr.data(); }   // mask == truth never fires (cost 0 on equality)
+    oct_phmm_reads R {}; R.n_reads = n; R.bases = target; R.qualities = qualities; R.offsets = target_offsets;
+    R.mapping_quality = mapq.data(); R.reverse_strand = zeros8.data(); R.ref_begin = zeros64.data(); R.n_rows = n; R.row_offsets = nullptr;
+    oct_phmm_haplotypes H {}; H.n_haps = n; H.bases = truth; H.offsets = truth_offsets; H.ref_begin = zeros64.data();
+    H.gap_open = gap_open; H.gap_extend = gap_extend; H.snv_mask_fwd = snv_mask; H.snv_prior_fwd = snv_prior;
+    H.snv_mask_rev = snv_mask; H.snv_prior_rev = snv_prior;
+    // regions: every window is its own region (one row x one haplotype), no pairs beyond the diagonal
+    std::vector<uint32_t> reg(n + 1); for (uint32_t i = 0; i <= n; ++i) reg[i] = i;
+    oct_phmm_regions RG {}; RG.n_regions = n; RG.row_offsets = reg.data(); RG.hap_offsets = reg.data(); RG.has_flank = nullptr; RG.flank = nullptr;
+    std::vector<uint64_t> poff(n + 1, 0); uint32_t dummy_pos = 0;
+    oct_phmm_positions P {poff.data(), &dummy_pos};
+    oct_phmm_batch* b = nullptr;
+    int rc = oct_phmm_batch_upload(h, &R, &H, &RG, nullptr, &P, &b, status);
+    if (rc != OCT_PHMM_OK) return rc;
+    struct Guard { oct_phmm_handle* h; oct_phmm_batch* b; std::vector<void*> extra; ~Guard() { rt::stream_sync(h->stream); for (void* p : extra) rt::dev_free(p); oct_phmm_batch_free(h, b); } } guard {h, b, {}};
+    rt::Stream s = h->stream;
+    // route each window to the fast or generic kernel exactly as k_classify would
+    std::vector<uint8_t> racgt(n); std::vector<uint32_t> hclean(n);
+    RT(rt::d2h(racgt.data(), b->d.racgt, n, s)); RT(rt::d2h(hclean.data(), b->d.hclean, n * sizeof(uint32_t), s)); RT(rt::stream_sync(s));
+    std::vector<DevTask> tasks[2]; std::vector<uint32_t> origin[2];
+    // every window is its own haplotype and a DP task group must stay within one haplotype: give each window a whole
+    // group (one real task + G-1 padding copies). This is a test seam, not the throughput path.
+    for (uint32_t i = 0; i < n; ++i) {
+        const int gen = !(racgt[i] && hclean[i]);
+        tasks[gen].push_back(DevTask {i, i, i, 0}); origin[gen].push_back(i);
+        for (uint32_t k = 1; k < G; ++k) tasks[gen].push_back(DevTask {kPadTask, i, i, 0});
+    }
+    std::vector<int32_t> init(n, kNoScore);
+    RT(rt::h2d(b->d.pair_best, init.data(), n * sizeof(int32_t), s));
+    for (int gen = 0; gen < 2; ++gen) {
+        std::vector<DevTask>& t = tasks[gen];
+        if (t.empty()) continue;
+        const uint32_t nt = (uint32_t)t.size(), real = nt / G;
+        void* d_tasks = nullptr; RT(rt::dev_malloc(&d_tasks, nt * sizeof(DevTask))); guard.extra.push_back(d_tasks);
+        RT(rt::h2d(d_tasks, t.data(), nt * sizeof(DevTask), s));
+        void* d_ends = nullptr; RT(rt::dev_malloc(&d_ends, nt * sizeof(TraceEnd))); guard.extra.push_back(d_ends);
+        WalkParams w {}; std::vector<uint32_t> aoff(nt + 1, 0); std::vector<int32_t> l(nt, 0), r(nt, 0);
+        void *d_fp = nullptr, *d_a1 = nullptr, *d_a2 = nullptr, *d_aoff = nullptr, *d_l = nullptr, *d_r = nullptr, *d_fl = nullptr, *d_ms = nullptr;
+        size_t aln_bytes = 0;
+        if (traceback) {
+            for (uint32_t j = 0; j < nt; ++j) {
+                const uint32_t i = t[j].read; const uint32_t T = target_offsets[i + 1] - target_offsets[i];
+                aoff[j + 1] = aoff[j] + 2 * (T + B) + 1;
+                if (lhs_flank) { l[j] = lhs_flank[i]; r[j] = rhs_flank[i]; }
+            }
+            aln_bytes = aoff[nt];
+            RT(rt::dev_malloc(&d_fp, nt * sizeof(int32_t))); guard.extra.push_back(d_fp);
+            RT(rt::dev_malloc(&d_a1, aln_bytes)); guard.extra.push_back(d_a1); RT(rt::dev_malloc(&d_a2, aln_bytes)); guard.extra.push_back(d_a2);
+            RT(rt::dev_memset(d_a1, 0, aln_bytes, s)); RT(rt::dev_memset(d_a2, 0, aln_bytes, s));
+            RT(rt::dev_malloc(&d_aoff, (nt + 1) * sizeof(uint32_t))); guard.extra.push_back(d_aoff);
+            RT(rt::h2d(d_aoff, aoff.data(), (nt + 1) * sizeof(uint32_t), s));
+            w.out_first_pos = (int32_t*)d_fp; w.out_align1 = (char*)d_a1; w.out_align2 = (char*)d_a2; w.out_align_off = (const uint32_t*)d_aoff;
+            if (lhs_flank) {
+                RT(rt::dev_malloc(&d_l, nt * 4)); guard.extra.push_back(d_l); RT(rt::dev_malloc(&d_r, nt * 4)); guard.extra.push_back(d_r);
+                RT(rt::dev_malloc(&d_fl, nt * 4)); guard.extra.push_back(d_fl); RT(rt::dev_malloc(&d_ms, nt * 4)); guard.extra.push_back(d_ms);
+                RT(rt::h2d(d_l, l.data(), nt * 4, s)); RT(rt::h2d(d_r, r.data(), nt * 4, s));
+                w.seam_lhs = (const int32_t*)d_l; w.seam_rhs = (const int32_t*)d_r; w.out_flank = (int32_t*)d_fl; w.out_mask_size = (int32_t*)d_ms;
+            }
+        }
+        const int kind = traceback ? (gen ? kTraceGen : kTraceFast) : (gen ? kScoreGen : kScoreFast);
+        rc = run_dp_kind(h, b, kind, (const DevTask*)d_tasks, nt, (TraceEnd*)d_ends, nuc_prior, traceback ? &w : nullptr, status);
+        if (rc != OCT_PHMM_OK) return rc;
+        if (traceback) {
+            std::vector<TraceEnd> ends(nt); std::vector<int32_t> fp(nt), fl(nt), ms(nt); std::vector<char> a1(aln_bytes), a2(aln_bytes);
+            RT(rt::d2h(ends.data(), d_ends, nt * sizeof(TraceEnd), s)); RT(rt::d2h(fp.data(), d_fp, nt * 4, s));
+            RT(rt::d2h(a1.data(), d_a1, aln_bytes, s)); RT(rt::d2h(a2.data(), d_a2, aln_bytes, s));
+            if (lhs_flank) { RT(rt::d2h(fl.data(), d_fl, nt * 4, s)); RT(rt::d2h(ms.data(), d_ms, nt * 4, s)); }
+            RT(rt::stream_sync(s));
+            for (uint32_t w = 0; w < real; ++w) {
+                const uint32_t i = origin[gen][w], j = w * G;
+                scores[i] = ends[j].score; first_pos[i] = fp[j];
+                const uint32_t len = aoff[j + 1] - aoff[j];
+                memcpy(align1 + align_offsets[i], a1.data() + aoff[j], len); memcpy(align2 + align_offsets[i], a2.data() + aoff[j], len);
+                if (lhs_flank) { flank_score[i] = fl[j]; target_mask_size[i] = ms[j]; }
+            }
+        }
+    }
+    if (!traceback) { RT(rt::d2h(scores, b->d.pair_best, n * sizeof(int32_t), s)); RT(rt::stream_sync(s)); }
+    return ok(status);
+}

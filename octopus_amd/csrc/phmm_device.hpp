@@ -1,0 +1,92 @@
+// Device-side data model shared by the kernels (phmm_kernels.hpp) and the host API (oct_phmm.hip).
+// gfx950 only: wave64, DPP wave/row shifts, packed-int16 VALU.
+#pragma once
+#include <stdint.h>
+#include "phmm_hw.hpp"
+
+namespace octphmm {
+
+constexpr int      kMaxSlots   = 16;           // candidate slots per (read, haplotype) pair: mapped positions + 1
+constexpr int32_t  kNoScore    = 0x7fffffff;   // "lowest()" in the integer penalty domain
+constexpr uint32_t kPadTask    = 0xffffffffu;  // DevTask::pair of a padding task
+constexpr int      kBlockWaves = 4;            // waves per DP workgroup
+constexpr int      kGroupsPerWave = 4;         // task groups each wave works through per workgroup
+
+// Task kinds = DP kernel variants. "fast" = reads are pure ACGT and the haplotype holds only ACGT (and no
+// '0' in its masks), so the match cost is one byte-permute out of a per-position cap table; "generic" = any
+// bytes, cost evaluated with the reference's equality tests.
+enum Kind : int { kScoreFast = 0, kTraceFast = 1, kScoreGen = 2, kTraceGen = 3, kNumKinds = 4 };
+
+struct DevTask {
+    uint32_t pair;   // (read, haplotype) pair index in output order, kPadTask for padding
+    uint32_t read;
+    uint32_t hap;
+    uint32_t off;    // alignment_offset = max(0, position - B): first haplotype base of the band window
+};
+
+struct TraceEnd {    // what the DP kernel hands to the walk kernel, per traceback task
+    int32_t score;   // (minscore - null_score) >> 2, simd_pair_hmm.hpp:323
+    int32_t sidx;    // minscoreidx (-1: never updated)
+};
+
+struct DevBatch {
+    // reads (AlignedRead fields)
+    uint32_t n_reads;
+    const uint8_t*  rbases;   const uint8_t* rquals;  const uint32_t* roff;
+    const uint8_t*  rmapq;    const uint8_t* rrev;    const int64_t*  rbegin;
+    uint8_t*        racgt;                            // [n_reads] 1 = only A/C/G/T
+    uint32_t n_rows;          const uint32_t* row_off; // may be null (row == read)
+    // haplotypes + the six vectors of HaplotypeLikelihoodModel::reset
+    uint32_t n_haps;
+    const uint8_t*  hbases;   const uint32_t* hoff;   const int64_t* hbegin;
+    const int8_t*   go;       const int8_t*  ge;
+    const uint8_t*  maskF;    const int8_t*  priorF;  const uint8_t* maskR;  const int8_t* priorR;
+    // per-base DP tables, 8 B per base per strand: {caps or raw, go | ge << 16}
+    uint2* tabFastF; uint2* tabFastR; uint2* tabGenF; uint2* tabGenR;
+    uint32_t* hclean;                                 // [n_haps] 1 = eligible for the fast kernels
+    // derived per haplotype / region
+    const uint32_t* hap_region; const uint64_t* hap_out_off; const uint64_t* hap_pair_off;
+    uint32_t n_regions;
+    const uint32_t* reg_row0; const uint32_t* reg_read0; const uint32_t* reg_lhs; const uint32_t* reg_rhs;
+    // candidate mapping positions (CSR over pairs)
+    const uint64_t* pos_off;  const uint32_t* pos;
+    // per pair
+    uint64_t  n_pairs;
+    int32_t*  pair_best;      // min phred penalty over candidates, kNoScore = none
+    uint32_t* pair_cls;       // 2 bits per candidate slot: 0 none, 1 score-only DP, 2 traceback DP
+    uint32_t* pair_extra;     // position of the extra slot (original or shifted original)
+    uint4*    pair_cnt;       // [n_pairs + 1] per-kind task counts, exclusive-scanned in place
+    // configuration
+    int band, nuc_prior, max_pos, use_mapq, mapq_cap, mapq_trigger;
+    // counters: [0] candidates [1] fast path [2] score-only DP [3] traceback DP [4] band cells [5] pairs
+    unsigned long long* stats;
+    unsigned long long* err_key;                      // min over failing pairs of (hap << 32 | read); ~0 = none
+};
+
+struct DpParams {
+    const DevTask* tasks; uint32_t n_tasks;           // n_tasks is a multiple of the group size
+    const uint8_t* rbases; const uint8_t* rquals; const uint32_t* roff; const uint8_t* rrev;
+    const uint32_t* hoff; const uint2* tabF; const uint2* tabR;
+    int32_t*  pair_best;                              // score-only kernels: atomicMin target
+    uint32_t* bp; TraceEnd* ends;                     // traceback kernels
+    uint32_t  k_cap;                                  // diagonals pairs (T_max + B) the bp scratch is sized for
+    uint32_t  t_cap;                                  // longest read in the batch
+    uint32_t  lh_cap;                                 // longest haplotype in the batch
+    uint32_t  nuc4;                                   // packed {nuc_prior << 2, nuc_prior << 2}
+    uint32_t  groups_per_block;
+};
+
+struct WalkParams {
+    const DevTask* tasks; uint32_t n_tasks; const TraceEnd* ends; const uint32_t* bp; uint32_t k_cap; int band;
+    const uint8_t* rbases; const uint8_t* rquals; const uint32_t* roff; const uint8_t* rrev;
+    const uint8_t* hbases; const uint32_t* hoff; const int8_t* go; const int8_t* ge;
+    const uint8_t* maskF; const int8_t* priorF; const uint8_t* maskR; const int8_t* priorR;
+    const uint32_t* hap_region; const uint32_t* reg_lhs; const uint32_t* reg_rhs;
+    int nuc_prior;
+    int32_t* pair_best;                               // populate path: atomicMin of the flank-adjusted penalty
+    // test seam outputs (null on the populate path)
+    int32_t* out_first_pos; char* out_align1; char* out_align2; const uint32_t* out_align_off;
+    const int32_t* seam_lhs; const int32_t* seam_rhs; int32_t* out_flank; int32_t* out_mask_size;
+};
+
+} // namespace octphmm

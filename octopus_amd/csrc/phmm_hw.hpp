@@ -1,0 +1,76 @@
+// gfx950 intrinsic layer used by phmm_kernels.hpp: DPP lane shifts, byte permute, packed-int16 VALU.
+//
+// The product build (hipcc --offload-arch=gfx950) uses the real builtins below. The unit tests can compile the
+// SAME kernel source for the host with -DOCTPHMM_SIM, in which case tests/sim/hipsim.hpp provides lockstep
+// emulations of exactly these functions (test infrastructure only; never part of liboct_phmm.so).
+#pragma once
+#include <stdint.h>
+
+#if defined(OCTPHMM_SIM)
+#include "hipsim.hpp"
+#else
+#include <hip/hip_runtime.h>
+
+#define OCT_DEVICE __device__ __forceinline__
+#define OCT_HD __host__ __device__ __forceinline__
+#define OCT_KERNEL(name) __global__ void name
+#define OCT_DYN_SMEM(ptr) extern __shared__ __attribute__((aligned(16))) unsigned char ptr[]
+
+namespace octphmm { namespace hw {
+
+// lane i <- lane i-1 within each 16-lane row; first lane of a row keeps `fill`
+OCT_DEVICE uint32_t dpp_row_shr1(uint32_t fill, uint32_t v)  { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x111, 0xf, 0xf, false); }
+// lane i <- lane i+1 within each 16-lane row; last lane of a row keeps `fill`
+OCT_DEVICE uint32_t dpp_row_shl1(uint32_t fill, uint32_t v)  { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xf, 0xf, false); }
+// same across the whole wave64 (gfx9 DPP wave_shr:1 / wave_shl:1)
+OCT_DEVICE uint32_t dpp_wave_shr1(uint32_t fill, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false); }
+OCT_DEVICE uint32_t dpp_wave_shl1(uint32_t fill, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false); }
+
+// v_perm_b32: result byte n = byte sel.byte[n] of the 8-byte value {hi, lo} (0-3 -> lo, 4-7 -> hi, 0x0c -> 0x00, >= 0x0d -> 0xff)
+OCT_DEVICE uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// v_pk_mad_u16: per 16-bit half a * b + c (wrapping)
+OCT_DEVICE uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+OCT_DEVICE void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+OCT_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
+OCT_DEVICE uint32_t shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+OCT_DEVICE uint32_t readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+OCT_DEVICE void block_sync() { __syncthreads(); }
+OCT_DEVICE int  atomic_min_i32(int32_t* p, int32_t v) { return atomicMin(p, v); }
+OCT_DEVICE unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
+OCT_DEVICE unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
+OCT_DEVICE uint32_t atomic_and_u32(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
+OCT_DEVICE uint32_t thread_idx() { return threadIdx.x; }
+OCT_DEVICE uint32_t block_idx() { return blockIdx.x; }
+OCT_DEVICE uint32_t block_dim() { return blockDim.x; }
+OCT_DEVICE uint32_t grid_dim() { return gridDim.x; }
+
+}} // namespace octphmm::hw
+#endif
+
+namespace octphmm { namespace hw {
+
+typedef short          s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// packed 2 x int16 VALU (v_pk_add_u16, v_pk_add_i16 clamp, v_pk_min_i16, v_pk_min_u16, v_pk_lshlrev_b16, v_pk_mul_lo_u16, v_pk_sub_u16)
+OCT_DEVICE uint32_t pk_add(uint32_t a, uint32_t b)     { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b))); }
+OCT_DEVICE uint32_t pk_sub(uint32_t a, uint32_t b)     { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b))); }
+OCT_DEVICE uint32_t pk_add_sat(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+OCT_DEVICE uint32_t pk_min_i(uint32_t a, uint32_t b)   { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+OCT_DEVICE uint32_t pk_min_u(uint32_t a, uint32_t b)   { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+OCT_DEVICE uint32_t pk_shl2(uint32_t a)                { const u16x2 two = {2, 2}; return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) << two)); }
+OCT_DEVICE uint32_t pk_mul(uint32_t a, uint32_t b)     { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b))); }
+
+}} // namespace octphmm::hw

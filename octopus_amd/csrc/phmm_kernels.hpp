@@ -1,0 +1,635 @@
+// HIP kernels of the pair-HMM haplotype-likelihood path for gfx950 (MI355X).
+//
+// Reference behaviour reproduced (paths relative to /root/reference/src):
+//   k_classify   HaplotypeLikelihoodModel::max_score candidate logic (core/models/haplotype_likelihood_model.cpp:187-259),
+//                hmm::detail::try_naive_evaluate (core/models/pairhmm/pair_hmm.hpp:278-319),
+//                window / flank tests of simd_evaluate_helper (pair_hmm.hpp:123-137,731-739)
+//   k_dp         simd::PairHMM::align_helper (core/models/pairhmm/simd_pair_hmm.hpp:240-324) incl. update_traceback (:147-163)
+//   k_walk       set_alignments (:165-231) fused with calculate_flank_score_helper (:347-430) and the flank discount of
+//                simd_evaluate_helper (pair_hmm.hpp:754-764)
+//   k_epilogue   mapping-quality mixture of HaplotypeLikelihoodModel::evaluate (haplotype_likelihood_model.cpp:285-303) and the
+//                per-template sum (:313-320)
+//
+// DP layout: one band diagonal per lane, B lanes per task row, 64/B rows per wave, and TWO tasks per row packed in
+// the low/high int16 halves of every VGPR (v_pk_add_u16 / v_pk_min_i16 wrap and compare exactly like the reference's
+// _mm_add_epi16 / _mm_min_epi16 lanes). Lane i of a row owns cells (t = k-i, x = k+i) and (t, x+1) at iteration k, so both
+// the read index and the haplotype index advance by one per iteration and every lane reads its own operands straight
+// from LDS; only the D and I states move between lanes (one DPP shift each).
+#pragma once
+#include "phmm_device.hpp"
+
+namespace octphmm {
+
+constexpr uint32_t INF2 = 0x78007800u;   // infinity_ = SHRT_MAX - 0x7FF in both halves (simd_pair_hmm.hpp:55-56)
+constexpr uint32_t NUL2 = 0x80008000u;   // null_score_ = SHRT_MIN (:61)
+constexpr double   kLn10Div10 = 0.230258509299404568401799145468436420760110148862877297603; // utils/maths.hpp:41
+constexpr double   kLowest = -1.7976931348623157e308;
+
+OCT_DEVICE uint32_t ld8(const uint8_t* p) { return *p; }
+OCT_DEVICE uint64_t ld64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+OCT_DEVICE bool is_acgt(uint32_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+OCT_DEVICE uint32_t base_code(uint32_t c) { return (c >> 1) & 3u; }   // A 0, C 1, T 2, G 3
+
+template <class T>
+OCT_DEVICE uint32_t upper_bound_idx(const T* a, uint32_t n, T v)   // largest i in [0,n) with a[i] <= v (a[0] <= v assumed)
+{
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-read flags, per-haplotype-base DP tables
+// ------------------------------------------------------------------------------------------------------------------
+OCT_KERNEL(k_read_flags)(DevBatch b)
+{
+    const uint32_t r = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (r >= b.n_reads) return;
+    uint32_t ok = 1;
+    for (uint32_t i = b.roff[r]; i < b.roff[r + 1]; ++i) ok &= is_acgt(b.rbases[i]) ? 1u : 0u;
+    b.racgt[r] = (uint8_t)ok;
+}
+
+OCT_DEVICE uint32_t cap_of(uint32_t r, uint32_t h, uint32_t m, uint32_t p)
+{
+    // cost cap for read base r at a haplotype position: 0 on a match, the SNV prior if r equals the mask base, else none;
+    // the read quality is min'ed in by the DP (update_match_state, simd_pair_hmm.hpp:121-132)
+    if (r == h) return 0;
+    return r == m ? p : 255u;
+}
+
+OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases)
+{
+    const uint32_t g = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (g >= n_bases) return;
+    const uint32_t h = b.hbases[g], mf = b.maskF[g], mr = b.maskR[g];
+    const uint32_t pf = (uint8_t)b.priorF[g], pr = (uint8_t)b.priorR[g];
+    const uint32_t gg = ((uint32_t)(uint8_t)b.go[g] << 2) | ((uint32_t)(uint8_t)b.ge[g] << 18);   // {go<<2, ge<<2} as int16 halves
+    const uint32_t A = 'A', C = 'C', T = 'T', G = 'G';                                             // column order = base_code
+    b.tabFastF[g] = make_uint2(cap_of(A, h, mf, pf) | cap_of(C, h, mf, pf) << 8 | cap_of(T, h, mf, pf) << 16 | cap_of(G, h, mf, pf) << 24, gg);
+    b.tabFastR[g] = make_uint2(cap_of(A, h, mr, pr) | cap_of(C, h, mr, pr) << 8 | cap_of(T, h, mr, pr) << 16 | cap_of(G, h, mr, pr) << 24, gg);
+    const uint32_t isn = h == 'N' ? 1u : 0u;
+    b.tabGenF[g] = make_uint2(h | mf << 8 | pf << 16 | isn << 24, gg);
+    b.tabGenR[g] = make_uint2(h | mr << 8 | pr << 16 | isn << 24, gg);
+    if (!is_acgt(h) || mf == '0' || mr == '0') {
+        const uint32_t hap = upper_bound_idx(b.hoff, b.n_haps + 1, g);
+        hw::atomic_and_u32(&b.hclean[hap], 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// candidate enumeration + scalar fast path
+// ------------------------------------------------------------------------------------------------------------------
+OCT_DEVICE uint32_t first_mismatch(const uint8_t* a, const uint8_t* b, uint32_t from, uint32_t n)
+{
+    uint32_t i = from;
+    while (i + 8 <= n) {
+        const uint64_t x = ld64u(a + i) ^ ld64u(b + i);
+        if (x) return i + (uint32_t)(__builtin_ctzll(x) >> 3);
+        i += 8;
+    }
+    while (i < n) { if (a[i] != b[i]) return i; ++i; }
+    return n;
+}
+OCT_DEVICE bool bytes_equal(const uint8_t* a, const uint8_t* b, uint32_t n) { return first_mismatch(a, b, 0, n) == n; }
+
+// hmm::detail::try_naive_evaluate, pair_hmm.hpp:278-319. Returns true when handled; *pen = phred penalty.
+OCT_DEVICE bool try_naive(const uint8_t* truth, uint32_t Lh, const uint8_t* target, uint32_t T, const uint8_t* quals, uint32_t pos,
+                          const int8_t* go, const int8_t* ge, const uint8_t* mask, const int8_t* prior,
+                          uint32_t lhs, uint32_t rhs, int32_t* pen)
+{
+    const uint8_t* tr = truth + pos;
+    const uint32_t i1 = first_mismatch(target, tr, 0, T);
+    if (i1 == T) { *pen = 0; return true; }
+    if (first_mismatch(target, tr, i1 + 1, T) != T) return false;
+    const uint64_t idx = (uint64_t)i1 + pos;
+    if (idx < (uint64_t)lhs || idx >= ((uint64_t)Lh - (uint64_t)rhs)) { *pen = 0; return true; }   // is_in_flank :206-214
+    uint32_t mp = quals[i1];
+    if (mask[idx] == target[i1]) { const uint32_t p = (uint8_t)prior[idx]; if (p < mp) mp = p; }     // get_mismatch_penalty :250-263
+    const int32_t gop = go[idx];
+    if ((int32_t)mp <= gop) { *pen = (int32_t)mp; return true; }
+    if (bytes_equal(target + i1 + 1, tr + i1, T - i1 - 1)) { *pen = gop; return true; }            // :305
+    if (bytes_equal(target + i1, tr + i1 + 1, T - i1)) { *pen = gop; return true; }                // :309
+    if ((int32_t)mp <= gop + (int32_t)ge[idx]) { *pen = (int32_t)mp; return true; }                // :313
+    return false;
+}
+
+OCT_DEVICE bool pos_in_range(uint64_t p, uint32_t T, uint32_t Lh, uint32_t B)   // num_out_of_range_bases(...) == 0, model.cpp:187-207
+{
+    return p >= B && p + T + B <= Lh;
+}
+OCT_DEVICE int32_t num_out_of_range(uint64_t p, uint32_t T, uint32_t Lh, uint32_t B)
+{
+    if (p < B) return (int32_t)(B - p);
+    const uint64_t e = p + T + B;
+    if (e > Lh) return (int32_t)Lh - (int32_t)e;
+    return 0;
+}
+
+OCT_DEVICE uint64_t wave_sum(uint64_t v)
+{
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint64_t o = (uint64_t)hw::shfl_xor(lo, m) | ((uint64_t)hw::shfl_xor(hi, m) << 32);
+        const uint64_t s = (((uint64_t)hi << 32) | lo) + o;
+        lo = (uint32_t)s; hi = (uint32_t)(s >> 32);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Pass 1: one thread per (read, haplotype) pair. Runs the candidate-position logic and the scalar fast path, leaves the
+// best fast-path penalty in pair_best, classifies every remaining candidate as score-only or traceback DP.
+OCT_KERNEL(k_classify)(DevBatch b)
+{
+    const uint64_t e = (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    unsigned long long st_cand = 0, st_fast = 0, st_score = 0, st_trace = 0, st_cells = 0, st_pairs = 0;
+    if (e < b.n_pairs) {
+        const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
+        const uint32_t g = b.hap_region[h];
+        const uint32_t r = b.reg_read0[g] + (uint32_t)(e - b.hap_pair_off[h]);
+        const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, ho = b.hoff[h], Lh = b.hoff[h + 1] - ho;
+        const uint32_t B = (uint32_t)b.band, lhs = b.reg_lhs[g], rhs = b.reg_rhs[g];
+        const uint8_t* target = b.rbases + ro; const uint8_t* quals = b.rquals + ro; const uint8_t* truth = b.hbases + ho;
+        const bool fwd = !b.rrev[r];
+        const uint8_t* mask = (fwd ? b.maskF : b.maskR) + ho; const int8_t* prior = (fwd ? b.priorF : b.priorR) + ho;
+        const int8_t* go = b.go + ho; const int8_t* ge = b.ge + ho;
+        const uint64_t orig = (uint64_t)(b.rbegin[r] - b.hbegin[h]);                               // begin_distance, model.cpp:220
+        const uint32_t* P = b.pos + b.pos_off[e]; const uint32_t npos = (uint32_t)(b.pos_off[e + 1] - b.pos_off[e]);
+        int32_t best = kNoScore; uint32_t cls = 0, n_score = 0, n_trace = 0, extra = 0;
+        bool orig_mapped = false, any = false;
+        auto visit = [&](uint32_t slot, uint32_t p) {
+            ++st_cand;
+            int32_t pen;
+            if (try_naive(truth, Lh, target, T, quals, p, go, ge, mask, prior, lhs, rhs, &pen)) { ++st_fast; if (pen < best) best = pen; return; }
+            const uint32_t off = p > B ? p - B : 0;                                                 // pair_hmm.hpp:735
+            if ((uint64_t)off + T + 2 * B - 1 > Lh) return;                                         // :736-738 -> lowest()
+            const bool adjusted = (uint64_t)p < (uint64_t)lhs + B || (uint64_t)p + T + B > (uint64_t)Lh - (uint64_t)rhs;   // :123-137
+            st_cells += 2ull * B * (T + B);
+            if (adjusted) { cls |= 2u << (2 * slot); ++n_trace; ++st_trace; } else { cls |= 1u << (2 * slot); ++n_score; ++st_score; }
+        };
+        for (uint32_t j = 0; j < npos; ++j) {                                                       // model.cpp:223-232
+            const uint32_t p = P[j];
+            if ((uint64_t)p == orig) orig_mapped = true;
+            if (pos_in_range(p, T, Lh, B)) { any = true; visit(j, p); }
+        }
+        if (!orig_mapped && pos_in_range(orig, T, Lh, B)) { any = true; extra = (uint32_t)orig; visit((uint32_t)b.max_pos, extra); }   // :233-237
+        if (!any) {                                                                                  // :238-256
+            const int32_t min_shift = num_out_of_range(orig, T, Lh, B);
+            uint64_t fin = orig; bool err = false;
+            if (min_shift > 0) { fin += (uint64_t)min_shift; if (!pos_in_range(fin, T, Lh, B)) err = true; }
+            else { const uint32_t left = (uint32_t)(-min_shift); if (orig >= left) fin -= left; else err = true; }
+            if (err) hw::atomic_min_u64(b.err_key, ((unsigned long long)h << 32) | r);
+            else { extra = (uint32_t)fin; visit((uint32_t)b.max_pos, extra); }
+        }
+        b.pair_best[e] = best; b.pair_cls[e] = cls; b.pair_extra[e] = extra;
+        const bool generic = !(b.racgt[r] && b.hclean[h]);
+        b.pair_cnt[e] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
+        st_pairs = 1;
+    }
+    st_cand = wave_sum(st_cand); st_fast = wave_sum(st_fast); st_score = wave_sum(st_score);
+    st_trace = wave_sum(st_trace); st_cells = wave_sum(st_cells); st_pairs = wave_sum(st_pairs);
+    if ((hw::thread_idx() & 63) == 0) {
+        if (st_cand)  hw::atomic_add_u64(b.stats + 0, st_cand);
+        if (st_fast)  hw::atomic_add_u64(b.stats + 1, st_fast);
+        if (st_score) hw::atomic_add_u64(b.stats + 2, st_score);
+        if (st_trace) hw::atomic_add_u64(b.stats + 3, st_trace);
+        if (st_cells) hw::atomic_add_u64(b.stats + 4, st_cells);
+        if (st_pairs) hw::atomic_add_u64(b.stats + 5, st_pairs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// exclusive scan of the per-pair task counts (uint4, one component per task kind), in place over n = n_pairs + 1 items
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kScanThreads = 256, kScanItems = 4, kScanTile = kScanThreads * kScanItems;
+
+OCT_DEVICE uint4 add4(uint4 a, uint4 b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+OCT_KERNEL(k_scan_tiles)(uint4* data, uint64_t n, uint4* tile_sums, int apply)
+{
+    OCT_DYN_SMEM(smem);
+    uint4* sh = (uint4*)smem;                                   // [kScanThreads]
+    const uint32_t tid = hw::thread_idx();
+    const uint64_t base = (uint64_t)hw::block_idx() * kScanTile + (uint64_t)tid * kScanItems;
+    uint4 v[kScanItems]; uint4 sum = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = 0; i < kScanItems; ++i) { v[i] = base + i < n ? data[base + i] : make_uint4(0, 0, 0, 0); sum = add4(sum, v[i]); }
+    sh[tid] = sum;
+    hw::block_sync();
+    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {           // inclusive Hillis-Steele over the thread sums
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (tid >= d) o = sh[tid - d];
+        hw::block_sync();
+        sh[tid] = add4(sh[tid], o);
+        hw::block_sync();
+    }
+    if (!apply) {
+        if (tid == kScanThreads - 1) tile_sums[hw::block_idx()] = sh[tid];
+        return;
+    }
+    uint4 run = add4(tile_sums[hw::block_idx()], tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0));
+    for (uint32_t i = 0; i < kScanItems; ++i) if (base + i < n) { data[base + i] = run; run = add4(run, v[i]); }
+}
+
+OCT_KERNEL(k_scan_tile_sums)(uint4* tile_sums, uint32_t n_tiles)
+{
+    if (hw::thread_idx() != 0 || hw::block_idx() != 0) return;
+    uint4 run = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = 0; i < n_tiles; ++i) { const uint4 v = tile_sums[i]; tile_sums[i] = run; run = add4(run, v); }
+}
+
+// Per haplotype and kind: first task slot, with every haplotype's task run padded to a multiple of the group size so
+// that a DP task group never straddles two haplotypes. hap_base[n_haps] = padded totals.
+OCT_KERNEL(k_hap_bases)(DevBatch b, uint4* hap_base, uint32_t group)
+{
+    if (hw::thread_idx() != 0 || hw::block_idx() != 0) return;
+    uint4 run = make_uint4(0, 0, 0, 0);
+    auto up = [&](uint32_t c) { return (c + group - 1) / group * group; };
+    for (uint32_t h = 0; h < b.n_haps; ++h) {
+        const uint4 a = b.pair_cnt[b.hap_pair_off[h]], z = b.pair_cnt[b.hap_pair_off[h + 1]];
+        hap_base[h] = run;
+        run = add4(run, make_uint4(up(z.x - a.x), up(z.y - a.y), up(z.z - a.z), up(z.w - a.w)));
+    }
+    hap_base[b.n_haps] = run;
+}
+
+struct TaskArrays { DevTask* t[kNumKinds]; };
+
+// Pass 2: write the DP tasks of every pair at hap_base + (scanned count - scanned count at the haplotype's first pair).
+OCT_KERNEL(k_emit)(DevBatch b, const uint4* hap_base, TaskArrays out)
+{
+    const uint64_t e = (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (e >= b.n_pairs) return;
+    const uint32_t cls = b.pair_cls[e];
+    if (!cls) return;
+    const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
+    const uint32_t r = b.reg_read0[b.hap_region[h]] + (uint32_t)(e - b.hap_pair_off[h]);
+    const bool generic = !(b.racgt[r] && b.hclean[h]);
+    const uint4 s = b.pair_cnt[e], s0 = b.pair_cnt[b.hap_pair_off[h]], hb = hap_base[h];
+    uint32_t at_score = generic ? hb.z + (s.z - s0.z) : hb.x + (s.x - s0.x);
+    uint32_t at_trace = generic ? hb.w + (s.w - s0.w) : hb.y + (s.y - s0.y);
+    DevTask* ts = out.t[generic ? kScoreGen : kScoreFast]; DevTask* tt = out.t[generic ? kTraceGen : kTraceFast];
+    const uint32_t* P = b.pos + b.pos_off[e];
+    const uint32_t B = (uint32_t)b.band;
+    for (uint32_t slot = 0; slot <= (uint32_t)b.max_pos; ++slot) {
+        const uint32_t k = (cls >> (2 * slot)) & 3u;
+        if (!k) continue;
+        const uint32_t p = slot < (uint32_t)b.max_pos ? P[slot] : b.pair_extra[e];
+        DevTask t; t.pair = (uint32_t)e; t.read = r; t.hap = h; t.off = p > B ? p - B : 0;
+        if (k == 1) ts[at_score++] = t; else tt[at_trace++] = t;
+    }
+}
+
+OCT_KERNEL(k_emit_pad)(DevBatch b, const uint4* hap_base, TaskArrays out, uint32_t group)
+{
+    const uint32_t idx = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    const uint32_t h = idx / (kNumKinds * group), rem = idx % (kNumKinds * group), kind = rem / group, slot = rem % group;
+    if (h >= b.n_haps) return;
+    const uint4 a = b.pair_cnt[b.hap_pair_off[h]], z = b.pair_cnt[b.hap_pair_off[h + 1]], hb = hap_base[h];
+    const uint32_t cnt = kind == 0 ? z.x - a.x : kind == 1 ? z.y - a.y : kind == 2 ? z.z - a.z : z.w - a.w;
+    const uint32_t base = kind == 0 ? hb.x : kind == 1 ? hb.y : kind == 2 ? hb.z : hb.w;
+    const uint32_t padded = (cnt + group - 1) / group * group;
+    if (cnt == 0 || slot >= padded - cnt) return;
+    DevTask t = out.t[kind][base + cnt - 1];
+    t.pair = kPadTask;
+    out.t[kind][base + cnt + slot] = t;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the banded min-plus DP
+// ------------------------------------------------------------------------------------------------------------------
+template <int B> OCT_DEVICE uint32_t shift_up(uint32_t fill, uint32_t v, uint32_t li)     // lane i <- lane i-1, first lane of a task row <- fill
+{
+    if constexpr (B == 16) return hw::dpp_row_shr1(fill, v);
+    else if constexpr (B == 64) return hw::dpp_wave_shr1(fill, v);
+    else if constexpr (B == 8) { const uint32_t r = hw::dpp_row_shr1(fill, v); return li == 0 ? fill : r; }
+    else { const uint32_t r = hw::dpp_wave_shr1(fill, v); return li == 0 ? fill : r; }
+}
+template <int B> OCT_DEVICE uint32_t shift_down(uint32_t fill, uint32_t v, uint32_t li)   // lane i <- lane i+1, last lane of a task row <- fill
+{
+    if constexpr (B == 16) return hw::dpp_row_shl1(fill, v);
+    else if constexpr (B == 64) return hw::dpp_wave_shl1(fill, v);
+    else if constexpr (B == 8) { const uint32_t r = hw::dpp_row_shl1(fill, v); return li == B - 1 ? fill : r; }
+    else { const uint32_t r = hw::dpp_wave_shl1(fill, v); return li == B - 1 ? fill : r; }
+}
+
+template <bool V> struct BoolC { static constexpr bool value = V; };
+
+// LDS footprint of one DP workgroup (bytes) — must match the carve-up in k_dp.
+OCT_HD constexpr uint32_t dp_rec_n(uint32_t t_cap, uint32_t B) { return (t_cap + 2 * B + 2 + 1) & ~1u; }
+inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B)
+{
+    const uint32_t rows = 64 / B;
+    return 2 * (lh_cap + 8) * 8 + kBlockWaves * rows * dp_rec_n(t_cap, B) * 12;
+}
+
+template <int B, bool TRACE, bool GENERIC>
+OCT_KERNEL(k_dp)(DpParams p)
+{
+    constexpr uint32_t ROWS = 64 / B, G = 2 * ROWS;
+    OCT_DYN_SMEM(smem);
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
+    const uint32_t row = lane / B, li = lane % B;
+    const uint32_t lh_n = p.lh_cap + 8, rec_n = dp_rec_n(p.t_cap, B);
+    uint2* tabF = (uint2*)smem;                      // [lh_n] forward-strand table of the current haplotype
+    uint2* tabR = tabF + lh_n;                       // [lh_n] reverse-strand table
+    uint2* recs = tabR + lh_n;                       // [kBlockWaves][ROWS][rec_n] read-side records
+    uint32_t* gates = (uint32_t*)(recs + kBlockWaves * ROWS * rec_n);   // [kBlockWaves][ROWS][rec_n] end-cell gates
+    uint2* rec_row = recs + (wave * ROWS + row) * rec_n;
+    uint32_t* gate_row = gates + (wave * ROWS + row) * rec_n;
+
+    const uint32_t n_groups = p.n_tasks / G;
+    const uint32_t g_begin = hw::block_idx() * p.groups_per_block;
+    const uint32_t g_end = g_begin + p.groups_per_block < n_groups ? g_begin + p.groups_per_block : n_groups;
+    const uint32_t NUC = p.nuc4;
+
+    uint32_t seg = g_begin;
+    while (seg < g_end) {
+        // ---- haplotype segment [seg, seg_end): stage its two strand tables in LDS ----
+        const uint32_t hap = p.tasks[seg * G].hap;
+        uint32_t seg_end = seg + 1;
+        while (seg_end < g_end && p.tasks[seg_end * G].hap == hap) ++seg_end;
+        const uint32_t ho = p.hoff[hap], Lh = p.hoff[hap + 1] - ho;
+        hw::block_sync();
+        for (uint32_t x = tid; x < lh_n; x += kBlockWaves * 64) {
+            const bool in = x < Lh;
+            tabF[x] = in ? p.tabF[ho + x] : make_uint2(0, 0);
+            tabR[x] = in ? p.tabR[ho + x] : make_uint2(0, 0);
+        }
+        hw::block_sync();
+
+        for (uint32_t g = seg + wave; g < seg_end; g += kBlockWaves) {
+            const DevTask tA = p.tasks[g * G + 2 * row], tB = p.tasks[g * G + 2 * row + 1];
+            const uint32_t roA = p.roff[tA.read], TA = p.roff[tA.read + 1] - roA;
+            const uint32_t roB = p.roff[tB.read], TB = p.roff[tB.read + 1] - roB;
+            uint32_t Tmax = TA > TB ? TA : TB;
+            for (int m = B; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(Tmax, m); Tmax = o > Tmax ? o : Tmax; }
+            const uint32_t K = Tmax + B;
+
+            // ---- stage the read-side records of this row: index j holds read position t = j - B ----
+            for (uint32_t j = li; j < Tmax + 2 * B; j += B) {
+                const int32_t t = (int32_t)j - B;
+                const bool inA = t >= 0 && (uint32_t)t < TA, inB = t >= 0 && (uint32_t)t < TB;
+                const uint32_t rA = inA ? ld8(p.rbases + roA + t) : 0, rB = inB ? ld8(p.rbases + roB + t) : 0;
+                const uint32_t qA = inA ? ld8(p.rquals + roA + t) : 64u, qB = inB ? ld8(p.rquals + roB + t) : 64u;   // max_quality_score_, :60,260,280
+                uint2 rec;
+                if constexpr (GENERIC) {
+                    // {target char as int16 (0x7800 = the never-matching _inf fill before the read, '0' after it, :259,279), quality << 2}
+                    const uint32_t cA = inA ? rA : (t < 0 ? 0x7800u : (uint32_t)'0'), cB = inB ? rB : (t < 0 ? 0x7800u : (uint32_t)'0');
+                    rec = make_uint2(cA | cB << 16, (qA << 2) | (qB << 18));
+                } else {
+                    // {v_perm selector picking this base's cap byte out of {capsB, capsA} (0x0d = 0xff = no cap), quality}
+                    const uint32_t sA = inA ? base_code(rA) : 0x0du, sB = inB ? 4u + base_code(rB) : 0x0du;
+                    rec = make_uint2(sA | 0x0c00u | sB << 16 | 0x0c000000u, qA | qB << 16);
+                }
+                rec_row[j] = rec;
+                gate_row[j] = ((uint32_t)t == TA ? 0u : 0x7fffu) | ((uint32_t)t == TB ? 0u : 0x7fff0000u);
+            }
+            hw::wave_lds_fence();
+
+            const uint2* pA = (p.rrev[tA.read] ? tabR : tabF) + tA.off + li;
+            const uint2* pB = (p.rrev[tB.read] ? tabR : tabF) + tB.off + li;
+            const uint2* rp = rec_row + (B - li);
+            const uint32_t* gp = gate_row + (B - li);
+            uint32_t* bpw = TRACE ? p.bp + ((size_t)g * p.k_cap) * 64 + lane : nullptr;
+
+            uint32_t M1 = INF2, I1 = INF2, D1 = INF2, M2 = INF2, I2 = INF2, D2 = INF2;     // :267
+            uint32_t y1 = INF2;                                                             // min(M1, I1) carried between iterations
+            uint32_t bestE = INF2, bestO = INF2;                                            // minscore :269, per diagonal parity
+            uint2 cA = pA[0], cB = pB[0];
+            uint32_t GO = hw::perm(cB.y, cA.y, 0x05040100u), GE = hw::perm(cB.y, cA.y, 0x07060302u);
+
+            auto cost = [&](const uint2 rr, const uint2 a, const uint2 b) -> uint32_t {
+                if constexpr (GENERIC) {
+                    // update_match_state with the reference's equality tests on raw bytes (:121-132)
+                    const uint32_t hh = hw::perm(b.x, a.x, 0x0c040c00u), mm = hw::perm(b.x, a.x, 0x0c050c01u);
+                    const uint32_t pp = hw::pk_shl2(hw::perm(b.x, a.x, 0x0c060c02u)), nn = hw::perm(b.x, a.x, 0x0c070c03u);
+                    const uint32_t ne = hw::pk_min_u(rr.x ^ hh, 0x00010001u), nf = hw::pk_min_u(rr.x ^ mm, 0x00010001u);
+                    const uint32_t inner = hw::pk_mad(nf, hw::pk_sub(rr.y, pp), pp);        // target == mask ? prior : quality
+                    uint32_t c = hw::pk_mul(ne, hw::pk_min_i(rr.y, inner));                 // 0 where target == truth
+                    const uint32_t nq = hw::pk_mad(nn, 0x88088808u, INF2);                  // truth == 'N' ? n_score_ (8) : infinity_
+                    return hw::pk_min_i(c, nq);
+                } else {
+                    const uint32_t cp = hw::perm(b.x, a.x, rr.x);                           // {capA, capB} for this read base
+                    return hw::pk_min_u(cp, rr.y);                                          // min(quality, cap), unshifted
+                }
+            };
+            auto add_cost = [&](uint32_t m, uint32_t c) -> uint32_t {
+                if constexpr (GENERIC) return hw::pk_add(m, c); else return hw::pk_mad(c, 0x00040004u, m);   // + (c << trace_bits_)
+            };
+
+            auto step = [&](uint32_t k, auto init_c, auto cap_c) {
+                constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value;
+                const uint2 rr = rp[k];
+                const uint2 nA = pA[k + 1], nB = pB[k + 1];
+                const uint32_t GOn = hw::perm(nB.y, nA.y, 0x05040100u), GEn = hw::perm(nB.y, nA.y, 0x07060302u);
+                uint32_t gate = 0;
+                if constexpr (CAP) gate = gp[k];
+                // ---- even diagonal s = 2k: lane li is cell (t = k-li, x = k+li) ----
+                uint32_t m1 = hw::pk_min_i(y1, D1);                                         // :284
+                if constexpr (INIT) { const bool first = k == li; m1 = first ? NUL2 : m1; M2 = first ? NUL2 : M2; }   // :282-283
+                if constexpr (CAP) bestE = hw::pk_min_i(bestE, hw::pk_add_sat(m1, gate));   // :285-291
+                M1 = add_cost(m1, cost(rr, cA, cB));                                        // :292
+                const uint32_t x2 = hw::pk_min_i(M2, I2);
+                const uint32_t dsh = hw::pk_min_i(hw::pk_add(D2, GEn), hw::pk_add(x2, GOn));
+                D1 = shift_up<B>(INF2, dsh, li);                                            // :293-294
+                I1 = hw::pk_add(hw::pk_min_i(hw::pk_add(I2, GE), hw::pk_add(M2, GO)), NUC); // :295
+                uint32_t bpe = 0;
+                if constexpr (TRACE) {                                                      // update_traceback :147-163
+                    const uint32_t tm = M1 & 0x00030003u, ti = I1 & 0x00030003u, td = D1 & 0x00030003u;
+                    M1 ^= tm; I1 = (I1 & ~0x00030003u) | 0x00010001u; D1 |= 0x00030003u;
+                    bpe = tm | ti << 2 | td << 4;
+                }
+                // ---- odd diagonal s = 2k+1: lane li is cell (t, x+1) ----
+                const uint32_t m2 = hw::pk_min_i(x2, D2);                                   // :308
+                if constexpr (CAP) bestO = hw::pk_min_i(bestO, hw::pk_add_sat(m2, gate));   // :309-315
+                M2 = add_cost(m2, cost(rr, nA, nB));                                        // :316
+                y1 = hw::pk_min_i(M1, I1);
+                D2 = hw::pk_min_i(hw::pk_add(D1, GEn), hw::pk_add(y1, GOn));                // :317
+                const uint32_t ish = hw::pk_add(hw::pk_min_i(hw::pk_add(I1, GE), hw::pk_add(M1, GO)), NUC);
+                I2 = shift_down<B>(INF2, ish, li);                                          // :318-319
+                if constexpr (TRACE) {
+                    const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
+                    M2 ^= tm; I2 = (I2 & ~0x00030003u) | 0x00010001u; D2 |= 0x00030003u;
+                    bpw[(size_t)k * 64] = bpe | (tm | ti << 2 | td << 4) << 6;
+                }
+                cA = nA; cB = nB; GO = GOn; GE = GEn;
+            };
+
+            uint32_t Tmin = TA < TB ? TA : TB;
+            for (int m = B; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(Tmin, m); Tmin = o < Tmin ? o : Tmin; }
+            const uint32_t kA = K < (uint32_t)B ? K : (uint32_t)B;       // rolling initialisation lasts B iterations
+            const uint32_t kB = Tmin > kA ? Tmin : kA;                   // no end cell before the shortest read is consumed
+            uint32_t k = 0;
+            for (; k < kA; ++k) step(k, BoolC<true>{}, BoolC<true>{});
+            for (; k < kB; ++k) step(k, BoolC<false>{}, BoolC<false>{});
+            for (; k < K; ++k)  step(k, BoolC<false>{}, BoolC<true>{});
+
+            // ---- first minimum over the row's end cells, per packed task (:285-291,309-315,323) ----
+            for (uint32_t half = 0; half < 2; ++half) {
+                const uint32_t Th = half ? TB : TA;
+                const uint32_t vE = ((bestE >> (16 * half)) & 0xffffu) ^ 0x8000u, vO = ((bestO >> (16 * half)) & 0xffffu) ^ 0x8000u;   // bias to unsigned order
+                const uint32_t sE = 2 * (Th + li);
+                const uint32_t kE = vE << 16 | sE, kO = vO << 16 | (sE + 1);
+                uint32_t key = kE < kO ? kE : kO;
+                for (int m = 1; m < B; m <<= 1) { const uint32_t o = hw::shfl_xor(key, m); key = o < key ? o : key; }
+                if (li == 0) {
+                    const DevTask& t = half ? tB : tA;
+                    const int32_t score = (int32_t)((key >> 16) >> 2);                      // (minscore - null_score_) >> 2
+                    if constexpr (TRACE) {
+                        TraceEnd e; e.score = score; e.sidx = (key >> 16) >= (0x7800u ^ 0x8000u) ? -1 : (int32_t)(key & 0xffffu);
+                        p.ends[g * G + 2 * row + half] = e;
+                    } else {
+                        if (t.pair != kPadTask) hw::atomic_min_i32(p.pair_best + t.pair, score);
+                    }
+                }
+            }
+            hw::wave_lds_fence();
+        }
+        seg = seg_end;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// traceback walk + flank score
+// ------------------------------------------------------------------------------------------------------------------
+template <int B>
+OCT_KERNEL(k_walk)(WalkParams w)
+{
+    constexpr uint32_t ROWS = 64 / B, G = 2 * ROWS;
+    const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (ti >= w.n_tasks) return;
+    const DevTask t = w.tasks[ti];
+    if (t.pair == kPadTask) return;
+    const TraceEnd end = w.ends[ti];
+    const uint32_t group = ti / G, slot = ti % G, row = slot >> 1, half = slot & 1;
+    const uint32_t ro = w.roff[t.read]; const int32_t T = (int32_t)(w.roff[t.read + 1] - ro);
+    const uint32_t ho = w.hoff[t.hap]; const int32_t Lh = (int32_t)(w.hoff[t.hap + 1] - ho);
+    const int32_t L = T + 2 * B - 1, off = (int32_t)t.off;
+    const uint8_t* target = w.rbases + ro; const int8_t* quals = (const int8_t*)w.rquals + ro;
+    const bool fwd = !w.rrev[t.read];
+    const uint8_t* truth = w.hbases + ho + off;
+    const uint8_t* mask = (fwd ? w.maskF : w.maskR) + ho + off; const int8_t* prior = (fwd ? w.priorF : w.priorR) + ho + off;
+    const int8_t* go = w.go + ho + off; const int8_t* ge = w.ge + ho + off;
+    const bool seam = w.out_first_pos != nullptr;
+    // flank sizes in window coordinates (pair_hmm.hpp:572-587)
+    int32_t lhs = 0, rhs = 0; bool want_flank = true;
+    if (seam) {
+        want_flank = w.seam_lhs != nullptr;
+        if (want_flank) { lhs = w.seam_lhs[ti]; rhs = w.seam_rhs[ti]; }
+    } else {
+        const uint32_t g = w.hap_region[t.hap];
+        lhs = (int32_t)w.reg_lhs[g];
+        if (lhs < off) lhs = 0; else { lhs -= off; if (lhs < 0) lhs = 0; }
+        rhs = (int32_t)w.reg_rhs[g];
+        if (off + L < Lh - rhs) rhs = 0; else { rhs += off + L; rhs -= Lh; if (rhs < 0) rhs = 0; }
+    }
+    const int32_t rhs_begin = L - rhs;
+    const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
+    const uint32_t* bp = w.bp + (size_t)group * w.k_cap * 64 + row * B;
+    auto bits_at = [&](int64_t flat) -> uint32_t {          // 6 backpointer bits of band cell `flat` = diagonal * B + lane
+        const int32_t s = (int32_t)(flat / B), i = (int32_t)(flat % B);
+        if (s >= 2 * (T + B)) return 0;                     // last row of the reference's array is never written (zeros)
+        return (bp[(size_t)(s >> 1) * 64 + i] >> (16 * half + 6 * (s & 1))) & 63u;
+    };
+    char* a1 = seam ? w.out_align1 + w.out_align_off[ti] : nullptr;
+    char* a2 = seam ? w.out_align2 + w.out_align_off[ti] : nullptr;
+
+    int32_t first_pos = 0, flank = 0, msz = 0, alnidx = 0;
+    bool ok = true;
+    int32_t sidx = end.sidx;
+    if (sidx < 0) ok = false;                               // minscore never updated (:176-179)
+    int32_t i = sidx / 2 - T, y = T, x = sidx - y;
+    if (ok) { const int64_t f0 = (int64_t)sidx * B + i; if (f0 < 0 || f0 >= n_flat) ok = false; }   // :186-190
+    if (ok) {
+        uint32_t state = bits_at((int64_t)sidx * B + i) & 3u;   // :191
+        sidx -= 2;
+        while (y > 0) {                                     // :194
+            if (sidx < 0 || i < 0) { ok = false; break; }   // :195-199
+            const int64_t f = (int64_t)sidx * B + i;
+            if (f >= n_flat) { ok = false; break; }         // the reference would read past its array here (UB)
+            const uint32_t bits = bits_at(f);
+            const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;   // :200 (our D bits sit at 4-5)
+            if (state == 0) {                               // match :201-204
+                sidx -= 2; --x; --y;
+                const uint32_t hc = truth[x], rc = target[y];
+                if (seam) { a1[alnidx] = (char)hc; a2[alnidx] = (char)rc; }
+                if (want_flank && (x < lhs || x >= rhs_begin)) {                      // calculate_flank_score_helper :383-397
+                    if (hc != rc) {
+                        if (hc != 'N') { int32_t q = quals[y]; if (mask[x] == rc && prior[x] < q) q = prior[x]; flank += q; }
+                        else flank += 2;
+                    }
+                    ++msz;
+                }
+            } else if (state == 1) {                        // insert :205-209
+                i += sidx & 1; sidx -= 1; --y;
+                if (seam) { a1[alnidx] = '-'; a2[alnidx] = (char)target[y]; }
+                if (want_flank && (x < lhs || x >= rhs_begin)) {                      // :399-411
+                    const int32_t gi = x - 1 < 0 ? 0 : x - 1;                         // x-1 == -1 is out of bounds in the reference (UB): clamp
+                    const bool prev_ins = y != 0 && new_state == 1;                   // first alignment column has prev_state = match (:369)
+                    flank += (prev_ins ? ge[gi] : go[gi]) + w.nuc_prior;
+                    ++msz;
+                }
+            } else {                                        // delete :210-215
+                sidx -= 1; i -= sidx & 1; --x;
+                if (seam) { a1[alnidx] = (char)truth[x]; a2[alnidx] = '-'; }
+                if (want_flank && (x < lhs || x >= rhs_begin)) flank += (new_state == 3 ? ge[x] : go[x]);   // :413-424
+            }
+            state = new_state;
+            ++alnidx;
+        }
+        first_pos = x;
+    }
+    if (!ok) first_pos = -1;
+    if (seam) {
+        w.out_first_pos[ti] = first_pos;
+        if (ok) {
+            a1[alnidx] = 0; a2[alnidx] = 0;
+            for (int32_t a = 0, b = alnidx - 1; a < b; ++a, --b) {   // :223-230
+                char c = a1[a]; a1[a] = a1[b]; a1[b] = c; c = a2[a]; a2[a] = a2[b]; a2[b] = c;
+            }
+            if (want_flank) { w.out_flank[ti] = flank; w.out_mask_size[ti] = msz; }
+        } else if (want_flank) { w.out_flank[ti] = 0; w.out_mask_size[ti] = 0; }
+        return;
+    }
+    if (!ok) return;                                        // lowest(): contributes nothing to the max (pair_hmm.hpp:750-752)
+    if (T - msz < 2) flank = 0;                             // :757-759
+    const int32_t score = end.score;
+    const int32_t pen = flank <= score ? score - flank : flank + score;   // :760-764
+    hw::atomic_min_i32(w.pair_best + t.pair, pen);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// epilogue: penalty -> ln likelihood, mapping-quality mixture, template sum
+// ------------------------------------------------------------------------------------------------------------------
+OCT_KERNEL(k_epilogue)(DevBatch b, double* out, uint64_t n_out)
+{
+    const uint64_t o = (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (o >= n_out) return;
+    const uint32_t h = upper_bound_idx(b.hap_out_off, b.n_haps + 1, o);
+    const uint32_t g = b.hap_region[h];
+    const uint32_t row = b.reg_row0[g] + (uint32_t)(o - b.hap_out_off[h]);
+    const uint32_t r0 = b.row_off ? b.row_off[row] : row, r1 = b.row_off ? b.row_off[row + 1] : row + 1;
+    double acc = 0;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint64_t e = b.hap_pair_off[h] + (r - b.reg_read0[g]);
+        const int32_t pen = b.pair_best[e];
+        const double ln_given_mapped = pen == kNoScore ? kLowest : -kLn10Div10 * (double)pen;
+        double res;
+        if (b.use_mapq) {                                   // model.cpp:285-300
+            int32_t mq = b.rmapq[r];
+            if (b.mapq_trigger >= 0 && mq >= b.mapq_trigger) mq = b.mapq_cap & 0xff;
+            const double ln_miss = -kLn10Div10 * mq;
+            const double ln_mapped = log(1.0 - exp(ln_miss));
+            const double x = ln_mapped + ln_given_mapped, y = ln_miss;
+            const double lo = x < y ? x : y, hi = x < y ? y : x;      // maths::log_sum_exp, utils/maths.hpp:294-298
+            res = hi + log1p(exp(lo - hi));
+        } else {
+            res = ln_given_mapped;
+        }
+        res = res > -1e-15 ? 0.0 : res;
+        acc = acc + res;
+    }
+    out[o] = acc;
+}
+
+} // namespace octphmm

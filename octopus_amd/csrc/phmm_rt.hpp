@@ -1,0 +1,52 @@
+// Thin runtime layer under the host API (oct_phmm.hip): device memory, copies, stream, events, kernel launch.
+// Product build = HIP runtime. With -DOCTPHMM_SIM (tests/sim only) the same host code drives the CPU wave
+// simulator instead, so the whole pipeline's logic is unit-tested without a GPU.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(OCTPHMM_SIM)
+#include "rt_sim.hpp"
+#else
+#include <hip/hip_runtime.h>
+
+namespace octphmm { namespace rt {
+
+typedef hipStream_t Stream;
+typedef hipEvent_t  Event;
+
+inline int last_error_code = 0;
+#define OCT_RT_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { octphmm::rt::last_error_code = (int)e_; return false; } } while (0)
+
+inline bool device_count(int* n) { OCT_RT_CHECK(hipGetDeviceCount(n)); return true; }
+inline bool set_device(int d) { OCT_RT_CHECK(hipSetDevice(d)); return true; }
+inline bool device_is_gfx950(int d)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) != hipSuccess) return false;
+    return __builtin_strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+inline bool stream_create(Stream* s) { OCT_RT_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return true; }
+inline void stream_destroy(Stream s) { (void)hipStreamDestroy(s); }
+inline bool stream_sync(Stream s) { OCT_RT_CHECK(hipStreamSynchronize(s)); return true; }
+inline bool dev_malloc(void** p, size_t n) { OCT_RT_CHECK(hipMalloc(p, n ? n : 16)); return true; }
+inline void dev_free(void* p) { if (p) (void)hipFree(p); }
+inline bool h2d(void* d, const void* h, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); return true; }
+inline bool d2h(void* h, const void* d, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); return true; }
+inline bool dev_memset(void* d, int v, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemsetAsync(d, v, n, s)); return true; }
+inline bool event_create(Event* e) { OCT_RT_CHECK(hipEventCreate(e)); return true; }
+inline void event_destroy(Event e) { (void)hipEventDestroy(e); }
+inline bool event_record(Event e, Stream s) { OCT_RT_CHECK(hipEventRecord(e, s)); return true; }
+inline bool event_elapsed_ms(float* ms, Event a, Event b) { OCT_RT_CHECK(hipEventElapsedTime(ms, a, b)); return true; }
+inline bool launch_ok() { OCT_RT_CHECK(hipGetLastError()); return true; }
+template <class K> inline bool allow_lds(K kernel, size_t bytes)
+{
+    OCT_RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return true;
+}
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+}} // namespace octphmm::rt
+
+#define OCT_LAUNCH(kernel, grid, block, smem, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), smem, stream, __VA_ARGS__)
+#endif

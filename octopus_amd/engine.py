@@ -1,0 +1,219 @@
+"""ctypes binding of liboct_phmm.so (include/oct_phmm.h) used by tests/ and bench.py.
+
+Plumbing only. `load()` fails loudly when the HIP library has not been built; there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+from . import abi
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "liboct_phmm.so"
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, status: Optional[abi.Status] = None, what: str = ""):
+        self.code = code
+        self.status = status
+        msg = status.message.decode("latin1") if status is not None else ""
+        super().__init__(f"oct_phmm error {code} {what}: {msg}")
+
+
+def build(force: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950 the kernels + host API into octopus_amd/liboct_phmm.so (in-tree)."""
+    srcs = [PKG_DIR / "csrc" / n for n in ("oct_phmm.hip", "phmm_kernels.hpp", "phmm_device.hpp", "phmm_hw.hpp", "phmm_rt.hpp")]
+    srcs.append(PKG_DIR.parent / "include" / "oct_phmm.h")
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return LIB_PATH
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           str(srcs[0]), "-o", str(LIB_PATH)]
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_LIBS = {}
+
+
+def load(path: Optional[Path] = None) -> C.CDLL:
+    p = Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise FileNotFoundError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    key = str(p)
+    if key not in _LIBS:
+        lib = C.CDLL(key)
+        lib.oct_phmm_create.argtypes = [C.POINTER(abi.Config), C.POINTER(C.c_void_p)]
+        lib.oct_phmm_destroy.argtypes = [C.c_void_p]
+        lib.oct_phmm_band_size.argtypes = [C.c_void_p]
+        lib.oct_phmm_strerror.restype = C.c_char_p
+        pv = C.c_void_p
+        lib.oct_phmm_populate.argtypes = [pv, pv, pv, pv, pv, pv, pv, pv]
+        lib.oct_phmm_batch_upload.argtypes = [pv, pv, pv, pv, pv, pv, C.POINTER(C.c_void_p), pv]
+        lib.oct_phmm_batch_run.argtypes = [pv, pv, pv]
+        lib.oct_phmm_batch_wait.argtypes = [pv, pv, pv]
+        lib.oct_phmm_batch_download.argtypes = [pv, pv, pv, pv]
+        lib.oct_phmm_batch_stats.argtypes = [pv, pv]
+        lib.oct_phmm_batch_out_size.argtypes = [pv]
+        lib.oct_phmm_batch_out_size.restype = C.c_size_t
+        lib.oct_phmm_batch_kernel_time.argtypes = [pv, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        lib.oct_phmm_batch_free.argtypes = [pv, pv]
+        _LIBS[key] = lib
+    return _LIBS[key]
+
+
+def _vp(x):
+    return None if x is None else C.cast(x, C.c_void_p)
+
+
+def _arr(a, dtype):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=dtype))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class ResidentBatch:
+    """A batch uploaded to HBM (oct_phmm_batch)."""
+
+    def __init__(self, engine: "Engine", batch: abi.Batch):
+        self.engine, self.batch = engine, batch
+        self.ptr = C.c_void_p()
+        st = abi.Status()
+        r, h, g, f, p = batch.c_args()
+        code = engine.lib.oct_phmm_batch_upload(engine.handle, _vp(r), _vp(h), _vp(g), _vp(f), _vp(p), C.byref(self.ptr), C.byref(st))
+        if code != abi.OK:
+            raise EngineError(code, st, "upload")
+
+    def run(self):
+        st = abi.Status()
+        code = self.engine.lib.oct_phmm_batch_run(self.engine.handle, self.ptr, C.byref(st))
+        if code != abi.OK:
+            raise EngineError(code, st, "run")
+
+    def wait(self):
+        st = abi.Status()
+        code = self.engine.lib.oct_phmm_batch_wait(self.engine.handle, self.ptr, C.byref(st))
+        if code != abi.OK:
+            raise EngineError(code, st, "wait")
+
+    def download(self) -> np.ndarray:
+        n = self.engine.lib.oct_phmm_batch_out_size(self.ptr)
+        out = np.empty(max(n, 1), dtype=np.float64)
+        st = abi.Status()
+        code = self.engine.lib.oct_phmm_batch_download(self.engine.handle, self.ptr, _ptr(out), C.byref(st))
+        if code != abi.OK:
+            raise EngineError(code, st, "download")
+        return out[:n]
+
+    def stats(self) -> dict:
+        s = abi.Stats()
+        self.engine.lib.oct_phmm_batch_stats(self.ptr, C.byref(s))
+        return s.as_dict()
+
+    def kernel_time(self):
+        ms, n = C.c_double(0), C.c_uint32(0)
+        self.engine.lib.oct_phmm_batch_kernel_time(self.ptr, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def free(self):
+        if self.ptr:
+            self.engine.lib.oct_phmm_batch_free(self.engine.handle, self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One oct_phmm_handle (= one HaplotypeLikelihoodModel configuration on one device)."""
+
+    def __init__(self, cfg: Optional[abi.Config] = None, lib_path: Optional[Path] = None):
+        self.lib = load(lib_path)
+        self.cfg = cfg if cfg is not None else abi.Config.default()
+        self.handle = C.c_void_p()
+        code = self.lib.oct_phmm_create(C.byref(self.cfg), C.byref(self.handle))
+        if code != abi.OK:
+            raise EngineError(code, None, "create: " + self.lib.oct_phmm_strerror(code).decode())
+
+    @property
+    def band_size(self) -> int:
+        return self.lib.oct_phmm_band_size(self.handle)
+
+    def close(self):
+        if self.handle:
+            self.lib.oct_phmm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def populate(self, batch: abi.Batch, raise_on_error: bool = True):
+        """HaplotypeLikelihoodArray::populate. Returns (out, status)."""
+        out = np.full(max(batch.out_size(), 1), np.nan, dtype=np.float64)
+        st = abi.Status()
+        r, h, g, f, p = batch.c_args()
+        code = self.lib.oct_phmm_populate(self.handle, _vp(r), _vp(h), _vp(g), _vp(f), _vp(p), _ptr(out), C.byref(st))
+        if code != abi.OK and raise_on_error:
+            raise EngineError(code, st, "populate")
+        return out[:batch.out_size()], st
+
+    def upload(self, batch: abi.Batch) -> ResidentBatch:
+        return ResidentBatch(self, batch)
+
+    def align_windows(self, truths, targets, quals, gap_open, gap_extend=None, gap_extend_scalar=1, snv_mask=None,
+                      snv_prior=None, nuc_prior=2, traceback=False, lhs_flank=None, rhs_flank=None):
+        """simd::PairHMM::align on explicit windows (test seam). Lists of bytes / arrays, one per window."""
+        n = len(truths)
+        cat = lambda xs, dt: (np.concatenate([np.frombuffer(bytes(x), np.uint8) if isinstance(x, (bytes, bytearray))
+                                              else np.asarray(x) for x in xs]).astype(dt) if n else np.zeros(0, dt))
+        off = lambda xs: np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.uint32)
+        tr, toff = cat(truths, np.uint8), off(truths)
+        tg, goff = cat(targets, np.uint8), off(targets)
+        q = cat(quals, np.uint8)
+        go = cat(gap_open, np.int8)
+        ge = None if gap_extend is None else cat(gap_extend, np.int8)
+        m = None if snv_mask is None else cat(snv_mask, np.uint8)
+        pr = None if snv_prior is None else cat(snv_prior, np.int8)
+        B = self.band_size
+        scores = np.zeros(n, np.int32)
+        fp = np.zeros(n, np.int32)
+        aoff = np.concatenate([[0], np.cumsum([2 * (len(t) + B) + 1 for t in targets])]).astype(np.uint32)
+        a1 = np.zeros(int(aoff[-1]) + 1, np.uint8)
+        a2 = np.zeros(int(aoff[-1]) + 1, np.uint8)
+        lf = None if lhs_flank is None else _arr(lhs_flank, np.int32)
+        rf = None if rhs_flank is None else _arr(rhs_flank, np.int32)
+        fl, ms = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        st = abi.Status()
+        self.lib.oct_phmm_align_windows.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p, C.c_int32,
+                                                    C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 10
+        code = self.lib.oct_phmm_align_windows(self.handle, n, _ptr(tr), _ptr(toff), _ptr(tg), _ptr(q), _ptr(goff), _ptr(go), _ptr(ge),
+                                               int(gap_extend_scalar), _ptr(m), _ptr(pr), int(nuc_prior), 1 if traceback else 0,
+                                               _ptr(scores), _ptr(fp), _ptr(a1), _ptr(a2), _ptr(aoff), _ptr(lf), _ptr(rf),
+                                               _ptr(fl) if lf is not None else None, _ptr(ms) if lf is not None else None, C.byref(st))
+        if code != abi.OK:
+            raise EngineError(code, st, "align_windows")
+        res = []
+        for i in range(n):
+            d = dict(score=int(scores[i]))
+            if traceback:
+                s1 = bytes(a1[aoff[i]:aoff[i + 1]]).split(b"\0")[0].decode("latin1")
+                s2 = bytes(a2[aoff[i]:aoff[i + 1]]).split(b"\0")[0].decode("latin1")
+                d.update(first_pos=int(fp[i]), align1=s1 if fp[i] >= 0 else "", align2=s2 if fp[i] >= 0 else "")
+                if lf is not None:
+                    d.update(flank_score=int(fl[i]), mask_size=int(ms[i]))
+            res.append(d)
+        return res

@@ -1,0 +1,171 @@
+// TEST INFRASTRUCTURE ONLY: a lockstep wave64 simulator that runs the REAL kernel source
+// (octopus_amd/csrc/phmm_kernels.hpp, compiled for the host with -DOCTPHMM_SIM) on CPU coroutines, so the
+// device code's logic (indexing, staging, packing, DPP shifts, reductions, walk) is unit-tested without a GPU.
+// It emulates exactly the functions of octopus_amd/csrc/phmm_hw.hpp. Never compiled into liboct_phmm.so.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <ucontext.h>
+#include <functional>
+#include <vector>
+
+#define OCT_DEVICE inline
+#define OCT_HD inline
+#define OCT_KERNEL(name) inline void name
+#define OCT_DYN_SMEM(ptr) unsigned char* ptr = hipsim::S().smem
+
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+
+namespace hipsim {
+
+enum Wait { kRun = 0, kWave = 1, kBlock = 2, kDone = 3 };
+
+struct Lane { ucontext_t ctx; char* stack = nullptr; int wait = kRun; };
+
+struct State {
+    std::vector<Lane> lanes;
+    ucontext_t sched;
+    uint32_t cur = 0, bid = 0, bdim = 0, gdim = 0;
+    unsigned char* smem = nullptr;
+    uint32_t xchg[1024];
+    std::function<void()> body;
+};
+inline State& S() { static State s; return s; }
+
+inline void yield_to_sched(int why) { State& s = S(); s.lanes[s.cur].wait = why; swapcontext(&s.lanes[s.cur].ctx, &s.sched); }
+inline void wave_sync() { yield_to_sched(kWave); }
+inline void block_sync_impl() { yield_to_sched(kBlock); }
+
+inline void lane_entry() { State& s = S(); s.body(); s.lanes[s.cur].wait = kDone; swapcontext(&s.lanes[s.cur].ctx, &s.sched); }
+
+// run one workgroup of `bdim` threads
+inline void run_block(uint32_t bid, uint32_t bdim, uint32_t gdim, size_t smem_bytes)
+{
+    State& s = S();
+    constexpr size_t kStack = 256 * 1024;
+    s.bid = bid; s.bdim = bdim; s.gdim = gdim;
+    std::vector<unsigned char> smem(smem_bytes + 64, 0xAB);
+    s.smem = (unsigned char*)(((uintptr_t)smem.data() + 15) & ~(uintptr_t)15);
+    if (s.lanes.size() < bdim) s.lanes.resize(bdim);
+    for (uint32_t t = 0; t < bdim; ++t) {
+        Lane& l = s.lanes[t];
+        if (!l.stack) l.stack = (char*)malloc(kStack);
+        getcontext(&l.ctx);
+        l.ctx.uc_stack.ss_sp = l.stack; l.ctx.uc_stack.ss_size = kStack; l.ctx.uc_link = &s.sched;
+        makecontext(&l.ctx, (void (*)())lane_entry, 0);
+        l.wait = kRun;
+    }
+    for (;;) {
+        bool progressed = false, all_done = true;
+        for (uint32_t t = 0; t < bdim; ++t) {
+            if (s.lanes[t].wait == kRun) { s.cur = t; swapcontext(&s.sched, &s.lanes[t].ctx); progressed = true; }
+            if (s.lanes[t].wait != kDone) all_done = false;
+        }
+        if (all_done) break;
+        // release waves whose live lanes all wait at a wave sync
+        for (uint32_t w0 = 0; w0 < bdim; w0 += 64) {
+            bool all = true, any = false;
+            for (uint32_t t = w0; t < w0 + 64 && t < bdim; ++t) {
+                if (s.lanes[t].wait == kDone) continue;
+                any = true;
+                if (s.lanes[t].wait != kWave) all = false;
+            }
+            if (any && all) { for (uint32_t t = w0; t < w0 + 64 && t < bdim; ++t) if (s.lanes[t].wait == kWave) s.lanes[t].wait = kRun; progressed = true; }
+        }
+        {
+            bool all = true, any = false;
+            for (uint32_t t = 0; t < bdim; ++t) { if (s.lanes[t].wait == kDone) continue; any = true; if (s.lanes[t].wait != kBlock) all = false; }
+            if (any && all) { for (uint32_t t = 0; t < bdim; ++t) if (s.lanes[t].wait == kBlock) s.lanes[t].wait = kRun; progressed = true; }
+        }
+        if (!progressed) { fprintf(stderr, "hipsim: deadlock (divergent cross-lane op or barrier) in block %u\n", bid); abort(); }
+    }
+}
+
+template <class F>
+inline void launch(uint32_t grid, uint32_t block, size_t smem_bytes, F&& f)
+{
+    S().body = f;
+    for (uint32_t b = 0; b < grid; ++b) run_block(b, block, grid, smem_bytes);
+}
+
+inline uint32_t xchg_read(uint32_t v, int src_off_fn(uint32_t lane), uint32_t fill)
+{
+    State& s = S();
+    const uint32_t t = s.cur, lane = t & 63;
+    s.xchg[t] = v;
+    wave_sync();
+    const int src = src_off_fn(lane);
+    const uint32_t r = src < 0 ? fill : s.xchg[(t & ~63u) + (uint32_t)src];
+    wave_sync();
+    return r;
+}
+
+} // namespace hipsim
+
+namespace octphmm { namespace hw {
+
+inline uint32_t dpp_row_shr1(uint32_t fill, uint32_t v)  { return hipsim::xchg_read(v, [](uint32_t l) { return (l & 15) == 0 ? -1 : (int)l - 1; }, fill); }
+inline uint32_t dpp_row_shl1(uint32_t fill, uint32_t v)  { return hipsim::xchg_read(v, [](uint32_t l) { return (l & 15) == 15 ? -1 : (int)l + 1; }, fill); }
+inline uint32_t dpp_wave_shr1(uint32_t fill, uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return l == 0 ? -1 : (int)l - 1; }, fill); }
+inline uint32_t dpp_wave_shl1(uint32_t fill, uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return l == 63 ? -1 : (int)l + 1; }, fill); }
+
+inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    const uint64_t src = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t s = (sel >> (8 * n)) & 0xff;
+        uint32_t byte;
+        if (s < 8) byte = (uint32_t)(src >> (8 * s)) & 0xff;
+        else if (s == 0x0c) byte = 0;
+        else if (s > 0x0c) byte = 0xff;
+        else { fprintf(stderr, "hipsim: v_perm_b32 selector %u not modelled\n", s); abort(); }
+        r |= byte << (8 * n);
+    }
+    return r;
+}
+inline uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t lo = ((a & 0xffff) * (b & 0xffff) + (c & 0xffff)) & 0xffff;
+    const uint32_t hi = ((a >> 16) * (b >> 16) + (c >> 16)) & 0xffff;
+    return lo | hi << 16;
+}
+inline void wave_lds_fence() { hipsim::wave_sync(); }
+inline uint32_t shfl_xor(uint32_t v, int mask)
+{
+    hipsim::State& s = hipsim::S();
+    const uint32_t t = s.cur;
+    s.xchg[t] = v;
+    hipsim::wave_sync();
+    const uint32_t r = s.xchg[(t & ~63u) + ((t & 63) ^ (uint32_t)mask)];
+    hipsim::wave_sync();
+    return r;
+}
+inline uint32_t shfl(uint32_t v, int src)
+{
+    hipsim::State& s = hipsim::S();
+    const uint32_t t = s.cur;
+    s.xchg[t] = v;
+    hipsim::wave_sync();
+    const uint32_t r = s.xchg[(t & ~63u) + (uint32_t)src];
+    hipsim::wave_sync();
+    return r;
+}
+inline uint32_t readfirstlane(uint32_t v) { return shfl(v, 0); }
+inline void block_sync() { hipsim::block_sync_impl(); }
+inline int atomic_min_i32(int32_t* p, int32_t v) { const int32_t o = *p; if (v < o) *p = v; return o; }
+inline unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { const auto o = *p; if (v < o) *p = v; return o; }
+inline unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { const auto o = *p; *p = o + v; return o; }
+inline uint32_t atomic_and_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o & v; return o; }
+inline uint32_t thread_idx() { return hipsim::S().cur; }
+inline uint32_t block_idx() { return hipsim::S().bid; }
+inline uint32_t block_dim() { return hipsim::S().bdim; }
+inline uint32_t grid_dim() { return hipsim::S().gdim; }
+
+}} // namespace octphmm::hw

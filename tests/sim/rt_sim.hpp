@@ -1,0 +1,35 @@
+// TEST INFRASTRUCTURE ONLY: host stand-in for octopus_amd/csrc/phmm_rt.hpp so that the library's host API can
+// drive the CPU wave simulator (tests/sim/hipsim.hpp). "Device" memory is plain host memory.
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+#include "hipsim.hpp"
+
+namespace octphmm { namespace rt {
+
+typedef int Stream;
+typedef int Event;
+inline int last_error_code = 0;
+
+inline bool device_count(int* n) { *n = 1; return true; }
+inline bool set_device(int) { return true; }
+inline bool device_is_gfx950(int) { return true; }
+inline bool stream_create(Stream* s) { *s = 0; return true; }
+inline void stream_destroy(Stream) {}
+inline bool stream_sync(Stream) { return true; }
+inline bool dev_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); if (*p) memset(*p, 0xCD, n ? n : 16); return *p != nullptr; }
+inline void dev_free(void* p) { free(p); }
+inline bool h2d(void* d, const void* h, size_t n, Stream) { if (n) memcpy(d, h, n); return true; }
+inline bool d2h(void* h, const void* d, size_t n, Stream) { if (n) memcpy(h, d, n); return true; }
+inline bool dev_memset(void* d, int v, size_t n, Stream) { if (n) memset(d, v, n); return true; }
+inline bool event_create(Event* e) { *e = 0; return true; }
+inline void event_destroy(Event) {}
+inline bool event_record(Event, Stream) { return true; }
+inline bool event_elapsed_ms(float* ms, Event, Event) { *ms = 0.f; return true; }
+inline bool launch_ok() { return true; }
+template <class K> inline bool allow_lds(K, size_t) { return true; }
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+}} // namespace octphmm::rt
+
+#define OCT_LAUNCH(kernel, grid, block, smem, stream, ...) hipsim::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,27 @@
+"""CPU suite: the real kernel source (octopus_amd/csrc/phmm_kernels.hpp) executed by the lockstep wave simulator,
+checked against the reference's golden vectors and the oracle. No GPU needed."""
+import pytest
+
+import check_l1
+
+
+def test_sim_golden_vectors(golden_records):
+    assert check_l1.check_golden("sim", golden_records) == 22
+
+
+@pytest.mark.parametrize("band,n", [(8, 24), (16, 24), (32, 10), (64, 6)])
+def test_sim_random_windows_fast_kernel(band, n):
+    check_l1.check_random("sim", band, n, seed=100 + band, with_n=False)
+
+
+@pytest.mark.parametrize("band,n", [(8, 16), (16, 16), (32, 6)])
+def test_sim_random_windows_generic_kernel(band, n):
+    check_l1.check_random("sim", band, n, seed=200 + band, with_n=True)
+
+
+def test_sim_unmasked_overload():
+    check_l1.check_random("sim", 16, 10, seed=7, masked=False, with_n=False)
+
+
+def test_sim_int16_overflow_wraps_like_reference():
+    check_l1.check_random("sim", 16, 8, seed=9, t_lo=150, t_hi=151, q_max=125, junk=True, with_n=False)
