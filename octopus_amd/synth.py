@@ -1,0 +1,193 @@
+"""Synthetic workloads of BASELINE.json's configs: deterministic, numpy only, no oracle.
+
+One "region" = what one HaplotypeLikelihoodArray::populate call sees: H candidate haplotypes derived from a
+base haplotype by a few SNV/indel edits, R Illumina-like reads sampled from them, the per-haplotype penalty
+vectors of the default `PCR-free.HiSeq-2500` error model where nothing repeats (gap open 45, extend 3, SNV
+prior 125, masks = haplotype rotated by one base) plus planted homopolymers with that model's open penalties
+(reference core/models/error/error_model_factory.cpp:231-238), and an inactive-flank state.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+
+from . import abi
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+# PCR-free HiSeq-2500 homopolymer (A/T) gap-open penalties by repeat length (error_model_factory.cpp:234)
+HOMOPOLYMER_OPEN = np.array([45, 45, 43, 43, 41, 38, 35, 32, 29, 25, 21, 20, 19, 18, 17, 17, 16, 16, 15, 14], dtype=np.int8)
+
+
+def _penalties(seq: np.ndarray):
+    """Default-model penalty vectors for one haplotype sequence."""
+    L = len(seq)
+    go = np.full(L, 45, np.int8)
+    ge = np.full(L, 3, np.int8)
+    # homopolymer runs -> table penalty over the run
+    change = np.flatnonzero(np.diff(seq) != 0) + 1
+    starts = np.concatenate([[0], change])
+    ends = np.concatenate([change, [L]])
+    for s, e in zip(starts, ends):
+        n = e - s
+        if n >= 3:
+            go[s:e] = HOMOPOLYMER_OPEN[min(n, len(HOMOPOLYMER_OPEN) - 1)]
+    mask_f = np.roll(seq, 1)    # repeat_based_snv_error_model.cpp:174-178: masks are the haplotype rotated by one base
+    mask_r = np.roll(seq, -1)
+    pr = np.full(L, 125, np.int8)
+    return go, ge, mask_f, pr.copy(), mask_r, pr.copy()
+
+
+def make_haplotypes(rng: np.random.Generator, H: int, Lh: int, n_homopolymers: int = 3):
+    base = BASES[rng.integers(0, 4, Lh)].copy()
+    for _ in range(n_homopolymers):
+        n = int(rng.integers(8, 16))
+        a = int(rng.integers(20, Lh - 20 - n))
+        base[a:a + n] = BASES[rng.integers(0, 4)]
+    haps = [base]
+    maps = [np.arange(Lh + 1)]          # base coordinate -> haplotype coordinate
+    for _ in range(H - 1):
+        seq = list(base)
+        cmap = np.arange(Lh + 1)
+        for _e in range(int(rng.integers(1, 4))):
+            p = int(rng.integers(60, max(61, Lh - 60)))
+            kind = rng.random()
+            if kind < 0.7:
+                alt = BASES[rng.integers(0, 4)]
+                q = int(cmap[p])
+                if 0 <= q < len(seq):
+                    seq[q] = int(alt)
+            elif kind < 0.85:
+                n = int(rng.integers(1, 11))
+                q = int(cmap[p])
+                del seq[q:q + n]
+                cmap[p + 1:] = np.maximum(cmap[p + 1:] - n, cmap[p])
+            else:
+                n = int(rng.integers(1, 11))
+                q = int(cmap[p])
+                seq[q:q] = [int(b) for b in BASES[rng.integers(0, 4, n)]]
+                cmap[p:] += n
+        arr = np.array(seq, dtype=np.uint8)
+        if len(arr) < Lh:     # padded back to Lh
+            arr = np.concatenate([arr, BASES[rng.integers(0, 4, Lh - len(arr))]])
+        arr = arr[:Lh]
+        haps.append(arr)
+        maps.append(np.minimum(cmap, Lh))
+    return haps, maps
+
+
+def make_reads(rng: np.random.Generator, haps, maps, R: int, T: int, B: int, min_diffs: int = 0):
+    """R reads of length T sampled from uniformly chosen haplotypes, Illumina-like qualities and errors."""
+    H, Lh = len(haps), len(haps[0])
+    src = rng.integers(0, H, R)
+    start = rng.integers(B, Lh - T - B + 1, R)              # start in BASE coordinates = the read's reference begin
+    quals = rng.choice(np.array([37, 25, 12, 2], dtype=np.uint8), size=(R, T), p=[0.7, 0.2, 0.08, 0.02])
+    decay = np.concatenate([np.zeros(T - min(30, T)), np.linspace(0, 20, min(30, T))]).astype(np.int64)
+    quals = np.clip(quals.astype(np.int64) - decay[None, :], 2, 64).astype(np.uint8)
+    reads = np.empty((R, T), dtype=np.uint8)
+    for r in range(R):
+        h = haps[src[r]]
+        s = int(min(maps[src[r]][start[r]], Lh - T))
+        reads[r] = h[s:s + T]
+    err = rng.random((R, T)) < np.power(10.0, -quals.astype(np.float64) / 10.0)
+    sub = BASES[rng.integers(0, 4, (R, T))]
+    reads = np.where(err, sub, reads)
+    indel = np.flatnonzero(rng.random(R) < 0.005)
+    for r in indel:
+        p = int(rng.integers(10, T - 10))
+        n = int(rng.integers(1, 4))
+        row = list(reads[r])
+        if rng.random() < 0.5:
+            del row[p:p + n]
+            row += [int(b) for b in BASES[rng.integers(0, 4, n)]]
+        else:
+            row[p:p] = [int(b) for b in BASES[rng.integers(0, 4, n)]]
+        reads[r] = np.array(row[:T], dtype=np.uint8)
+    if min_diffs:
+        for r in range(R):
+            idx = rng.choice(T, size=min_diffs, replace=False)
+            reads[r, idx] = BASES[(np.searchsorted(BASES, reads[r, idx]) + rng.integers(1, 4, min_diffs)) % 4]
+    reverse = (rng.random(R) < 0.5).astype(np.uint8)
+    mapq = np.full(R, 60, np.uint8)
+    return reads, quals, start.astype(np.int64), reverse, mapq, src
+
+
+def make_region(rng: np.random.Generator, R: int, H: int, T: int = 150, Lh: int = 300, B: int = 16,
+                flank=(40, 40), min_diffs: int = 0, positions: str = "true"):
+    """Arrays of one populate() call. positions: 'true' = each read's start mapped through the haplotype's edits
+    (a stand-in for the k-mer mapper's output), 'none' = leave mapping to the library."""
+    haps, maps = make_haplotypes(rng, H, Lh)
+    reads, quals, begin, reverse, mapq, _ = make_reads(rng, haps, maps, R, T, B, min_diffs)
+    pos = None
+    if positions == "true":
+        pos = np.stack([np.minimum(m[begin], Lh - T) for m in maps]).astype(np.uint32)     # [H, R]
+    return dict(haps=haps, reads=reads, quals=quals, begin=begin, reverse=reverse, mapq=mapq, flank=flank, pos=pos)
+
+
+def batch_from_regions(regions: List[dict]) -> abi.Batch:
+    """Concatenate regions into one flat C-ABI batch (region tables + flank states + CSR positions)."""
+    rb, rq, ro, mq, rv, beg = [], [], [0], [], [], []
+    hb, ho, go, ge, mf, pf, mr, pr = [], [0], [], [], [], [], [], []
+    reg_rows, reg_haps, flank = [0], [0], []
+    pos_off, pos_val = [np.zeros(1, np.uint64)], []
+    have_pos = all(g["pos"] is not None for g in regions)
+    total = 0
+    for g in regions:
+        R, T = g["reads"].shape
+        rb.append(g["reads"].reshape(-1)); rq.append(g["quals"].reshape(-1))
+        ro.extend((ro[-1] + T * (np.arange(R) + 1)).tolist())
+        mq.append(g["mapq"]); rv.append(g["reverse"]); beg.append(g["begin"])
+        for h in g["haps"]:
+            a, b, c, d, e, f = _penalties(h)
+            hb.append(h); ho.append(ho[-1] + len(h)); go.append(a); ge.append(b); mf.append(c); pf.append(d); mr.append(e); pr.append(f)
+        reg_rows.append(reg_rows[-1] + R); reg_haps.append(reg_haps[-1] + len(g["haps"]))
+        flank.append(g["flank"] if g["flank"] is not None else (0, 0))
+        if have_pos:
+            n = len(g["haps"]) * R
+            pos_off.append(total + 1 + np.arange(n, dtype=np.uint64))
+            pos_val.append(g["pos"].reshape(-1))
+            total += n
+    b = abi.Batch(
+        read_bases=np.concatenate(rb), read_quals=np.concatenate(rq), read_offsets=np.asarray(ro, np.uint32),
+        mapq=np.concatenate(mq), reverse=np.concatenate(rv), read_ref_begin=np.concatenate(beg), row_offsets=None,
+        hap_bases=np.concatenate(hb), hap_offsets=np.asarray(ho, np.uint32), hap_ref_begin=np.zeros(len(hb), np.int64),
+        gap_open=np.concatenate(go), gap_extend=np.concatenate(ge), snv_mask_fwd=np.concatenate(mf),
+        snv_prior_fwd=np.concatenate(pf), snv_mask_rev=np.concatenate(mr), snv_prior_rev=np.concatenate(pr))
+    if len(regions) == 1:
+        b.flank = regions[0]["flank"]
+    else:
+        b.region_row_offsets = np.asarray(reg_rows, np.uint32); b.region_hap_offsets = np.asarray(reg_haps, np.uint32)
+        b.region_has_flank = np.asarray([1 if g["flank"] is not None else 0 for g in regions], np.uint8)
+        b.region_flank = np.asarray(flank, np.uint32)
+    if have_pos:
+        b.pos_offsets = np.concatenate(pos_off); b.pos_values = np.concatenate(pos_val).astype(np.uint32)
+    return b
+
+
+def config_batch(name: str, seed: int = 42, B: int = 16, positions: str = "true") -> abi.Batch:
+    """BASELINE.json configs: '1k x 64' (configs[0]/[1]), '100k x 128' (configs[2]), 'stress' (every read >= 2 differences)."""
+    rng = np.random.default_rng(seed)
+    if name == "1kx64":
+        return batch_from_regions([make_region(rng, 1000, 64, B=B, positions=positions)])
+    if name == "100kx128":
+        return batch_from_regions([make_region(rng, 100_000, 128, B=B, positions=positions)])
+    if name == "100kx128-nofast":
+        return batch_from_regions([make_region(rng, 100_000, 128, B=B, min_diffs=2, positions=positions)])
+    if name == "10kx64":
+        return batch_from_regions([make_region(rng, 10_000, 64, B=B, positions=positions)])
+    if name == "tiny":
+        return batch_from_regions([make_region(rng, 40, 6, B=B, positions=positions)])
+    raise KeyError(name)
+
+
+def region_stream(seed: int, n_regions: int, B: int = 16, positions: str = "true") -> List[dict]:
+    """BASELINE.json configs[3] stand-in: active-region stream, R ~ lognormal(median 300, sigma 0.8) in [20, 5000],
+    H ~ min(200, geometric(mean 24)), Lh = 300 + U[0, 200], T = 150."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_regions):
+        R = int(np.clip(rng.lognormal(np.log(300), 0.8), 20, 5000))
+        H = int(min(200, rng.geometric(1 / 24.0)))
+        Lh = 300 + int(rng.integers(0, 201))
+        out.append(make_region(rng, R, max(H, 1), Lh=Lh, B=B, positions=positions))
+    return out

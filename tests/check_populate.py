@@ -1,0 +1,152 @@
+"""Backend-independent parity checks of the whole populate() path against the CPU oracle."""
+import numpy as np
+
+import oracle
+from backends import make_engine
+from octopus_amd import abi, synth
+
+
+def mapper_positions(batch: abi.Batch, max_positions=10, rng=None, junk=0.0):
+    """CSR of candidate positions per (haplotype, read) pair from the oracle's k-mer mapper restatement, optionally
+    salted with random (possibly out-of-range / duplicate) positions to exercise max_score's bookkeeping."""
+    ro, ho = batch.region_tables()
+    first = (lambda row: row) if batch.row_offsets is None else (lambda row: int(batch.row_offsets[row]))
+    offs, vals = [0], []
+    for g in range(len(ro) - 1):
+        r0, r1 = first(int(ro[g])), first(int(ro[g + 1]))
+        for h in range(int(ho[g]), int(ho[g + 1])):
+            hs = bytes(batch.hap_bases[batch.hap_offsets[h]:batch.hap_offsets[h + 1]])
+            for r in range(r0, r1):
+                rs = bytes(batch.read_bases[batch.read_offsets[r]:batch.read_offsets[r + 1]])
+                p = oracle.map_query_to_target(rs, hs, max_positions)
+                if rng is not None and rng.random() < junk:
+                    extra = [int(x) for x in rng.integers(0, len(hs) + 5, int(rng.integers(1, 4)))]
+                    p = sorted(set(p + extra))[:max_positions]
+                    if rng.random() < 0.3:
+                        p = []
+                vals.extend(p)
+                offs.append(len(vals))
+    batch.pos_offsets = np.asarray(offs, np.uint64)
+    batch.pos_values = np.asarray(vals if vals else [0], np.uint32)
+    return batch
+
+
+def compare(backend, batch, tol=0.0, **cfg_kw):
+    cfg = abi.Config.default(**cfg_kw)
+    want, wst, wstats = oracle.populate(cfg, batch, n_threads=2)
+    eng = make_engine(backend, **cfg_kw)
+    rb = eng.upload(batch)
+    rb.run()
+    try:
+        got = rb.download()
+        code = abi.OK
+        st = None
+    except Exception as e:  # EngineError
+        got, code, st = None, e.code, e.status
+    stats = rb.stats()
+    rb.free()
+    eng.close()
+    assert code == wst.code, (code, wst.code, wst.message)
+    if code == abi.ESHORT_HAPLOTYPE:
+        assert (st.hap_index, st.read_index, st.required_extension) == (wst.hap_index, wst.read_index, wst.required_extension)
+        return None
+    assert got.shape == want.shape
+    if tol == 0.0:
+        bad = np.flatnonzero(got != want)
+    else:
+        bad = np.flatnonzero(~(np.abs(got - want) <= tol))
+    assert bad.size == 0, (bad[:10], got[bad[:10]], want[bad[:10]])
+    for k in ("n_pairs", "n_candidates", "n_fast_path", "n_dp_score_only", "n_dp_traceback", "band_cells"):
+        assert stats[k] == wstats[k], (k, stats, wstats)
+    return stats
+
+
+def small_region(seed, R=24, H=5, T=60, Lh=150, B=8, flank=(20, 20), ragged=False, with_n=False):
+    rng = np.random.default_rng(seed)
+    g = synth.make_region(rng, R, H, T=T, Lh=Lh, B=B, flank=flank, positions="none")
+    if with_n:
+        g["reads"][rng.integers(0, R, 3), rng.integers(0, T, 3)] = ord("N")
+        g["haps"][1][int(rng.integers(0, Lh))] = ord("N")
+    return g, rng
+
+
+def check_basic(backend, tol=0.0):
+    out = {}
+    for B, flank in ((8, (20, 20)), (16, None), (16, (30, 25))):
+        g, rng = small_region(11 + B, B=B, T=50, Lh=150, flank=flank)
+        batch = mapper_positions(synth.batch_from_regions([g]), rng=rng, junk=0.3)
+        out[(B, flank)] = compare(backend, batch, tol, max_indel_error=B)
+    s = out[(8, (20, 20))]
+    assert s["n_dp_traceback"] > 0 and s["n_fast_path"] > 0
+    assert out[(16, None)]["n_dp_traceback"] == 0 and out[(16, None)]["n_dp_score_only"] > 0
+    return out
+
+
+def check_generic_bytes(backend, tol=0.0):
+    g, rng = small_region(5, with_n=True)
+    batch = mapper_positions(synth.batch_from_regions([g]), rng=rng, junk=0.2)
+    return compare(backend, batch, tol, max_indel_error=8)
+
+
+def check_templates_and_regions(backend, tol=0.0):
+    g1, rng = small_region(21, R=12, H=3)
+    g2, _ = small_region(22, R=9, H=4, flank=None)
+    g3, _ = small_region(23, R=7, H=2, T=40, Lh=120)
+    batch = synth.batch_from_regions([g1, g2, g3])
+    # templates: rows of 1-2 consecutive reads that never straddle a region
+    rows, r = [0], 0
+    for R in (12, 9, 7):
+        end = r + R
+        while r < end:
+            r += 2 if (end - r >= 2 and rng.random() < 0.6) else 1
+            rows.append(r)
+    batch.row_offsets = np.asarray(rows, np.uint32)
+    region_rows = [0]
+    for lim in (12, 21, 28):
+        region_rows.append(rows.index(lim))
+    batch.region_row_offsets = np.asarray(region_rows, np.uint32)
+    batch = mapper_positions(batch, rng=rng, junk=0.2)
+    return compare(backend, batch, tol, max_indel_error=8)
+
+
+def check_ragged_and_edges(backend, tol=0.0):
+    """Variable read lengths (including reads shorter than the band), reads hanging off either haplotype end
+    (shifted-original fallback), and a ShortHaplotypeError."""
+    rng = np.random.default_rng(77)
+    B, Lh = 8, 120
+    hap = synth.BASES[rng.integers(0, 4, Lh)]
+    haps = [hap.copy(), hap.copy()]
+    haps[1][60] = ord("A") if haps[1][60] != ord("A") else ord("C")
+    reads, quals, begins = [], [], []
+    for T, start in ((5, 30), (7, 50), (33, 20), (64, 10), (80, 20), (40, 0), (40, 3), (40, 78), (40, 75), (100, 5)):
+        s = min(start, Lh - T)
+        seq = hap[s:s + T].copy()
+        if T > 20:
+            seq[T // 2] = ord("G") if seq[T // 2] != ord("G") else ord("T")
+            seq[T // 3] = ord("G") if seq[T // 3] != ord("G") else ord("T")
+        reads.append(seq); quals.append(rng.integers(2, 60, T).astype(np.uint8)); begins.append(start)
+    def mk(reads, quals, begins, haps):
+        rl = [dict(seq=bytes(r), quals=q, mapq=int(rng.integers(0, 70)), reverse=bool(rng.integers(0, 2)), begin=b)
+              for r, q, b in zip(reads, quals, begins)]
+        hl = []
+        for h in haps:
+            go, ge, mf, pf, mr, pr = synth._penalties(h)
+            hl.append(dict(seq=bytes(h), begin=0, gap_open=go, gap_extend=ge, mask_fwd=mf, prior_fwd=pf, mask_rev=mr, prior_rev=pr))
+        return abi.Batch.from_lists(rl, hl, flank=(10, 10))
+    batch = mapper_positions(mk(reads, quals, begins, haps), rng=rng, junk=0.5)
+    stats = compare(backend, batch, tol, max_indel_error=8)
+    # a read longer than the haplotype can hold with its pads -> ShortHaplotypeError with the reference's extension
+    T = Lh - 2 * B + 3
+    bad = mapper_positions(mk([hap[:T].copy()], [np.full(T, 30, np.uint8)], [2], haps))
+    assert compare(backend, bad, tol, max_indel_error=8) is None
+    return stats
+
+
+def check_mapping_quality_options(backend, tol=0.0):
+    g, rng = small_region(31)
+    g["mapq"] = rng.integers(0, 255, len(g["mapq"])).astype(np.uint8)
+    batch = mapper_positions(synth.batch_from_regions([g]), rng=rng)
+    compare(backend, batch, tol, max_indel_error=8, use_mapping_quality=0)
+    compare(backend, batch, tol, max_indel_error=8, mapping_quality_cap=60, mapping_quality_cap_trigger=40)
+    compare(backend, batch, tol, max_indel_error=8, mapping_quality_cap=30, mapping_quality_cap_trigger=40)   # trigger >= cap is dropped
+    compare(backend, batch, tol, max_indel_error=8, use_flank_state=0)

@@ -1,0 +1,23 @@
+"""CPU suite: the whole populate() pipeline (host API + every kernel) on the wave simulator vs the oracle, bit for bit."""
+import check_populate as cp
+
+
+def test_sim_populate_basic():
+    cp.check_basic("sim")
+
+
+def test_sim_populate_generic_bytes():
+    s = cp.check_generic_bytes("sim")
+    assert s["n_dp_score_only"] + s["n_dp_traceback"] > 0
+
+
+def test_sim_populate_templates_and_regions():
+    cp.check_templates_and_regions("sim")
+
+
+def test_sim_populate_ragged_reads_edges_and_short_haplotype():
+    cp.check_ragged_and_edges("sim")
+
+
+def test_sim_populate_mapping_quality_and_flank_options():
+    cp.check_mapping_quality_options("sim")
