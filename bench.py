@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py — one "step" = one pass of the hot path (HaplotypeLikelihoodArray::populate on the GPU: candidate
+classification + scalar fast path, banded pair-HMM DP with and without traceback, flank walk, mapping-quality
+epilogue) over one synthetic batch that is already resident in HBM.
+
+Workload at N=1: BASELINE.json configs[2] — 100k Illumina-like 150 bp reads x 128 300 bp haplotypes, band 16,
+int16 lanes, flank state 40/40 (the largest single-GPU configuration; configs[1], the 1k x 64 batch, is a parity
+test and is additionally timed as `small_batch_ms`). N>1: one process per GPU, each with its own region of the same
+shape (weak scaling, no collective: regions are independent), value = sum over ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (one 32-bit VALU op per lane per clock)
+
+
+def algorithmic_bytes_per_task(T: int, B: int) -> int:
+    """2T (bases + quals) + 5 (T + 2B - 1) (haplotype window, gap open/extend, SNV mask/prior) + 8 + 8."""
+    return 2 * T + 5 * (T + 2 * B - 1) + 16
+
+
+def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
+    """The reference's own SIMD pair-HMM (oracle/_ref, built from /root/reference in place) driven by the oracle's
+    restated upper layers, all host cores, on a bounded sample of the same workload."""
+    import oracle
+    from octopus_amd import abi, synth
+    cores = oracle.host_cores()
+    kind = "port"
+    backend = "oracle"
+    if oracle.have_ref():
+        kind, backend = "reference", ("sse2" if oracle.ref_isa_supported("sse2") else "native")
+    oracle.set_l1_backend(backend)
+    cfg = abi.Config.default(max_indel_error=B)
+    rng = np.random.default_rng(seed)
+    R, H = 4000, 32
+    batch = synth.batch_from_regions([synth.make_region(rng, R, H, B=B)])
+    t0 = time.perf_counter()
+    _, st, stats = oracle.populate(cfg, batch, n_threads=cores)
+    dt = time.perf_counter() - t0
+    reps = 1
+    while dt * reps < 3.0 and reps < 64:      # repeat the sample until the clock is meaningful, bounded
+        reps *= 2
+    if reps > 1:
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.populate(cfg, batch, n_threads=cores)
+        dt = (time.perf_counter() - t0) / reps
+    out = {"value": stats["band_cells"] / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": kind,
+           "sample": f"{R} reads x {H} haplotypes of the same generator, {reps} repetition(s), L1 = reference {backend.upper()} kernels"
+                     if kind == "reference" else f"{R} reads x {H} haplotypes, scalar C port",
+           "loglik_per_s": stats["n_pairs"] / dt}
+    if kind == "reference" and oracle.ref_isa_supported("avx2"):
+        oracle.set_l1_backend("native")
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.populate(cfg, batch, n_threads=cores)
+        dt2 = (time.perf_counter() - t0) / reps
+        out["value_native_isa"] = stats["band_cells"] / dt2 / 1e9
+    oracle.set_l1_backend("oracle")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="100kx128")
+    ap.add_argument("--band", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist  # RCCL; only the barrier + max-reduce of the timing contract use it
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from octopus_amd import abi, engine, synth
+    B = args.band
+    T, LH = 150, 300
+    cfg = abi.Config.default(max_indel_error=B, device_id=local_rank)
+    eng = engine.Engine(cfg)                      # fails loudly if liboct_phmm.so / a gfx950 device is missing
+    batch = synth.config_batch(args.workload, seed=42 + rank, B=B)
+    rb = eng.upload(batch)                        # inputs resident in HBM before the timed region
+
+    def sync_all():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        rb.run(); rb.wait()
+    sync_all()
+    t0 = time.perf_counter()
+    dp_ms, dp_launches = 0.0, 0
+    for _ in range(args.steps):
+        rb.run(); rb.wait()
+        ms, n = rb.kernel_time()
+        dp_ms += ms; dp_launches += n
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    stats = rb.stats()
+    cells, pairs = stats["band_cells"], stats["n_pairs"]
+    n_tasks = stats["n_dp_score_only"] + stats["n_dp_traceback"]
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([float(cells), float(pairs)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        cells, pairs = float(c[0].item()), float(c[1].item())
+
+    if rank == 0:
+        per_step = elapsed / args.steps
+        # dominant kernel = the DP launches (HIP events on the library's own stream around each k_dp launch)
+        avg_launch_s = (dp_ms / 1e3) / max(dp_launches, 1)
+        tasks_per_launch = n_tasks * args.steps / max(dp_launches, 1)
+        alg_bytes = algorithmic_bytes_per_task(T, B) * tasks_per_launch
+        achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        lane_ops = 45.0 * B * (T + B) * tasks_per_launch        # ~45 lane-ops per lane per row pair
+        out = {
+            "metric": "pair-HMM band cell-updates/s", "value": cells / per_step / 1e9, "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: Illumina-like 150 bp reads x 300 bp haplotypes per region, band {B}, "
+                                   f"int16 lanes, flank 40/40, one region per GPU", "band": B, "read_len": T, "hap_len": LH,
+                       "pairs_per_step": pairs, "dp_tasks_per_step": n_tasks, "parallelism": f"regions sharded over {world} GPU(s), no collective"},
+            "loglik_per_s": pairs / per_step,
+            "stats": stats,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_dp (all four variants, event-timed per launch)",
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": dp_launches / args.steps,
+                         "valu": {"achieved_lane_ops_per_s": lane_ops / avg_launch_s if avg_launch_s > 0 else 0.0,
+                                  "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                                  "frac": (lane_ops / avg_launch_s / VALU_PEAK_LANE_OPS) if avg_launch_s > 0 else 0.0,
+                                  "note": "the path is integer-VALU bound (SURVEY.md §8d); reference-op accounting, int32-lane peak"}},
+        }
+        if world == 1:
+            small = eng.upload(synth.config_batch("1kx64", seed=42, B=B))
+            for _ in range(3):
+                small.run(); small.wait()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                small.run(); small.wait()
+            out["small_batch_ms"] = (time.perf_counter() - t1) / 10 * 1e3
+            small.free()
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(B, seed=42)
+        print(json.dumps(out))
+    rb.free()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

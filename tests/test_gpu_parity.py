@@ -1,0 +1,88 @@
+"""Parity tests proper: the HIP library on a real MI355X, through the C ABI, against the oracle and the
+reference's golden vectors. Integer scores / alignments / flank scores must be identical; ln-likelihoods agree to
+1e-9 (north-star tolerance is 1e-4; the only non-integer step is the fp64 mapping-quality mixture, where device
+log/exp may differ from glibc in the last ulps)."""
+import numpy as np
+import pytest
+
+import check_l1
+import check_populate as cp
+import oracle
+from backends import make_engine
+from octopus_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def test_gpu_golden_vectors(golden_records):
+    assert check_l1.check_golden("gpu", golden_records) == 22
+
+
+@pytest.mark.parametrize("band,n", [(8, 300), (16, 600), (32, 200), (64, 100)])
+def test_gpu_random_windows_fast_kernel(band, n):
+    check_l1.check_random("gpu", band, n, seed=1000 + band, with_n=False)
+
+
+@pytest.mark.parametrize("band,n", [(8, 200), (16, 300), (32, 100), (64, 50)])
+def test_gpu_random_windows_generic_kernel(band, n):
+    check_l1.check_random("gpu", band, n, seed=2000 + band, with_n=True)
+
+
+def test_gpu_unmasked_overload():
+    check_l1.check_random("gpu", 16, 100, seed=7, masked=False, with_n=False)
+
+
+def test_gpu_int16_overflow_wraps_like_reference():
+    check_l1.check_random("gpu", 16, 100, seed=9, t_lo=150, t_hi=151, q_max=125, junk=True, with_n=False)
+
+
+def test_gpu_populate_basic():
+    cp.check_basic("gpu", TOL)
+
+
+def test_gpu_populate_generic_bytes():
+    cp.check_generic_bytes("gpu", TOL)
+
+
+def test_gpu_populate_templates_and_regions():
+    cp.check_templates_and_regions("gpu", TOL)
+
+
+def test_gpu_populate_ragged_reads_edges_and_short_haplotype():
+    cp.check_ragged_and_edges("gpu", TOL)
+
+
+def test_gpu_populate_mapping_quality_and_flank_options():
+    cp.check_mapping_quality_options("gpu", TOL)
+
+
+def test_gpu_config2_1k_by_64_matches_oracle():
+    """BASELINE.json configs[1]: the 1k x 64 batch (150 bp reads, 300 bp haplotypes, B = 16, flank 40/40)."""
+    batch = synth.config_batch("1kx64", seed=42, B=16)
+    stats = cp.compare("gpu", batch, TOL, max_indel_error=16)
+    assert stats["n_pairs"] == 64000 and stats["n_dp_traceback"] > 1000 and stats["n_fast_path"] > 1000
+
+
+def test_gpu_large_batch_properties():
+    """At a size the oracle cannot check in seconds: size-independent properties. (a) every ln-likelihood <= 0 and
+    finite, (b) idempotence: running the resident batch twice gives identical bytes, (c) a sub-batch of the same
+    reads/haplotypes reproduces the corresponding rows exactly, and that sub-batch matches the oracle."""
+    rng = np.random.default_rng(5)
+    g = synth.make_region(rng, 20000, 32, B=16)
+    batch = synth.batch_from_regions([g])
+    eng = make_engine("gpu", max_indel_error=16)
+    rb = eng.upload(batch)
+    rb.run(); a = rb.download().copy()
+    rb.run(); b = rb.download().copy()
+    rb.free()
+    assert np.array_equal(a, b)
+    assert np.all(np.isfinite(a)) and np.all(a <= 0)
+    m = a.reshape(32, 20000)
+    sub = dict(g); sub["reads"] = g["reads"][:500]; sub["quals"] = g["quals"][:500]; sub["begin"] = g["begin"][:500]
+    sub["reverse"] = g["reverse"][:500]; sub["mapq"] = g["mapq"][:500]; sub["pos"] = g["pos"][:, :500]
+    small, _ = eng.populate(synth.batch_from_regions([sub]))
+    assert np.array_equal(small.reshape(32, 500), m[:, :500])
+    want, _, _ = oracle.populate(abi.Config.default(max_indel_error=16), synth.batch_from_regions([sub]), n_threads=4)
+    assert np.max(np.abs(want - small)) <= TOL
+    eng.close()
