@@ -152,7 +152,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
     p.rbases = b->d.rbases; p.rquals = b->d.rquals; p.roff = b->d.roff; p.rrev = b->d.rrev; p.hoff = b->d.hoff;
     p.tabF = gen ? b->d.tabGenF : b->d.tabFastF; p.tabR = gen ? b->d.tabGenR : b->d.tabFastR;
     p.pair_best = b->d.pair_best;
-    p.k_cap = b->t_cap + (uint32_t)B; p.t_cap = b->t_cap; p.lh_cap = b->lh_cap;
+    p.k_cap = ((b->t_cap + (uint32_t)B + 3) & ~3u) + 4; p.t_cap = b->t_cap; p.lh_cap = b->lh_cap;
     const uint32_t n4 = ((uint32_t)(int8_t)nuc_prior << 2) & 0xffffu;       // vectorise_left_shift_bits(int8_t), simd_pair_hmm.hpp:74-78,257
     p.nuc4 = n4 | n4 << 16;
     p.groups_per_block = kBlockWaves * kGroupsPerWave;

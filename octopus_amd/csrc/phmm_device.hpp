@@ -69,7 +69,7 @@ struct DpParams {
     const uint32_t* hoff; const uint2* tabF; const uint2* tabR;
     int32_t*  pair_best;                              // score-only kernels: atomicMin target
     uint32_t* bp; TraceEnd* ends;                     // traceback kernels
-    uint32_t  k_cap;                                  // diagonals pairs (T_max + B) the bp scratch is sized for
+    uint32_t  k_cap;                                  // dwords per lane row of the bp scratch: iterations (T_max + B) rounded up to quads
     uint32_t  t_cap;                                  // longest read in the batch
     uint32_t  lh_cap;                                 // longest haplotype in the batch
     uint32_t  nuc4;                                   // packed {nuc_prior << 2, nuc_prior << 2}

@@ -315,11 +315,11 @@ template <int B> OCT_DEVICE uint32_t shift_down(uint32_t fill, uint32_t v, uint3
 template <bool V> struct BoolC { static constexpr bool value = V; };
 
 // LDS footprint of one DP workgroup (bytes) — must match the carve-up in k_dp.
-OCT_HD constexpr uint32_t dp_rec_n(uint32_t t_cap, uint32_t B) { return (t_cap + 2 * B + 2 + 1) & ~1u; }
+OCT_HD constexpr uint32_t dp_rec_n(uint32_t t_cap, uint32_t B) { return (t_cap + 2 * B + 12) & ~3u; }
 inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B)
 {
     const uint32_t rows = 64 / B;
-    return 2 * (lh_cap + 8) * 8 + kBlockWaves * rows * dp_rec_n(t_cap, B) * 12;
+    return 2 * ((lh_cap + 8 + 1) & ~1u) * 8 + kBlockWaves * rows * dp_rec_n(t_cap, B) * 12;
 }
 
 template <int B, bool TRACE, bool GENERIC>
@@ -329,7 +329,7 @@ OCT_KERNEL(k_dp)(DpParams p)
     OCT_DYN_SMEM(smem);
     const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
     const uint32_t row = lane / B, li = lane % B;
-    const uint32_t lh_n = p.lh_cap + 8, rec_n = dp_rec_n(p.t_cap, B);
+    const uint32_t lh_n = (p.lh_cap + 8 + 1) & ~1u, rec_n = dp_rec_n(p.t_cap, B);
     uint2* tabF = (uint2*)smem;                      // [lh_n] forward-strand table of the current haplotype
     uint2* tabR = tabF + lh_n;                       // [lh_n] reverse-strand table
     uint2* recs = tabR + lh_n;                       // [kBlockWaves][ROWS][rec_n] read-side records
@@ -361,28 +361,45 @@ OCT_KERNEL(k_dp)(DpParams p)
             const DevTask tA = p.tasks[g * G + 2 * row], tB = p.tasks[g * G + 2 * row + 1];
             const uint32_t roA = p.roff[tA.read], TA = p.roff[tA.read + 1] - roA;
             const uint32_t roB = p.roff[tB.read], TB = p.roff[tB.read + 1] - roB;
-            uint32_t Tmax = TA > TB ? TA : TB;
-            for (int m = B; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(Tmax, m); Tmax = o > Tmax ? o : Tmax; }
-            const uint32_t K = Tmax + B;
+            uint32_t Tmax = TA > TB ? TA : TB, Tmin = TA < TB ? TA : TB;
+            for (int m = B; m < 64; m <<= 1) {
+                const uint32_t o = hw::shfl_xor(Tmax, m), u = hw::shfl_xor(Tmin, m);
+                Tmax = o > Tmax ? o : Tmax; Tmin = u < Tmin ? u : Tmin;
+            }
+            Tmax = hw::readfirstlane(Tmax); Tmin = hw::readfirstlane(Tmin);          // wave-uniform loop bounds (SGPRs)
+            const uint32_t K4 = (Tmax + B + 3) & ~3u;                                 // iterations, run in quads
 
-            // ---- stage the read-side records of this row: index j holds read position t = j - B ----
-            for (uint32_t j = li; j < Tmax + 2 * B; j += B) {
-                const int32_t t = (int32_t)j - B;
-                const bool inA = t >= 0 && (uint32_t)t < TA, inB = t >= 0 && (uint32_t)t < TB;
-                const uint32_t rA = inA ? ld8(p.rbases + roA + t) : 0, rB = inB ? ld8(p.rbases + roB + t) : 0;
-                const uint32_t qA = inA ? ld8(p.rquals + roA + t) : 64u, qB = inB ? ld8(p.rquals + roB + t) : 64u;   // max_quality_score_, :60,260,280
-                uint2 rec;
-                if constexpr (GENERIC) {
-                    // {target char as int16 (0x7800 = the never-matching _inf fill before the read, '0' after it, :259,279), quality << 2}
-                    const uint32_t cA = inA ? rA : (t < 0 ? 0x7800u : (uint32_t)'0'), cB = inB ? rB : (t < 0 ? 0x7800u : (uint32_t)'0');
-                    rec = make_uint2(cA | cB << 16, (qA << 2) | (qB << 18));
-                } else {
-                    // {v_perm selector picking this base's cap byte out of {capsB, capsA} (0x0d = 0xff = no cap), quality}
-                    const uint32_t sA = inA ? base_code(rA) : 0x0du, sB = inB ? 4u + base_code(rB) : 0x0du;
-                    rec = make_uint2(sA | 0x0c00u | sB << 16 | 0x0c000000u, qA | qB << 16);
+            // ---- stage the read-side records of this row: index j holds read position t = j - B; 4 positions per lane per trip ----
+            for (uint32_t j0 = 4 * li; j0 < K4 + B + 1; j0 += 4 * B) {
+                const int32_t t0 = (int32_t)j0 - B;
+                auto load4 = [&](const uint8_t* base, uint32_t T) -> uint32_t {
+                    if (t0 >= 0 && (uint32_t)t0 + 4 <= T) { uint32_t v; __builtin_memcpy(&v, base + t0, 4); return v; }
+                    uint32_t v = 0;
+                    for (int c = 0; c < 4; ++c) { const int32_t t = t0 + c; if (t >= 0 && (uint32_t)t < T) v |= (uint32_t)base[t] << (8 * c); }
+                    return v;
+                };
+                const uint32_t wrA = load4(p.rbases + roA, TA), wqA = load4(p.rquals + roA, TA);
+                const uint32_t wrB = load4(p.rbases + roB, TB), wqB = load4(p.rquals + roB, TB);
+                uint32_t gq[4];
+                for (int c = 0; c < 4; ++c) {
+                    const int32_t t = t0 + c;
+                    const bool inA = t >= 0 && (uint32_t)t < TA, inB = t >= 0 && (uint32_t)t < TB;
+                    const uint32_t rA = (wrA >> (8 * c)) & 0xffu, rB = (wrB >> (8 * c)) & 0xffu;
+                    const uint32_t qA = inA ? (wqA >> (8 * c)) & 0xffu : 64u, qB = inB ? (wqB >> (8 * c)) & 0xffu : 64u;   // max_quality_score_, :60,260,280
+                    uint2 rec;
+                    if constexpr (GENERIC) {
+                        // {target char as int16 (0x7800 = the never-matching _inf fill before the read, '0' after it, :259,279), quality << 2}
+                        const uint32_t cA = inA ? rA : (t < 0 ? 0x7800u : (uint32_t)'0'), cB = inB ? rB : (t < 0 ? 0x7800u : (uint32_t)'0');
+                        rec = make_uint2(cA | cB << 16, (qA << 2) | (qB << 18));
+                    } else {
+                        // {v_perm selector picking this base's cap byte out of {capsB, capsA} (0x0d = 0xff = no cap), quality}
+                        const uint32_t sA = inA ? base_code(rA) : 0x0du, sB = inB ? 4u + base_code(rB) : 0x0du;
+                        rec = make_uint2(sA | 0x0c00u | sB << 16 | 0x0c000000u, qA | qB << 16);
+                    }
+                    rec_row[j0 + c] = rec;
+                    gq[c] = ((uint32_t)t == TA ? 0u : 0x7fffu) | ((uint32_t)t == TB ? 0u : 0x7fff0000u);
                 }
-                rec_row[j] = rec;
-                gate_row[j] = ((uint32_t)t == TA ? 0u : 0x7fffu) | ((uint32_t)t == TB ? 0u : 0x7fff0000u);
+                *(uint4*)(gate_row + j0) = make_uint4(gq[0], gq[1], gq[2], gq[3]);
             }
             hw::wave_lds_fence();
 
@@ -390,79 +407,85 @@ OCT_KERNEL(k_dp)(DpParams p)
             const uint2* pB = (p.rrev[tB.read] ? tabR : tabF) + tB.off + li;
             const uint2* rp = rec_row + (B - li);
             const uint32_t* gp = gate_row + (B - li);
-            uint32_t* bpw = TRACE ? p.bp + ((size_t)g * p.k_cap) * 64 + lane : nullptr;
+            uint4* bpw = TRACE ? (uint4*)(p.bp + ((size_t)g * 64 + lane) * p.k_cap) : nullptr;   // this lane's backpointer row
 
             uint32_t M1 = INF2, I1 = INF2, D1 = INF2, M2 = INF2, I2 = INF2, D2 = INF2;     // :267
             uint32_t y1 = INF2;                                                             // min(M1, I1) carried between iterations
             uint32_t bestE = INF2, bestO = INF2;                                            // minscore :269, per diagonal parity
-            uint2 cA = pA[0], cB = pB[0];
+            // software pipeline: operands of iteration k are in registers when it starts, those of k+1 are in flight
+            uint2 rr = rp[0];
+            uint2 cA = pA[0], cB = pB[0], nA = pA[1], nB = pB[1];
             uint32_t GO = hw::perm(cB.y, cA.y, 0x05040100u), GE = hw::perm(cB.y, cA.y, 0x07060302u);
+            uint32_t GOn = hw::perm(nB.y, nA.y, 0x05040100u), GEn = hw::perm(nB.y, nA.y, 0x07060302u);
 
-            auto cost = [&](const uint2 rr, const uint2 a, const uint2 b) -> uint32_t {
+            auto cost = [&](const uint2 r2, const uint2 a, const uint2 b) -> uint32_t {
                 if constexpr (GENERIC) {
                     // update_match_state with the reference's equality tests on raw bytes (:121-132)
                     const uint32_t hh = hw::perm(b.x, a.x, 0x0c040c00u), mm = hw::perm(b.x, a.x, 0x0c050c01u);
                     const uint32_t pp = hw::pk_shl2(hw::perm(b.x, a.x, 0x0c060c02u)), nn = hw::perm(b.x, a.x, 0x0c070c03u);
-                    const uint32_t ne = hw::pk_min_u(rr.x ^ hh, 0x00010001u), nf = hw::pk_min_u(rr.x ^ mm, 0x00010001u);
-                    const uint32_t inner = hw::pk_mad(nf, hw::pk_sub(rr.y, pp), pp);        // target == mask ? prior : quality
-                    uint32_t c = hw::pk_mul(ne, hw::pk_min_i(rr.y, inner));                 // 0 where target == truth
+                    const uint32_t ne = hw::pk_min_u(r2.x ^ hh, 0x00010001u), nf = hw::pk_min_u(r2.x ^ mm, 0x00010001u);
+                    const uint32_t inner = hw::pk_mad(nf, hw::pk_sub(r2.y, pp), pp);        // target == mask ? prior : quality
+                    uint32_t c = hw::pk_mul(ne, hw::pk_min_i(r2.y, inner));                 // 0 where target == truth
                     const uint32_t nq = hw::pk_mad(nn, 0x88088808u, INF2);                  // truth == 'N' ? n_score_ (8) : infinity_
                     return hw::pk_min_i(c, nq);
                 } else {
-                    const uint32_t cp = hw::perm(b.x, a.x, rr.x);                           // {capA, capB} for this read base
-                    return hw::pk_min_u(cp, rr.y);                                          // min(quality, cap), unshifted
+                    const uint32_t cp = hw::perm(b.x, a.x, r2.x);                           // {capA, capB} for this read base
+                    return hw::pk_min_u(cp, r2.y);                                          // min(quality, cap), unshifted
                 }
             };
             auto add_cost = [&](uint32_t m, uint32_t c) -> uint32_t {
                 if constexpr (GENERIC) return hw::pk_add(m, c); else return hw::pk_mad(c, 0x00040004u, m);   // + (c << trace_bits_)
             };
 
-            auto step = [&](uint32_t k, auto init_c, auto cap_c) {
+            auto quad = [&](uint32_t k0, auto init_c, auto cap_c) {
                 constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value;
-                const uint2 rr = rp[k];
-                const uint2 nA = pA[k + 1], nB = pB[k + 1];
-                const uint32_t GOn = hw::perm(nB.y, nA.y, 0x05040100u), GEn = hw::perm(nB.y, nA.y, 0x07060302u);
-                uint32_t gate = 0;
-                if constexpr (CAP) gate = gp[k];
-                // ---- even diagonal s = 2k: lane li is cell (t = k-li, x = k+li) ----
-                uint32_t m1 = hw::pk_min_i(y1, D1);                                         // :284
-                if constexpr (INIT) { const bool first = k == li; m1 = first ? NUL2 : m1; M2 = first ? NUL2 : M2; }   // :282-283
-                if constexpr (CAP) bestE = hw::pk_min_i(bestE, hw::pk_add_sat(m1, gate));   // :285-291
-                M1 = add_cost(m1, cost(rr, cA, cB));                                        // :292
-                const uint32_t x2 = hw::pk_min_i(M2, I2);
-                const uint32_t dsh = hw::pk_min_i(hw::pk_add(D2, GEn), hw::pk_add(x2, GOn));
-                D1 = shift_up<B>(INF2, dsh, li);                                            // :293-294
-                I1 = hw::pk_add(hw::pk_min_i(hw::pk_add(I2, GE), hw::pk_add(M2, GO)), NUC); // :295
-                uint32_t bpe = 0;
-                if constexpr (TRACE) {                                                      // update_traceback :147-163
-                    const uint32_t tm = M1 & 0x00030003u, ti = I1 & 0x00030003u, td = D1 & 0x00030003u;
-                    M1 ^= tm; I1 = (I1 & ~0x00030003u) | 0x00010001u; D1 |= 0x00030003u;
-                    bpe = tm | ti << 2 | td << 4;
+                uint32_t bw[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t k = k0 + u;
+                    const uint2 rr_nx = rp[k + 1];                                          // prefetch iteration k+1
+                    const uint2 nnA = pA[k + 2], nnB = pB[k + 2];
+                    uint32_t gate = 0;
+                    if constexpr (CAP) gate = gp[k];
+                    // ---- even diagonal s = 2k: lane li is cell (t = k-li, x = k+li) ----
+                    uint32_t m1 = hw::pk_min_i(y1, D1);                                     // :284
+                    if constexpr (INIT) { const bool first = k == li; m1 = first ? NUL2 : m1; M2 = first ? NUL2 : M2; }   // :282-283
+                    if constexpr (CAP) bestE = hw::pk_min_i(bestE, hw::pk_add_sat(m1, gate));   // :285-291
+                    M1 = add_cost(m1, cost(rr, cA, cB));                                    // :292
+                    const uint32_t x2 = hw::pk_min_i(M2, I2);
+                    const uint32_t dsh = hw::pk_min_i(hw::pk_add(D2, GEn), hw::pk_add(x2, GOn));
+                    D1 = shift_up<B>(INF2, dsh, li);                                        // :293-294
+                    I1 = hw::pk_add(hw::pk_min_i(hw::pk_add(I2, GE), hw::pk_add(M2, GO)), NUC);   // :295
+                    uint32_t bpe = 0;
+                    if constexpr (TRACE) {                                                  // update_traceback :147-163
+                        const uint32_t tm = M1 & 0x00030003u, ti = I1 & 0x00030003u, td = D1 & 0x00030003u;
+                        M1 ^= tm; I1 = (I1 & ~0x00030003u) | 0x00010001u; D1 |= 0x00030003u;
+                        bpe = tm | ti << 2 | td << 4;
+                    }
+                    // ---- odd diagonal s = 2k+1: lane li is cell (t, x+1) ----
+                    const uint32_t m2 = hw::pk_min_i(x2, D2);                               // :308
+                    if constexpr (CAP) bestO = hw::pk_min_i(bestO, hw::pk_add_sat(m2, gate));   // :309-315
+                    M2 = add_cost(m2, cost(rr, nA, nB));                                    // :316
+                    y1 = hw::pk_min_i(M1, I1);
+                    D2 = hw::pk_min_i(hw::pk_add(D1, GEn), hw::pk_add(y1, GOn));            // :317
+                    const uint32_t ish = hw::pk_add(hw::pk_min_i(hw::pk_add(I1, GE), hw::pk_add(M1, GO)), NUC);
+                    I2 = shift_down<B>(INF2, ish, li);                                      // :318-319
+                    if constexpr (TRACE) {
+                        const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
+                        M2 ^= tm; I2 = (I2 & ~0x00030003u) | 0x00010001u; D2 |= 0x00030003u;
+                        bw[u] = bpe | (tm | ti << 2 | td << 4) << 6;
+                    }
+                    rr = rr_nx; cA = nA; cB = nB; GO = GOn; GE = GEn; nA = nnA; nB = nnB;
+                    GOn = hw::perm(nB.y, nA.y, 0x05040100u); GEn = hw::perm(nB.y, nA.y, 0x07060302u);
                 }
-                // ---- odd diagonal s = 2k+1: lane li is cell (t, x+1) ----
-                const uint32_t m2 = hw::pk_min_i(x2, D2);                                   // :308
-                if constexpr (CAP) bestO = hw::pk_min_i(bestO, hw::pk_add_sat(m2, gate));   // :309-315
-                M2 = add_cost(m2, cost(rr, nA, nB));                                        // :316
-                y1 = hw::pk_min_i(M1, I1);
-                D2 = hw::pk_min_i(hw::pk_add(D1, GEn), hw::pk_add(y1, GOn));                // :317
-                const uint32_t ish = hw::pk_add(hw::pk_min_i(hw::pk_add(I1, GE), hw::pk_add(M1, GO)), NUC);
-                I2 = shift_down<B>(INF2, ish, li);                                          // :318-319
-                if constexpr (TRACE) {
-                    const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
-                    M2 ^= tm; I2 = (I2 & ~0x00030003u) | 0x00010001u; D2 |= 0x00030003u;
-                    bpw[(size_t)k * 64] = bpe | (tm | ti << 2 | td << 4) << 6;
-                }
-                cA = nA; cB = nB; GO = GOn; GE = GEn;
+                if constexpr (TRACE) bpw[k0 >> 2] = make_uint4(bw[0], bw[1], bw[2], bw[3]);
             };
 
-            uint32_t Tmin = TA < TB ? TA : TB;
-            for (int m = B; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(Tmin, m); Tmin = o < Tmin ? o : Tmin; }
-            const uint32_t kA = K < (uint32_t)B ? K : (uint32_t)B;       // rolling initialisation lasts B iterations
-            const uint32_t kB = Tmin > kA ? Tmin : kA;                   // no end cell before the shortest read is consumed
+            const uint32_t kB = (Tmin & ~3u) > (uint32_t)B ? (Tmin & ~3u) : (uint32_t)B;   // no end cell before the shortest read is consumed
             uint32_t k = 0;
-            for (; k < kA; ++k) step(k, BoolC<true>{}, BoolC<true>{});
-            for (; k < kB; ++k) step(k, BoolC<false>{}, BoolC<false>{});
-            for (; k < K; ++k)  step(k, BoolC<false>{}, BoolC<true>{});
+            for (; k < (uint32_t)B; k += 4) quad(k, BoolC<true>{}, BoolC<true>{});         // rolling initialisation lasts B iterations
+            for (; k < kB; k += 4) quad(k, BoolC<false>{}, BoolC<false>{});
+            for (; k < K4; k += 4) quad(k, BoolC<false>{}, BoolC<true>{});
 
             // ---- first minimum over the row's end cells, per packed task (:285-291,309-315,323) ----
             for (uint32_t half = 0; half < 2; ++half) {
@@ -525,11 +548,11 @@ OCT_KERNEL(k_walk)(WalkParams w)
     }
     const int32_t rhs_begin = L - rhs;
     const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
-    const uint32_t* bp = w.bp + (size_t)group * w.k_cap * 64 + row * B;
+    const uint32_t* bp = w.bp + ((size_t)group * 64 + row * B) * w.k_cap;      // row of band lane 0 of this task; lane i is i * k_cap further
     auto bits_at = [&](int64_t flat) -> uint32_t {          // 6 backpointer bits of band cell `flat` = diagonal * B + lane
         const int32_t s = (int32_t)(flat / B), i = (int32_t)(flat % B);
         if (s >= 2 * (T + B)) return 0;                     // last row of the reference's array is never written (zeros)
-        return (bp[(size_t)(s >> 1) * 64 + i] >> (16 * half + 6 * (s & 1))) & 63u;
+        return (bp[(size_t)i * w.k_cap + (s >> 1)] >> (16 * half + 6 * (s & 1))) & 63u;
     };
     char* a1 = seam ? w.out_align1 + w.out_align_off[ti] : nullptr;
     char* a2 = seam ? w.out_align2 + w.out_align_off[ti] : nullptr;
