@@ -39,6 +39,7 @@ struct oct_phmm_batch {
     double* d_out = nullptr;
     uint32_t n_tasks[kNumKinds] = {0, 0, 0, 0};
     unsigned long long h_stats[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
     bool ran = false;
     double dp_ms = 0; uint32_t dp_launches = 0;
@@ -146,20 +147,20 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
     const int B = h->band;
     const uint32_t G = 2 * (64 / B);
     const bool tr = kind == kTraceFast || kind == kTraceGen, gen = kind == kScoreGen || kind == kTraceGen;
-    const size_t lds = dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B);
+    const size_t lds = dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr);
     if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
     DpParams p {};
     p.rbases = b->d.rbases; p.rquals = b->d.rquals; p.roff = b->d.roff; p.rrev = b->d.rrev; p.hoff = b->d.hoff;
     p.tabF = gen ? b->d.tabGenF : b->d.tabFastF; p.tabR = gen ? b->d.tabGenR : b->d.tabFastR;
     p.pair_best = b->d.pair_best;
-    p.k_cap = ((b->t_cap + (uint32_t)B + 3) & ~3u) + 4; p.t_cap = b->t_cap; p.lh_cap = b->lh_cap;
+    p.k_cap = bp_tiles(b->t_cap, (uint32_t)B); p.t_cap = b->t_cap; p.lh_cap = b->lh_cap;
     const uint32_t n4 = ((uint32_t)(int8_t)nuc_prior << 2) & 0xffffu;       // vectorise_left_shift_bits(int8_t), simd_pair_hmm.hpp:74-78,257
     p.nuc4 = n4 | n4 << 16;
     p.groups_per_block = kBlockWaves * kGroupsPerWave;
     const uint32_t n_groups = n_tasks / G;
     uint32_t chunk_groups = n_groups;
     if (tr) {
-        const size_t per_group = (size_t)p.k_cap * 64 * sizeof(uint32_t);
+        const size_t per_group = (size_t)p.k_cap * 4096;
         const size_t fit = std::max<size_t>(1, h->bp_budget / per_group);
         chunk_groups = (uint32_t)std::min<size_t>(n_groups, fit);
         chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / p.groups_per_block * p.groups_per_block);
@@ -376,7 +377,7 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     RT(dalloc(bp, &d.hclean, (size_t)H->n_haps));
     RT(dalloc(bp, &d.pair_best, (size_t)b->n_pairs)); RT(dalloc(bp, &d.pair_cls, (size_t)b->n_pairs));
     RT(dalloc(bp, &d.pair_extra, (size_t)b->n_pairs)); RT(dalloc(bp, &d.pair_cnt, (size_t)b->n_pairs + 1));
-    RT(dalloc(bp, &d.stats, (size_t)8)); d.err_key = d.stats + 6;
+    RT(dalloc(bp, &d.stats, (size_t)kStatSlots * 8 + 8)); d.err_key = d.stats + (size_t)kStatSlots * 8;
     RT(dalloc(bp, &b->d_hap_base, (size_t)H->n_haps + 1));
     b->n_tiles = (uint32_t)((b->n_pairs + 1 + kScanTile - 1) / kScanTile);
     RT(dalloc(bp, &b->d_tile_sums, (size_t)b->n_tiles + 1));
@@ -403,7 +404,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
     b->timers.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
     const uint32_t G = 2 * (64 / (uint32_t)h->band);
-    RT(rt::dev_memset(d.stats, 0, 6 * sizeof(unsigned long long), s));
+    RT(rt::dev_memset(d.stats, 0, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s));
     RT(rt::dev_memset(d.err_key, 0xff, sizeof(unsigned long long), s));
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
     if (b->n_pairs) {
@@ -412,7 +413,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d); RT(rt::launch_ok());
         const uint64_t n_scan = b->n_pairs + 1;
         OCT_LAUNCH(k_scan_tiles, b->n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, d.pair_cnt, n_scan, b->d_tile_sums, 0); RT(rt::launch_ok());
-        OCT_LAUNCH(k_scan_tile_sums, 1, 64, 0, s, b->d_tile_sums, b->n_tiles); RT(rt::launch_ok());
+        OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, b->d_tile_sums, b->n_tiles); RT(rt::launch_ok());
         OCT_LAUNCH(k_scan_tiles, b->n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, d.pair_cnt, n_scan, b->d_tile_sums, 1); RT(rt::launch_ok());
         OCT_LAUNCH(k_hap_bases, 1, 64, 0, s, d, b->d_hap_base, G); RT(rt::launch_ok());
         uint4 totals;
@@ -442,7 +443,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         }
     }
     if (b->n_out) { OCT_LAUNCH(k_epilogue, (uint32_t)((b->n_out + 255) / 256), 256, 0, s, d, b->d_out, b->n_out); RT(rt::launch_ok()); }
-    RT(rt::d2h(b->h_stats, d.stats, 6 * sizeof(unsigned long long), s));
+    b->h_stat_stripes.assign((size_t)kStatSlots * 8, 0);
+    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s));
     RT(rt::d2h(&b->h_err_key, d.err_key, sizeof(unsigned long long), s));
     b->ran = true;
     return ok(status);
@@ -453,6 +455,7 @@ extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_ph
     if (!h || !b || b->owner != h || !b->ran) return fail(status, OCT_PHMM_EINVAL, "batch was not run");
     RT(rt::set_device(h->cfg.device_id));
     RT(rt::stream_sync(h->stream));
+    for (int k = 0; k < 6; ++k) { b->h_stats[k] = 0; for (uint32_t sl = 0; sl < kStatSlots; ++sl) b->h_stats[k] += b->h_stat_stripes[(size_t)sl * 8 + k]; }
     b->dp_ms = 0; b->dp_launches = 0;
     for (auto& t : b->timers) { float ms = 0; RT(rt::event_elapsed_ms(&ms, t.first, t.second)); b->dp_ms += ms; ++b->dp_launches; }
     if (b->h_err_key != ~0ull) {

@@ -11,6 +11,7 @@ constexpr int32_t  kNoScore    = 0x7fffffff;   // "lowest()" in the integer pena
 constexpr uint32_t kPadTask    = 0xffffffffu;  // DevTask::pair of a padding task
 constexpr int      kBlockWaves = 4;            // waves per DP workgroup
 constexpr int      kGroupsPerWave = 4;         // task groups each wave works through per workgroup
+constexpr uint32_t kStatSlots  = 256;          // statistics counters are striped over this many 64-byte lines
 
 // Task kinds = DP kernel variants. "fast" = reads are pure ACGT and the haplotype holds only ACGT (and no
 // '0' in its masks), so the match cost is one byte-permute out of a per-position cap table; "generic" = any
@@ -58,7 +59,7 @@ struct DevBatch {
     uint4*    pair_cnt;       // [n_pairs + 1] per-kind task counts, exclusive-scanned in place
     // configuration
     int band, nuc_prior, max_pos, use_mapq, mapq_cap, mapq_trigger;
-    // counters: [0] candidates [1] fast path [2] score-only DP [3] traceback DP [4] band cells [5] pairs
+    // counters, kStatSlots stripes of 8: [0] candidates [1] fast path [2] score-only DP [3] traceback DP [4] band cells [5] pairs
     unsigned long long* stats;
     unsigned long long* err_key;                      // min over failing pairs of (hap << 32 | read); ~0 = none
 };
@@ -69,7 +70,7 @@ struct DpParams {
     const uint32_t* hoff; const uint2* tabF; const uint2* tabR;
     int32_t*  pair_best;                              // score-only kernels: atomicMin target
     uint32_t* bp; TraceEnd* ends;                     // traceback kernels
-    uint32_t  k_cap;                                  // dwords per lane row of the bp scratch: iterations (T_max + B) rounded up to quads
+    uint32_t  k_cap;                                  // 16-iteration backpointer tiles (4 KB each) per task group in the bp scratch
     uint32_t  t_cap;                                  // longest read in the batch
     uint32_t  lh_cap;                                 // longest haplotype in the batch
     uint32_t  nuc4;                                   // packed {nuc_prior << 2, nuc_prior << 2}

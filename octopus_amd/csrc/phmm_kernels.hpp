@@ -189,12 +189,14 @@ OCT_KERNEL(k_classify)(DevBatch b)
     st_cand = wave_sum(st_cand); st_fast = wave_sum(st_fast); st_score = wave_sum(st_score);
     st_trace = wave_sum(st_trace); st_cells = wave_sum(st_cells); st_pairs = wave_sum(st_pairs);
     if ((hw::thread_idx() & 63) == 0) {
-        if (st_cand)  hw::atomic_add_u64(b.stats + 0, st_cand);
-        if (st_fast)  hw::atomic_add_u64(b.stats + 1, st_fast);
-        if (st_score) hw::atomic_add_u64(b.stats + 2, st_score);
-        if (st_trace) hw::atomic_add_u64(b.stats + 3, st_trace);
-        if (st_cells) hw::atomic_add_u64(b.stats + 4, st_cells);
-        if (st_pairs) hw::atomic_add_u64(b.stats + 5, st_pairs);
+        // counters are spread over kStatSlots cache lines (summed on the host) so that ~10^5 waves do not serialise on one line
+        unsigned long long* st = b.stats + (size_t)(hw::block_idx() % kStatSlots) * 8;
+        if (st_cand)  hw::atomic_add_u64(st + 0, st_cand);
+        if (st_fast)  hw::atomic_add_u64(st + 1, st_fast);
+        if (st_score) hw::atomic_add_u64(st + 2, st_score);
+        if (st_trace) hw::atomic_add_u64(st + 3, st_trace);
+        if (st_cells) hw::atomic_add_u64(st + 4, st_cells);
+        if (st_pairs) hw::atomic_add_u64(st + 5, st_pairs);
     }
 }
 
@@ -230,11 +232,25 @@ OCT_KERNEL(k_scan_tiles)(uint4* data, uint64_t n, uint4* tile_sums, int apply)
     for (uint32_t i = 0; i < kScanItems; ++i) if (base + i < n) { data[base + i] = run; run = add4(run, v[i]); }
 }
 
-OCT_KERNEL(k_scan_tile_sums)(uint4* tile_sums, uint32_t n_tiles)
+OCT_KERNEL(k_scan_tile_sums)(uint4* tile_sums, uint32_t n_tiles)   // one block of kScanThreads threads
 {
-    if (hw::thread_idx() != 0 || hw::block_idx() != 0) return;
-    uint4 run = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = 0; i < n_tiles; ++i) { const uint4 v = tile_sums[i]; tile_sums[i] = run; run = add4(run, v); }
+    OCT_DYN_SMEM(smem);
+    uint4* sh = (uint4*)smem;
+    const uint32_t tid = hw::thread_idx();
+    const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads, lo = tid * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    uint4 sum = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lo; i < hi; ++i) sum = add4(sum, tile_sums[i]);
+    sh[tid] = sum;
+    hw::block_sync();
+    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (tid >= d) o = sh[tid - d];
+        hw::block_sync();
+        sh[tid] = add4(sh[tid], o);
+        hw::block_sync();
+    }
+    uint4 run = tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lo; i < hi; ++i) { const uint4 v = tile_sums[i]; tile_sums[i] = run; run = add4(run, v); }
 }
 
 // Per haplotype and kind: first task slot, with every haplotype's task run padded to a multiple of the group size so
@@ -316,11 +332,14 @@ template <bool V> struct BoolC { static constexpr bool value = V; };
 
 // LDS footprint of one DP workgroup (bytes) — must match the carve-up in k_dp.
 OCT_HD constexpr uint32_t dp_rec_n(uint32_t t_cap, uint32_t B) { return (t_cap + 2 * B + 12) & ~3u; }
-inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B)
+constexpr uint32_t kTileStride = 66;   // dwords per row of the 16 x 64 backpointer transpose tile (66: conflict-free both ways)
+inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool trace)
 {
     const uint32_t rows = 64 / B;
-    return 2 * ((lh_cap + 8 + 1) & ~1u) * 8 + kBlockWaves * rows * dp_rec_n(t_cap, B) * 12;
+    return 2 * ((lh_cap + 8 + 1) & ~1u) * 8 + kBlockWaves * rows * dp_rec_n(t_cap, B) * 8 + (trace ? kBlockWaves * 16 * kTileStride * 4 : 0);
 }
+// traceback scratch: per task group, ceil(iterations / 16) tiles of 64 lanes x 16 iterations, each lane's 16 dwords contiguous
+OCT_HD constexpr uint32_t bp_tiles(uint32_t t_cap, uint32_t B) { return (t_cap + B + 15) / 16 + 1; }
 
 template <int B, bool TRACE, bool GENERIC>
 OCT_KERNEL(k_dp)(DpParams p)
@@ -333,9 +352,9 @@ OCT_KERNEL(k_dp)(DpParams p)
     uint2* tabF = (uint2*)smem;                      // [lh_n] forward-strand table of the current haplotype
     uint2* tabR = tabF + lh_n;                       // [lh_n] reverse-strand table
     uint2* recs = tabR + lh_n;                       // [kBlockWaves][ROWS][rec_n] read-side records
-    uint32_t* gates = (uint32_t*)(recs + kBlockWaves * ROWS * rec_n);   // [kBlockWaves][ROWS][rec_n] end-cell gates
+    uint32_t* tiles = (uint32_t*)(recs + kBlockWaves * ROWS * rec_n);   // [kBlockWaves][16][kTileStride] backpointer transpose tiles (TRACE)
     uint2* rec_row = recs + (wave * ROWS + row) * rec_n;
-    uint32_t* gate_row = gates + (wave * ROWS + row) * rec_n;
+    uint32_t* tile = tiles + wave * 16 * kTileStride;
 
     const uint32_t n_groups = p.n_tasks / G;
     const uint32_t g_begin = hw::block_idx() * p.groups_per_block;
@@ -380,7 +399,6 @@ OCT_KERNEL(k_dp)(DpParams p)
                 };
                 const uint32_t wrA = load4(p.rbases + roA, TA), wqA = load4(p.rquals + roA, TA);
                 const uint32_t wrB = load4(p.rbases + roB, TB), wqB = load4(p.rquals + roB, TB);
-                uint32_t gq[4];
                 for (int c = 0; c < 4; ++c) {
                     const int32_t t = t0 + c;
                     const bool inA = t >= 0 && (uint32_t)t < TA, inB = t >= 0 && (uint32_t)t < TB;
@@ -397,17 +415,15 @@ OCT_KERNEL(k_dp)(DpParams p)
                         rec = make_uint2(sA | 0x0c00u | sB << 16 | 0x0c000000u, qA | qB << 16);
                     }
                     rec_row[j0 + c] = rec;
-                    gq[c] = ((uint32_t)t == TA ? 0u : 0x7fffu) | ((uint32_t)t == TB ? 0u : 0x7fff0000u);
                 }
-                *(uint4*)(gate_row + j0) = make_uint4(gq[0], gq[1], gq[2], gq[3]);
             }
             hw::wave_lds_fence();
 
             const uint2* pA = (p.rrev[tA.read] ? tabR : tabF) + tA.off + li;
             const uint2* pB = (p.rrev[tB.read] ? tabR : tabF) + tB.off + li;
             const uint2* rp = rec_row + (B - li);
-            const uint32_t* gp = gate_row + (B - li);
-            uint4* bpw = TRACE ? (uint4*)(p.bp + ((size_t)g * 64 + lane) * p.k_cap) : nullptr;   // this lane's backpointer row
+            const uint32_t kendA = TA + li, kendB = TB + li;          // the iteration whose M cells are this lane's end cells (t == T)
+            uint4* bpg = TRACE ? (uint4*)(p.bp + (size_t)g * p.k_cap * 1024) : nullptr;   // this group's tiles (k_cap tiles of 4 KB)
 
             uint32_t M1 = INF2, I1 = INF2, D1 = INF2, M2 = INF2, I2 = INF2, D2 = INF2;     // :267
             uint32_t y1 = INF2;                                                             // min(M1, I1) carried between iterations
@@ -437,16 +453,29 @@ OCT_KERNEL(k_dp)(DpParams p)
                 if constexpr (GENERIC) return hw::pk_add(m, c); else return hw::pk_mad(c, 0x00040004u, m);   // + (c << trace_bits_)
             };
 
+            // every 16 iterations: transpose the 16 x 64 tile through LDS so that each lane's 16 words become one 64-byte line and
+            // the wave stores 4 fully coalesced 1 KB pieces (k_walk then fetches one line per 16 walk steps)
+            auto flush_tile = [&](uint32_t kt) {
+                hw::wave_lds_fence();
+                uint4* dst = bpg + (size_t)kt * 256;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t src = 16 * j + (lane >> 2), kq = (lane & 3) * 4;
+                    dst[j * 64 + lane] = make_uint4(tile[(kq + 0) * kTileStride + src], tile[(kq + 1) * kTileStride + src],
+                                                    tile[(kq + 2) * kTileStride + src], tile[(kq + 3) * kTileStride + src]);
+                }
+                hw::wave_lds_fence();
+            };
+
             auto quad = [&](uint32_t k0, auto init_c, auto cap_c) {
                 constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value;
-                uint32_t bw[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t k = k0 + u;
                     const uint2 rr_nx = rp[k + 1];                                          // prefetch iteration k+1
                     const uint2 nnA = pA[k + 2], nnB = pB[k + 2];
-                    uint32_t gate = 0;
-                    if constexpr (CAP) gate = gp[k];
+                    uint32_t gate = 0;                                                      // 0 on an end cell, +32767 (saturating) elsewhere
+                    if constexpr (CAP) gate = (k == kendA ? 0u : 0x7fffu) | (k == kendB ? 0u : 0x7fff0000u);
                     // ---- even diagonal s = 2k: lane li is cell (t = k-li, x = k+li) ----
                     uint32_t m1 = hw::pk_min_i(y1, D1);                                     // :284
                     if constexpr (INIT) { const bool first = k == li; m1 = first ? NUL2 : m1; M2 = first ? NUL2 : M2; }   // :282-283
@@ -473,12 +502,14 @@ OCT_KERNEL(k_dp)(DpParams p)
                     if constexpr (TRACE) {
                         const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
                         M2 ^= tm; I2 = (I2 & ~0x00030003u) | 0x00010001u; D2 |= 0x00030003u;
-                        bw[u] = bpe | (tm | ti << 2 | td << 4) << 6;
+                        tile[(k & 15) * kTileStride + lane] = bpe | (tm | ti << 2 | td << 4) << 6;
                     }
                     rr = rr_nx; cA = nA; cB = nB; GO = GOn; GE = GEn; nA = nnA; nB = nnB;
                     GOn = hw::perm(nB.y, nA.y, 0x05040100u); GEn = hw::perm(nB.y, nA.y, 0x07060302u);
                 }
-                if constexpr (TRACE) bpw[k0 >> 2] = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+                if constexpr (TRACE) {
+                    if (((k0 + 4) & 15) == 0) flush_tile(k0 >> 4);
+                }
             };
 
             const uint32_t kB = (Tmin & ~3u) > (uint32_t)B ? (Tmin & ~3u) : (uint32_t)B;   // no end cell before the shortest read is consumed
@@ -486,6 +517,7 @@ OCT_KERNEL(k_dp)(DpParams p)
             for (; k < (uint32_t)B; k += 4) quad(k, BoolC<true>{}, BoolC<true>{});         // rolling initialisation lasts B iterations
             for (; k < kB; k += 4) quad(k, BoolC<false>{}, BoolC<false>{});
             for (; k < K4; k += 4) quad(k, BoolC<false>{}, BoolC<true>{});
+            if constexpr (TRACE) { if (K4 & 15) flush_tile(K4 >> 4); }
 
             // ---- first minimum over the row's end cells, per packed task (:285-291,309-315,323) ----
             for (uint32_t half = 0; half < 2; ++half) {
@@ -548,11 +580,17 @@ OCT_KERNEL(k_walk)(WalkParams w)
     }
     const int32_t rhs_begin = L - rhs;
     const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
-    const uint32_t* bp = w.bp + ((size_t)group * 64 + row * B) * w.k_cap;      // row of band lane 0 of this task; lane i is i * k_cap further
+    // backpointers of this group: k_cap tiles of [64 lanes][16 iterations] dwords; one 64-byte line = 16 consecutive iterations of one lane
+    const uint4* bpg = (const uint4*)(w.bp + (size_t)group * w.k_cap * 1024);
+    uint32_t line_id = 0xffffffffu; uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
     auto bits_at = [&](int64_t flat) -> uint32_t {          // 6 backpointer bits of band cell `flat` = diagonal * B + lane
         const int32_t s = (int32_t)(flat / B), i = (int32_t)(flat % B);
         if (s >= 2 * (T + B)) return 0;                     // last row of the reference's array is never written (zeros)
-        return (bp[(size_t)i * w.k_cap + (s >> 1)] >> (16 * half + 6 * (s & 1))) & 63u;
+        const uint32_t k = (uint32_t)s >> 1, id = (k >> 4) * 64 + row * B + (uint32_t)i;
+        if (id != line_id) { const uint4* l = bpg + (size_t)id * 4; c0 = l[0]; c1 = l[1]; c2 = l[2]; c3 = l[3]; line_id = id; }
+        const uint4 q = (k & 8) ? ((k & 4) ? c3 : c2) : ((k & 4) ? c1 : c0);
+        const uint32_t wv = (k & 2) ? ((k & 1) ? q.w : q.z) : ((k & 1) ? q.y : q.x);
+        return (wv >> (16 * half + 6 * (s & 1))) & 63u;
     };
     char* a1 = seam ? w.out_align1 + w.out_align_off[ti] : nullptr;
     char* a2 = seam ? w.out_align2 + w.out_align_off[ti] : nullptr;
