@@ -3,6 +3,7 @@
 #include "../../include/oct_phmm.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <memory>
@@ -23,7 +24,9 @@ struct oct_phmm_handle {
     rt::Stream stream {};
     rt::Event ev[2] {};
     uint32_t* bp = nullptr; size_t bp_bytes = 0;          // traceback scratch, grown on demand
-    size_t bp_budget = (size_t)2 << 30;
+    // traceback scratch budget: large, so that all traceback tasks of a batch run in ONE DP launch and ONE walk launch (the walk
+    // is a latency-bound pointer chase that needs every task in flight to hide it); MI355X has 288 GB. OCT_PHMM_BP_BUDGET_GB overrides.
+    size_t bp_budget = (size_t)96 << 30;
 };
 
 struct oct_phmm_batch {
@@ -243,6 +246,7 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     h->cfg = *cfg; h->band = band;
     if (h->cfg.mapping_quality_cap_trigger >= 0 && h->cfg.mapping_quality_cap_trigger >= h->cfg.mapping_quality_cap)
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
+    if (const char* e = getenv("OCT_PHMM_BP_BUDGET_GB")) { const long gb = atol(e); if (gb > 0) h->bp_budget = (size_t)gb << 30; }
     if (!rt::stream_create(&h->stream)) return OCT_PHMM_EHIP;
     *out = h.release();
     return OCT_PHMM_OK;

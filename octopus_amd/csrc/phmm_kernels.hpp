@@ -612,9 +612,9 @@ OCT_KERNEL(k_walk)(WalkParams w)
             const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;   // :200 (our D bits sit at 4-5)
             if (state == 0) {                               // match :201-204
                 sidx -= 2; --x; --y;
-                const uint32_t hc = truth[x], rc = target[y];
-                if (seam) { a1[alnidx] = (char)hc; a2[alnidx] = (char)rc; }
+                if (seam) { a1[alnidx] = (char)truth[x]; a2[alnidx] = (char)target[y]; }
                 if (want_flank && (x < lhs || x >= rhs_begin)) {                      // calculate_flank_score_helper :383-397
+                    const uint32_t hc = truth[x], rc = target[y];
                     if (hc != rc) {
                         if (hc != 'N') { int32_t q = quals[y]; if (mask[x] == rc && prior[x] < q) q = prior[x]; flank += q; }
                         else flank += 2;
