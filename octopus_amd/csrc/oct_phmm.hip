@@ -122,11 +122,13 @@ bool launch_dp(int band, bool tr, bool gen, const DpParams& p, uint32_t n_blocks
 bool launch_walk(int band, const WalkParams& w, rt::Stream s)
 {
     const uint32_t blocks = (w.n_tasks + 255) / 256;
+    const size_t lds = 256 * kWalkEvents * sizeof(uint32_t);
+    const bool strings = w.out_align1 != nullptr;      // test seam: the gapped strings come from the simple per-step walker
     switch (band) {
-        case 8:  OCT_LAUNCH((k_walk<8>), blocks, 256, 0, s, w); break;
-        case 16: OCT_LAUNCH((k_walk<16>), blocks, 256, 0, s, w); break;
-        case 32: OCT_LAUNCH((k_walk<32>), blocks, 256, 0, s, w); break;
-        case 64: OCT_LAUNCH((k_walk<64>), blocks, 256, 0, s, w); break;
+        case 8:  OCT_LAUNCH((k_walk<8>), blocks, 256, lds, s, w);  if (strings) OCT_LAUNCH((k_walk_strings<8>), blocks, 256, 0, s, w); break;
+        case 16: OCT_LAUNCH((k_walk<16>), blocks, 256, lds, s, w); if (strings) OCT_LAUNCH((k_walk_strings<16>), blocks, 256, 0, s, w); break;
+        case 32: OCT_LAUNCH((k_walk<32>), blocks, 256, lds, s, w); if (strings) OCT_LAUNCH((k_walk_strings<32>), blocks, 256, 0, s, w); break;
+        case 64: OCT_LAUNCH((k_walk<64>), blocks, 256, lds, s, w); if (strings) OCT_LAUNCH((k_walk_strings<64>), blocks, 256, 0, s, w); break;
         default: return false;
     }
     return rt::launch_ok();

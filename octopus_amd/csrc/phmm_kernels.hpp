@@ -480,7 +480,8 @@ OCT_KERNEL(k_dp)(DpParams p)
                     uint32_t m1 = hw::pk_min_i(y1, D1);                                     // :284
                     if constexpr (INIT) { const bool first = k == li; m1 = first ? NUL2 : m1; M2 = first ? NUL2 : M2; }   // :282-283
                     if constexpr (CAP) bestE = hw::pk_min_i(bestE, hw::pk_add_sat(m1, gate));   // :285-291
-                    M1 = add_cost(m1, cost(rr, cA, cB));                                    // :292
+                    const uint32_t ce = cost(rr, cA, cB);
+                    M1 = add_cost(m1, ce);                                                  // :292
                     const uint32_t x2 = hw::pk_min_i(M2, I2);
                     const uint32_t dsh = hw::pk_min_i(hw::pk_add(D2, GEn), hw::pk_add(x2, GOn));
                     D1 = shift_up<B>(INF2, dsh, li);                                        // :293-294
@@ -489,12 +490,13 @@ OCT_KERNEL(k_dp)(DpParams p)
                     if constexpr (TRACE) {                                                  // update_traceback :147-163
                         const uint32_t tm = M1 & 0x00030003u, ti = I1 & 0x00030003u, td = D1 & 0x00030003u;
                         M1 ^= tm; I1 = (I1 & ~0x00030003u) | 0x00010001u; D1 |= 0x00030003u;
-                        bpe = tm | ti << 2 | td << 4;
+                        bpe = tm | ti << 2 | td << 4 | hw::pk_min_u(ce, 0x00010001u) << 12;   // + "this match cell costs something" flag
                     }
                     // ---- odd diagonal s = 2k+1: lane li is cell (t, x+1) ----
                     const uint32_t m2 = hw::pk_min_i(x2, D2);                               // :308
                     if constexpr (CAP) bestO = hw::pk_min_i(bestO, hw::pk_add_sat(m2, gate));   // :309-315
-                    M2 = add_cost(m2, cost(rr, nA, nB));                                    // :316
+                    const uint32_t co = cost(rr, nA, nB);
+                    M2 = add_cost(m2, co);                                                  // :316
                     y1 = hw::pk_min_i(M1, I1);
                     D2 = hw::pk_min_i(hw::pk_add(D1, GEn), hw::pk_add(y1, GOn));            // :317
                     const uint32_t ish = hw::pk_add(hw::pk_min_i(hw::pk_add(I1, GE), hw::pk_add(M1, GO)), NUC);
@@ -502,7 +504,7 @@ OCT_KERNEL(k_dp)(DpParams p)
                     if constexpr (TRACE) {
                         const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
                         M2 ^= tm; I2 = (I2 & ~0x00030003u) | 0x00010001u; D2 |= 0x00030003u;
-                        tile[(k & 15) * kTileStride + lane] = bpe | (tm | ti << 2 | td << 4) << 6;
+                        tile[(k & 15) * kTileStride + lane] = bpe | (tm | ti << 2 | td << 4) << 6 | hw::pk_min_u(co, 0x00010001u) << 13;
                     }
                     rr = rr_nx; cA = nA; cB = nB; GO = GOn; GE = GEn; nA = nnA; nB = nnB;
                     GOn = hw::perm(nB.y, nA.y, 0x05040100u); GEn = hw::perm(nB.y, nA.y, 0x07060302u);
@@ -548,7 +550,7 @@ OCT_KERNEL(k_dp)(DpParams p)
 // traceback walk + flank score
 // ------------------------------------------------------------------------------------------------------------------
 template <int B>
-OCT_KERNEL(k_walk)(WalkParams w)
+OCT_KERNEL(k_walk_strings)(WalkParams w)   // test seam only: emits the gapped strings (set_alignments :165-231), one step per iteration
 {
     constexpr uint32_t ROWS = 64 / B, G = 2 * ROWS;
     const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
@@ -641,15 +643,158 @@ OCT_KERNEL(k_walk)(WalkParams w)
         first_pos = x;
     }
     if (!ok) first_pos = -1;
-    if (seam) {
-        w.out_first_pos[ti] = first_pos;
+    if (seam) {                                             // first_pos / flank score / mask size are reported by k_walk
         if (ok) {
             a1[alnidx] = 0; a2[alnidx] = 0;
             for (int32_t a = 0, b = alnidx - 1; a < b; ++a, --b) {   // :223-230
                 char c = a1[a]; a1[a] = a1[b]; a1[b] = c; c = a2[a]; a2[a] = a2[b]; a2[b] = c;
             }
-            if (want_flank) { w.out_flank[ti] = flank; w.out_mask_size[ti] = msz; }
-        } else if (want_flank) { w.out_flank[ti] = 0; w.out_mask_size[ti] = 0; }
+        }
+        (void)first_pos;
+        return;
+    }
+    if (!ok) return;                                        // lowest(): contributes nothing to the max (pair_hmm.hpp:750-752)
+    if (T - msz < 2) flank = 0;                             // :757-759
+    const int32_t score = end.score;
+    const int32_t pen = flank <= score ? score - flank : flank + score;   // :760-764
+    hw::atomic_min_i32(w.pair_best + t.pair, pen);
+}
+
+// Production walk: one thread per traceback task, all 64 tasks of a wave sweep the band iterations k from the top tile down IN
+// LOCKSTEP. Per 16-iteration tile every lane holds its own 64-byte backpointer line in registers (statically indexed in the
+// unrolled sweep), so a tile costs one batch of line loads for the whole wave instead of a memory round trip per step. In-flank
+// penalties are not loaded while walking: the DP left a "this match cell costs something" flag next to the labels, gap columns are
+// rare, and both are queued as events in LDS and priced in a second uniform loop.
+constexpr uint32_t kWalkEvents = 12;
+
+template <int B>
+OCT_KERNEL(k_walk)(WalkParams w)
+{
+    constexpr uint32_t ROWS = 64 / B, G = 2 * ROWS;
+    OCT_DYN_SMEM(smem);
+    uint32_t* evbuf = (uint32_t*)smem + hw::thread_idx() * kWalkEvents;
+    const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    DevTask t; t.pair = kPadTask; t.read = 0; t.hap = 0; t.off = 0;
+    if (ti < w.n_tasks) t = w.tasks[ti];
+    const bool active = t.pair != kPadTask;
+    TraceEnd end; end.score = 0; end.sidx = -1;
+    if (active) end = w.ends[ti];
+    const uint32_t group = ti / G, slot = ti % G, row = slot >> 1, half = slot & 1;
+    const uint32_t ro = w.roff[t.read]; const int32_t T = active ? (int32_t)(w.roff[t.read + 1] - ro) : 1;
+    const uint32_t ho = w.hoff[t.hap]; const int32_t Lh = (int32_t)(w.hoff[t.hap + 1] - ho);
+    const int32_t L = T + 2 * B - 1, off = (int32_t)t.off;
+    const bool seam = w.out_first_pos != nullptr;
+    int32_t lhs = 0, rhs = 0; bool want_flank = true;                     // flank sizes in window coordinates (pair_hmm.hpp:572-587)
+    if (seam) {
+        want_flank = w.seam_lhs != nullptr;
+        if (want_flank && active) { lhs = w.seam_lhs[ti]; rhs = w.seam_rhs[ti]; }
+    } else if (active) {
+        const uint32_t g = w.hap_region[t.hap];
+        lhs = (int32_t)w.reg_lhs[g];
+        if (lhs < off) lhs = 0; else { lhs -= off; if (lhs < 0) lhs = 0; }
+        rhs = (int32_t)w.reg_rhs[g];
+        if (off + L < Lh - rhs) rhs = 0; else { rhs += off + L; rhs -= Lh; if (rhs < 0) rhs = 0; }
+    }
+    const int32_t rhs_begin = L - rhs;
+    const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
+    const uint4* bpg = (const uint4*)(w.bp + (size_t)group * w.k_cap * 1024);
+    const uint32_t hshift = 16 * half;
+
+    // walker state (set_alignments :180-193)
+    int32_t sidx = end.sidx, i = sidx / 2 - T, y = T, x = sidx - T;
+    int32_t flank = 0, msz = 0; uint32_t nev = 0, state = 0;
+    bool ok = active && sidx >= 0, fin = !ok, started = false;
+    if (ok) { const int64_t f0 = (int64_t)sidx * B + i; if (f0 < 0 || f0 >= n_flat) { ok = false; fin = true; } }   // :186-190
+
+    auto price_event = [&](uint32_t e) {                                  // calculate_flank_score_helper :383-424, for one alignment column
+        const uint32_t kind = e >> 30; const int32_t ex = (int32_t)(e & 0x7fffu), ey = (int32_t)((e >> 15) & 0x7fffu);
+        const uint32_t hb = ho + (uint32_t)off + (uint32_t)ex;
+        if (kind == 0) {
+            const bool fwd = !w.rrev[t.read];
+            const uint32_t hc = w.hbases[hb], rc = w.rbases[ro + ey];
+            if (hc != rc) {
+                if (hc != 'N') {
+                    int32_t q = ((const int8_t*)w.rquals)[ro + ey];
+                    const uint32_t m = (fwd ? w.maskF : w.maskR)[hb]; const int32_t pr = (fwd ? w.priorF : w.priorR)[hb];
+                    if (m == rc && pr < q) q = pr;
+                    flank += q;
+                } else flank += 2;
+            }
+        } else flank += (kind == 1 ? w.go : w.ge)[hb];
+    };
+    auto push_event = [&](uint32_t kind, int32_t ex, int32_t ey) {
+        const uint32_t e = kind << 30 | (uint32_t)ey << 15 | (uint32_t)ex;
+        if (nev < kWalkEvents) evbuf[nev++] = e; else price_event(e);
+    };
+    // one alignment column from backpointer word `wv` of cell (sidx, i)
+    auto step = [&](uint32_t wv) {
+        const uint32_t par = (uint32_t)sidx & 1u;
+        const uint32_t bits = (wv >> (hshift + 6 * par)) & 63u, mism = (wv >> (hshift + 12 + par)) & 1u;
+        if (!started) { state = bits & 3u; sidx -= 2; started = true; return; }                 // :191-192
+        const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;                 // :200
+        if (state == 0) {                                                                       // match :201-204, :383-397
+            sidx -= 2; --x; --y;
+            if (want_flank && (x < lhs || x >= rhs_begin)) { ++msz; if (mism) push_event(0, x, y); }
+        } else if (state == 1) {                                                                // insert :205-209, :399-411
+            i += sidx & 1; sidx -= 1; --y;
+            if (want_flank && (x < lhs || x >= rhs_begin)) {
+                ++msz; flank += w.nuc_prior;
+                push_event((y != 0 && new_state == 1) ? 2u : 1u, x - 1 < 0 ? 0 : x - 1, 0);     // x-1 == -1 is out of bounds in the reference (UB): clamp
+            }
+        } else {                                                                                // delete :210-215, :413-424
+            sidx -= 1; i -= sidx & 1; --x;
+            if (want_flank && (x < lhs || x >= rhs_begin)) push_event(new_state == 3 ? 2u : 1u, x, 0);
+        }
+        state = new_state;
+        if (y <= 0) fin = true;                                                                 // :194
+    };
+    auto slow_word = [&](int64_t flat) -> uint32_t {                                            // any cell by flat index = diagonal * B + lane
+        const int32_t s = (int32_t)(flat / B), li = (int32_t)(flat % B);
+        if (s >= 2 * (T + B)) return 0;                                                         // last row of the reference's array is never written
+        const uint32_t k = (uint32_t)s >> 1;
+        return w.bp[(size_t)group * w.k_cap * 1024 + ((size_t)(k >> 4) * 64 + row * B + (uint32_t)li) * 16 + (k & 15)];
+    };
+
+    uint32_t kmax = ok ? (uint32_t)(sidx >> 1) : 0;
+    for (int m = 1; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(kmax, m); kmax = o > kmax ? o : kmax; }
+    kmax = hw::readfirstlane(kmax);
+    for (int32_t kt = (int32_t)(kmax >> 4); kt >= 0; --kt) {
+        uint32_t c[16];
+        int32_t line_i = -1;
+        auto load_line = [&]() {
+            const uint4* l = bpg + ((size_t)kt * 64 + row * B + (uint32_t)i) * 4;
+            const uint4 q0 = l[0], q1 = l[1], q2 = l[2], q3 = l[3];
+            c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y; c[6] = q1.z; c[7] = q1.w;
+            c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w; c[12] = q3.x; c[13] = q3.y; c[14] = q3.z; c[15] = q3.w;
+            line_i = i;
+        };
+        if (!fin && i >= 0 && i < B) load_line(); else { for (int q = 0; q < 16; ++q) c[q] = 0; }
+#pragma unroll
+        for (int kk = 15; kk >= 0; --kk) {
+            const int32_t k = kt * 16 + kk;
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                if (!fin && (sidx >> 1) == k && sidx >= 0) {
+                    if (i < 0) { ok = false; fin = true; }                                      // :195-199
+                    else if (i >= B) {                                                          // the reference indexes its array flat: lane overflow reads the next diagonal
+                        const int64_t f = (int64_t)sidx * B + i;
+                        if (f >= n_flat) { ok = false; fin = true; } else step(slow_word(f));
+                    } else {
+                        if (i != line_i) load_line();
+                        step(c[kk]);
+                    }
+                }
+            }
+        }
+    }
+    if (!fin) ok = false;                                                                       // ran off the first diagonal with target bases left (:195-199)
+    const int32_t first_pos = ok ? x : -1;
+    if (ok) for (uint32_t e = 0; e < nev; ++e) price_event(evbuf[e]);
+    if (seam) {
+        if (active) {
+            w.out_first_pos[ti] = first_pos;
+            if (want_flank) { w.out_flank[ti] = ok ? flank : 0; w.out_mask_size[ti] = ok ? msz : 0; }
+        }
         return;
     }
     if (!ok) return;                                        // lowest(): contributes nothing to the max (pair_hmm.hpp:750-752)
