@@ -47,7 +47,7 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
     cfg = abi.Config.default(max_indel_error=B)
     rng = np.random.default_rng(seed)
     R, H = 4000, 32
-    batch = synth.batch_from_regions([synth.make_region(rng, R, H, B=B)])
+    batch = synth.batch_from_regions([synth.make_region(rng, R, H, B=B, positions="none")])
     t0 = time.perf_counter()
     _, st, stats = oracle.populate(cfg, batch, n_threads=cores)
     dt = time.perf_counter() - t0
@@ -99,7 +99,7 @@ def main():
     T, LH = 150, 300
     cfg = abi.Config.default(max_indel_error=B, device_id=local_rank)
     eng = engine.Engine(cfg)                      # fails loudly if liboct_phmm.so / a gfx950 device is missing
-    batch = synth.config_batch(args.workload, seed=42 + rank, B=B)
+    batch = synth.config_batch(args.workload, seed=42 + rank, B=B, positions="none")   # candidate positions come from the device k-mer mapper
     rb = eng.upload(batch)                        # inputs resident in HBM before the timed region
 
     def sync_all():
@@ -157,7 +157,7 @@ def main():
                                   "note": "the path is integer-VALU bound (SURVEY.md §8d); reference-op accounting, int32-lane peak"}},
         }
         if world == 1:
-            small = eng.upload(synth.config_batch("1kx64", seed=42, B=B))
+            small = eng.upload(synth.config_batch("1kx64", seed=42, B=B, positions="none"))
             for _ in range(3):
                 small.run(); small.wait()
             t1 = time.perf_counter()

@@ -44,7 +44,8 @@ struct oct_phmm_batch {
     unsigned long long h_stats[6] = {0, 0, 0, 0, 0, 0};
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
-    bool ran = false;
+    bool ran = false, device_map = false;
+    uint32_t* d_blk_hap = nullptr; uint32_t* d_blk_read0 = nullptr; uint32_t n_map_blocks = 0;
     double dp_ms = 0; uint32_t dp_launches = 0;
     std::vector<std::pair<rt::Event, rt::Event>> timers;
     oct_phmm_handle* owner = nullptr;
@@ -285,7 +286,6 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
 {
     if (!h || !R || !H || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
     *out = nullptr;
-    if (!positions) return fail(status, OCT_PHMM_EUNSUPPORTED, "device k-mer mapping not built yet: pass mapping positions");
     if ((R->n_reads && (!R->bases || !R->qualities || !R->offsets || !R->mapping_quality || !R->reverse_strand || !R->ref_begin))
         || (H->n_haps && (!H->bases || !H->offsets || !H->ref_begin || !H->gap_open || !H->gap_extend || !H->snv_mask_fwd
                           || !H->snv_prior_fwd || !H->snv_mask_rev || !H->snv_prior_rev)))
@@ -329,17 +329,28 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
                 if (R->ref_begin[r] < H->ref_begin[hp]) return fail(status, OCT_PHMM_EINVAL, "read begins before its haplotype (contains() violated)");
         }
     }
+    reg_row0[G] = g_row[G]; reg_read0[G] = first_read(g_row[G]);
     b->n_out = hap_out_off[H->n_haps]; b->n_pairs = hap_pair_off[H->n_haps];
     if (b->n_pairs >= 0xffffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "more than 2^32-1 pairs in one batch");
     for (uint32_t r = 0; r < R->n_reads; ++r) b->t_cap = std::max(b->t_cap, R->offsets[r + 1] - R->offsets[r]);
     for (uint32_t hp = 0; hp < H->n_haps; ++hp) b->lh_cap = std::max(b->lh_cap, H->offsets[hp + 1] - H->offsets[hp]);
     if (b->t_cap + (uint32_t)h->band >= 32768) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long for int16 diagonal indices");
     for (uint32_t r = 0; r < R->n_reads; ++r) if (R->offsets[r + 1] == R->offsets[r]) return fail(status, OCT_PHMM_EINVAL, "empty read");
-    const uint64_t n_pos = positions->offsets ? positions->offsets[b->n_pairs] : 0;
-    if (b->n_pairs && !positions->offsets) return fail(status, OCT_PHMM_EINVAL, "positions.offsets null");
-    for (uint64_t e = 0; e < b->n_pairs; ++e) {
-        if (positions->offsets[e + 1] < positions->offsets[e] || positions->offsets[e + 1] - positions->offsets[e] > (uint64_t)h->cfg.max_mapping_positions)
-            return fail(status, OCT_PHMM_EINVAL, "more mapping positions than max_mapping_positions");
+    std::vector<uint32_t> h_pos; std::vector<uint8_t> h_npos;
+    const uint32_t S = (uint32_t)h->cfg.max_mapping_positions;
+    if (positions) {
+        if (b->n_pairs && (!positions->offsets || !positions->positions)) return fail(status, OCT_PHMM_EINVAL, "positions arrays null");
+        h_pos.assign((size_t)b->n_pairs * S + 1, 0); h_npos.assign((size_t)b->n_pairs + 1, 0);
+        for (uint64_t e = 0; e < b->n_pairs; ++e) {
+            const uint64_t p0 = positions->offsets[e], p1 = positions->offsets[e + 1];
+            if (p1 < p0 || p1 - p0 > S) return fail(status, OCT_PHMM_EINVAL, "more mapping positions than max_mapping_positions");
+            h_npos[e] = (uint8_t)(p1 - p0);
+            for (uint64_t j = p0; j < p1; ++j) h_pos[e * S + (j - p0)] = positions->positions[j];
+        }
+    } else {
+        b->device_map = true;
+        if (b->lh_cap >= 65536 || kmer_map_lds_bytes(b->lh_cap) > rt::kMaxLdsBytes)
+            return fail(status, OCT_PHMM_EUNSUPPORTED, "haplotype too long for the LDS-resident k-mer mapper");
     }
     b->h_roff.assign(R->offsets, R->offsets + R->n_reads + 1); b->h_hoff.assign(H->offsets, H->offsets + H->n_haps + 1);
     b->h_rbegin.assign(R->ref_begin, R->ref_begin + R->n_reads); b->h_hbegin.assign(H->ref_begin, H->ref_begin + H->n_haps);
@@ -375,8 +386,23 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     RT(upload(bp, s, reg_read0.data(), reg_read0.size(), &d.reg_read0));
     RT(upload(bp, s, reg_lhs.data(), reg_lhs.size(), &d.reg_lhs));
     RT(upload(bp, s, reg_rhs.data(), reg_rhs.size(), &d.reg_rhs));
-    RT(upload(bp, s, positions->offsets, (size_t)b->n_pairs + 1, &d.pos_off));
-    RT(upload(bp, s, positions->positions, (size_t)n_pos, &d.pos));
+    RT(dalloc(bp, &d.pos, (size_t)b->n_pairs * S + 1)); RT(dalloc(bp, &d.npos, (size_t)b->n_pairs + 1));
+    d.bin_start = nullptr; d.bin_idx = nullptr;
+    if (positions) {
+        RT(rt::h2d(d.pos, h_pos.data(), (size_t)b->n_pairs * S * sizeof(uint32_t), s));
+        RT(rt::h2d(d.npos, h_npos.data(), (size_t)b->n_pairs, s));
+    } else {
+        RT(dalloc(bp, &d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1)); RT(dalloc(bp, &d.bin_idx, (size_t)n_hap_bases + 1));
+        std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, 64-read chunk of its region)
+        for (uint32_t hp = 0; hp < H->n_haps; ++hp) {
+            const uint32_t g = hap_region[hp];
+            for (uint32_t r = reg_read0[g]; r < first_read(g_row[g + 1]); r += kMapReadsPerBlock) { blk_hap.push_back(hp); blk_read0.push_back(r); }
+        }
+        b->n_map_blocks = (uint32_t)blk_hap.size();
+        const uint32_t* dh = nullptr; const uint32_t* dr = nullptr;
+        RT(upload(bp, s, blk_hap.data(), blk_hap.size(), &dh)); RT(upload(bp, s, blk_read0.data(), blk_read0.size(), &dr));
+        b->d_blk_hap = const_cast<uint32_t*>(dh); b->d_blk_read0 = const_cast<uint32_t*>(dr);
+    }
     RT(dalloc(bp, &d.racgt, (size_t)R->n_reads));
     RT(dalloc(bp, &d.tabFastF, (size_t)n_hap_bases)); RT(dalloc(bp, &d.tabFastR, (size_t)n_hap_bases));
     RT(dalloc(bp, &d.tabGenF, (size_t)n_hap_bases));  RT(dalloc(bp, &d.tabGenR, (size_t)n_hap_bases));
@@ -413,6 +439,13 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     RT(rt::dev_memset(d.stats, 0, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s));
     RT(rt::dev_memset(d.err_key, 0xff, sizeof(unsigned long long), s));
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
+    if (b->n_pairs && b->device_map) {
+        // candidate mapping positions on the device (HaplotypeLikelihoodArray::populate does this per haplotype, array.cpp:118-158)
+        OCT_LAUNCH(k_kmer_tables, b->n_haps, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d); RT(rt::launch_ok());
+        const size_t lds = kmer_map_lds_bytes(b->lh_cap);
+        RT(rt::allow_lds(k_kmer_map, lds));
+        OCT_LAUNCH(k_kmer_map, b->n_map_blocks, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap, (const uint32_t*)b->d_blk_read0, b->lh_cap); RT(rt::launch_ok());
+    }
     if (b->n_pairs) {
         RT(rt::dev_memset(d.pair_cnt + b->n_pairs, 0, sizeof(uint4), s));
         const uint32_t pair_blocks = (uint32_t)((b->n_pairs + 255) / 256);

@@ -49,8 +49,10 @@ struct DevBatch {
     const uint32_t* hap_region; const uint64_t* hap_out_off; const uint64_t* hap_pair_off;
     uint32_t n_regions;
     const uint32_t* reg_row0; const uint32_t* reg_read0; const uint32_t* reg_lhs; const uint32_t* reg_rhs;
-    // candidate mapping positions (CSR over pairs)
-    const uint64_t* pos_off;  const uint32_t* pos;
+    // candidate mapping positions per pair: pos[e * max_pos + j], j < npos[e] (host-provided or written by k_kmer_map)
+    uint32_t* pos; uint8_t* npos;
+    // 6-mer tables per haplotype (k_kmer_tables): bin_start[h * 4097 + hash], bin_idx[hoff[h] + slot]
+    uint16_t* bin_start; uint16_t* bin_idx;
     // per pair
     uint64_t  n_pairs;
     int32_t*  pair_best;      // min phred penalty over candidates, kNoScore = none

@@ -46,6 +46,8 @@ OCT_DEVICE void wave_lds_fence()
 OCT_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
 OCT_DEVICE uint32_t shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 OCT_DEVICE uint32_t readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+OCT_DEVICE uint64_t ballot(bool p) { return __ballot(p); }
+OCT_DEVICE uint32_t atomic_add_lds_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 OCT_DEVICE void block_sync() { __syncthreads(); }
 OCT_DEVICE int  atomic_min_i32(int32_t* p, int32_t v) { return atomicMin(p, v); }
 OCT_DEVICE unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }

@@ -78,6 +78,130 @@ OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// candidate mapping positions: 6-mer voting (utils/kmer_mapper.hpp)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kKmer = 6, kKmerBins = 4096;                 // mapperKmerSize (haplotype_likelihood_array.hpp:103), num_kmers(6)
+
+OCT_DEVICE uint32_t kmer_code(uint32_t c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   // perfect_hash :25-39 (everything else 0)
+OCT_DEVICE uint32_t kmer_hash6(const uint8_t* s)               // perfect_kmer_hash<6> :43-53: sum of 4^j * code(base j)
+{
+    uint32_t h = 0;
+    for (uint32_t j = 0; j < kKmer; ++j) h |= kmer_code(s[j]) << (2 * j);
+    return h;
+}
+
+// make_kmer_hash_table (:85-106) for every haplotype: one workgroup per haplotype, CSR bins (order inside a bin does not
+// affect the vote counts). LDS: 4096 counters + 256 scan slots.
+OCT_KERNEL(k_kmer_tables)(DevBatch b)
+{
+    OCT_DYN_SMEM(smem);
+    uint32_t* hist = (uint32_t*)smem;            // [4096]
+    uint32_t* part = hist + kKmerBins;           // [256]
+    const uint32_t h = hw::block_idx(), tid = hw::thread_idx(), nt = hw::block_dim();
+    const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;
+    for (uint32_t i = tid; i < kKmerBins; i += nt) hist[i] = 0;
+    hw::block_sync();
+    for (uint32_t p = tid; p < nk; p += nt) hw::atomic_add_lds_u32(&hist[kmer_hash6(b.hbases + ho + p)], 1u);
+    hw::block_sync();
+    // exclusive scan of the 4096 counters: 16 per thread (256 threads)
+    const uint32_t per = kKmerBins / 256;
+    uint32_t sum = 0;
+    if (tid < 256) for (uint32_t i = 0; i < per; ++i) sum += hist[tid * per + i];
+    if (tid < 256) part[tid] = sum;
+    hw::block_sync();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t o = 0;
+        if (tid < 256 && tid >= d) o = part[tid - d];
+        hw::block_sync();
+        if (tid < 256) part[tid] += o;
+        hw::block_sync();
+    }
+    if (tid < 256) {
+        uint32_t run = tid ? part[tid - 1] : 0;
+        for (uint32_t i = 0; i < per; ++i) { const uint32_t c = hist[tid * per + i]; hist[tid * per + i] = run; b.bin_start[(size_t)h * (kKmerBins + 1) + tid * per + i] = (uint16_t)run; run += c; }
+        if (tid == 255) b.bin_start[(size_t)h * (kKmerBins + 1) + kKmerBins] = (uint16_t)run;
+    }
+    hw::block_sync();
+    for (uint32_t p = tid; p < nk; p += nt) {
+        const uint32_t slot = hw::atomic_add_lds_u32(&hist[kmer_hash6(b.hbases + ho + p)], 1u);
+        b.bin_idx[ho + slot] = (uint16_t)p;
+    }
+}
+
+// map_query_to_target (:120-159): one wave per (haplotype, read) pair; the workgroup keeps the haplotype's bins in LDS and its
+// four waves stride over a chunk of the region's reads. Votes of a 64-lane batch that fall on the same diagonal are merged with
+// a ballot before they touch the LDS counter (the true diagonal collects almost all of them).
+constexpr uint32_t kMapReadsPerBlock = 64;
+inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + ((lh_cap + 1) & ~1u) * 2 + kBlockWaves * (lh_cap + 64) * 4; }
+
+OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap)
+{
+    OCT_DYN_SMEM(smem);
+    uint16_t* bins = (uint16_t*)smem;                                  // [4097]
+    uint16_t* idx = bins + kKmerBins + 2;                              // [lh_cap rounded to even]
+    uint32_t* counts_all = (uint32_t*)(idx + ((lh_cap + 1) & ~1u));    // [waves][lh_cap + 64]
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
+    const uint32_t h = blk_hap[hw::block_idx()], r_first = blk_read0[hw::block_idx()];
+    const uint32_t g = b.hap_region[h];
+    const uint32_t reg_r0 = b.reg_read0[g], reg_r1 = b.reg_read0[g + 1];
+    const uint32_t r_end = r_first + kMapReadsPerBlock < reg_r1 ? r_first + kMapReadsPerBlock : reg_r1;
+    const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;   // table.second
+    for (uint32_t i = tid; i <= kKmerBins; i += kBlockWaves * 64) bins[i] = b.bin_start[(size_t)h * (kKmerBins + 1) + i];
+    for (uint32_t i = tid; i < nk; i += kBlockWaves * 64) idx[i] = b.bin_idx[ho + i];
+    uint32_t* counts = counts_all + wave * (lh_cap + 64);
+    for (uint32_t d = lane; d < nk + 64; d += 64) counts[d] = 0;
+    hw::block_sync();
+    for (uint32_t r = r_first + wave; r < r_end; r += kBlockWaves) {
+        const uint64_t e = b.hap_pair_off[h] + (r - reg_r0);
+        const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;   // compute_kmer_hashes :57-69
+        for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            const bool valid = q < nq;
+            const uint32_t hq = valid ? kmer_hash6(b.rbases + ro + q) : 0;
+            const uint32_t b0 = bins[hq], n = valid ? (uint32_t)bins[hq + 1] - b0 : 0;
+            uint32_t nmax = n;
+            for (int m = 1; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }
+            nmax = hw::readfirstlane(nmax);
+            for (uint32_t j = 0; j < nmax; ++j) {
+                const uint32_t ti = j < n ? idx[b0 + j] : 0;
+                bool vote = j < n && ti >= q;                          // :130
+                const uint32_t d = ti - q;                             // mapping_begin :131
+                uint64_t pending = hw::ballot(vote);
+                while (pending) {
+                    const uint32_t src = (uint32_t)__builtin_ctzll(pending);
+                    const uint32_t d0 = hw::shfl(d, (int)src);
+                    const uint64_t same = hw::ballot(vote && d == d0);
+                    if (lane == src) counts[d0] += (uint32_t)__builtin_popcountll(same);   // ++mapping_counts[mapping_begin], :132
+                    pending &= ~same;
+                    vote = vote && d != d0;
+                }
+            }
+        }
+        hw::wave_lds_fence();
+        // max_hit_count, then the ascending positions that reach it, at most max_pos of them (:145-157)
+        uint32_t mx = 0;
+        for (uint32_t d = lane; d < nk; d += 64) { const uint32_t c = counts[d]; mx = c > mx ? c : mx; }
+        for (int m = 1; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(mx, m); mx = o > mx ? o : mx; }
+        mx = hw::readfirstlane(mx);
+        uint32_t n_out = 0;
+        if (mx > 0) {
+            for (uint32_t d0 = 0; d0 < nk && n_out < (uint32_t)b.max_pos; d0 += 64) {
+                const uint32_t d = d0 + lane;
+                const bool is = d < nk && counts[d] == mx;
+                const uint64_t mask = hw::ballot(is);
+                const uint32_t rank = n_out + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                if (is && rank < (uint32_t)b.max_pos) b.pos[e * (uint64_t)b.max_pos + rank] = d;
+                n_out += (uint32_t)__builtin_popcountll(mask);
+            }
+            if (n_out > (uint32_t)b.max_pos) n_out = (uint32_t)b.max_pos;
+        }
+        if (lane == 0) b.npos[e] = (uint8_t)n_out;
+        for (uint32_t d = lane; d < nk; d += 64) counts[d] = 0;       // reset_mapping_counts :115-118
+        hw::wave_lds_fence();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // candidate enumeration + scalar fast path
 // ------------------------------------------------------------------------------------------------------------------
 OCT_DEVICE uint32_t first_mismatch(const uint8_t* a, const uint8_t* b, uint32_t from, uint32_t n)
@@ -154,7 +278,7 @@ OCT_KERNEL(k_classify)(DevBatch b)
         const uint8_t* mask = (fwd ? b.maskF : b.maskR) + ho; const int8_t* prior = (fwd ? b.priorF : b.priorR) + ho;
         const int8_t* go = b.go + ho; const int8_t* ge = b.ge + ho;
         const uint64_t orig = (uint64_t)(b.rbegin[r] - b.hbegin[h]);                               // begin_distance, model.cpp:220
-        const uint32_t* P = b.pos + b.pos_off[e]; const uint32_t npos = (uint32_t)(b.pos_off[e + 1] - b.pos_off[e]);
+        const uint32_t* P = b.pos + e * (uint64_t)b.max_pos; const uint32_t npos = b.npos[e];
         int32_t best = kNoScore; uint32_t cls = 0, n_score = 0, n_trace = 0, extra = 0;
         bool orig_mapped = false, any = false;
         auto visit = [&](uint32_t slot, uint32_t p) {
@@ -284,7 +408,7 @@ OCT_KERNEL(k_emit)(DevBatch b, const uint4* hap_base, TaskArrays out)
     uint32_t at_score = generic ? hb.z + (s.z - s0.z) : hb.x + (s.x - s0.x);
     uint32_t at_trace = generic ? hb.w + (s.w - s0.w) : hb.y + (s.y - s0.y);
     DevTask* ts = out.t[generic ? kScoreGen : kScoreFast]; DevTask* tt = out.t[generic ? kTraceGen : kTraceFast];
-    const uint32_t* P = b.pos + b.pos_off[e];
+    const uint32_t* P = b.pos + e * (uint64_t)b.max_pos;
     const uint32_t B = (uint32_t)b.band;
     for (uint32_t slot = 0; slot <= (uint32_t)b.max_pos; ++slot) {
         const uint32_t k = (cls >> (2 * slot)) & 3u;

@@ -150,3 +150,32 @@ def check_mapping_quality_options(backend, tol=0.0):
     compare(backend, batch, tol, max_indel_error=8, mapping_quality_cap=60, mapping_quality_cap_trigger=40)
     compare(backend, batch, tol, max_indel_error=8, mapping_quality_cap=30, mapping_quality_cap_trigger=40)   # trigger >= cap is dropped
     compare(backend, batch, tol, max_indel_error=8, use_flank_state=0)
+
+
+def check_device_kmer_mapper(backend, tol=0.0):
+    """positions == NULL: the library maps reads with its own 6-mer voter (utils/kmer_mapper.hpp restated on the device);
+    the oracle maps with its CPU restatement. Repeat-rich haplotypes make ties (several equally voted offsets)."""
+    out = []
+    for seed, B, kw in ((41, 8, {}), (42, 16, dict(R=30, H=4, T=70, Lh=200)), (43, 8, dict(with_n=True))):
+        g, rng = small_region(seed, B=B, **kw)
+        # plant a tandem repeat and a homopolymer in every haplotype so that many diagonals tie
+        for h in g["haps"]:
+            a = int(rng.integers(10, len(h) - 50))
+            h[a:a + 24] = np.tile(h[a:a + 3], 8)
+            h[a + 30:a + 42] = h[a + 30]
+        batch = synth.batch_from_regions([g])
+        assert batch.pos_offsets is None
+        out.append(compare(backend, batch, tol, max_indel_error=B))
+    # ragged reads incl. reads shorter than a k-mer (no candidates), several regions
+    g1, rng = small_region(44, R=10, H=3)
+    g2, _ = small_region(45, R=6, H=2, T=40, Lh=100, flank=None)
+    batch = synth.batch_from_regions([g1, g2])
+    out.append(compare(backend, batch, tol, max_indel_error=8))
+    rng = np.random.default_rng(46)
+    hap = synth.BASES[rng.integers(0, 4, 90)]
+    go, ge, mf, pf, mr, pr = synth._penalties(hap)
+    reads = [dict(seq=bytes(hap[s:s + T]), quals=rng.integers(5, 50, T).astype(np.uint8), mapq=40, reverse=False, begin=s)
+             for T, s in ((4, 20), (5, 30), (6, 40), (7, 12), (30, 25))]
+    hl = [dict(seq=bytes(hap), begin=0, gap_open=go, gap_extend=ge, mask_fwd=mf, prior_fwd=pf, mask_rev=mr, prior_rev=pr)]
+    out.append(compare(backend, abi.Batch.from_lists(reads, hl, flank=None), tol, max_indel_error=8))
+    return out

@@ -158,6 +158,18 @@ inline uint32_t shfl(uint32_t v, int src)
     return r;
 }
 inline uint32_t readfirstlane(uint32_t v) { return shfl(v, 0); }
+inline uint64_t ballot(bool p)
+{
+    hipsim::State& s = hipsim::S();
+    const uint32_t t = s.cur;
+    s.xchg[t] = p ? 1u : 0u;
+    hipsim::wave_sync();
+    uint64_t m = 0;
+    for (uint32_t l = 0; l < 64; ++l) if ((t & ~63u) + l < s.bdim && s.lanes[(t & ~63u) + l].wait != hipsim::kDone && s.xchg[(t & ~63u) + l]) m |= 1ull << l;
+    hipsim::wave_sync();
+    return m;
+}
+inline uint32_t atomic_add_lds_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline void block_sync() { hipsim::block_sync_impl(); }
 inline int atomic_min_i32(int32_t* p, int32_t v) { const int32_t o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { const auto o = *p; if (v < o) *p = v; return o; }

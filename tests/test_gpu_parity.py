@@ -57,6 +57,17 @@ def test_gpu_populate_mapping_quality_and_flank_options():
     cp.check_mapping_quality_options("gpu", TOL)
 
 
+def test_gpu_device_kmer_mapper_matches_reference_mapper():
+    cp.check_device_kmer_mapper("gpu", TOL)
+
+
+def test_gpu_config2_with_device_mapping_matches_oracle():
+    """configs[1] again, but with positions == NULL: 6-mer mapping runs on the device (oracle maps on the CPU)."""
+    batch = synth.config_batch("1kx64", seed=42, B=16, positions="none")
+    stats = cp.compare("gpu", batch, TOL, max_indel_error=16)
+    assert stats["n_pairs"] == 64000
+
+
 def test_gpu_config2_1k_by_64_matches_oracle():
     """BASELINE.json configs[1]: the 1k x 64 batch (150 bp reads, 300 bp haplotypes, B = 16, flank 40/40)."""
     batch = synth.config_batch("1kx64", seed=42, B=16)

@@ -21,3 +21,7 @@ def test_sim_populate_ragged_reads_edges_and_short_haplotype():
 
 def test_sim_populate_mapping_quality_and_flank_options():
     cp.check_mapping_quality_options("sim")
+
+
+def test_sim_device_kmer_mapper_matches_reference_mapper():
+    cp.check_device_kmer_mapper("sim")
