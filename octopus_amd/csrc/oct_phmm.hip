@@ -387,12 +387,13 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     RT(upload(bp, s, reg_lhs.data(), reg_lhs.size(), &d.reg_lhs));
     RT(upload(bp, s, reg_rhs.data(), reg_rhs.size(), &d.reg_rhs));
     RT(dalloc(bp, &d.pos, (size_t)b->n_pairs * S + 1)); RT(dalloc(bp, &d.npos, (size_t)b->n_pairs + 1));
-    d.bin_start = nullptr; d.bin_idx = nullptr;
+    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr;
     if (positions) {
         RT(rt::h2d(d.pos, h_pos.data(), (size_t)b->n_pairs * S * sizeof(uint32_t), s));
         RT(rt::h2d(d.npos, h_npos.data(), (size_t)b->n_pairs, s));
     } else {
         RT(dalloc(bp, &d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1)); RT(dalloc(bp, &d.bin_idx, (size_t)n_hap_bases + 1));
+        RT(dalloc(bp, &d.rhash, (size_t)n_read_bases + 1));
         std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, 64-read chunk of its region)
         for (uint32_t hp = 0; hp < H->n_haps; ++hp) {
             const uint32_t g = hap_region[hp];
@@ -441,6 +442,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
     if (b->n_pairs && b->device_map) {
         // candidate mapping positions on the device (HaplotypeLikelihoodArray::populate does this per haplotype, array.cpp:118-158)
+        const uint32_t n_rb = b->h_roff[b->n_reads];
+        OCT_LAUNCH(k_read_hashes, (n_rb + 255) / 256, 256, 0, s, d, n_rb); RT(rt::launch_ok());
         OCT_LAUNCH(k_kmer_tables, b->n_haps, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d); RT(rt::launch_ok());
         const size_t lds = kmer_map_lds_bytes(b->lh_cap);
         RT(rt::allow_lds(k_kmer_map, lds));

@@ -128,9 +128,19 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b)
     }
 }
 
+// compute_kmer_hashes<6> (:57-69) for every read, once per batch like the reference (haplotype_likelihood_array.cpp:118-131):
+// rhash[roff[r] + q] for q <= T - 6.
+OCT_KERNEL(k_read_hashes)(DevBatch b, uint32_t n_bases)
+{
+    const uint32_t g = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (g >= n_bases) return;
+    const uint32_t r = upper_bound_idx(b.roff, b.n_reads + 1, g);
+    if (g + kKmer <= b.roff[r + 1]) b.rhash[g] = (uint16_t)kmer_hash6(b.rbases + g);
+}
+
 // map_query_to_target (:120-159): one wave per (haplotype, read) pair; the workgroup keeps the haplotype's bins in LDS and its
-// four waves stride over a chunk of the region's reads. Votes of a 64-lane batch that fall on the same diagonal are merged with
-// a ballot before they touch the LDS counter (the true diagonal collects almost all of them).
+// four waves stride over a chunk of the region's reads. Votes go to per-wave LDS counters; a 64-lane batch whose votes all fall on
+// one diagonal (the normal case: the read's true offset) is merged into a single add.
 constexpr uint32_t kMapReadsPerBlock = 64;
 inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + ((lh_cap + 1) & ~1u) * 2 + kBlockWaves * (lh_cap + 64) * 4; }
 
@@ -151,29 +161,26 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
     uint32_t* counts = counts_all + wave * (lh_cap + 64);
     for (uint32_t d = lane; d < nk + 64; d += 64) counts[d] = 0;
     hw::block_sync();
+    const uint32_t max_pos = (uint32_t)b.max_pos;
     for (uint32_t r = r_first + wave; r < r_end; r += kBlockWaves) {
         const uint64_t e = b.hap_pair_off[h] + (r - reg_r0);
         const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;   // compute_kmer_hashes :57-69
         for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
             const uint32_t q = q0 + lane;
             const bool valid = q < nq;
-            const uint32_t hq = valid ? kmer_hash6(b.rbases + ro + q) : 0;
+            const uint32_t hq = valid ? b.rhash[ro + q] : 0;
             const uint32_t b0 = bins[hq], n = valid ? (uint32_t)bins[hq + 1] - b0 : 0;
-            uint32_t nmax = n;
-            for (int m = 1; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(nmax, m); nmax = o > nmax ? o : nmax; }
-            nmax = hw::readfirstlane(nmax);
-            for (uint32_t j = 0; j < nmax; ++j) {
+            for (uint32_t j = 0; hw::ballot(j < n) != 0; ++j) {
                 const uint32_t ti = j < n ? idx[b0 + j] : 0;
-                bool vote = j < n && ti >= q;                          // :130
+                const bool vote = j < n && ti >= q;                    // :130
                 const uint32_t d = ti - q;                             // mapping_begin :131
-                uint64_t pending = hw::ballot(vote);
-                while (pending) {
-                    const uint32_t src = (uint32_t)__builtin_ctzll(pending);
-                    const uint32_t d0 = hw::shfl(d, (int)src);
-                    const uint64_t same = hw::ballot(vote && d == d0);
-                    if (lane == src) counts[d0] += (uint32_t)__builtin_popcountll(same);   // ++mapping_counts[mapping_begin], :132
-                    pending &= ~same;
-                    vote = vote && d != d0;
+                const uint64_t voters = hw::ballot(vote);
+                if (voters == 0) continue;
+                const uint32_t d0 = hw::shfl(d, (int)__builtin_ctzll(voters));
+                if (hw::ballot(vote && d != d0) == 0) {                // every vote on one diagonal: one add
+                    if (lane == 0) counts[d0] += (uint32_t)__builtin_popcountll(voters);
+                } else if (vote) {
+                    hw::atomic_add_lds_u32(&counts[d], 1u);            // ++mapping_counts[mapping_begin], :132
                 }
             }
         }
@@ -182,21 +189,19 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
         uint32_t mx = 0;
         for (uint32_t d = lane; d < nk; d += 64) { const uint32_t c = counts[d]; mx = c > mx ? c : mx; }
         for (int m = 1; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(mx, m); mx = o > mx ? o : mx; }
-        mx = hw::readfirstlane(mx);
         uint32_t n_out = 0;
-        if (mx > 0) {
-            for (uint32_t d0 = 0; d0 < nk && n_out < (uint32_t)b.max_pos; d0 += 64) {
-                const uint32_t d = d0 + lane;
-                const bool is = d < nk && counts[d] == mx;
-                const uint64_t mask = hw::ballot(is);
-                const uint32_t rank = n_out + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                if (is && rank < (uint32_t)b.max_pos) b.pos[e * (uint64_t)b.max_pos + rank] = d;
-                n_out += (uint32_t)__builtin_popcountll(mask);
-            }
-            if (n_out > (uint32_t)b.max_pos) n_out = (uint32_t)b.max_pos;
+        for (uint32_t d0 = 0; d0 < nk; d0 += 64) {
+            const uint32_t d = d0 + lane;
+            const uint32_t c = d < nk ? counts[d] : 0;
+            if (d < nk) counts[d] = 0;                                 // reset_mapping_counts :115-118
+            const bool is = mx > 0 && c == mx;
+            const uint64_t mask = hw::ballot(is);
+            const uint32_t rank = n_out + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (is && rank < max_pos) b.pos[e * (uint64_t)max_pos + rank] = d;
+            n_out += (uint32_t)__builtin_popcountll(mask);
         }
+        if (n_out > max_pos) n_out = max_pos;
         if (lane == 0) b.npos[e] = (uint8_t)n_out;
-        for (uint32_t d = lane; d < nk; d += 64) counts[d] = 0;       // reset_mapping_counts :115-118
         hw::wave_lds_fence();
     }
 }

@@ -534,7 +534,7 @@ typedef struct {
     double* out;
     /* per-haplotype error records (ShortHaplotypeError) */
     uint8_t* hap_err; uint32_t* hap_err_read; uint32_t* hap_err_ext;
-    volatile uint32_t next_hap;
+    volatile uint32_t next_hap; uint32_t n_items; uint32_t* hap_item_off;   /* work items = (haplotype, ROW_CHUNK rows) */
     pthread_mutex_t mu;
     oct_phmm_stats stats;
 } pop_ctx;
@@ -625,12 +625,16 @@ static int evaluate_read(pop_ctx* c, worker_state* w, uint32_t h, uint32_t r, ui
     return 0;
 }
 
-static void populate_haplotype(pop_ctx* c, worker_state* w, uint32_t h)
+#define ROW_CHUNK 128   /* rows per work item: (haplotype, row chunk) items keep every host core busy even with few haplotypes */
+
+static void populate_haplotype(pop_ctx* c, worker_state* w, uint32_t h, uint32_t chunk)
 {
     /* body of populate_haplotype, haplotype_likelihood_array.cpp:132-160 (TemplateMap) / :78-99 (ReadMap) */
     const uint32_t g = c->hap_region[h];
-    const uint32_t row0 = c->reg_row_off[g], row1 = c->reg_row_off[g + 1];
-    const uint32_t first_read = row_first_read(c->reads, row0);
+    const uint32_t reg_row0 = c->reg_row_off[g], reg_row1 = c->reg_row_off[g + 1];
+    const uint32_t row0 = reg_row0 + chunk * ROW_CHUNK, row1 = row0 + ROW_CHUNK < reg_row1 ? row0 + ROW_CHUNK : reg_row1;
+    if (row0 >= reg_row1) return;
+    const uint32_t first_read = row_first_read(c->reads, reg_row0);
     const int has_flank = c->cfg->use_flank_state && c->reg_has_flank && c->reg_has_flank[g];
     const uint32_t lhs = has_flank ? c->reg_flank[g].lhs_flank : 0, rhs = has_flank ? c->reg_flank[g].rhs_flank : 0; /* model.cpp:276-282 */
     const uint32_t ho = c->haps->offsets[h], Lh = c->haps->offsets[h + 1] - ho;
@@ -653,12 +657,14 @@ static void populate_haplotype(pop_ctx* c, worker_state* w, uint32_t h)
             double v = 0; uint32_t ext = 0;
             ++w->st.n_pairs;
             if (evaluate_read(c, w, h, r, lhs, rhs, pos, npos, &v, &ext)) {
-                if (!c->hap_err[h]) { c->hap_err[h] = 1; c->hap_err_read[h] = r; c->hap_err_ext[h] = ext; }
+                pthread_mutex_lock(&c->mu);                                 /* keep the first failing read of this haplotype in serial order */
+                if (!c->hap_err[h] || r < c->hap_err_read[h]) { c->hap_err[h] = 1; c->hap_err_read[h] = r; c->hap_err_ext[h] = ext; }
+                pthread_mutex_unlock(&c->mu);
                 return;                                                     /* the exception aborts populate */
             }
             acc = acc + v;
         }
-        c->out[c->hap_out_off[h] + (row - row0)] = acc;
+        c->out[c->hap_out_off[h] + (row - reg_row0)] = acc;
     }
 }
 
@@ -667,9 +673,12 @@ static void* pop_worker(void* arg)
     pop_ctx* c = (pop_ctx*)arg;
     worker_state w; memset(&w, 0, sizeof(w));
     for (;;) {
-        const uint32_t h = __sync_fetch_and_add(&c->next_hap, 1);
-        if (h >= c->haps->n_haps) break;
-        populate_haplotype(c, &w, h);
+        const uint32_t item = __sync_fetch_and_add(&c->next_hap, 1);
+        if (item >= c->n_items) break;
+        /* item -> (haplotype, chunk) through the per-haplotype item offsets */
+        uint32_t lo = 0, hi = c->haps->n_haps;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (c->hap_item_off[mid] <= item) lo = mid; else hi = mid; }
+        populate_haplotype(c, &w, lo, item - c->hap_item_off[lo]);
     }
     pthread_mutex_lock(&c->mu);
     c->stats.n_pairs += w.st.n_pairs; c->stats.n_candidates += w.st.n_candidates; c->stats.n_fast_path += w.st.n_fast_path;
@@ -727,6 +736,12 @@ int oracle_populate(const oct_phmm_config* cfg,
             for (uint32_t i = 0; i + KMER <= T; ++i) c.read_hashes[ro + i] = (uint16_t)kmer_hash(reads->bases + ro + i);
         }
     }
+    c.hap_item_off = (uint32_t*)calloc(nh + 2, sizeof(uint32_t));
+    for (uint32_t h = 0; h < nh; ++h) {
+        const uint32_t g = c.hap_region[h], rows = c.reg_row_off[g + 1] - c.reg_row_off[g];
+        c.hap_item_off[h + 1] = c.hap_item_off[h] + (rows + ROW_CHUNK - 1) / ROW_CHUNK;
+    }
+    c.n_items = c.hap_item_off[nh];
     pthread_mutex_init(&c.mu, NULL);
     if (n_threads < 1) n_threads = 1;
     if (n_threads == 1) pop_worker(&c);
@@ -745,7 +760,7 @@ int oracle_populate(const oct_phmm_config* cfg,
         break;
     }
     if (stats) *stats = c.stats;
-    free(c.hap_region); free(c.hap_out_off); free(c.hap_pair_off); free(c.hap_err); free(c.hap_err_read); free(c.hap_err_ext); free(c.read_hashes);
+    free(c.hap_item_off); free(c.hap_region); free(c.hap_out_off); free(c.hap_pair_off); free(c.hap_err); free(c.hap_err_read); free(c.hap_err_ext); free(c.read_hashes);
     return code;
 }
 
