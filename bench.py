@@ -25,7 +25,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (one 32-bit VALU op per lane per clock)
+# Packed-int16 / min / perm / DPP wave64 instructions issue at 4 cycles per SIMD on gfx950 (tools/valu_ubench.hip, measured):
+# 256 CU x 4 SIMD x 2.4 GHz / 4 = 614 G wave-instructions/s is the issue peak the DP kernels run against.
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
+# VALU wave-instructions per DP iteration per wave (8 tasks at B = 16), counted in the ISA of this build
+VALU_PER_ITER = {"score": 31.3, "trace": 53.0}
+PMC_SUMMARY = ROOT / "profiles" / "r01_step4_pmc_summary.json"
 
 
 def algorithmic_bytes_per_task(T: int, B: int) -> int:
@@ -46,13 +51,13 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
     oracle.set_l1_backend(backend)
     cfg = abi.Config.default(max_indel_error=B)
     rng = np.random.default_rng(seed)
-    R, H = 4000, 32
+    R, H = 40_000, 64          # ~25 s of single-core SSE2 work, spread over all host threads
     batch = synth.batch_from_regions([synth.make_region(rng, R, H, B=B, positions="none")])
     t0 = time.perf_counter()
     _, st, stats = oracle.populate(cfg, batch, n_threads=cores)
     dt = time.perf_counter() - t0
     reps = 1
-    while dt * reps < 3.0 and reps < 64:      # repeat the sample until the clock is meaningful, bounded
+    while dt * reps < 2.0 and reps < 16:      # repeat the sample until the clock is meaningful, bounded
         reps *= 2
     if reps > 1:
         t0 = time.perf_counter()
@@ -138,23 +143,33 @@ def main():
         tasks_per_launch = n_tasks * args.steps / max(dp_launches, 1)
         alg_bytes = algorithmic_bytes_per_task(T, B) * tasks_per_launch
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        lane_ops = 45.0 * B * (T + B) * tasks_per_launch        # ~45 lane-ops per lane per row pair
+        # VALU view (what actually binds): wave-instructions the DP launches issued per second vs the 4-cycle issue peak
+        groups = lambda n: n / (2 * (64 // B))
+        valu_instr = (groups(stats["n_dp_score_only"]) * VALU_PER_ITER["score"] + groups(stats["n_dp_traceback"]) * VALU_PER_ITER["trace"]) * (T + B)
+        dp_s_per_step = (dp_ms / 1e3) / args.steps
+        traffic = None
+        if PMC_SUMMARY.exists():        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+            pm = json.loads(PMC_SUMMARY.read_text()).get("octphmm::k_dp<16, true, false>", {})
+            if "hbm_read_bytes_corrected" in pm and "hbm_write_bytes" in pm:
+                traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
         out = {
             "metric": "pair-HMM band cell-updates/s", "value": cells / per_step / 1e9, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: Illumina-like 150 bp reads x 300 bp haplotypes per region, band {B}, "
-                                   f"int16 lanes, flank 40/40, one region per GPU", "band": B, "read_len": T, "hap_len": LH,
+                                   f"int16 lanes, flank 40/40, device k-mer mapping, one region per GPU", "band": B, "read_len": T, "hap_len": LH,
                        "pairs_per_step": pairs, "dp_tasks_per_step": n_tasks, "parallelism": f"regions sharded over {world} GPU(s), no collective"},
             "loglik_per_s": pairs / per_step,
             "stats": stats,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_dp (all four variants, event-timed per launch)",
+                         "traffic": traffic, "traffic_note": "bytes per launch of k_dp<16,true,false> from profiles/r01_step4_pmc_summary.json "
+                                                             "(FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), measured with host-provided positions",
+                         "kernel": "k_dp (score-only + traceback launches, HIP-event timed on the library stream)",
                          "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": dp_launches / args.steps,
-                         "valu": {"achieved_lane_ops_per_s": lane_ops / avg_launch_s if avg_launch_s > 0 else 0.0,
-                                  "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                                  "frac": (lane_ops / avg_launch_s / VALU_PEAK_LANE_OPS) if avg_launch_s > 0 else 0.0,
-                                  "note": "the path is integer-VALU bound (SURVEY.md §8d); reference-op accounting, int32-lane peak"}},
+                         "valu": {"achieved_wave_instr_per_s": valu_instr / dp_s_per_step if dp_s_per_step > 0 else 0.0,
+                                  "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
+                                  "frac": (valu_instr / dp_s_per_step / VALU_PEAK_WAVE_INSTR) if dp_s_per_step > 0 else 0.0,
+                                  "note": "the DP is integer-VALU bound, not HBM bound (SURVEY.md 8d); PMC: SQ_ACTIVE_INST_VALU = 93-100 % of kernel cycles"}},
         }
         if world == 1:
             small = eng.upload(synth.config_batch("1kx64", seed=42, B=B, positions="none"))

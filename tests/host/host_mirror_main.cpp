@@ -1,0 +1,56 @@
+// Test driver for octopus_amd/host/haplotype_likelihood_array.hpp: reads a scenario on stdin, runs populate() through the C++ mirror,
+// prints the matrix via the reference-style accessors. Linked against liboct_phmm.so (GPU) or tests/sim/libphmm_sim.so (CPU simulator).
+//   scenario: "cfg band use_mapq flank lhs rhs templates" / "H n" then n x "begin seq" / "S n_samples" then per sample "name n_rows",
+//   per row "k" then k x "begin reverse mapq seq quals(comma separated)"
+#include <cstdio>
+#include <iostream>
+#include <sstream>
+#include "../../octopus_amd/host/haplotype_likelihood_array.hpp"
+
+using namespace octopus_amd;
+
+int main()
+{
+    int band, use_mapq, has_flank, templates; unsigned lhs, rhs;
+    std::string tok;
+    std::cin >> tok >> band >> use_mapq >> has_flank >> lhs >> rhs >> templates;
+    std::size_t nh; std::cin >> tok >> nh;
+    std::vector<Haplotype> haps(nh);
+    for (auto& h : haps) std::cin >> h.begin_ >> h.sequence_;
+    std::size_t ns; std::cin >> tok >> ns;
+    TemplateMap tm; ReadMap rm; std::vector<SampleName> names;
+    for (std::size_t s = 0; s < ns; ++s) {
+        std::string name; std::size_t nrows; std::cin >> name >> nrows; names.push_back(name);
+        tm.emplace_back(name, std::vector<AlignedTemplate> {}); rm.emplace_back(name, std::vector<AlignedRead> {});
+        for (std::size_t r = 0; r < nrows; ++r) {
+            std::size_t k; std::cin >> k; AlignedTemplate t;
+            for (std::size_t j = 0; j < k; ++j) {
+                AlignedRead rd; int rev, mq; std::string q; std::cin >> rd.begin_ >> rev >> mq >> rd.sequence_ >> q;
+                rd.reverse_ = rev; rd.mapping_quality_ = static_cast<std::uint8_t>(mq);
+                std::stringstream ss {q}; std::string item; while (std::getline(ss, item, ',')) rd.base_qualities_.push_back(static_cast<std::uint8_t>(std::stoi(item)));
+                t.push_back(rd); rm.back().second.push_back(rd);
+            }
+            tm.back().second.push_back(t);
+        }
+    }
+    HaplotypeLikelihoodModel::Config cfg; cfg.max_indel_error = band; cfg.use_mapping_quality = use_mapq;
+    try {
+        HaplotypeLikelihoodModel model {cfg};
+        std::printf("pad_requirement %u\n", model.pad_requirement());
+        HaplotypeLikelihoodArray arr {model, names};
+        HaplotypeLikelihoodArray::FlankState fs {lhs, rhs};
+        if (templates) arr.populate(tm, haps, has_flank ? &fs : nullptr); else arr.populate(rm, haps, has_flank ? &fs : nullptr);
+        for (std::size_t h = 0; h < haps.size(); ++h)
+            for (const auto& n : names) { std::printf("L %zu %s", h, n.c_str()); for (double v : arr(n, haps[h])) std::printf(" %.17g", v); std::printf("\n"); }
+        arr.prime(names.front());
+        std::printf("primed %zu contains %d\n", arr.num_likelihoods(), arr.contains(haps.front()) ? 1 : 0);
+        const auto merged = arr.merge_samples(names);
+        std::printf("merged %zu\n", merged[0].size());
+        if (haps.size() > 1) { arr.reset({haps.back()}); std::printf("reset %zu %d\n", arr.haplotypes().size(), arr.contains(haps.front()) ? 1 : 0); }
+    } catch (const HaplotypeLikelihoodModel::ShortHaplotypeError& e) {
+        std::printf("ShortHaplotypeError %zu %zu\n", e.haplotype_index(), e.required_extension());
+    } catch (const HaplotypeLikelihoodModel::TooLargeBandSizeError& e) {
+        std::printf("TooLargeBandSizeError %d %d\n", e.requested(), e.max());
+    }
+    return 0;
+}

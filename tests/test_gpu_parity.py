@@ -5,6 +5,7 @@ log/exp may differ from glibc in the last ulps)."""
 import numpy as np
 import pytest
 
+import check_host_mirror
 import check_l1
 import check_populate as cp
 import oracle
@@ -73,6 +74,10 @@ def test_gpu_config2_1k_by_64_matches_oracle():
     batch = synth.config_batch("1kx64", seed=42, B=16)
     stats = cp.compare("gpu", batch, TOL, max_indel_error=16)
     assert stats["n_pairs"] == 64000 and stats["n_dp_traceback"] > 1000 and stats["n_fast_path"] > 1000
+
+
+def test_gpu_cpp_host_mirror_matches_oracle_and_maps_errors():
+    check_host_mirror.check("gpu", TOL)
 
 
 def test_gpu_large_batch_properties():
