@@ -21,6 +21,7 @@ using namespace octphmm;
 struct oct_phmm_handle {
     oct_phmm_config cfg;
     int band = 0;
+    bool wide = false;                                   // int32 lanes (Config::use_int_scores)
     rt::Stream stream {};
     rt::Event ev[2] {};
     uint32_t* bp = nullptr; size_t bp_bytes = 0;          // traceback scratch, grown on demand
@@ -120,19 +121,41 @@ bool launch_dp(int band, bool tr, bool gen, const DpParams& p, uint32_t n_blocks
         default: return false;
     }
 }
-bool launch_walk(int band, const WalkParams& w, rt::Stream s)
+template <int B, bool TR>
+bool launch_dp32_inst(const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
+{
+    if (!rt::allow_lds((k_dp32<B, TR>), lds)) return false;
+    OCT_LAUNCH((k_dp32<B, TR>), n_blocks, kBlockWaves * 64, lds, s, p);
+    return rt::launch_ok();
+}
+bool launch_dp32(int band, bool tr, const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
+{
+    switch (band) {
+        case 8:  return tr ? launch_dp32_inst<8, true>(p, n_blocks, lds, s) : launch_dp32_inst<8, false>(p, n_blocks, lds, s);
+        case 16: return tr ? launch_dp32_inst<16, true>(p, n_blocks, lds, s) : launch_dp32_inst<16, false>(p, n_blocks, lds, s);
+        case 32: return tr ? launch_dp32_inst<32, true>(p, n_blocks, lds, s) : launch_dp32_inst<32, false>(p, n_blocks, lds, s);
+        case 64: return tr ? launch_dp32_inst<64, true>(p, n_blocks, lds, s) : launch_dp32_inst<64, false>(p, n_blocks, lds, s);
+        default: return false;
+    }
+}
+template <int B, int TPR>
+bool launch_walk_inst(const WalkParams& w, rt::Stream s)
 {
     const uint32_t blocks = (w.n_tasks + 255) / 256;
     const size_t lds = 256 * kWalkEvents * sizeof(uint32_t);
-    const bool strings = w.out_align1 != nullptr;      // test seam: the gapped strings come from the simple per-step walker
+    OCT_LAUNCH((k_walk<B, TPR>), blocks, 256, lds, s, w);
+    if (w.out_align1 != nullptr) OCT_LAUNCH((k_walk_strings<B, TPR>), blocks, 256, 0, s, w);   // test seam: gapped strings from the simple per-step walker
+    return rt::launch_ok();
+}
+bool launch_walk(int band, bool wide, const WalkParams& w, rt::Stream s)
+{
     switch (band) {
-        case 8:  OCT_LAUNCH((k_walk<8>), blocks, 256, lds, s, w);  if (strings) OCT_LAUNCH((k_walk_strings<8>), blocks, 256, 0, s, w); break;
-        case 16: OCT_LAUNCH((k_walk<16>), blocks, 256, lds, s, w); if (strings) OCT_LAUNCH((k_walk_strings<16>), blocks, 256, 0, s, w); break;
-        case 32: OCT_LAUNCH((k_walk<32>), blocks, 256, lds, s, w); if (strings) OCT_LAUNCH((k_walk_strings<32>), blocks, 256, 0, s, w); break;
-        case 64: OCT_LAUNCH((k_walk<64>), blocks, 256, lds, s, w); if (strings) OCT_LAUNCH((k_walk_strings<64>), blocks, 256, 0, s, w); break;
+        case 8:  return wide ? launch_walk_inst<8, 1>(w, s) : launch_walk_inst<8, 2>(w, s);
+        case 16: return wide ? launch_walk_inst<16, 1>(w, s) : launch_walk_inst<16, 2>(w, s);
+        case 32: return wide ? launch_walk_inst<32, 1>(w, s) : launch_walk_inst<32, 2>(w, s);
+        case 64: return wide ? launch_walk_inst<64, 1>(w, s) : launch_walk_inst<64, 2>(w, s);
         default: return false;
     }
-    return rt::launch_ok();
 }
 
 bool ensure_bp(oct_phmm_handle* h, size_t bytes)
@@ -151,7 +174,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
 {
     if (!n_tasks) return OCT_PHMM_OK;
     const int B = h->band;
-    const uint32_t G = 2 * (64 / B);
+    const uint32_t G = (h->wide ? 1 : 2) * (64 / B);
     const bool tr = kind == kTraceFast || kind == kTraceGen, gen = kind == kScoreGen || kind == kTraceGen;
     const size_t lds = dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr);
     if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
@@ -180,7 +203,8 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
         rt::Event e0, e1;
         RT(rt::event_create(&e0)); RT(rt::event_create(&e1));
         RT(rt::event_record(e0, h->stream));
-        if (!launch_dp(B, tr, gen, p, n_blocks, lds, h->stream)) return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
+        if (!(h->wide ? launch_dp32(B, tr, p, n_blocks, lds, h->stream) : launch_dp(B, tr, gen, p, n_blocks, lds, h->stream)))
+            return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         RT(rt::event_record(e1, h->stream));
         b->timers.emplace_back(e0, e1);
         if (tr) {
@@ -197,7 +221,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
                 w.out_first_pos += o; w.out_align_off += o;
                 if (w.seam_lhs) { w.seam_lhs += o; w.seam_rhs += o; w.out_flank += o; w.out_mask_size += o; }
             }
-            if (!launch_walk(B, w, h->stream)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
+            if (!launch_walk(B, h->wide, w, h->stream)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
         }
     }
     return OCT_PHMM_OK;
@@ -238,7 +262,7 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     *out = nullptr;
     const int band = band_for(cfg->max_indel_error);
     if (band < 0) return OCT_PHMM_EBAND;
-    if (band > 64 || cfg->use_int_scores) return OCT_PHMM_EUNSUPPORTED;            // see DESIGN.md "limits"
+    if (band > 64) return OCT_PHMM_EUNSUPPORTED;                                    // see DESIGN.md "limits"
     if (cfg->max_mapping_positions < 0 || cfg->max_mapping_positions >= kMaxSlots) return OCT_PHMM_EUNSUPPORTED;
     int n = 0;
     if (!rt::device_count(&n) || n <= 0 || cfg->device_id < 0 || cfg->device_id >= n) return OCT_PHMM_ENODEVICE;
@@ -246,7 +270,7 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     if (!rt::set_device(cfg->device_id)) return OCT_PHMM_EHIP;
     std::unique_ptr<oct_phmm_handle> h(new (std::nothrow) oct_phmm_handle());
     if (!h) return OCT_PHMM_EHIP;
-    h->cfg = *cfg; h->band = band;
+    h->cfg = *cfg; h->band = band; h->wide = cfg->use_int_scores != 0;
     if (h->cfg.mapping_quality_cap_trigger >= 0 && h->cfg.mapping_quality_cap_trigger >= h->cfg.mapping_quality_cap)
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
     if (const char* e = getenv("OCT_PHMM_BP_BUDGET_GB")) { const long gb = atol(e); if (gb > 0) h->bp_budget = (size_t)gb << 30; }
@@ -359,7 +383,7 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     rt::Stream s = h->stream;
     DevBatch& d = b->d;
     d.n_reads = R->n_reads; d.n_rows = n_rows; d.n_haps = H->n_haps; d.n_regions = G; d.n_pairs = b->n_pairs;
-    d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions;
+    d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions; d.wide = h->wide ? 1 : 0;
     d.use_mapq = h->cfg.use_mapping_quality; d.mapq_cap = h->cfg.mapping_quality_cap; d.mapq_trigger = h->cfg.mapping_quality_cap_trigger;
     oct_phmm_batch* bp = b.get();
     RT(upload(bp, s, (const uint8_t*)R->bases, n_read_bases, &d.rbases));
@@ -436,7 +460,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     DevBatch& d = b->d;
     for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
     b->timers.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
-    const uint32_t G = 2 * (64 / (uint32_t)h->band);
+    const uint32_t G = (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
     RT(rt::dev_memset(d.stats, 0, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s));
     RT(rt::dev_memset(d.err_key, 0xff, sizeof(unsigned long long), s));
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
@@ -577,7 +601,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
         || (lhs_flank && (!traceback || !rhs_flank || !flank_score || !target_mask_size || !snv_mask)))
         return fail(status, OCT_PHMM_EINVAL, "null argument");
     if (!n) return ok(status);
-    const uint32_t B = (uint32_t)h->band, G = 2 * (64 / B);
+    const uint32_t B = (uint32_t)h->band, G = (h->wide ? 1u : 2u) * (64 / B);
     const uint32_t n_truth = truth_offsets[n], n_target = target_offsets[n];
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t L = truth_offsets[i + 1] - truth_offsets[i], T = target_offsets[i + 1] - target_offsets[i];
@@ -610,7 +634,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
     // every window is its own haplotype and a DP task group must stay within one haplotype: give each window a whole
     // group (one real task + G-1 padding copies). This is a test seam, not the throughput path.
     for (uint32_t i = 0; i < n; ++i) {
-        const int gen = !(racgt[i] && hclean[i]);
+        const int gen = h->wide || !(racgt[i] && hclean[i]);
         tasks[gen].push_back(DevTask {i, i, i, 0}); origin[gen].push_back(i);
         for (uint32_t k = 1; k < G; ++k) tasks[gen].push_back(DevTask {kPadTask, i, i, 0});
     }

@@ -60,7 +60,7 @@ struct DevBatch {
     uint32_t* pair_extra;     // position of the extra slot (original or shifted original)
     uint4*    pair_cnt;       // [n_pairs + 1] per-kind task counts, exclusive-scanned in place
     // configuration
-    int band, nuc_prior, max_pos, use_mapq, mapq_cap, mapq_trigger;
+    int band, nuc_prior, max_pos, use_mapq, mapq_cap, mapq_trigger, wide;   // wide = int32 lanes (Config::use_int_scores)
     // counters, kStatSlots stripes of 8: [0] candidates [1] fast path [2] score-only DP [3] traceback DP [4] band cells [5] pairs
     unsigned long long* stats;
     unsigned long long* err_key;                      // min over failing pairs of (hap << 32 | read); ~0 = none

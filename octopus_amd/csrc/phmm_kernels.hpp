@@ -311,7 +311,7 @@ OCT_KERNEL(k_classify)(DevBatch b)
             else { extra = (uint32_t)fin; visit((uint32_t)b.max_pos, extra); }
         }
         b.pair_best[e] = best; b.pair_cls[e] = cls; b.pair_extra[e] = extra;
-        const bool generic = !(b.racgt[r] && b.hclean[h]);
+        const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
         b.pair_cnt[e] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
         st_pairs = 1;
     }
@@ -408,7 +408,7 @@ OCT_KERNEL(k_emit)(DevBatch b, const uint4* hap_base, TaskArrays out)
     if (!cls) return;
     const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
     const uint32_t r = b.reg_read0[b.hap_region[h]] + (uint32_t)(e - b.hap_pair_off[h]);
-    const bool generic = !(b.racgt[r] && b.hclean[h]);
+    const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
     const uint4 s = b.pair_cnt[e], s0 = b.pair_cnt[b.hap_pair_off[h]], hb = hap_base[h];
     uint32_t at_score = generic ? hb.z + (s.z - s0.z) : hb.x + (s.x - s0.x);
     uint32_t at_trace = generic ? hb.w + (s.w - s0.w) : hb.y + (s.y - s0.y);
@@ -676,18 +676,168 @@ OCT_KERNEL(k_dp)(DpParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// int32 lanes (Config::use_int_scores, "--use-wide-hmm-scores"): one task per band row, plain 32-bit VALU, generic byte tests.
+// Same staging, tiles and traceback word format as k_dp (labels in the low 16 bits), so k_walk<B, 1> serves it unchanged.
+// Deliberately simple (no loop phases): this is the reference's slow precision mode, not the throughput path.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t INF32 = 0x7ffff800u;      // INT_MAX - 0x7FF (simd_pair_hmm.hpp:55-56 with ScoreType = int)
+constexpr uint32_t NUL32 = 0x80000000u;      // INT_MIN
+
+OCT_DEVICE uint32_t min_i32(uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b ? a : b; }
+
+template <int B> OCT_DEVICE uint32_t shift_up32(uint32_t v, uint32_t li)
+{
+    if constexpr (B == 16) return hw::dpp_row_shr1(INF32, v);
+    else if constexpr (B == 64) return hw::dpp_wave_shr1(INF32, v);
+    else if constexpr (B == 8) { const uint32_t r = hw::dpp_row_shr1(INF32, v); return li == 0 ? INF32 : r; }
+    else { const uint32_t r = hw::dpp_wave_shr1(INF32, v); return li == 0 ? INF32 : r; }
+}
+template <int B> OCT_DEVICE uint32_t shift_down32(uint32_t v, uint32_t li)
+{
+    if constexpr (B == 16) return hw::dpp_row_shl1(INF32, v);
+    else if constexpr (B == 64) return hw::dpp_wave_shl1(INF32, v);
+    else if constexpr (B == 8) { const uint32_t r = hw::dpp_row_shl1(INF32, v); return li == B - 1 ? INF32 : r; }
+    else { const uint32_t r = hw::dpp_wave_shl1(INF32, v); return li == B - 1 ? INF32 : r; }
+}
+
+template <int B, bool TRACE>
+OCT_KERNEL(k_dp32)(DpParams p)
+{
+    constexpr uint32_t ROWS = 64 / B, G = ROWS;
+    OCT_DYN_SMEM(smem);
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
+    const uint32_t row = lane / B, li = lane % B;
+    const uint32_t lh_n = (p.lh_cap + 8 + 1) & ~1u, rec_n = dp_rec_n(p.t_cap, B);
+    uint2* tabF = (uint2*)smem;
+    uint2* tabR = tabF + lh_n;
+    uint2* recs = tabR + lh_n;
+    uint32_t* tiles = (uint32_t*)(recs + kBlockWaves * ROWS * rec_n);
+    uint2* rec_row = recs + (wave * ROWS + row) * rec_n;
+    uint32_t* tile = tiles + wave * 16 * kTileStride;
+    const uint32_t n_groups = p.n_tasks / G;
+    const uint32_t g_begin = hw::block_idx() * p.groups_per_block;
+    const uint32_t g_end = g_begin + p.groups_per_block < n_groups ? g_begin + p.groups_per_block : n_groups;
+    const uint32_t NUC = p.nuc4 & 0xffffu; const uint32_t NUC32 = (uint32_t)(int32_t)(int16_t)NUC;   // sign-extended (nuc_prior << 2)
+
+    uint32_t seg = g_begin;
+    while (seg < g_end) {
+        const uint32_t hap = p.tasks[seg * G].hap;
+        uint32_t seg_end = seg + 1;
+        while (seg_end < g_end && p.tasks[seg_end * G].hap == hap) ++seg_end;
+        const uint32_t ho = p.hoff[hap], Lh = p.hoff[hap + 1] - ho;
+        hw::block_sync();
+        for (uint32_t x = tid; x < lh_n; x += kBlockWaves * 64) {
+            const bool in = x < Lh;
+            tabF[x] = in ? p.tabF[ho + x] : make_uint2(0, 0);
+            tabR[x] = in ? p.tabR[ho + x] : make_uint2(0, 0);
+        }
+        hw::block_sync();
+        for (uint32_t g = seg + wave; g < seg_end; g += kBlockWaves) {
+            const DevTask tA = p.tasks[g * G + row];
+            const uint32_t roA = p.roff[tA.read], TA = p.roff[tA.read + 1] - roA;
+            uint32_t Tmax = TA;
+            for (int m = B; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(Tmax, m); Tmax = o > Tmax ? o : Tmax; }
+            Tmax = hw::readfirstlane(Tmax);
+            const uint32_t K = Tmax + B, K16 = (K + 15) & ~15u;
+            for (uint32_t j = li; j < K + B + 2; j += B) {            // read-side records: {target char (0x100 / '0' padding), quality << 2}
+                const int32_t t = (int32_t)j - B;
+                const bool in = t >= 0 && (uint32_t)t < TA;
+                const uint32_t r = in ? ld8(p.rbases + roA + t) : (t < 0 ? 0x100u : (uint32_t)'0');
+                const uint32_t q = in ? ld8(p.rquals + roA + t) : 64u;
+                rec_row[j] = make_uint2(r, q << 2);
+            }
+            hw::wave_lds_fence();
+            const uint2* pA = (p.rrev[tA.read] ? tabR : tabF) + tA.off + li;
+            const uint2* rp = rec_row + (B - li);
+            const uint32_t kend = TA + li;
+            uint4* bpg = TRACE ? (uint4*)(p.bp + (size_t)g * p.k_cap * 1024) : nullptr;
+            uint32_t M1 = INF32, I1 = INF32, D1 = INF32, M2 = INF32, I2 = INF32, D2 = INF32, bestE = INF32, bestO = INF32;
+            auto cost = [&](const uint2 r2, const uint2 a, uint32_t* mism) -> uint32_t {      // update_match_state :121-132 on raw bytes
+                const uint32_t h = a.x & 0xffu, m = (a.x >> 8) & 0xffu, p4 = ((a.x >> 16) & 0xffu) << 2, isn = a.x >> 24;
+                const uint32_t inner = r2.x == m ? p4 : r2.y;
+                uint32_t c = min_i32(r2.y, inner);
+                if (r2.x == h) c = 0;
+                *mism = r2.x != h ? 1u : 0u;
+                return min_i32(c, isn ? 8u : INF32);
+            };
+            auto flush_tile = [&](uint32_t kt) {
+                hw::wave_lds_fence();
+                uint4* dst = bpg + (size_t)kt * 256;
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t src = 16 * j + (lane >> 2), kq = (lane & 3) * 4;
+                    dst[j * 64 + lane] = make_uint4(tile[(kq + 0) * kTileStride + src], tile[(kq + 1) * kTileStride + src],
+                                                    tile[(kq + 2) * kTileStride + src], tile[(kq + 3) * kTileStride + src]);
+                }
+                hw::wave_lds_fence();
+            };
+            for (uint32_t k = 0; k < K16; ++k) {
+                if (k < K) {
+                    const uint2 rr = rp[k], cA = pA[k], nA = pA[k + 1];
+                    const uint32_t GO = cA.y & 0xffffu, GE = cA.y >> 16, GOn = nA.y & 0xffffu, GEn = nA.y >> 16;
+                    if (k == li) { M1 = NUL32; M2 = NUL32; }                                // rolling initialiser (k == li < B)
+                    uint32_t mismE, mismO;
+                    const uint32_t m1 = min_i32(M1, min_i32(I1, D1));                       // :284
+                    if (k == kend) bestE = min_i32(bestE, m1);                              // :285-291
+                    M1 = m1 + cost(rr, cA, &mismE);                                         // :292
+                    const uint32_t x2 = min_i32(M2, I2);
+                    D1 = shift_up32<B>(min_i32(D2 + GEn, x2 + GOn), li);                    // :293-294
+                    I1 = min_i32(I2 + GE, M2 + GO) + NUC32;                                 // :295
+                    uint32_t bpe = 0;
+                    if constexpr (TRACE) {
+                        const uint32_t tm = M1 & 3u, ti = I1 & 3u, td = D1 & 3u;
+                        M1 ^= tm; I1 = (I1 & ~3u) | 1u; D1 |= 3u;
+                        bpe = tm | ti << 2 | td << 4 | mismE << 12;
+                    }
+                    const uint32_t m2 = min_i32(x2, D2);                                    // :308
+                    if (k == kend) bestO = min_i32(bestO, m2);
+                    M2 = m2 + cost(rr, nA, &mismO);                                         // :316
+                    const uint32_t y1 = min_i32(M1, I1);
+                    D2 = min_i32(D1 + GEn, y1 + GOn);                                       // :317
+                    I2 = shift_down32<B>(min_i32(I1 + GE, M1 + GO) + NUC32, li);            // :318-319
+                    if constexpr (TRACE) {
+                        const uint32_t tm = M2 & 3u, ti = I2 & 3u, td = D2 & 3u;
+                        M2 ^= tm; I2 = (I2 & ~3u) | 1u; D2 |= 3u;
+                        tile[(k & 15) * kTileStride + lane] = bpe | (tm | ti << 2 | td << 4) << 6 | mismO << 13;
+                    }
+                }
+                if constexpr (TRACE) { if ((k & 15) == 15) flush_tile(k >> 4); }
+            }
+            // first minimum over the row's end cells (:285-291,309-315,323): 64-bit key = (biased value, diagonal index)
+            const uint32_t vE = bestE ^ 0x80000000u, vO = bestO ^ 0x80000000u, sE = 2 * (TA + li);
+            uint32_t kv = vE, ks = sE;
+            if (vO < vE) { kv = vO; ks = sE + 1; }
+            for (int m = 1; m < B; m <<= 1) {
+                const uint32_t ov = hw::shfl_xor(kv, m), os = hw::shfl_xor(ks, m);
+                if (ov < kv || (ov == kv && os < ks)) { kv = ov; ks = os; }
+            }
+            if (li == 0) {
+                const int32_t score = (int32_t)kv >> 2;                                     // (minscore - INT_MIN) >> 2 in wrapping int arithmetic
+                if constexpr (TRACE) {
+                    TraceEnd e; e.score = score; e.sidx = kv >= (INF32 ^ 0x80000000u) ? -1 : (int32_t)ks;
+                    p.ends[g * G + row] = e;
+                } else {
+                    if (tA.pair != kPadTask) hw::atomic_min_i32(p.pair_best + tA.pair, score);
+                }
+            }
+            hw::wave_lds_fence();
+        }
+        seg = seg_end;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // traceback walk + flank score
 // ------------------------------------------------------------------------------------------------------------------
-template <int B>
+template <int B, int TPR>
 OCT_KERNEL(k_walk_strings)(WalkParams w)   // test seam only: emits the gapped strings (set_alignments :165-231), one step per iteration
 {
-    constexpr uint32_t ROWS = 64 / B, G = 2 * ROWS;
+    constexpr uint32_t ROWS = 64 / B, G = TPR * ROWS;
     const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (ti >= w.n_tasks) return;
     const DevTask t = w.tasks[ti];
     if (t.pair == kPadTask) return;
     const TraceEnd end = w.ends[ti];
-    const uint32_t group = ti / G, slot = ti % G, row = slot >> 1, half = slot & 1;
+    const uint32_t group = ti / G, slot = ti % G, row = slot / TPR, half = slot % TPR;
     const uint32_t ro = w.roff[t.read]; const int32_t T = (int32_t)(w.roff[t.read + 1] - ro);
     const uint32_t ho = w.hoff[t.hap]; const int32_t Lh = (int32_t)(w.hoff[t.hap + 1] - ho);
     const int32_t L = T + 2 * B - 1, off = (int32_t)t.off;
@@ -796,10 +946,10 @@ OCT_KERNEL(k_walk_strings)(WalkParams w)   // test seam only: emits the gapped s
 // rare, and both are queued as events in LDS and priced in a second uniform loop.
 constexpr uint32_t kWalkEvents = 12;
 
-template <int B>
+template <int B, int TPR>
 OCT_KERNEL(k_walk)(WalkParams w)
 {
-    constexpr uint32_t ROWS = 64 / B, G = 2 * ROWS;
+    constexpr uint32_t ROWS = 64 / B, G = TPR * ROWS;
     OCT_DYN_SMEM(smem);
     uint32_t* evbuf = (uint32_t*)smem + hw::thread_idx() * kWalkEvents;
     const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
@@ -808,7 +958,7 @@ OCT_KERNEL(k_walk)(WalkParams w)
     const bool active = t.pair != kPadTask;
     TraceEnd end; end.score = 0; end.sidx = -1;
     if (active) end = w.ends[ti];
-    const uint32_t group = ti / G, slot = ti % G, row = slot >> 1, half = slot & 1;
+    const uint32_t group = ti / G, slot = ti % G, row = slot / TPR, half = slot % TPR;
     const uint32_t ro = w.roff[t.read]; const int32_t T = active ? (int32_t)(w.roff[t.read + 1] - ro) : 1;
     const uint32_t ho = w.hoff[t.hap]; const int32_t Lh = (int32_t)(w.hoff[t.hap + 1] - ho);
     const int32_t L = T + 2 * B - 1, off = (int32_t)t.off;

@@ -179,3 +179,13 @@ def check_device_kmer_mapper(backend, tol=0.0):
     hl = [dict(seq=bytes(hap), begin=0, gap_open=go, gap_extend=ge, mask_fwd=mf, prior_fwd=pf, mask_rev=mr, prior_rev=pr)]
     out.append(compare(backend, abi.Batch.from_lists(reads, hl, flank=None), tol, max_indel_error=8))
     return out
+
+
+def check_int32_lanes(backend, tol=0.0):
+    """Config::use_int_scores: the whole populate path on int32 lanes."""
+    g, rng = small_region(51, with_n=True)
+    batch = mapper_positions(synth.batch_from_regions([g]), rng=rng, junk=0.2)
+    a = compare(backend, batch, tol, max_indel_error=8, use_int_scores=1)
+    g2, _ = small_region(52, B=16, T=50, Lh=150, flank=(30, 25))
+    b = compare(backend, synth.batch_from_regions([g2]), tol, max_indel_error=16, use_int_scores=1)
+    return a, b

@@ -30,6 +30,19 @@ def test_gpu_random_windows_generic_kernel(band, n):
     check_l1.check_random("gpu", band, n, seed=2000 + band, with_n=True)
 
 
+def test_gpu_int32_lanes_golden_vectors(golden_records):
+    assert check_l1.check_golden("gpu", golden_records, score_bits=32) == 17
+
+
+@pytest.mark.parametrize("band,n", [(8, 100), (16, 200), (32, 60), (64, 30)])
+def test_gpu_int32_lanes_random_windows(band, n):
+    check_l1.check_random("gpu", band, n, seed=3000 + band, with_n=True, score_bits=32)
+
+
+def test_gpu_populate_int32_lanes():
+    cp.check_int32_lanes("gpu", TOL)
+
+
 def test_gpu_unmasked_overload():
     check_l1.check_random("gpu", 16, 100, seed=7, masked=False, with_n=False)
 

@@ -25,3 +25,16 @@ def test_sim_unmasked_overload():
 
 def test_sim_int16_overflow_wraps_like_reference():
     check_l1.check_random("sim", 16, 8, seed=9, t_lo=150, t_hi=151, q_max=125, junk=True, with_n=False)
+
+
+def test_sim_int32_lanes_golden_vectors(golden_records):
+    assert check_l1.check_golden("sim", golden_records, score_bits=32) == 17
+
+
+@pytest.mark.parametrize("band,n", [(8, 10), (16, 10), (32, 4), (64, 3)])
+def test_sim_int32_lanes_random_windows(band, n):
+    check_l1.check_random("sim", band, n, seed=300 + band, with_n=True, score_bits=32)
+
+
+def test_sim_int32_lanes_do_not_wrap_where_int16_does():
+    check_l1.check_random("sim", 16, 4, seed=9, t_lo=150, t_hi=151, q_max=125, junk=True, with_n=False, score_bits=32)

@@ -25,3 +25,8 @@ def test_sim_populate_mapping_quality_and_flank_options():
 
 def test_sim_device_kmer_mapper_matches_reference_mapper():
     cp.check_device_kmer_mapper("sim")
+
+
+def test_sim_populate_int32_lanes():
+    a, b = cp.check_int32_lanes("sim")
+    assert a["n_dp_traceback"] > 0 and b["n_dp_score_only"] + b["n_dp_traceback"] > 0
