@@ -46,6 +46,7 @@ struct oct_phmm_batch {
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
+    bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
     uint32_t* d_blk_hap = nullptr; uint32_t* d_blk_read0 = nullptr; uint32_t n_map_blocks = 0;
     double dp_ms = 0; uint32_t dp_launches = 0;
     std::vector<std::pair<rt::Event, rt::Event>> timers;
@@ -97,27 +98,27 @@ bool dalloc(oct_phmm_batch* b, T** dev, size_t n)
 
 bool monotone(const uint32_t* off, uint32_t n) { for (uint32_t i = 0; i < n; ++i) if (off[i + 1] < off[i]) return false; return true; }
 
-// kernel dispatch over (band, traceback, generic)
-template <int B, bool TR, bool GEN>
+// kernel dispatch over (band, traceback, generic bytes, 32-bit adds)
+template <int B, bool TR, bool GEN, bool FA>
 bool launch_dp_inst(const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
 {
-    if (!rt::allow_lds((k_dp<B, TR, GEN>), lds)) return false;
-    OCT_LAUNCH((k_dp<B, TR, GEN>), n_blocks, kBlockWaves * 64, lds, s, p);
+    if (!rt::allow_lds((k_dp<B, TR, GEN, FA>), lds)) return false;
+    OCT_LAUNCH((k_dp<B, TR, GEN, FA>), n_blocks, kBlockWaves * 64, lds, s, p);
     return rt::launch_ok();
 }
-template <int B>
+template <int B, bool FA>
 bool launch_dp_band(bool tr, bool gen, const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
 {
-    if (tr) return gen ? launch_dp_inst<B, true, true>(p, n_blocks, lds, s) : launch_dp_inst<B, true, false>(p, n_blocks, lds, s);
-    return gen ? launch_dp_inst<B, false, true>(p, n_blocks, lds, s) : launch_dp_inst<B, false, false>(p, n_blocks, lds, s);
+    if (tr) return gen ? launch_dp_inst<B, true, true, FA>(p, n_blocks, lds, s) : launch_dp_inst<B, true, false, FA>(p, n_blocks, lds, s);
+    return gen ? launch_dp_inst<B, false, true, FA>(p, n_blocks, lds, s) : launch_dp_inst<B, false, false, FA>(p, n_blocks, lds, s);
 }
-bool launch_dp(int band, bool tr, bool gen, const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
+bool launch_dp(int band, bool tr, bool gen, bool fa, const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
 {
     switch (band) {
-        case 8:  return launch_dp_band<8>(tr, gen, p, n_blocks, lds, s);
-        case 16: return launch_dp_band<16>(tr, gen, p, n_blocks, lds, s);
-        case 32: return launch_dp_band<32>(tr, gen, p, n_blocks, lds, s);
-        case 64: return launch_dp_band<64>(tr, gen, p, n_blocks, lds, s);
+        case 8:  return fa ? launch_dp_band<8, true>(tr, gen, p, n_blocks, lds, s) : launch_dp_band<8, false>(tr, gen, p, n_blocks, lds, s);
+        case 16: return fa ? launch_dp_band<16, true>(tr, gen, p, n_blocks, lds, s) : launch_dp_band<16, false>(tr, gen, p, n_blocks, lds, s);
+        case 32: return fa ? launch_dp_band<32, true>(tr, gen, p, n_blocks, lds, s) : launch_dp_band<32, false>(tr, gen, p, n_blocks, lds, s);
+        case 64: return fa ? launch_dp_band<64, true>(tr, gen, p, n_blocks, lds, s) : launch_dp_band<64, false>(tr, gen, p, n_blocks, lds, s);
         default: return false;
     }
 }
@@ -203,7 +204,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
         rt::Event e0, e1;
         RT(rt::event_create(&e0)); RT(rt::event_create(&e1));
         RT(rt::event_record(e0, h->stream));
-        if (!(h->wide ? launch_dp32(B, tr, p, n_blocks, lds, h->stream) : launch_dp(B, tr, gen, p, n_blocks, lds, h->stream)))
+        if (!(h->wide ? launch_dp32(B, tr, p, n_blocks, lds, h->stream) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, h->stream)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         RT(rt::event_record(e1, h->stream));
         b->timers.emplace_back(e0, e1);
@@ -358,7 +359,24 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     if (b->n_pairs >= 0xffffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "more than 2^32-1 pairs in one batch");
     for (uint32_t r = 0; r < R->n_reads; ++r) b->t_cap = std::max(b->t_cap, R->offsets[r + 1] - R->offsets[r]);
     for (uint32_t hp = 0; hp < H->n_haps; ++hp) b->lh_cap = std::max(b->lh_cap, H->offsets[hp + 1] - H->offsets[hp]);
-    if (b->t_cap + (uint32_t)h->band >= 32768) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long for int16 diagonal indices");
+    if (b->t_cap + (uint32_t)h->band >= 16384) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long for the LDS-resident path");
+    {
+        // Can any biased int16 lane exceed 0xFFFF (= the reference's own lane wrapping)? Every finite cell is bounded by the pure-match
+        // path along its diagonal plus one gap opening, every not-yet-initialised ("infinite") cell by infinity_ plus the deletion chain's
+        // growth (the 0x7FF tolerance the reference itself relies on, simd_pair_hmm.hpp:55). If neither can, a 32-bit add of two packed
+        // halves never carries between them and k_dp uses v_add_u32 (FASTADD); otherwise it keeps v_pk_add_u16. Results are identical.
+        uint64_t sum_q_max = 0; uint32_t gomax = 0, gemax = 0;
+        for (uint32_t r = 0; r < R->n_reads; ++r) {
+            uint64_t sq = 0;
+            for (uint32_t i = R->offsets[r]; i < R->offsets[r + 1]; ++i) sq += R->qualities[i];
+            sum_q_max = std::max(sum_q_max, sq);
+        }
+        for (uint32_t i = 0; i < n_hap_bases; ++i) { gomax = std::max<uint32_t>(gomax, (uint32_t)H->gap_open[i]); gemax = std::max<uint32_t>(gemax, (uint32_t)H->gap_extend[i]); }
+        const uint64_t B64 = (uint64_t)h->band, nuc = (uint64_t)std::max(0, h->cfg.nuc_prior);
+        const uint64_t finite = 4 * (sum_q_max + 2 * 64 * B64 + gomax + gemax + nuc) + 1024;
+        const uint64_t garbage = 4 * (2 * B64 * gemax + 64 + gomax + gemax + nuc) + 64;
+        b->fast_adds = finite < 0xF800u && garbage < 0x7FFu && h->cfg.nuc_prior >= 0 && !getenv("OCT_PHMM_EXACT_ADDS");
+    }
     for (uint32_t r = 0; r < R->n_reads; ++r) if (R->offsets[r + 1] == R->offsets[r]) return fail(status, OCT_PHMM_EINVAL, "empty read");
     std::vector<uint32_t> h_pos; std::vector<uint8_t> h_npos;
     const uint32_t S = (uint32_t)h->cfg.max_mapping_positions;

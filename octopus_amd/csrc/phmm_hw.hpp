@@ -70,6 +70,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 OCT_DEVICE uint32_t pk_add(uint32_t a, uint32_t b)     { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b))); }
 OCT_DEVICE uint32_t pk_sub(uint32_t a, uint32_t b)     { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b))); }
 OCT_DEVICE uint32_t pk_add_sat(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
+OCT_DEVICE uint32_t pk_add_sat_u(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
 OCT_DEVICE uint32_t pk_min_i(uint32_t a, uint32_t b)   { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
 OCT_DEVICE uint32_t pk_min_u(uint32_t a, uint32_t b)   { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
 OCT_DEVICE uint32_t pk_shl2(uint32_t a)                { const u16x2 two = {2, 2}; return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) << two)); }

@@ -470,7 +470,7 @@ inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool t
 // traceback scratch: per task group, ceil(iterations / 16) tiles of 64 lanes x 16 iterations, each lane's 16 dwords contiguous
 OCT_HD constexpr uint32_t bp_tiles(uint32_t t_cap, uint32_t B) { return (t_cap + B + 15) / 16 + 1; }
 
-template <int B, bool TRACE, bool GENERIC>
+template <int B, bool TRACE, bool GENERIC, bool FASTADD>
 OCT_KERNEL(k_dp)(DpParams p)
 {
     constexpr uint32_t ROWS = 64 / B, G = 2 * ROWS;
@@ -489,6 +489,12 @@ OCT_KERNEL(k_dp)(DpParams p)
     const uint32_t g_begin = hw::block_idx() * p.groups_per_block;
     const uint32_t g_end = g_begin + p.groups_per_block < n_groups ? g_begin + p.groups_per_block : n_groups;
     const uint32_t NUC = p.nuc4;
+    // State words are kept biased by 0x8000 per half (null_score_ -> 0x0000, infinity_ -> 0xF800): a wrapping add is bit-identical to the
+    // reference's int16 add, the signed min becomes an unsigned min, and a half only carries into its neighbour where the reference's
+    // own lane would wrap. FASTADD (chosen by the host when its bounds prove no lane can wrap) then uses plain
+    // v_add_u32 (2 cycles) instead of v_pk_add_u16 (4 cycles).
+    constexpr uint32_t INFB = INF2 ^ 0x80008000u, NULB = NUL2 ^ 0x80008000u;
+    auto sadd = [](uint32_t x, uint32_t y) -> uint32_t { if constexpr (FASTADD) return x + y; else return hw::pk_add(x, y); };
 
     uint32_t seg = g_begin;
     while (seg < g_end) {
@@ -554,16 +560,17 @@ OCT_KERNEL(k_dp)(DpParams p)
             const uint32_t kendA = TA + li, kendB = TB + li;          // the iteration whose M cells are this lane's end cells (t == T)
             uint4* bpg = TRACE ? (uint4*)(p.bp + (size_t)g * p.k_cap * 1024) : nullptr;   // this group's tiles (k_cap tiles of 4 KB)
 
-            uint32_t M1 = INF2, I1 = INF2, D1 = INF2, M2 = INF2, I2 = INF2, D2 = INF2;     // :267
-            uint32_t y1 = INF2;                                                             // min(M1, I1) carried between iterations
-            uint32_t bestE = INF2, bestO = INF2;                                            // minscore :269, per diagonal parity
+            uint32_t M1 = INFB, I1 = INFB, D1 = INFB, M2 = INFB, I2 = INFB, D2 = INFB;     // :267
+            uint32_t y1 = INFB;                                                             // min(M1, I1) carried between iterations
+            uint32_t bestE = INFB, bestO = INFB;                                            // minscore :269, per diagonal parity
             // software pipeline: operands of iteration k are in registers when it starts, those of k+1 are in flight
             uint2 rr = rp[0];
             uint2 cA = pA[0], cB = pB[0], nA = pA[1], nB = pB[1];
             uint32_t GO = hw::perm(cB.y, cA.y, 0x05040100u), GE = hw::perm(cB.y, cA.y, 0x07060302u);
             uint32_t GOn = hw::perm(nB.y, nA.y, 0x05040100u), GEn = hw::perm(nB.y, nA.y, 0x07060302u);
 
-            auto cost = [&](const uint2 r2, const uint2 a, const uint2 b) -> uint32_t {
+            // returns the packed match cost; fsrc = a word that is non-zero per half exactly where the walk would charge a flank penalty
+            auto cost = [&](const uint2 r2, const uint2 a, const uint2 b, uint32_t& fsrc) -> uint32_t {
                 if constexpr (GENERIC) {
                     // update_match_state with the reference's equality tests on raw bytes (:121-132)
                     const uint32_t hh = hw::perm(b.x, a.x, 0x0c040c00u), mm = hw::perm(b.x, a.x, 0x0c050c01u);
@@ -572,14 +579,19 @@ OCT_KERNEL(k_dp)(DpParams p)
                     const uint32_t inner = hw::pk_mad(nf, hw::pk_sub(r2.y, pp), pp);        // target == mask ? prior : quality
                     uint32_t c = hw::pk_mul(ne, hw::pk_min_i(r2.y, inner));                 // 0 where target == truth
                     const uint32_t nq = hw::pk_mad(nn, 0x88088808u, INF2);                  // truth == 'N' ? n_score_ (8) : infinity_
+                    fsrc = ne;                                                              // target != truth (also charges 2 on 'N', even at quality 0)
                     return hw::pk_min_i(c, nq);
                 } else {
                     const uint32_t cp = hw::perm(b.x, a.x, r2.x);                           // {capA, capB} for this read base
-                    return hw::pk_min_u(cp, r2.y);                                          // min(quality, cap), unshifted
+                    const uint32_t c = hw::pk_min_u(cp, r2.y);                              // min(quality, cap), unshifted
+                    fsrc = c;                                                               // the flank penalty of this column is exactly c
+                    return c;
                 }
             };
+            // bit `bit` (and bit + 16) set where the half's cost is non-zero; costs stay below 0x4000 so the add cannot leave its half
+            auto flag_of = [](uint32_t c, int bit) -> uint32_t { const uint32_t msk = 0x00010001u << bit; return (c + (msk - 0x00010001u)) & msk; };
             auto add_cost = [&](uint32_t m, uint32_t c) -> uint32_t {
-                if constexpr (GENERIC) return hw::pk_add(m, c); else return hw::pk_mad(c, 0x00040004u, m);   // + (c << trace_bits_)
+                if constexpr (GENERIC) return sadd(m, c); else return hw::pk_mad(c, 0x00040004u, m);   // + (c << trace_bits_)
             };
 
             // every 16 iterations: transpose the 16 x 64 tile through LDS so that each lane's 16 words become one 64-byte line and
@@ -603,37 +615,38 @@ OCT_KERNEL(k_dp)(DpParams p)
                     const uint32_t k = k0 + u;
                     const uint2 rr_nx = rp[k + 1];                                          // prefetch iteration k+1
                     const uint2 nnA = pA[k + 2], nnB = pB[k + 2];
-                    uint32_t gate = 0;                                                      // 0 on an end cell, +32767 (saturating) elsewhere
-                    if constexpr (CAP) gate = (k == kendA ? 0u : 0x7fffu) | (k == kendB ? 0u : 0x7fff0000u);
+                    uint32_t gate = 0;                                                      // 0 on an end cell, saturating +65535 elsewhere
+                    if constexpr (CAP) gate = (k == kendA ? 0u : 0xffffu) | (k == kendB ? 0u : 0xffff0000u);
                     // ---- even diagonal s = 2k: lane li is cell (t = k-li, x = k+li) ----
-                    uint32_t m1 = hw::pk_min_i(y1, D1);                                     // :284
-                    if constexpr (INIT) { const bool first = k == li; m1 = first ? NUL2 : m1; M2 = first ? NUL2 : M2; }   // :282-283
-                    if constexpr (CAP) bestE = hw::pk_min_i(bestE, hw::pk_add_sat(m1, gate));   // :285-291
-                    const uint32_t ce = cost(rr, cA, cB);
+                    uint32_t m1 = hw::pk_min_u(y1, D1);                                     // :284
+                    if constexpr (INIT) { const bool first = k == li; m1 = first ? NULB : m1; M2 = first ? NULB : M2; }   // :282-283
+                    if constexpr (CAP) bestE = hw::pk_min_u(bestE, hw::pk_add_sat_u(m1, gate));   // :285-291
+                    uint32_t fe = 0, fo = 0;
+                    const uint32_t ce = cost(rr, cA, cB, fe);
                     M1 = add_cost(m1, ce);                                                  // :292
-                    const uint32_t x2 = hw::pk_min_i(M2, I2);
-                    const uint32_t dsh = hw::pk_min_i(hw::pk_add(D2, GEn), hw::pk_add(x2, GOn));
-                    D1 = shift_up<B>(INF2, dsh, li);                                        // :293-294
-                    I1 = hw::pk_add(hw::pk_min_i(hw::pk_add(I2, GE), hw::pk_add(M2, GO)), NUC);   // :295
+                    const uint32_t x2 = hw::pk_min_u(M2, I2);
+                    const uint32_t dsh = hw::pk_min_u(sadd(D2, GEn), sadd(x2, GOn));
+                    D1 = shift_up<B>(INFB, dsh, li);                                        // :293-294
+                    I1 = sadd(hw::pk_min_u(sadd(I2, GE), sadd(M2, GO)), NUC);               // :295
                     uint32_t bpe = 0;
                     if constexpr (TRACE) {                                                  // update_traceback :147-163
                         const uint32_t tm = M1 & 0x00030003u, ti = I1 & 0x00030003u, td = D1 & 0x00030003u;
                         M1 ^= tm; I1 = (I1 & ~0x00030003u) | 0x00010001u; D1 |= 0x00030003u;
-                        bpe = tm | ti << 2 | td << 4 | hw::pk_min_u(ce, 0x00010001u) << 12;   // + "this match cell costs something" flag
+                        bpe = tm | ti << 2 | td << 4 | flag_of(fe, 15);                     // + "this match cell costs something" flag
                     }
                     // ---- odd diagonal s = 2k+1: lane li is cell (t, x+1) ----
-                    const uint32_t m2 = hw::pk_min_i(x2, D2);                               // :308
-                    if constexpr (CAP) bestO = hw::pk_min_i(bestO, hw::pk_add_sat(m2, gate));   // :309-315
-                    const uint32_t co = cost(rr, nA, nB);
+                    const uint32_t m2 = hw::pk_min_u(x2, D2);                               // :308
+                    if constexpr (CAP) bestO = hw::pk_min_u(bestO, hw::pk_add_sat_u(m2, gate));   // :309-315
+                    const uint32_t co = cost(rr, nA, nB, fo);
                     M2 = add_cost(m2, co);                                                  // :316
-                    y1 = hw::pk_min_i(M1, I1);
-                    D2 = hw::pk_min_i(hw::pk_add(D1, GEn), hw::pk_add(y1, GOn));            // :317
-                    const uint32_t ish = hw::pk_add(hw::pk_min_i(hw::pk_add(I1, GE), hw::pk_add(M1, GO)), NUC);
-                    I2 = shift_down<B>(INF2, ish, li);                                      // :318-319
+                    y1 = hw::pk_min_u(M1, I1);
+                    D2 = hw::pk_min_u(sadd(D1, GEn), sadd(y1, GOn));                        // :317
+                    const uint32_t ish = sadd(hw::pk_min_u(sadd(I1, GE), sadd(M1, GO)), NUC);
+                    I2 = shift_down<B>(INFB, ish, li);                                      // :318-319
                     if constexpr (TRACE) {
                         const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
                         M2 ^= tm; I2 = (I2 & ~0x00030003u) | 0x00010001u; D2 |= 0x00030003u;
-                        tile[(k & 15) * kTileStride + lane] = bpe | (tm | ti << 2 | td << 4) << 6 | hw::pk_min_u(co, 0x00010001u) << 13;
+                        tile[(k & 15) * kTileStride + lane] = bpe | (tm | ti << 2 | td << 4) << 6 | flag_of(fo, 14);
                     }
                     rr = rr_nx; cA = nA; cB = nB; GO = GOn; GE = GEn; nA = nnA; nB = nnB;
                     GOn = hw::perm(nB.y, nA.y, 0x05040100u); GEn = hw::perm(nB.y, nA.y, 0x07060302u);
@@ -653,7 +666,7 @@ OCT_KERNEL(k_dp)(DpParams p)
             // ---- first minimum over the row's end cells, per packed task (:285-291,309-315,323) ----
             for (uint32_t half = 0; half < 2; ++half) {
                 const uint32_t Th = half ? TB : TA;
-                const uint32_t vE = ((bestE >> (16 * half)) & 0xffffu) ^ 0x8000u, vO = ((bestO >> (16 * half)) & 0xffffu) ^ 0x8000u;   // bias to unsigned order
+                const uint32_t vE = (bestE >> (16 * half)) & 0xffffu, vO = (bestO >> (16 * half)) & 0xffffu;   // biased: unsigned order
                 const uint32_t sE = 2 * (Th + li);
                 const uint32_t kE = vE << 16 | sE, kO = vO << 16 | (sE + 1);
                 uint32_t key = kE < kO ? kE : kO;
@@ -786,7 +799,7 @@ OCT_KERNEL(k_dp32)(DpParams p)
                     if constexpr (TRACE) {
                         const uint32_t tm = M1 & 3u, ti = I1 & 3u, td = D1 & 3u;
                         M1 ^= tm; I1 = (I1 & ~3u) | 1u; D1 |= 3u;
-                        bpe = tm | ti << 2 | td << 4 | mismE << 12;
+                        bpe = tm | ti << 2 | td << 4 | mismE << 15;
                     }
                     const uint32_t m2 = min_i32(x2, D2);                                    // :308
                     if (k == kend) bestO = min_i32(bestO, m2);
@@ -797,7 +810,7 @@ OCT_KERNEL(k_dp32)(DpParams p)
                     if constexpr (TRACE) {
                         const uint32_t tm = M2 & 3u, ti = I2 & 3u, td = D2 & 3u;
                         M2 ^= tm; I2 = (I2 & ~3u) | 1u; D2 |= 3u;
-                        tile[(k & 15) * kTileStride + lane] = bpe | (tm | ti << 2 | td << 4) << 6 | mismO << 13;
+                        tile[(k & 15) * kTileStride + lane] = bpe | (tm | ti << 2 | td << 4) << 6 | mismO << 14;
                     }
                 }
                 if constexpr (TRACE) { if ((k & 15) == 15) flush_tile(k >> 4); }
@@ -1008,7 +1021,7 @@ OCT_KERNEL(k_walk)(WalkParams w)
     // one alignment column from backpointer word `wv` of cell (sidx, i)
     auto step = [&](uint32_t wv) {
         const uint32_t par = (uint32_t)sidx & 1u;
-        const uint32_t bits = (wv >> (hshift + 6 * par)) & 63u, mism = (wv >> (hshift + 12 + par)) & 1u;
+        const uint32_t bits = (wv >> (hshift + 6 * par)) & 63u, mism = (wv >> (hshift + 15 - par)) & 1u;
         if (!started) { state = bits & 3u; sidx -= 2; started = true; return; }                 // :191-192
         const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;                 // :200
         if (state == 0) {                                                                       // match :201-204, :383-397

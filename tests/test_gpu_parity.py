@@ -43,6 +43,13 @@ def test_gpu_populate_int32_lanes():
     cp.check_int32_lanes("gpu", TOL)
 
 
+def test_gpu_exact_add_mode_gives_same_results(monkeypatch):
+    monkeypatch.setenv("OCT_PHMM_EXACT_ADDS", "1")
+    check_l1.check_random("gpu", 16, 200, seed=1016, with_n=False)
+    check_l1.check_random("gpu", 8, 100, seed=2008, with_n=True)
+    cp.check_basic("gpu", TOL)
+
+
 def test_gpu_unmasked_overload():
     check_l1.check_random("gpu", 16, 100, seed=7, masked=False, with_n=False)
 

@@ -38,3 +38,10 @@ def test_sim_int32_lanes_random_windows(band, n):
 
 def test_sim_int32_lanes_do_not_wrap_where_int16_does():
     check_l1.check_random("sim", 16, 4, seed=9, t_lo=150, t_hi=151, q_max=125, junk=True, with_n=False, score_bits=32)
+
+
+def test_sim_exact_add_mode_gives_same_results(monkeypatch):
+    """The host picks v_add_u32 adds only when its bounds prove no lane can wrap; forcing the v_pk_add_u16 path must not change anything."""
+    monkeypatch.setenv("OCT_PHMM_EXACT_ADDS", "1")
+    check_l1.check_random("sim", 16, 10, seed=116, with_n=False)
+    check_l1.check_random("sim", 8, 8, seed=208, with_n=True)
