@@ -47,6 +47,18 @@ OCT_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor
 OCT_DEVICE uint32_t shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 OCT_DEVICE uint32_t readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 OCT_DEVICE uint64_t ballot(bool p) { return __ballot(p); }
+// wave-wide unsigned max, result in every lane: DPP row shifts + row broadcasts (no LDS round trips), then a scalar broadcast
+OCT_DEVICE uint32_t wave_max_u32(uint32_t v)
+{
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8  -> lane 15 of each row holds the row max
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave max
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 OCT_DEVICE uint32_t atomic_add_lds_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 OCT_DEVICE void block_sync() { __syncthreads(); }
 OCT_DEVICE int  atomic_min_i32(int32_t* p, int32_t v) { return atomicMin(p, v); }

@@ -185,20 +185,34 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
             }
         }
         hw::wave_lds_fence();
-        // max_hit_count, then the ascending positions that reach it, at most max_pos of them (:145-157)
+        // max_hit_count, then the ascending positions that reach it, at most max_pos of them (:145-157). The first 8 chunks of the
+        // counters are read once into registers (and cleared: reset_mapping_counts :115-118) and reused by the output pass.
+        uint32_t cr[8];
         uint32_t mx = 0;
-        for (uint32_t d = lane; d < nk; d += 64) { const uint32_t c = counts[d]; mx = c > mx ? c : mx; }
-        for (int m = 1; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(mx, m); mx = o > mx ? o : mx; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t d = (uint32_t)q * 64 + lane;
+            cr[q] = d < nk ? counts[d] : 0;
+            if (d < nk) counts[d] = 0;
+            mx = cr[q] > mx ? cr[q] : mx;
+        }
+        for (uint32_t d = 512 + lane; d < nk; d += 64) { const uint32_t c = counts[d]; mx = c > mx ? c : mx; }
+        mx = hw::wave_max_u32(mx);
         uint32_t n_out = 0;
-        for (uint32_t d0 = 0; d0 < nk; d0 += 64) {
-            const uint32_t d = d0 + lane;
-            const uint32_t c = d < nk ? counts[d] : 0;
-            if (d < nk) counts[d] = 0;                                 // reset_mapping_counts :115-118
-            const bool is = mx > 0 && c == mx;
+        auto emit = [&](uint32_t d, uint32_t c) {
+            const bool is = mx > 0 && d < nk && c == mx;
             const uint64_t mask = hw::ballot(is);
             const uint32_t rank = n_out + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
             if (is && rank < max_pos) b.pos[e * (uint64_t)max_pos + rank] = d;
             n_out += (uint32_t)__builtin_popcountll(mask);
+        };
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { if ((uint32_t)q * 64 < nk) emit((uint32_t)q * 64 + lane, cr[q]); }
+        for (uint32_t d0 = 512; d0 < nk; d0 += 64) {
+            const uint32_t d = d0 + lane;
+            const uint32_t c = d < nk ? counts[d] : 0;
+            if (d < nk) counts[d] = 0;
+            emit(d, c);
         }
         if (n_out > max_pos) n_out = max_pos;
         if (lane == 0) b.npos[e] = (uint8_t)n_out;
@@ -1064,9 +1078,12 @@ OCT_KERNEL(k_walk)(WalkParams w)
 #pragma unroll
         for (int kk = 15; kk >= 0; --kk) {
             const int32_t k = kt * 16 + kk;
-#pragma unroll
-            for (int rep = 0; rep < 2; ++rep) {
-                if (!fin && (sidx >> 1) == k && sidx >= 0) {
+            // a lane takes one step per iteration k while it follows matches; an insertion/deletion can add a second step at the same k
+            // (odd -> even diagonal), so the second pass runs only when some lane of the wave asks for it
+            for (int rep = 0; rep < 3; ++rep) {
+                const bool here = !fin && (sidx >> 1) == k && sidx >= 0;
+                if (rep > 0 && hw::ballot(here) == 0) break;
+                if (here) {
                     if (i < 0) { ok = false; fin = true; }                                      // :195-199
                     else if (i >= B) {                                                          // the reference indexes its array flat: lane overflow reads the next diagonal
                         const int64_t f = (int64_t)sidx * B + i;
