@@ -1078,12 +1078,9 @@ OCT_KERNEL(k_walk)(WalkParams w)
 #pragma unroll
         for (int kk = 15; kk >= 0; --kk) {
             const int32_t k = kt * 16 + kk;
-            // a lane takes one step per iteration k while it follows matches; an insertion/deletion can add a second step at the same k
-            // (odd -> even diagonal), so the second pass runs only when some lane of the wave asks for it
-            for (int rep = 0; rep < 3; ++rep) {
-                const bool here = !fin && (sidx >> 1) == k && sidx >= 0;
-                if (rep > 0 && hw::ballot(here) == 0) break;
-                if (here) {
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {                                                 // an insertion/deletion can add a second step at the same k
+                if (!fin && (sidx >> 1) == k && sidx >= 0) {
                     if (i < 0) { ok = false; fin = true; }                                      // :195-199
                     else if (i >= B) {                                                          // the reference indexes its array flat: lane overflow reads the next diagonal
                         const int64_t f = (int64_t)sidx * B + i;
