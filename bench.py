@@ -51,13 +51,13 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
     oracle.set_l1_backend(backend)
     cfg = abi.Config.default(max_indel_error=B)
     rng = np.random.default_rng(seed)
-    R, H = 40_000, 64          # ~25 s of single-core SSE2 work, spread over all host threads
+    R, H = 20_000, 64          # ~5 s of single-core SSE2 work per pass, spread over the host threads the cgroup grants
     batch = synth.batch_from_regions([synth.make_region(rng, R, H, B=B, positions="none")])
     t0 = time.perf_counter()
     _, st, stats = oracle.populate(cfg, batch, n_threads=cores)
     dt = time.perf_counter() - t0
     reps = 1
-    while dt * reps < 2.0 and reps < 16:      # repeat the sample until the clock is meaningful, bounded
+    while dt * reps < 4.0 and reps < 32:      # repeat the sample until the clock is meaningful, bounded (~10-20 s of CPU work in total)
         reps *= 2
     if reps > 1:
         t0 = time.perf_counter()

@@ -176,4 +176,13 @@ def time_align_windows(band, score_bits, truth, truth_offsets, target, quals, ta
 
 
 def host_cores() -> int:
-    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    """Host threads the CPU baseline may use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes expose 256 logical
+    CPUs but grant a 16-CPU quota; oversubscribing it only adds throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
