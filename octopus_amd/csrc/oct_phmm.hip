@@ -22,6 +22,7 @@ struct oct_phmm_handle {
     oct_phmm_config cfg;
     int band = 0;
     bool wide = false;                                   // int32 lanes (Config::use_int_scores)
+    int  lanes_c = 1;                                    // band diagonals per lane on the streaming path (band / 64) for bands 128, 256
     rt::Stream stream {};
     rt::Event ev[2] {};
     uint32_t* bp = nullptr; size_t bp_bytes = 0;          // traceback scratch, grown on demand
@@ -46,6 +47,8 @@ struct oct_phmm_batch {
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
+    bool stream = false;          // streaming DP path (k_dp_wide): band 128/256, or band 64 with reads/haplotypes too long for LDS
+    bool map_big = false;         // haplotypes too long for the LDS-resident k-mer mapper
     bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
     uint32_t* d_blk_hap = nullptr; uint32_t* d_blk_read0 = nullptr; uint32_t n_map_blocks = 0;
     double dp_ms = 0; uint32_t dp_launches = 0;
@@ -139,22 +142,41 @@ bool launch_dp32(int band, bool tr, const DpParams& p, uint32_t n_blocks, size_t
         default: return false;
     }
 }
-template <int B, int TPR>
+template <int B, int TPR, int C>
 bool launch_walk_inst(const WalkParams& w, rt::Stream s)
 {
     const uint32_t blocks = (w.n_tasks + 255) / 256;
     const size_t lds = 256 * kWalkEvents * sizeof(uint32_t);
-    OCT_LAUNCH((k_walk<B, TPR>), blocks, 256, lds, s, w);
-    if (w.out_align1 != nullptr) OCT_LAUNCH((k_walk_strings<B, TPR>), blocks, 256, 0, s, w);   // test seam: gapped strings from the simple per-step walker
+    OCT_LAUNCH((k_walk<B, TPR, C>), blocks, 256, lds, s, w);
+    if (w.out_align1 != nullptr) OCT_LAUNCH((k_walk_strings<B, TPR, C>), blocks, 256, 0, s, w);   // test seam: gapped strings from the simple per-step walker
     return rt::launch_ok();
 }
-bool launch_walk(int band, bool wide, const WalkParams& w, rt::Stream s)
+bool launch_walk(int band, bool one_per_row, const WalkParams& w, rt::Stream s)
 {
     switch (band) {
-        case 8:  return wide ? launch_walk_inst<8, 1>(w, s) : launch_walk_inst<8, 2>(w, s);
-        case 16: return wide ? launch_walk_inst<16, 1>(w, s) : launch_walk_inst<16, 2>(w, s);
-        case 32: return wide ? launch_walk_inst<32, 1>(w, s) : launch_walk_inst<32, 2>(w, s);
-        case 64: return wide ? launch_walk_inst<64, 1>(w, s) : launch_walk_inst<64, 2>(w, s);
+        case 8:   return one_per_row ? launch_walk_inst<8, 1, 1>(w, s) : launch_walk_inst<8, 2, 1>(w, s);
+        case 16:  return one_per_row ? launch_walk_inst<16, 1, 1>(w, s) : launch_walk_inst<16, 2, 1>(w, s);
+        case 32:  return one_per_row ? launch_walk_inst<32, 1, 1>(w, s) : launch_walk_inst<32, 2, 1>(w, s);
+        case 64:  return one_per_row ? launch_walk_inst<64, 1, 1>(w, s) : launch_walk_inst<64, 2, 1>(w, s);
+        case 128: return launch_walk_inst<128, 1, 2>(w, s);
+        case 256: return launch_walk_inst<256, 1, 4>(w, s);
+        default: return false;
+    }
+}
+template <int C, bool TR>
+bool launch_dp_wide_inst(bool w16, const DpParams& p, rt::Stream s)
+{
+    const uint32_t blocks = (p.n_tasks + kBlockWaves - 1) / kBlockWaves;
+    if (w16) OCT_LAUNCH((k_dp_wide<C, TR, true>), blocks, kBlockWaves * 64, 0, s, p);
+    else     OCT_LAUNCH((k_dp_wide<C, TR, false>), blocks, kBlockWaves * 64, 0, s, p);
+    return rt::launch_ok();
+}
+bool launch_dp_wide(int c, bool tr, bool w16, const DpParams& p, rt::Stream s)
+{
+    switch (c) {
+        case 1: return tr ? launch_dp_wide_inst<1, true>(w16, p, s) : launch_dp_wide_inst<1, false>(w16, p, s);
+        case 2: return tr ? launch_dp_wide_inst<2, true>(w16, p, s) : launch_dp_wide_inst<2, false>(w16, p, s);
+        case 4: return tr ? launch_dp_wide_inst<4, true>(w16, p, s) : launch_dp_wide_inst<4, false>(w16, p, s);
         default: return false;
     }
 }
@@ -175,9 +197,10 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
 {
     if (!n_tasks) return OCT_PHMM_OK;
     const int B = h->band;
-    const uint32_t G = (h->wide ? 1 : 2) * (64 / B);
+    const uint32_t C = (uint32_t)h->lanes_c;
+    const uint32_t G = b->stream ? 1u : (h->wide ? 1 : 2) * (64 / B);
     const bool tr = kind == kTraceFast || kind == kTraceGen, gen = kind == kScoreGen || kind == kTraceGen;
-    const size_t lds = dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr);
+    const size_t lds = b->stream ? 0 : dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr);
     if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
     DpParams p {};
     p.rbases = b->d.rbases; p.rquals = b->d.rquals; p.roff = b->d.roff; p.rrev = b->d.rrev; p.hoff = b->d.hoff;
@@ -190,7 +213,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
     const uint32_t n_groups = n_tasks / G;
     uint32_t chunk_groups = n_groups;
     if (tr) {
-        const size_t per_group = (size_t)p.k_cap * 4096;
+        const size_t per_group = (size_t)p.k_cap * 4096 * (b->stream ? C : 1);
         const size_t fit = std::max<size_t>(1, h->bp_budget / per_group);
         chunk_groups = (uint32_t)std::min<size_t>(n_groups, fit);
         chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / p.groups_per_block * p.groups_per_block);
@@ -204,7 +227,8 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
         rt::Event e0, e1;
         RT(rt::event_create(&e0)); RT(rt::event_create(&e1));
         RT(rt::event_record(e0, h->stream));
-        if (!(h->wide ? launch_dp32(B, tr, p, n_blocks, lds, h->stream) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, h->stream)))
+        if (!(b->stream ? launch_dp_wide((int)C, tr, !h->wide, p, h->stream)
+                        : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, h->stream) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, h->stream)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         RT(rt::event_record(e1, h->stream));
         b->timers.emplace_back(e0, e1);
@@ -222,7 +246,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
                 w.out_first_pos += o; w.out_align_off += o;
                 if (w.seam_lhs) { w.seam_lhs += o; w.seam_rhs += o; w.out_flank += o; w.out_mask_size += o; }
             }
-            if (!launch_walk(B, h->wide, w, h->stream)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
+            if (!launch_walk(B, h->wide || b->stream, w, h->stream)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
         }
     }
     return OCT_PHMM_OK;
@@ -263,7 +287,6 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     *out = nullptr;
     const int band = band_for(cfg->max_indel_error);
     if (band < 0) return OCT_PHMM_EBAND;
-    if (band > 64) return OCT_PHMM_EUNSUPPORTED;                                    // see DESIGN.md "limits"
     if (cfg->max_mapping_positions < 0 || cfg->max_mapping_positions >= kMaxSlots) return OCT_PHMM_EUNSUPPORTED;
     int n = 0;
     if (!rt::device_count(&n) || n <= 0 || cfg->device_id < 0 || cfg->device_id >= n) return OCT_PHMM_ENODEVICE;
@@ -271,7 +294,7 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     if (!rt::set_device(cfg->device_id)) return OCT_PHMM_EHIP;
     std::unique_ptr<oct_phmm_handle> h(new (std::nothrow) oct_phmm_handle());
     if (!h) return OCT_PHMM_EHIP;
-    h->cfg = *cfg; h->band = band; h->wide = cfg->use_int_scores != 0;
+    h->cfg = *cfg; h->band = band; h->wide = cfg->use_int_scores != 0; h->lanes_c = band > 64 ? band / 64 : 1;
     if (h->cfg.mapping_quality_cap_trigger >= 0 && h->cfg.mapping_quality_cap_trigger >= h->cfg.mapping_quality_cap)
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
     if (const char* e = getenv("OCT_PHMM_BP_BUDGET_GB")) { const long gb = atol(e); if (gb > 0) h->bp_budget = (size_t)gb << 30; }
@@ -359,7 +382,12 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     if (b->n_pairs >= 0xffffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "more than 2^32-1 pairs in one batch");
     for (uint32_t r = 0; r < R->n_reads; ++r) b->t_cap = std::max(b->t_cap, R->offsets[r + 1] - R->offsets[r]);
     for (uint32_t hp = 0; hp < H->n_haps; ++hp) b->lh_cap = std::max(b->lh_cap, H->offsets[hp + 1] - H->offsets[hp]);
-    if (b->t_cap + (uint32_t)h->band >= 16384) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long for the LDS-resident path");
+    {
+        const bool fits = h->band <= 64 && dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)h->band, true) <= rt::kMaxLdsBytes;
+        b->stream = h->band > 64 || (h->band == 64 && !fits);
+        if (!b->stream && !fits) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident kernels at this band (use band >= 64)");
+        if (b->t_cap + 2 * (uint32_t)h->band >= 32768) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long (walk events hold 15-bit coordinates)");
+    }
     {
         // Can any biased int16 lane exceed 0xFFFF (= the reference's own lane wrapping)? Every finite cell is bounded by the pure-match
         // path along its diagonal plus one gap opening, every not-yet-initialised ("infinite") cell by infinity_ plus the deletion chain's
@@ -391,8 +419,9 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
         }
     } else {
         b->device_map = true;
-        if (b->lh_cap >= 65536 || kmer_map_lds_bytes(b->lh_cap) > rt::kMaxLdsBytes)
-            return fail(status, OCT_PHMM_EUNSUPPORTED, "haplotype too long for the LDS-resident k-mer mapper");
+        b->map_big = kmer_map_lds_bytes(b->lh_cap) > rt::kMaxLdsBytes || getenv("OCT_PHMM_BIG_MAPPER") != nullptr;   // env: test hook
+        if (b->lh_cap >= 65536 || (size_t)b->lh_cap * 4 + 64 > rt::kMaxLdsBytes)
+            return fail(status, OCT_PHMM_EUNSUPPORTED, "haplotype too long for the k-mer mapper (>= 40k bases)");
     }
     b->h_roff.assign(R->offsets, R->offsets + R->n_reads + 1); b->h_hoff.assign(H->offsets, H->offsets + H->n_haps + 1);
     b->h_rbegin.assign(R->ref_begin, R->ref_begin + R->n_reads); b->h_hbegin.assign(H->ref_begin, H->ref_begin + H->n_haps);
@@ -401,7 +430,7 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     rt::Stream s = h->stream;
     DevBatch& d = b->d;
     d.n_reads = R->n_reads; d.n_rows = n_rows; d.n_haps = H->n_haps; d.n_regions = G; d.n_pairs = b->n_pairs;
-    d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions; d.wide = h->wide ? 1 : 0;
+    d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions; d.wide = (h->wide || b->stream) ? 1 : 0;
     d.use_mapq = h->cfg.use_mapping_quality; d.mapq_cap = h->cfg.mapping_quality_cap; d.mapq_trigger = h->cfg.mapping_quality_cap_trigger;
     oct_phmm_batch* bp = b.get();
     RT(upload(bp, s, (const uint8_t*)R->bases, n_read_bases, &d.rbases));
@@ -478,7 +507,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     DevBatch& d = b->d;
     for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
     b->timers.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
-    const uint32_t G = (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
+    const uint32_t G = b->stream ? 1u : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
     RT(rt::dev_memset(d.stats, 0, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s));
     RT(rt::dev_memset(d.err_key, 0xff, sizeof(unsigned long long), s));
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
@@ -487,9 +516,15 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         const uint32_t n_rb = b->h_roff[b->n_reads];
         OCT_LAUNCH(k_read_hashes, (n_rb + 255) / 256, 256, 0, s, d, n_rb); RT(rt::launch_ok());
         OCT_LAUNCH(k_kmer_tables, b->n_haps, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d); RT(rt::launch_ok());
-        const size_t lds = kmer_map_lds_bytes(b->lh_cap);
-        RT(rt::allow_lds(k_kmer_map, lds));
-        OCT_LAUNCH(k_kmer_map, b->n_map_blocks, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap, (const uint32_t*)b->d_blk_read0, b->lh_cap); RT(rt::launch_ok());
+        if (b->map_big) {
+            const size_t lds = (size_t)b->lh_cap * 4 + 64;
+            RT(rt::allow_lds(k_kmer_map_big, lds));
+            OCT_LAUNCH(k_kmer_map_big, (uint32_t)b->n_pairs, 256, lds, s, d); RT(rt::launch_ok());
+        } else {
+            const size_t lds = kmer_map_lds_bytes(b->lh_cap);
+            RT(rt::allow_lds(k_kmer_map, lds));
+            OCT_LAUNCH(k_kmer_map, b->n_map_blocks, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap, (const uint32_t*)b->d_blk_read0, b->lh_cap); RT(rt::launch_ok());
+        }
     }
     if (b->n_pairs) {
         RT(rt::dev_memset(d.pair_cnt + b->n_pairs, 0, sizeof(uint4), s));
@@ -619,7 +654,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
         || (lhs_flank && (!traceback || !rhs_flank || !flank_score || !target_mask_size || !snv_mask)))
         return fail(status, OCT_PHMM_EINVAL, "null argument");
     if (!n) return ok(status);
-    const uint32_t B = (uint32_t)h->band, G = (h->wide ? 1u : 2u) * (64 / B);
+    const uint32_t B = (uint32_t)h->band;
     const uint32_t n_truth = truth_offsets[n], n_target = target_offsets[n];
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t L = truth_offsets[i + 1] - truth_offsets[i], T = target_offsets[i + 1] - target_offsets[i];
@@ -645,6 +680,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
     if (rc != OCT_PHMM_OK) return rc;
     struct Guard { oct_phmm_handle* h; oct_phmm_batch* b; std::vector<void*> extra; ~Guard() { rt::stream_sync(h->stream); for (void* p : extra) rt::dev_free(p); oct_phmm_batch_free(h, b); } } guard {h, b, {}};
     rt::Stream s = h->stream;
+    const uint32_t G = b->stream ? 1u : (h->wide ? 1u : 2u) * (64 / B);
     // route each window to the fast or generic kernel exactly as k_classify would
     std::vector<uint8_t> racgt(n); std::vector<uint32_t> hclean(n);
     RT(rt::d2h(racgt.data(), b->d.racgt, n, s)); RT(rt::d2h(hclean.data(), b->d.hclean, n * sizeof(uint32_t), s)); RT(rt::stream_sync(s));
@@ -652,7 +688,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
     // every window is its own haplotype and a DP task group must stay within one haplotype: give each window a whole
     // group (one real task + G-1 padding copies). This is a test seam, not the throughput path.
     for (uint32_t i = 0; i < n; ++i) {
-        const int gen = h->wide || !(racgt[i] && hclean[i]);
+        const int gen = h->wide || b->stream || !(racgt[i] && hclean[i]);
         tasks[gen].push_back(DevTask {i, i, i, 0}); origin[gen].push_back(i);
         for (uint32_t k = 1; k < G; ++k) tasks[gen].push_back(DevTask {kPadTask, i, i, 0});
     }

@@ -220,6 +220,46 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
     }
 }
 
+// Long haplotypes (bins + per-wave counters no longer fit LDS beside each other): one workgroup per (haplotype, read) pair, the
+// diagonal counters alone in LDS, bins read from global memory. Same votes, same result as k_kmer_map; for the long-read configuration.
+OCT_KERNEL(k_kmer_map_big)(DevBatch b)
+{
+    OCT_DYN_SMEM(smem);
+    uint32_t* counts = (uint32_t*)smem;                                // [nk]
+    __shared__ uint32_t s_max, s_nout;
+    const uint64_t e = hw::block_idx();
+    const uint32_t tid = hw::thread_idx(), nt = hw::block_dim();
+    const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
+    const uint32_t g = b.hap_region[h];
+    const uint32_t r = b.reg_read0[g] + (uint32_t)(e - b.hap_pair_off[h]);
+    const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;
+    const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;
+    const uint16_t* bins = b.bin_start + (size_t)h * (kKmerBins + 1);
+    for (uint32_t d = tid; d < nk; d += nt) counts[d] = 0;
+    if (tid == 0) { s_max = 0; s_nout = 0; }
+    hw::block_sync();
+    for (uint32_t q = tid; q < nq; q += nt) {
+        const uint32_t hq = b.rhash[ro + q];
+        for (uint32_t j = bins[hq]; j < bins[hq + 1]; ++j) {
+            const uint32_t ti = b.bin_idx[ho + j];
+            if (ti >= q) hw::atomic_add_lds_u32(&counts[ti - q], 1u);   // :130-132
+        }
+    }
+    hw::block_sync();
+    uint32_t mx = 0;
+    for (uint32_t d = tid; d < nk; d += nt) mx = counts[d] > mx ? counts[d] : mx;
+    if (mx) hw::atomic_max_lds_u32(&s_max, mx);
+    hw::block_sync();
+    mx = s_max;
+    if (tid == 0 && mx > 0) {                                          // ascending scan by one thread: this path serves a few hundred pairs
+        uint32_t n = 0;
+        for (uint32_t d = 0; d < nk && n < (uint32_t)b.max_pos; ++d) if (counts[d] == mx) b.pos[e * (uint64_t)b.max_pos + n++] = d;
+        s_nout = n;
+    }
+    hw::block_sync();
+    if (tid == 0) b.npos[e] = (uint8_t)s_nout;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // candidate enumeration + scalar fast path
 // ------------------------------------------------------------------------------------------------------------------
@@ -853,12 +893,138 @@ OCT_KERNEL(k_dp32)(DpParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Wide / long path: band 64 x C (C = 1, 2, 4 adjacent diagonals per lane, one task per wave), int16 or int32 semantics, operands streamed
+// from HBM/L2 instead of staged in LDS. Serves bands 128 and 256 (simd_pair_hmm_wrapper.hpp:207-208) and reads/haplotypes too long
+// for the LDS-resident kernels (BASELINE.json configs[4]: 10 kb reads, 20 kb haplotypes, band 256, int32 lanes). Plain 32-bit VALU with the
+// reference's wrap emulated by a sign-extension after every add when W16; generic byte tests; same traceback word format, written
+// as [tile][plane c][lane][16 iterations] so that k_walk<B, 1, C> fetches one 64-byte line per 16 steps of a diagonal.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool W16> OCT_DEVICE uint32_t wadd(uint32_t a, uint32_t b)
+{
+    if constexpr (W16) return (uint32_t)(int32_t)(int16_t)(uint16_t)(a + b); else return a + b;
+}
+
+template <int C, bool TRACE, bool W16>
+OCT_KERNEL(k_dp_wide)(DpParams p)
+{
+    constexpr int B = 64 * C;
+    constexpr uint32_t INFW = W16 ? 0x00007800u : INF32;
+    constexpr uint32_t NULW = W16 ? 0xffff8000u : NUL32;
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
+    const uint32_t task = hw::block_idx() * kBlockWaves + wave;
+    if (task >= p.n_tasks) return;                                      // whole waves only
+    const DevTask t = p.tasks[task];
+    const uint32_t ro = p.roff[t.read], T = p.roff[t.read + 1] - ro;
+    const uint32_t K = T + B;
+    const uint2* tab = (p.rrev[t.read] ? p.tabR : p.tabF) + p.hoff[t.hap] + t.off;   // generic table of the band window
+    const uint32_t i0 = lane * C;                                       // this lane's first band diagonal
+    const uint32_t NUCW = (uint32_t)(int32_t)(int16_t)(p.nuc4 & 0xffffu);
+    uint32_t M1[C], I1[C], D1[C], M2[C], I2[C], D2[C];
+    for (int c = 0; c < C; ++c) M1[c] = I1[c] = D1[c] = M2[c] = I2[c] = D2[c] = INFW;
+    uint32_t best = INFW, best_s = 0; bool have = false;
+    // operand windows: hap records x = k + i0 + c (c = 0..C), read records t = k - i0 - c (c = 0..C-1)
+    uint2 hw_[C + 1];
+    for (int c = 0; c <= C; ++c) hw_[c] = tab[i0 + c];
+    auto read_rec = [&](int32_t tt) -> uint2 {
+        if (tt < 0) return make_uint2(0x100u, 64u << 2);
+        if ((uint32_t)tt >= T) return make_uint2((uint32_t)'0', 64u << 2);
+        return make_uint2(ld8(p.rbases + ro + tt), ld8(p.rquals + ro + tt) << 2);
+    };
+    uint2 rw[C];
+    for (int c = 0; c < C; ++c) rw[c] = read_rec(-(int32_t)i0 - c);
+    auto cost = [&](const uint2 r2, const uint2 a, uint32_t* mism) -> uint32_t {           // update_match_state :121-132
+        const uint32_t h = a.x & 0xffu, m = (a.x >> 8) & 0xffu, p4 = ((a.x >> 16) & 0xffu) << 2, isn = a.x >> 24;
+        const uint32_t inner = r2.x == m ? p4 : r2.y;
+        uint32_t c = min_i32(r2.y, inner);
+        if (r2.x == h) c = 0;
+        *mism = r2.x != h ? 1u : 0u;
+        return min_i32(c, isn ? 8u : INFW);
+    };
+    uint32_t* bpt = TRACE ? p.bp + (size_t)task * p.k_cap * C * 1024 : nullptr;
+    for (uint32_t k = 0; k < K; ++k) {
+        uint32_t dsh[C], ish[C], bpe[C];
+        for (int c = 0; c < C; ++c) {
+            const uint32_t i = i0 + c;
+            const uint2 cA = hw_[c], nA = hw_[c + 1];
+            const uint32_t GO = cA.y & 0xffffu, GE = cA.y >> 16, GOn = nA.y & 0xffffu, GEn = nA.y >> 16;
+            if (k == i) { M1[c] = NULW; M2[c] = NULW; }                                     // rolling initialiser
+            uint32_t mE, mO;
+            const uint32_t m1 = min_i32(M1[c], min_i32(I1[c], D1[c]));                      // :284
+            if (k == T + i && (int32_t)m1 < (int32_t)best) { best = m1; best_s = 2 * k; have = true; }   // :285-291 (k - T == i)
+            M1[c] = wadd<W16>(m1, cost(rw[c], cA, &mE));                                    // :292
+            const uint32_t x2 = min_i32(M2[c], I2[c]);
+            dsh[c] = min_i32(wadd<W16>(D2[c], GEn), wadd<W16>(x2, GOn));                    // :293 (shifted below)
+            I1[c] = wadd<W16>(min_i32(wadd<W16>(I2[c], GE), wadd<W16>(M2[c], GO)), NUCW);   // :295
+            bpe[c] = mE << 15;
+            (void)mO;
+        }
+        {   // :294 D1 <- shifted one diagonal up, infinity_ into diagonal 0
+            const uint32_t from_below = hw::dpp_wave_shr1(INFW, dsh[C - 1]);
+            for (int c = C - 1; c >= 1; --c) D1[c] = dsh[c - 1];
+            D1[0] = from_below;
+        }
+        if constexpr (TRACE) {
+            for (int c = 0; c < C; ++c) {
+                const uint32_t tm = M1[c] & 3u, ti = I1[c] & 3u, td = D1[c] & 3u;
+                M1[c] ^= tm; I1[c] = (I1[c] & ~3u) | 1u; D1[c] |= 3u;
+                bpe[c] |= tm | ti << 2 | td << 4;
+            }
+        }
+        for (int c = 0; c < C; ++c) {
+            const uint32_t i = i0 + c;
+            const uint2 cA = hw_[c], nA = hw_[c + 1];
+            const uint32_t GO = cA.y & 0xffffu, GE = cA.y >> 16, GOn = nA.y & 0xffffu, GEn = nA.y >> 16;
+            uint32_t mO;
+            const uint32_t m2 = min_i32(min_i32(M2[c], I2[c]), D2[c]);                      // :308
+            if (k == T + i && (int32_t)m2 < (int32_t)best) { best = m2; best_s = 2 * k + 1; have = true; }
+            M2[c] = wadd<W16>(m2, cost(rw[c], nA, &mO));                                    // :316
+            const uint32_t y1 = min_i32(M1[c], I1[c]);
+            D2[c] = min_i32(wadd<W16>(D1[c], GEn), wadd<W16>(y1, GOn));                     // :317
+            ish[c] = wadd<W16>(min_i32(wadd<W16>(I1[c], GE), wadd<W16>(M1[c], GO)), NUCW);  // :318 (shifted below)
+            bpe[c] |= mO << 14;
+        }
+        {   // :318-319 I2 <- shifted one diagonal down, infinity_ into the last diagonal
+            const uint32_t from_above = hw::dpp_wave_shl1(INFW, ish[0]);
+            for (int c = 0; c < C - 1; ++c) I2[c] = ish[c + 1];
+            I2[C - 1] = from_above;
+        }
+        if constexpr (TRACE) {
+            for (int c = 0; c < C; ++c) {
+                const uint32_t tm = M2[c] & 3u, ti = I2[c] & 3u, td = D2[c] & 3u;
+                M2[c] ^= tm; I2[c] = (I2[c] & ~3u) | 1u; D2[c] |= 3u;
+                bpt[(((size_t)(k >> 4) * C + c) * 64 + lane) * 16 + (k & 15)] = bpe[c] | (tm | ti << 2 | td << 4) << 6;
+            }
+        }
+        // slide the operand windows by one position
+        for (int c = 0; c < C; ++c) hw_[c] = hw_[c + 1];
+        hw_[C] = tab[k + 1 + i0 + C];
+        for (int c = C - 1; c >= 1; --c) rw[c] = rw[c - 1];
+        rw[0] = read_rec((int32_t)(k + 1) - (int32_t)i0);
+    }
+    // first minimum over the end cells: per lane the candidates were visited in increasing diagonal order, so strict < kept the first
+    uint32_t kv = have ? (W16 ? ((best + 0x8000u) & 0xffffu) : (best ^ 0x80000000u)) : 0xffffffffu, ks = best_s;
+    if (!have) ks = 0xffffffffu;
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t ov = hw::shfl_xor(kv, m), os = hw::shfl_xor(ks, m);
+        if (ov < kv || (ov == kv && os < ks)) { kv = ov; ks = os; }
+    }
+    if (lane == 0) {
+        // no end cell below infinity_: minscore stays infinity_, minscoreidx -1 (:269-270)
+        const bool none = kv == 0xffffffffu;
+        const uint32_t biased = none ? (W16 ? ((INFW + 0x8000u) & 0xffffu) : (INFW ^ 0x80000000u)) : kv;
+        const int32_t score = W16 ? (int32_t)(biased >> 2) : ((int32_t)biased >> 2);
+        if constexpr (TRACE) { TraceEnd e; e.score = score; e.sidx = none ? -1 : (int32_t)ks; p.ends[task] = e; }
+        else if (t.pair != kPadTask) hw::atomic_min_i32(p.pair_best + t.pair, score);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // traceback walk + flank score
 // ------------------------------------------------------------------------------------------------------------------
-template <int B, int TPR>
+template <int B, int TPR, int C>
 OCT_KERNEL(k_walk_strings)(WalkParams w)   // test seam only: emits the gapped strings (set_alignments :165-231), one step per iteration
 {
-    constexpr uint32_t ROWS = 64 / B, G = TPR * ROWS;
+    constexpr uint32_t ROWS = 64 * C / B, G = TPR * ROWS;   // C > 1: band 64 x C on one wave, diagonal i lives in lane i / C, plane i % C
     const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (ti >= w.n_tasks) return;
     const DevTask t = w.tasks[ti];
@@ -889,12 +1055,13 @@ OCT_KERNEL(k_walk_strings)(WalkParams w)   // test seam only: emits the gapped s
     const int32_t rhs_begin = L - rhs;
     const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
     // backpointers of this group: k_cap tiles of [64 lanes][16 iterations] dwords; one 64-byte line = 16 consecutive iterations of one lane
-    const uint4* bpg = (const uint4*)(w.bp + (size_t)group * w.k_cap * 1024);
+    const uint4* bpg = (const uint4*)(w.bp + (size_t)group * w.k_cap * C * 1024);
     uint32_t line_id = 0xffffffffu; uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
     auto bits_at = [&](int64_t flat) -> uint32_t {          // 6 backpointer bits of band cell `flat` = diagonal * B + lane
         const int32_t s = (int32_t)(flat / B), i = (int32_t)(flat % B);
         if (s >= 2 * (T + B)) return 0;                     // last row of the reference's array is never written (zeros)
-        const uint32_t k = (uint32_t)s >> 1, id = (k >> 4) * 64 + row * B + (uint32_t)i;
+        const uint32_t k = (uint32_t)s >> 1;
+        const uint32_t id = C == 1 ? (k >> 4) * 64 + row * B + (uint32_t)i : ((k >> 4) * C + (uint32_t)i % C) * 64 + (uint32_t)i / C;
         if (id != line_id) { const uint4* l = bpg + (size_t)id * 4; c0 = l[0]; c1 = l[1]; c2 = l[2]; c3 = l[3]; line_id = id; }
         const uint4 q = (k & 8) ? ((k & 4) ? c3 : c2) : ((k & 4) ? c1 : c0);
         const uint32_t wv = (k & 2) ? ((k & 1) ? q.w : q.z) : ((k & 1) ? q.y : q.x);
@@ -973,10 +1140,10 @@ OCT_KERNEL(k_walk_strings)(WalkParams w)   // test seam only: emits the gapped s
 // rare, and both are queued as events in LDS and priced in a second uniform loop.
 constexpr uint32_t kWalkEvents = 12;
 
-template <int B, int TPR>
+template <int B, int TPR, int C>
 OCT_KERNEL(k_walk)(WalkParams w)
 {
-    constexpr uint32_t ROWS = 64 / B, G = TPR * ROWS;
+    constexpr uint32_t ROWS = 64 * C / B, G = TPR * ROWS;   // C > 1: band 64 x C on one wave, diagonal i lives in lane i / C, plane i % C
     OCT_DYN_SMEM(smem);
     uint32_t* evbuf = (uint32_t*)smem + hw::thread_idx() * kWalkEvents;
     const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
@@ -1003,7 +1170,7 @@ OCT_KERNEL(k_walk)(WalkParams w)
     }
     const int32_t rhs_begin = L - rhs;
     const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
-    const uint4* bpg = (const uint4*)(w.bp + (size_t)group * w.k_cap * 1024);
+    const uint4* bpg = (const uint4*)(w.bp + (size_t)group * w.k_cap * C * 1024);
     const uint32_t hshift = 16 * half;
 
     // walker state (set_alignments :180-193)
@@ -1058,7 +1225,8 @@ OCT_KERNEL(k_walk)(WalkParams w)
         const int32_t s = (int32_t)(flat / B), li = (int32_t)(flat % B);
         if (s >= 2 * (T + B)) return 0;                                                         // last row of the reference's array is never written
         const uint32_t k = (uint32_t)s >> 1;
-        return w.bp[(size_t)group * w.k_cap * 1024 + ((size_t)(k >> 4) * 64 + row * B + (uint32_t)li) * 16 + (k & 15)];
+        const size_t line = C == 1 ? (size_t)(k >> 4) * 64 + row * B + (uint32_t)li : ((size_t)(k >> 4) * C + (uint32_t)li % C) * 64 + (uint32_t)li / C;
+        return w.bp[(size_t)group * w.k_cap * C * 1024 + line * 16 + (k & 15)];
     };
 
     uint32_t kmax = ok ? (uint32_t)(sidx >> 1) : 0;
@@ -1068,7 +1236,8 @@ OCT_KERNEL(k_walk)(WalkParams w)
         uint32_t c[16];
         int32_t line_i = -1;
         auto load_line = [&]() {
-            const uint4* l = bpg + ((size_t)kt * 64 + row * B + (uint32_t)i) * 4;
+            const size_t line = C == 1 ? (size_t)kt * 64 + row * B + (uint32_t)i : ((size_t)kt * C + (uint32_t)i % C) * 64 + (uint32_t)i / C;
+            const uint4* l = bpg + line * 4;
             const uint4 q0 = l[0], q1 = l[1], q2 = l[2], q3 = l[3];
             c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y; c[6] = q1.z; c[7] = q1.w;
             c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w; c[12] = q3.x; c[13] = q3.y; c[14] = q3.z; c[15] = q3.w;

@@ -189,3 +189,14 @@ def check_int32_lanes(backend, tol=0.0):
     g2, _ = small_region(52, B=16, T=50, Lh=150, flank=(30, 25))
     b = compare(backend, synth.batch_from_regions([g2]), tol, max_indel_error=16, use_int_scores=1)
     return a, b
+
+
+def check_wide_and_long(backend, tol=0.0, long_T=300, long_Lh=1000, n_reads=6):
+    """Bands 128/256 (streaming kernel) and a long-read region whose tables cannot live in LDS (BASELINE.json configs[4] in small):
+    int32 lanes, band 256, device k-mer mapping through the big-haplotype mapper when needed."""
+    g, rng = small_region(61, R=8, H=2, T=60, Lh=420, B=128, flank=(130, 130))
+    a = compare(backend, synth.batch_from_regions([g]), tol, max_indel_error=100)
+    g, rng = small_region(62, R=n_reads, H=2, T=long_T, Lh=long_Lh, B=256, flank=(280, 280))
+    g["quals"][:] = np.clip(g["quals"], 5, 15)            # PacBio-like low qualities -> many differences
+    b = compare(backend, synth.batch_from_regions([g]), tol, max_indel_error=256, use_int_scores=1)
+    return a, b

@@ -16,6 +16,7 @@
 #define OCT_HD inline
 #define OCT_KERNEL(name) inline void name
 #define OCT_DYN_SMEM(ptr) unsigned char* ptr = hipsim::S().smem
+#define __shared__ static   /* workgroups run one after another in the simulator */
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
@@ -174,6 +175,7 @@ inline uint32_t wave_max_u32(uint32_t v)
     for (int m = 1; m < 64; m <<= 1) { const uint32_t o = shfl_xor(v, m); v = o > v ? o : v; }
     return v;
 }
+inline uint32_t atomic_max_lds_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_add_lds_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline void block_sync() { hipsim::block_sync_impl(); }
 inline int atomic_min_i32(int32_t* p, int32_t v) { const int32_t o = *p; if (v < o) *p = v; return o; }

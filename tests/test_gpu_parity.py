@@ -50,6 +50,16 @@ def test_gpu_exact_add_mode_gives_same_results(monkeypatch):
     cp.check_basic("gpu", TOL)
 
 
+@pytest.mark.parametrize("band,bits,n", [(128, 16, 40), (128, 32, 30), (256, 32, 20), (256, 16, 20)])
+def test_gpu_wide_bands_streaming_kernel(band, bits, n):
+    check_l1.check_random("gpu", band, n, seed=4000 + band + bits, t_lo=40, t_hi=300, with_n=True, score_bits=bits)
+
+
+def test_gpu_populate_wide_bands_and_long_reads():
+    """Includes a reduced BASELINE.json configs[4]: 3 kb reads x 12 kb haplotypes (big-haplotype k-mer mapper), band 256, int32 lanes, traceback spilled to HBM."""
+    cp.check_wide_and_long("gpu", TOL, long_T=3000, long_Lh=12000, n_reads=6)
+
+
 def test_gpu_unmasked_overload():
     check_l1.check_random("gpu", 16, 100, seed=7, masked=False, with_n=False)
 

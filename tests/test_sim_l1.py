@@ -45,3 +45,8 @@ def test_sim_exact_add_mode_gives_same_results(monkeypatch):
     monkeypatch.setenv("OCT_PHMM_EXACT_ADDS", "1")
     check_l1.check_random("sim", 16, 10, seed=116, with_n=False)
     check_l1.check_random("sim", 8, 8, seed=208, with_n=True)
+
+
+@pytest.mark.parametrize("band,bits,n", [(128, 16, 4), (128, 32, 3), (256, 32, 2), (256, 16, 2)])
+def test_sim_wide_bands_streaming_kernel(band, bits, n):
+    check_l1.check_random("sim", band, n, seed=400 + band + bits, t_lo=40, t_hi=200, with_n=True, score_bits=bits)

@@ -30,3 +30,13 @@ def test_sim_device_kmer_mapper_matches_reference_mapper():
 def test_sim_populate_int32_lanes():
     a, b = cp.check_int32_lanes("sim")
     assert a["n_dp_traceback"] > 0 and b["n_dp_score_only"] + b["n_dp_traceback"] > 0
+
+
+def test_sim_populate_wide_bands_and_long_reads():
+    a, b = cp.check_wide_and_long("sim")
+    assert a["n_dp_score_only"] + a["n_dp_traceback"] > 0 and b["n_dp_score_only"] + b["n_dp_traceback"] > 0
+
+
+def test_sim_big_haplotype_mapper_matches_reference_mapper(monkeypatch):
+    monkeypatch.setenv("OCT_PHMM_BIG_MAPPER", "1")      # force the one-workgroup-per-pair mapper used for very long haplotypes
+    cp.check_device_kmer_mapper("sim")
