@@ -76,12 +76,15 @@ def make_haplotypes(rng: np.random.Generator, H: int, Lh: int, n_homopolymers: i
     return haps, maps
 
 
-def make_reads(rng: np.random.Generator, haps, maps, R: int, T: int, B: int, min_diffs: int = 0):
+def make_reads(rng: np.random.Generator, haps, maps, R: int, T: int, B: int, min_diffs: int = 0, q_values=None, indels_per_read: int = 0):
     """R reads of length T sampled from uniformly chosen haplotypes, Illumina-like qualities and errors."""
     H, Lh = len(haps), len(haps[0])
     src = rng.integers(0, H, R)
     start = rng.integers(B, Lh - T - B + 1, R)              # start in BASE coordinates = the read's reference begin
-    quals = rng.choice(np.array([37, 25, 12, 2], dtype=np.uint8), size=(R, T), p=[0.7, 0.2, 0.08, 0.02])
+    if q_values is None:
+        quals = rng.choice(np.array([37, 25, 12, 2], dtype=np.uint8), size=(R, T), p=[0.7, 0.2, 0.08, 0.02])
+    else:
+        quals = rng.integers(q_values[0], q_values[1] + 1, size=(R, T)).astype(np.uint8)
     decay = np.concatenate([np.zeros(T - min(30, T)), np.linspace(0, 20, min(30, T))]).astype(np.int64)
     quals = np.clip(quals.astype(np.int64) - decay[None, :], 2, 64).astype(np.uint8)
     reads = np.empty((R, T), dtype=np.uint8)
@@ -92,7 +95,7 @@ def make_reads(rng: np.random.Generator, haps, maps, R: int, T: int, B: int, min
     err = rng.random((R, T)) < np.power(10.0, -quals.astype(np.float64) / 10.0)
     sub = BASES[rng.integers(0, 4, (R, T))]
     reads = np.where(err, sub, reads)
-    indel = np.flatnonzero(rng.random(R) < 0.005)
+    indel = np.flatnonzero(rng.random(R) < 0.005) if not indels_per_read else np.repeat(np.arange(R), indels_per_read)
     for r in indel:
         p = int(rng.integers(10, T - 10))
         n = int(rng.integers(1, 4))
@@ -113,11 +116,11 @@ def make_reads(rng: np.random.Generator, haps, maps, R: int, T: int, B: int, min
 
 
 def make_region(rng: np.random.Generator, R: int, H: int, T: int = 150, Lh: int = 300, B: int = 16,
-                flank=(40, 40), min_diffs: int = 0, positions: str = "true"):
+                flank=(40, 40), min_diffs: int = 0, positions: str = "true", q_values=None, indels_per_read: int = 0):
     """Arrays of one populate() call. positions: 'true' = each read's start mapped through the haplotype's edits
     (a stand-in for the k-mer mapper's output), 'none' = leave mapping to the library."""
     haps, maps = make_haplotypes(rng, H, Lh)
-    reads, quals, begin, reverse, mapq, _ = make_reads(rng, haps, maps, R, T, B, min_diffs)
+    reads, quals, begin, reverse, mapq, _ = make_reads(rng, haps, maps, R, T, B, min_diffs, q_values, indels_per_read)
     pos = None
     if positions == "true":
         pos = np.stack([np.minimum(m[begin], Lh - T) for m in maps]).astype(np.uint32)     # [H, R]
@@ -175,6 +178,9 @@ def config_batch(name: str, seed: int = 42, B: int = 16, positions: str = "true"
         return batch_from_regions([make_region(rng, 100_000, 128, B=B, min_diffs=2, positions=positions)])
     if name == "10kx64":
         return batch_from_regions([make_region(rng, 10_000, 64, B=B, positions=positions)])
+    if name == "long64x8":      # BASELINE.json configs[4]: 10 kb reads x 20 kb haplotypes, band 256 (int32 lanes), PacBio-like Q 8-15, indel-rich
+        return batch_from_regions([make_region(rng, 64, 8, T=10_000, Lh=20_000, B=256, flank=(400, 400), positions=positions,
+                                               q_values=(8, 15), indels_per_read=40)])
     if name == "tiny":
         return batch_from_regions([make_region(rng, 40, 6, B=B, positions=positions)])
     raise KeyError(name)
