@@ -30,6 +30,14 @@ OCT_DEVICE uint32_t dpp_wave_shl1(uint32_t fill, uint32_t v) { return (uint32_t)
 OCT_DEVICE uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 // v_pk_mad_u16: per 16-bit half a * b + c (wrapping)
+// v_lshl_or_b32: (a << n) | b in one VALU op
+template <int N> OCT_DEVICE uint32_t lshl_or_impl(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(N), "v"(b));
+    return r;
+}
+#define OCT_LSHL_OR_DEFINED 1
 OCT_DEVICE uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;
@@ -47,6 +55,7 @@ OCT_DEVICE uint32_t shfl_xor(uint32_t v, int mask) { return (uint32_t)__shfl_xor
 OCT_DEVICE uint32_t shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 OCT_DEVICE uint32_t readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 OCT_DEVICE uint64_t ballot(bool p) { return __ballot(p); }
+OCT_DEVICE uint32_t readlane(uint32_t v, uint32_t src_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src_uniform); }
 // wave-wide unsigned max, result in every lane: DPP row shifts + row broadcasts (no LDS round trips), then a scalar broadcast
 OCT_DEVICE uint32_t wave_max_u32(uint32_t v)
 {
@@ -75,6 +84,12 @@ OCT_DEVICE uint32_t grid_dim() { return gridDim.x; }
 #endif
 
 namespace octphmm { namespace hw {
+
+#if defined(OCT_LSHL_OR_DEFINED)
+#define hw_lshl_or(a, n, b) octphmm::hw::lshl_or_impl<(n)>((a), (b))
+#else
+#define hw_lshl_or(a, n, b) ((((uint32_t)(a)) << (n)) | (uint32_t)(b))
+#endif
 
 typedef short          s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));

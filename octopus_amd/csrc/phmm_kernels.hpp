@@ -165,10 +165,12 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
     for (uint32_t r = r_first + wave; r < r_end; r += kBlockWaves) {
         const uint64_t e = b.hap_pair_off[h] + (r - reg_r0);
         const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;   // compute_kmer_hashes :57-69
+        uint32_t hq_next = lane < nq ? b.rhash[ro + lane] : 0;             // software pipeline: next batch's hashes are in flight
         for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
             const uint32_t q = q0 + lane;
             const bool valid = q < nq;
-            const uint32_t hq = valid ? b.rhash[ro + q] : 0;
+            const uint32_t hq = hq_next;
+            if (q0 + 64 < nq) hq_next = q + 64 < nq ? b.rhash[ro + q + 64] : 0;
             const uint32_t b0 = bins[hq], n = valid ? (uint32_t)bins[hq + 1] - b0 : 0;
             for (uint32_t j = 0; hw::ballot(j < n) != 0; ++j) {
                 const uint32_t ti = j < n ? idx[b0 + j] : 0;
@@ -176,9 +178,10 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
                 const uint32_t d = ti - q;                             // mapping_begin :131
                 const uint64_t voters = hw::ballot(vote);
                 if (voters == 0) continue;
-                const uint32_t d0 = hw::shfl(d, (int)__builtin_ctzll(voters));
+                const uint32_t src = (uint32_t)__builtin_ctzll(voters);
+                const uint32_t d0 = hw::readlane(d, src);
                 if (hw::ballot(vote && d != d0) == 0) {                // every vote on one diagonal: one add
-                    if (lane == 0) counts[d0] += (uint32_t)__builtin_popcountll(voters);
+                    if (lane == src) hw::atomic_add_lds_u32(&counts[d0], (uint32_t)__builtin_popcountll(voters));
                 } else if (vote) {
                     hw::atomic_add_lds_u32(&counts[d], 1u);            // ++mapping_counts[mapping_begin], :132
                 }
@@ -686,7 +689,7 @@ OCT_KERNEL(k_dp)(DpParams p)
                     if constexpr (TRACE) {                                                  // update_traceback :147-163
                         const uint32_t tm = M1 & 0x00030003u, ti = I1 & 0x00030003u, td = D1 & 0x00030003u;
                         M1 ^= tm; I1 = (I1 & ~0x00030003u) | 0x00010001u; D1 |= 0x00030003u;
-                        bpe = tm | ti << 2 | td << 4 | flag_of(fe, 15);                     // + "this match cell costs something" flag
+                        bpe = hw_lshl_or(td, 4, hw_lshl_or(ti, 2, tm | flag_of(fe, 15)));   // + "this match cell costs something" flag
                     }
                     // ---- odd diagonal s = 2k+1: lane li is cell (t, x+1) ----
                     const uint32_t m2 = hw::pk_min_u(x2, D2);                               // :308
@@ -700,7 +703,8 @@ OCT_KERNEL(k_dp)(DpParams p)
                     if constexpr (TRACE) {
                         const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
                         M2 ^= tm; I2 = (I2 & ~0x00030003u) | 0x00010001u; D2 |= 0x00030003u;
-                        tile[(k & 15) * kTileStride + lane] = bpe | (tm | ti << 2 | td << 4) << 6 | flag_of(fo, 14);
+                        const uint32_t bpo = hw_lshl_or(td, 4, hw_lshl_or(ti, 2, tm));
+                        tile[(k & 15) * kTileStride + lane] = hw_lshl_or(bpo, 6, bpe | flag_of(fo, 14));
                     }
                     rr = rr_nx; cA = nA; cB = nB; GO = GOn; GE = GEn; nA = nnA; nB = nnB;
                     GOn = hw::perm(nB.y, nA.y, 0x05040100u); GEn = hw::perm(nB.y, nA.y, 0x07060302u);

@@ -159,6 +159,7 @@ inline uint32_t shfl(uint32_t v, int src)
     return r;
 }
 inline uint32_t readfirstlane(uint32_t v) { return shfl(v, 0); }
+inline uint32_t readlane(uint32_t v, uint32_t src) { return shfl(v, (int)src); }
 inline uint64_t ballot(bool p)
 {
     hipsim::State& s = hipsim::S();
