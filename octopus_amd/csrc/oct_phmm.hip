@@ -23,9 +23,12 @@ struct oct_phmm_handle {
     int band = 0;
     bool wide = false;                                   // int32 lanes (Config::use_int_scores)
     int  lanes_c = 1;                                    // band diagonals per lane on the streaming path (band / 64) for bands 128, 256
-    rt::Stream stream {};
-    rt::Event ev[2] {};
-    uint32_t* bp = nullptr; size_t bp_bytes = 0;          // traceback scratch, grown on demand
+    static constexpr int kMaxSlices = 4;
+    rt::Stream stream {};                                 // slice 0 / uploads / downloads
+    rt::Stream extra_streams[kMaxSlices - 1] {};          // further slices run on their own streams so that latency-bound and VALU-bound kernels overlap
+    rt::Event ev_ready {};
+    uint32_t* bp[kMaxSlices] {}; size_t bp_bytes[kMaxSlices] {};   // traceback scratch per slice, grown on demand
+    rt::Stream slice_stream(int i) const { return i == 0 ? stream : extra_streams[i - 1]; }
     // traceback scratch budget: large, so that all traceback tasks of a batch run in ONE DP launch and ONE walk launch (the walk
     // is a latency-bound pointer chase that needs every task in flight to hide it); MI355X has 288 GB. OCT_PHMM_BP_BUDGET_GB overrides.
     size_t bp_budget = (size_t)96 << 30;
@@ -37,10 +40,16 @@ struct oct_phmm_batch {
     // host-side shape + small copies needed for error reporting
     uint32_t n_reads = 0, n_haps = 0, n_rows = 0, n_regions = 0, t_cap = 0, lh_cap = 0, n_hap_bases = 0;
     uint64_t n_pairs = 0, n_out = 0;
-    std::vector<uint32_t> h_roff, h_hoff; std::vector<int64_t> h_rbegin, h_hbegin;
+    std::vector<uint32_t> h_roff, h_hoff, h_blk_hap; std::vector<int64_t> h_rbegin, h_hbegin;
     // run state
-    uint4* d_hap_base = nullptr; uint4* d_tile_sums = nullptr; uint32_t n_tiles = 0;
-    DevTask* d_tasks = nullptr; size_t tasks_cap = 0; TraceEnd* d_ends = nullptr; size_t ends_cap = 0;
+    struct Slice {                     // whole haplotypes [hap0, hap1) = pairs [pair0, pair1) = outputs [out0, out1)
+        uint32_t hap0 = 0, hap1 = 0, blk0 = 0, blk1 = 0, n_tiles = 0; uint64_t pair0 = 0, pair1 = 0, out0 = 0, out1 = 0;
+        uint4* cnt = nullptr; uint4* tile_sums = nullptr; uint4* d_totals = nullptr; uint4 totals {};
+        DevTask* d_tasks = nullptr; size_t tasks_cap = 0; TraceEnd* d_ends = nullptr; size_t ends_cap = 0;
+        rt::Event done {};
+    };
+    std::vector<Slice> slices;
+    uint4* d_hap_base = nullptr;
     double* d_out = nullptr;
     uint32_t n_tasks[kNumKinds] = {0, 0, 0, 0};
     unsigned long long h_stats[6] = {0, 0, 0, 0, 0, 0};
@@ -181,21 +190,22 @@ bool launch_dp_wide(int c, bool tr, bool w16, const DpParams& p, rt::Stream s)
     }
 }
 
-bool ensure_bp(oct_phmm_handle* h, size_t bytes)
+bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 {
-    if (h->bp_bytes >= bytes) return true;
-    rt::dev_free(h->bp); h->bp = nullptr; h->bp_bytes = 0;
+    if (h->bp_bytes[slice] >= bytes) return true;
+    rt::dev_free(h->bp[slice]); h->bp[slice] = nullptr; h->bp_bytes[slice] = 0;
     void* p = nullptr;
     if (!rt::dev_malloc(&p, bytes)) return false;
-    h->bp = (uint32_t*)p; h->bp_bytes = bytes;
+    h->bp[slice] = (uint32_t*)p; h->bp_bytes[slice] = bytes;
     return true;
 }
 
 // Run one kind's task list through the DP kernel (+ walk for traceback kinds), chunked so the traceback scratch fits.
-int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
+int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
                 int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status)
 {
     if (!n_tasks) return OCT_PHMM_OK;
+    rt::Stream st = h->slice_stream(slice);
     const int B = h->band;
     const uint32_t C = (uint32_t)h->lanes_c;
     const uint32_t G = b->stream ? 1u : (h->wide ? 1 : 2) * (64 / B);
@@ -214,28 +224,28 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
     uint32_t chunk_groups = n_groups;
     if (tr) {
         const size_t per_group = (size_t)p.k_cap * 4096 * (b->stream ? C : 1);
-        const size_t fit = std::max<size_t>(1, h->bp_budget / per_group);
+        const size_t fit = std::max<size_t>(1, h->bp_budget / std::max<size_t>(1, b->slices.size()) / per_group);
         chunk_groups = (uint32_t)std::min<size_t>(n_groups, fit);
         chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / p.groups_per_block * p.groups_per_block);
-        if (!ensure_bp(h, (size_t)std::min(chunk_groups, n_groups) * per_group)) return fail(status, OCT_PHMM_EHIP, "traceback scratch allocation");
+        if (!ensure_bp(h, slice, (size_t)std::min(chunk_groups, n_groups) * per_group)) return fail(status, OCT_PHMM_EHIP, "traceback scratch allocation");
     }
     for (uint32_t g0 = 0; g0 < n_groups; g0 += chunk_groups) {
         const uint32_t ng = std::min(chunk_groups, n_groups - g0);
         p.tasks = tasks + (size_t)g0 * G; p.n_tasks = ng * G;
-        p.bp = h->bp; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
+        p.bp = h->bp[slice]; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
         const uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
         rt::Event e0, e1;
         RT(rt::event_create(&e0)); RT(rt::event_create(&e1));
-        RT(rt::event_record(e0, h->stream));
-        if (!(b->stream ? launch_dp_wide((int)C, tr, !h->wide, p, h->stream)
-                        : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, h->stream) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, h->stream)))
+        RT(rt::event_record(e0, st));
+        if (!(b->stream ? launch_dp_wide((int)C, tr, !h->wide, p, st)
+                        : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
-        RT(rt::event_record(e1, h->stream));
+        RT(rt::event_record(e1, st));
         b->timers.emplace_back(e0, e1);
         if (tr) {
             WalkParams w {};
             if (seam_walk) w = *seam_walk;
-            w.tasks = p.tasks; w.n_tasks = p.n_tasks; w.ends = p.ends; w.bp = h->bp; w.k_cap = p.k_cap; w.band = B;
+            w.tasks = p.tasks; w.n_tasks = p.n_tasks; w.ends = p.ends; w.bp = h->bp[slice]; w.k_cap = p.k_cap; w.band = B;
             w.rbases = b->d.rbases; w.rquals = b->d.rquals; w.roff = b->d.roff; w.rrev = b->d.rrev;
             w.hbases = b->d.hbases; w.hoff = b->d.hoff; w.go = b->d.go; w.ge = b->d.ge;
             w.maskF = b->d.maskF; w.priorF = b->d.priorF; w.maskR = b->d.maskR; w.priorR = b->d.priorR;
@@ -246,7 +256,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int kind, const DevTask* 
                 w.out_first_pos += o; w.out_align_off += o;
                 if (w.seam_lhs) { w.seam_lhs += o; w.seam_rhs += o; w.out_flank += o; w.out_mask_size += o; }
             }
-            if (!launch_walk(B, h->wide || b->stream, w, h->stream)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
+            if (!launch_walk(B, h->wide || b->stream, w, st)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
         }
     }
     return OCT_PHMM_OK;
@@ -299,6 +309,8 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
     if (const char* e = getenv("OCT_PHMM_BP_BUDGET_GB")) { const long gb = atol(e); if (gb > 0) h->bp_budget = (size_t)gb << 30; }
     if (!rt::stream_create(&h->stream)) return OCT_PHMM_EHIP;
+    for (auto& es : h->extra_streams) if (!rt::stream_create(&es)) return OCT_PHMM_EHIP;
+    if (!rt::event_create(&h->ev_ready)) return OCT_PHMM_EHIP;
     *out = h.release();
     return OCT_PHMM_OK;
 }
@@ -307,8 +319,9 @@ extern "C" void oct_phmm_destroy(oct_phmm_handle* h)
 {
     if (!h) return;
     rt::set_device(h->cfg.device_id);
-    rt::stream_sync(h->stream);
-    rt::dev_free(h->bp);
+    for (int i = 0; i < oct_phmm_handle::kMaxSlices; ++i) { rt::stream_sync(h->slice_stream(i)); rt::dev_free(h->bp[i]); }
+    for (int i = 1; i < oct_phmm_handle::kMaxSlices; ++i) rt::stream_destroy(h->slice_stream(i));
+    rt::event_destroy(h->ev_ready);
     rt::stream_destroy(h->stream);
     delete h;
 }
@@ -321,10 +334,10 @@ extern "C" int oct_phmm_band_size(const oct_phmm_handle* h) { return h ? h->band
 extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
 {
     if (!b) return;
-    if (h) { rt::set_device(h->cfg.device_id); rt::stream_sync(h->stream); }
+    if (h) { rt::set_device(h->cfg.device_id); for (int i = 0; i < oct_phmm_handle::kMaxSlices; ++i) rt::stream_sync(h->slice_stream(i)); }
     for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
     for (void* p : b->allocs) rt::dev_free(p);
-    rt::dev_free(b->d_tasks); rt::dev_free(b->d_ends);
+    for (auto& sl : b->slices) { rt::dev_free(sl.d_tasks); rt::dev_free(sl.d_ends); rt::event_destroy(sl.done); }
     delete b;
 }
 
@@ -471,6 +484,7 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
             for (uint32_t r = reg_read0[g]; r < first_read(g_row[g + 1]); r += kMapReadsPerBlock) { blk_hap.push_back(hp); blk_read0.push_back(r); }
         }
         b->n_map_blocks = (uint32_t)blk_hap.size();
+        b->h_blk_hap = blk_hap;
         const uint32_t* dh = nullptr; const uint32_t* dr = nullptr;
         RT(upload(bp, s, blk_hap.data(), blk_hap.size(), &dh)); RT(upload(bp, s, blk_read0.data(), blk_read0.size(), &dr));
         b->d_blk_hap = const_cast<uint32_t*>(dh); b->d_blk_read0 = const_cast<uint32_t*>(dr);
@@ -480,11 +494,36 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     RT(dalloc(bp, &d.tabGenF, (size_t)n_hap_bases));  RT(dalloc(bp, &d.tabGenR, (size_t)n_hap_bases));
     RT(dalloc(bp, &d.hclean, (size_t)H->n_haps));
     RT(dalloc(bp, &d.pair_best, (size_t)b->n_pairs)); RT(dalloc(bp, &d.pair_cls, (size_t)b->n_pairs));
-    RT(dalloc(bp, &d.pair_extra, (size_t)b->n_pairs)); RT(dalloc(bp, &d.pair_cnt, (size_t)b->n_pairs + 1));
+    RT(dalloc(bp, &d.pair_extra, (size_t)b->n_pairs)); RT(dalloc(bp, &d.pair_cnt, (size_t)b->n_pairs + oct_phmm_handle::kMaxSlices + 1));
     RT(dalloc(bp, &d.stats, (size_t)kStatSlots * 8 + 8)); d.err_key = d.stats + (size_t)kStatSlots * 8;
     RT(dalloc(bp, &b->d_hap_base, (size_t)H->n_haps + 1));
-    b->n_tiles = (uint32_t)((b->n_pairs + 1 + kScanTile - 1) / kScanTile);
-    RT(dalloc(bp, &b->d_tile_sums, (size_t)b->n_tiles + 1));
+    {
+        // Slices of whole haplotypes, each on its own stream: while slice i is in its VALU-bound DP kernels, slice i+1 runs its
+        // latency-bound mapper/classifier and slice i-1 its latency-bound walk. Small batches stay in one slice.
+        int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / 1500000));
+        if (const char* e = getenv("OCT_PHMM_SLICES")) n_slices = std::max(1, std::min(oct_phmm_handle::kMaxSlices, atoi(e)));
+        n_slices = (int)std::min<uint32_t>((uint32_t)n_slices, std::max<uint32_t>(1, H->n_haps));
+        uint4* totals = nullptr; RT(dalloc(bp, &totals, (size_t)n_slices));
+        uint32_t hap = 0, blk = 0;
+        for (int i = 0; i < n_slices; ++i) {
+            oct_phmm_batch::Slice sl;
+            sl.hap0 = hap;
+            const uint64_t target = b->n_pairs * (uint64_t)(i + 1) / (uint64_t)n_slices;
+            while (hap < H->n_haps && (i == n_slices - 1 || hap_pair_off[hap + 1] <= target || hap == sl.hap0)) ++hap;
+            if (i == n_slices - 1) hap = H->n_haps;
+            sl.hap1 = hap;
+            sl.pair0 = hap_pair_off[sl.hap0]; sl.pair1 = hap_pair_off[sl.hap1]; sl.out0 = hap_out_off[sl.hap0]; sl.out1 = hap_out_off[sl.hap1];
+            sl.cnt = d.pair_cnt + sl.pair0 + i;                      // each slice owns pair1 - pair0 + 1 scan entries
+            sl.n_tiles = (uint32_t)((sl.pair1 - sl.pair0 + 1 + kScanTile - 1) / kScanTile);
+            RT(dalloc(bp, &sl.tile_sums, (size_t)sl.n_tiles + 1));
+            sl.d_totals = totals + i;
+            RT(rt::event_create(&sl.done));
+            sl.blk0 = (uint32_t)(std::lower_bound(b->h_blk_hap.begin(), b->h_blk_hap.end(), sl.hap0) - b->h_blk_hap.begin());
+            sl.blk1 = (uint32_t)(std::lower_bound(b->h_blk_hap.begin(), b->h_blk_hap.end(), sl.hap1) - b->h_blk_hap.begin());
+            b->slices.push_back(sl);
+        }
+        (void)blk;
+    }
     RT(dalloc(bp, &b->d_out, (size_t)b->n_out));
     // per-read flags and per-base DP tables (once per batch; HaplotypeLikelihoodModel::reset analogue)
     std::vector<uint32_t> ones(H->n_haps + 1, 1u);
@@ -503,68 +542,99 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
 {
     if (!h || !b || b->owner != h) return fail(status, OCT_PHMM_EINVAL, "bad handle/batch");
     RT(rt::set_device(h->cfg.device_id));
-    rt::Stream s = h->stream;
+    rt::Stream s0 = h->stream;
     DevBatch& d = b->d;
     for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
     b->timers.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
     const uint32_t G = b->stream ? 1u : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
-    RT(rt::dev_memset(d.stats, 0, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s));
-    RT(rt::dev_memset(d.err_key, 0xff, sizeof(unsigned long long), s));
+    const int S = (int)b->slices.size();
+    RT(rt::dev_memset(d.stats, 0, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s0));
+    RT(rt::dev_memset(d.err_key, 0xff, sizeof(unsigned long long), s0));
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
     if (b->n_pairs && b->device_map) {
-        // candidate mapping positions on the device (HaplotypeLikelihoodArray::populate does this per haplotype, array.cpp:118-158)
-        const uint32_t n_rb = b->h_roff[b->n_reads];
-        OCT_LAUNCH(k_read_hashes, (n_rb + 255) / 256, 256, 0, s, d, n_rb); RT(rt::launch_ok());
-        OCT_LAUNCH(k_kmer_tables, b->n_haps, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d); RT(rt::launch_ok());
-        if (b->map_big) {
-            const size_t lds = (size_t)b->lh_cap * 4 + 64;
-            RT(rt::allow_lds(k_kmer_map_big, lds));
-            OCT_LAUNCH(k_kmer_map_big, (uint32_t)b->n_pairs, 256, lds, s, d); RT(rt::launch_ok());
-        } else {
-            const size_t lds = kmer_map_lds_bytes(b->lh_cap);
-            RT(rt::allow_lds(k_kmer_map, lds));
-            OCT_LAUNCH(k_kmer_map, b->n_map_blocks, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap, (const uint32_t*)b->d_blk_read0, b->lh_cap); RT(rt::launch_ok());
-        }
+        const uint32_t n_rb = b->h_roff[b->n_reads];      // compute_kmer_hashes once per read (array.cpp:118-131)
+        OCT_LAUNCH(k_read_hashes, (n_rb + 255) / 256, 256, 0, s0, d, n_rb); RT(rt::launch_ok());
     }
-    if (b->n_pairs) {
-        RT(rt::dev_memset(d.pair_cnt + b->n_pairs, 0, sizeof(uint4), s));
-        const uint32_t pair_blocks = (uint32_t)((b->n_pairs + 255) / 256);
-        OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d); RT(rt::launch_ok());
-        const uint64_t n_scan = b->n_pairs + 1;
-        OCT_LAUNCH(k_scan_tiles, b->n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, d.pair_cnt, n_scan, b->d_tile_sums, 0); RT(rt::launch_ok());
-        OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, b->d_tile_sums, b->n_tiles); RT(rt::launch_ok());
-        OCT_LAUNCH(k_scan_tiles, b->n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, d.pair_cnt, n_scan, b->d_tile_sums, 1); RT(rt::launch_ok());
-        OCT_LAUNCH(k_hap_bases, 1, 64, 0, s, d, b->d_hap_base, G); RT(rt::launch_ok());
-        uint4 totals;
-        RT(rt::d2h(&totals, b->d_hap_base + b->n_haps, sizeof(uint4), s));
-        RT(rt::stream_sync(s));                                  // the one host sync of the path: launch sizes
-        b->n_tasks[0] = totals.x; b->n_tasks[1] = totals.y; b->n_tasks[2] = totals.z; b->n_tasks[3] = totals.w;
+    RT(rt::event_record(h->ev_ready, s0));
+    for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(h->slice_stream(i), h->ev_ready));
+
+    // phase 1 of a slice: candidate mapping, classification + scalar fast path, task counts -> slot offsets (everything up to the one
+    // host read-back that sizes the DP launches)
+    auto phase1 = [&](int i) -> int {
+        oct_phmm_batch::Slice& sl = b->slices[i];
+        rt::Stream s = h->slice_stream(i);
+        const uint64_t np = sl.pair1 - sl.pair0;
+        if (!np) { sl.totals = make_uint4(0, 0, 0, 0); return OCT_PHMM_OK; }
+        if (b->device_map) {                              // HaplotypeLikelihoodArray::populate maps per haplotype (array.cpp:118-158)
+            OCT_LAUNCH(k_kmer_tables, sl.hap1 - sl.hap0, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d, sl.hap0); RT(rt::launch_ok());
+            if (b->map_big) {
+                const size_t lds = (size_t)b->lh_cap * 4 + 64;
+                RT(rt::allow_lds(k_kmer_map_big, lds));
+                OCT_LAUNCH(k_kmer_map_big, (uint32_t)np, 256, lds, s, d, sl.pair0); RT(rt::launch_ok());
+            } else if (sl.blk1 > sl.blk0) {
+                const size_t lds = kmer_map_lds_bytes(b->lh_cap);
+                RT(rt::allow_lds(k_kmer_map, lds));
+                OCT_LAUNCH(k_kmer_map, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
+                           (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap); RT(rt::launch_ok());
+            }
+        }
+        RT(rt::dev_memset(sl.cnt + np, 0, sizeof(uint4), s));
+        const uint32_t pair_blocks = (uint32_t)((np + 255) / 256);
+        OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt); RT(rt::launch_ok());
+        const uint64_t n_scan = np + 1;
+        OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 0); RT(rt::launch_ok());
+        OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.tile_sums, sl.n_tiles); RT(rt::launch_ok());
+        OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 1); RT(rt::launch_ok());
+        OCT_LAUNCH(k_hap_bases, 1, 64, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, b->d_hap_base, sl.d_totals, G); RT(rt::launch_ok());
+        RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s));
+        return OCT_PHMM_OK;
+    };
+    // phase 2: task emission, the DP kernels (+ traceback walk), epilogue for the slice's rows
+    auto phase2 = [&](int i) -> int {
+        oct_phmm_batch::Slice& sl = b->slices[i];
+        rt::Stream s = h->slice_stream(i);
+        const uint64_t np = sl.pair1 - sl.pair0;
+        const uint4 totals = sl.totals;
+        b->n_tasks[0] += totals.x; b->n_tasks[1] += totals.y; b->n_tasks[2] += totals.z; b->n_tasks[3] += totals.w;
         const size_t total = (size_t)totals.x + totals.y + totals.z + totals.w;
-        if (total > b->tasks_cap) {
-            rt::dev_free(b->d_tasks); b->d_tasks = nullptr; b->tasks_cap = 0;
-            void* p = nullptr; RT(rt::dev_malloc(&p, total * sizeof(DevTask))); b->d_tasks = (DevTask*)p; b->tasks_cap = total;
+        if (total > sl.tasks_cap) {
+            rt::dev_free(sl.d_tasks); sl.d_tasks = nullptr; sl.tasks_cap = 0;
+            void* p = nullptr; RT(rt::dev_malloc(&p, (total + total / 8) * sizeof(DevTask))); sl.d_tasks = (DevTask*)p; sl.tasks_cap = total + total / 8;
         }
         const size_t n_trace = (size_t)std::max(totals.y, totals.w);
-        if (n_trace > b->ends_cap) {
-            rt::dev_free(b->d_ends); b->d_ends = nullptr; b->ends_cap = 0;
-            void* p = nullptr; RT(rt::dev_malloc(&p, n_trace * sizeof(TraceEnd))); b->d_ends = (TraceEnd*)p; b->ends_cap = n_trace;
+        if (n_trace > sl.ends_cap) {
+            rt::dev_free(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
+            void* p = nullptr; RT(rt::dev_malloc(&p, (n_trace + n_trace / 8) * sizeof(TraceEnd))); sl.d_ends = (TraceEnd*)p; sl.ends_cap = n_trace + n_trace / 8;
         }
-        TaskArrays ta;
-        ta.t[0] = b->d_tasks; ta.t[1] = ta.t[0] + totals.x; ta.t[2] = ta.t[1] + totals.y; ta.t[3] = ta.t[2] + totals.z;
         if (total) {
-            OCT_LAUNCH(k_emit, pair_blocks, 256, 0, s, d, (const uint4*)b->d_hap_base, ta); RT(rt::launch_ok());
-            const uint32_t pad_threads = b->n_haps * kNumKinds * G;
-            OCT_LAUNCH(k_emit_pad, (pad_threads + 255) / 256, 256, 0, s, d, (const uint4*)b->d_hap_base, ta, G); RT(rt::launch_ok());
-            for (int k = 0; k < kNumKinds; ++k) {
-                const int rc = run_dp_kind(h, b, k, ta.t[k], b->n_tasks[k], b->d_ends, h->cfg.nuc_prior, nullptr, status);
+            TaskArrays ta;
+            ta.t[0] = sl.d_tasks; ta.t[1] = ta.t[0] + totals.x; ta.t[2] = ta.t[1] + totals.y; ta.t[3] = ta.t[2] + totals.z;
+            OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta); RT(rt::launch_ok());
+            const uint32_t pad_threads = (sl.hap1 - sl.hap0) * kNumKinds * G;
+            OCT_LAUNCH(k_emit_pad, (pad_threads + 255) / 256, 256, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, (const uint4*)b->d_hap_base, ta, G); RT(rt::launch_ok());
+            static const int order[kNumKinds] = {kTraceFast, kTraceGen, kScoreFast, kScoreGen};   // traceback first: its walk then overlaps the score-only DP of the next slice
+            for (int k : order) {
+                const int rc = run_dp_kind(h, b, i, k, ta.t[k], (k == 0 ? totals.x : k == 1 ? totals.y : k == 2 ? totals.z : totals.w), sl.d_ends, h->cfg.nuc_prior, nullptr, status);
                 if (rc != OCT_PHMM_OK) return rc;
             }
         }
+        if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
+        RT(rt::event_record(sl.done, s));
+        return OCT_PHMM_OK;
+    };
+    // software pipeline over slices: phase 1 of slice i+1 is enqueued before the host waits for slice i's task counts
+    int rc = S ? phase1(0) : OCT_PHMM_OK;
+    for (int i = 0; i < S && rc == OCT_PHMM_OK; ++i) {
+        if (i + 1 < S) rc = phase1(i + 1);
+        if (rc != OCT_PHMM_OK) break;
+        RT(rt::stream_sync(h->slice_stream(i)));              // the host read-back that sizes this slice's launches
+        rc = phase2(i);
     }
-    if (b->n_out) { OCT_LAUNCH(k_epilogue, (uint32_t)((b->n_out + 255) / 256), 256, 0, s, d, b->d_out, b->n_out); RT(rt::launch_ok()); }
+    if (rc != OCT_PHMM_OK) return rc;
+    for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(s0, b->slices[i].done));
     b->h_stat_stripes.assign((size_t)kStatSlots * 8, 0);
-    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s));
-    RT(rt::d2h(&b->h_err_key, d.err_key, sizeof(unsigned long long), s));
+    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s0));
+    RT(rt::d2h(&b->h_err_key, d.err_key, sizeof(unsigned long long), s0));
     b->ran = true;
     return ok(status);
 }
@@ -725,7 +795,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
             }
         }
         const int kind = traceback ? (gen ? kTraceGen : kTraceFast) : (gen ? kScoreGen : kScoreFast);
-        rc = run_dp_kind(h, b, kind, (const DevTask*)d_tasks, nt, (TraceEnd*)d_ends, nuc_prior, traceback ? &w : nullptr, status);
+        rc = run_dp_kind(h, b, 0, kind, (const DevTask*)d_tasks, nt, (TraceEnd*)d_ends, nuc_prior, traceback ? &w : nullptr, status);
         if (rc != OCT_PHMM_OK) return rc;
         if (traceback) {
             std::vector<TraceEnd> ends(nt); std::vector<int32_t> fp(nt), fl(nt), ms(nt); std::vector<char> a1(aln_bytes), a2(aln_bytes);

@@ -92,12 +92,12 @@ OCT_DEVICE uint32_t kmer_hash6(const uint8_t* s)               // perfect_kmer_h
 
 // make_kmer_hash_table (:85-106) for every haplotype: one workgroup per haplotype, CSR bins (order inside a bin does not
 // affect the vote counts). LDS: 4096 counters + 256 scan slots.
-OCT_KERNEL(k_kmer_tables)(DevBatch b)
+OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0)
 {
     OCT_DYN_SMEM(smem);
     uint32_t* hist = (uint32_t*)smem;            // [4096]
     uint32_t* part = hist + kKmerBins;           // [256]
-    const uint32_t h = hw::block_idx(), tid = hw::thread_idx(), nt = hw::block_dim();
+    const uint32_t h = hap0 + hw::block_idx(), tid = hw::thread_idx(), nt = hw::block_dim();
     const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;
     for (uint32_t i = tid; i < kKmerBins; i += nt) hist[i] = 0;
     hw::block_sync();
@@ -225,12 +225,12 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
 
 // Long haplotypes (bins + per-wave counters no longer fit LDS beside each other): one workgroup per (haplotype, read) pair, the
 // diagonal counters alone in LDS, bins read from global memory. Same votes, same result as k_kmer_map; for the long-read configuration.
-OCT_KERNEL(k_kmer_map_big)(DevBatch b)
+OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
 {
     OCT_DYN_SMEM(smem);
     uint32_t* counts = (uint32_t*)smem;                                // [nk]
     __shared__ uint32_t s_max, s_nout;
-    const uint64_t e = hw::block_idx();
+    const uint64_t e = pair0 + hw::block_idx();
     const uint32_t tid = hw::thread_idx(), nt = hw::block_dim();
     const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
     const uint32_t g = b.hap_region[h];
@@ -325,11 +325,12 @@ OCT_DEVICE uint64_t wave_sum(uint64_t v)
 
 // Pass 1: one thread per (read, haplotype) pair. Runs the candidate-position logic and the scalar fast path, leaves the
 // best fast-path penalty in pair_best, classifies every remaining candidate as score-only or traceback DP.
-OCT_KERNEL(k_classify)(DevBatch b)
+// A batch is processed in slices of whole haplotypes (pairs [pair0, pair1)); `cnt` is the slice's own scan array (pair1 - pair0 + 1 entries).
+OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt)
 {
-    const uint64_t e = (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
     unsigned long long st_cand = 0, st_fast = 0, st_score = 0, st_trace = 0, st_cells = 0, st_pairs = 0;
-    if (e < b.n_pairs) {
+    if (e < pair1) {
         const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
         const uint32_t g = b.hap_region[h];
         const uint32_t r = b.reg_read0[g] + (uint32_t)(e - b.hap_pair_off[h]);
@@ -369,7 +370,7 @@ OCT_KERNEL(k_classify)(DevBatch b)
         }
         b.pair_best[e] = best; b.pair_cls[e] = cls; b.pair_extra[e] = extra;
         const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
-        b.pair_cnt[e] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
+        cnt[e - pair0] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
         st_pairs = 1;
     }
     st_cand = wave_sum(st_cand); st_fast = wave_sum(st_fast); st_score = wave_sum(st_score);
@@ -441,32 +442,32 @@ OCT_KERNEL(k_scan_tile_sums)(uint4* tile_sums, uint32_t n_tiles)   // one block 
 
 // Per haplotype and kind: first task slot, with every haplotype's task run padded to a multiple of the group size so
 // that a DP task group never straddles two haplotypes. hap_base[n_haps] = padded totals.
-OCT_KERNEL(k_hap_bases)(DevBatch b, uint4* hap_base, uint32_t group)
+OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* cnt, uint64_t pair0, uint4* hap_base, uint4* totals, uint32_t group)
 {
     if (hw::thread_idx() != 0 || hw::block_idx() != 0) return;
     uint4 run = make_uint4(0, 0, 0, 0);
     auto up = [&](uint32_t c) { return (c + group - 1) / group * group; };
-    for (uint32_t h = 0; h < b.n_haps; ++h) {
-        const uint4 a = b.pair_cnt[b.hap_pair_off[h]], z = b.pair_cnt[b.hap_pair_off[h + 1]];
+    for (uint32_t h = hap0; h < hap1; ++h) {
+        const uint4 a = cnt[b.hap_pair_off[h] - pair0], z = cnt[b.hap_pair_off[h + 1] - pair0];
         hap_base[h] = run;
         run = add4(run, make_uint4(up(z.x - a.x), up(z.y - a.y), up(z.z - a.z), up(z.w - a.w)));
     }
-    hap_base[b.n_haps] = run;
+    *totals = run;
 }
 
 struct TaskArrays { DevTask* t[kNumKinds]; };
 
 // Pass 2: write the DP tasks of every pair at hap_base + (scanned count - scanned count at the haplotype's first pair).
-OCT_KERNEL(k_emit)(DevBatch b, const uint4* hap_base, TaskArrays out)
+OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt, const uint4* hap_base, TaskArrays out)
 {
-    const uint64_t e = (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
-    if (e >= b.n_pairs) return;
+    const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (e >= pair1) return;
     const uint32_t cls = b.pair_cls[e];
     if (!cls) return;
     const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
     const uint32_t r = b.reg_read0[b.hap_region[h]] + (uint32_t)(e - b.hap_pair_off[h]);
     const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
-    const uint4 s = b.pair_cnt[e], s0 = b.pair_cnt[b.hap_pair_off[h]], hb = hap_base[h];
+    const uint4 s = cnt[e - pair0], s0 = cnt[b.hap_pair_off[h] - pair0], hb = hap_base[h];
     uint32_t at_score = generic ? hb.z + (s.z - s0.z) : hb.x + (s.x - s0.x);
     uint32_t at_trace = generic ? hb.w + (s.w - s0.w) : hb.y + (s.y - s0.y);
     DevTask* ts = out.t[generic ? kScoreGen : kScoreFast]; DevTask* tt = out.t[generic ? kTraceGen : kTraceFast];
@@ -481,12 +482,12 @@ OCT_KERNEL(k_emit)(DevBatch b, const uint4* hap_base, TaskArrays out)
     }
 }
 
-OCT_KERNEL(k_emit_pad)(DevBatch b, const uint4* hap_base, TaskArrays out, uint32_t group)
+OCT_KERNEL(k_emit_pad)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* scan, uint64_t pair0, const uint4* hap_base, TaskArrays out, uint32_t group)
 {
     const uint32_t idx = hw::block_idx() * hw::block_dim() + hw::thread_idx();
-    const uint32_t h = idx / (kNumKinds * group), rem = idx % (kNumKinds * group), kind = rem / group, slot = rem % group;
-    if (h >= b.n_haps) return;
-    const uint4 a = b.pair_cnt[b.hap_pair_off[h]], z = b.pair_cnt[b.hap_pair_off[h + 1]], hb = hap_base[h];
+    const uint32_t h = hap0 + idx / (kNumKinds * group), rem = idx % (kNumKinds * group), kind = rem / group, slot = rem % group;
+    if (h >= hap1) return;
+    const uint4 a = scan[b.hap_pair_off[h] - pair0], z = scan[b.hap_pair_off[h + 1] - pair0], hb = hap_base[h];
     const uint32_t cnt = kind == 0 ? z.x - a.x : kind == 1 ? z.y - a.y : kind == 2 ? z.z - a.z : z.w - a.w;
     const uint32_t base = kind == 0 ? hb.x : kind == 1 ? hb.y : kind == 2 ? hb.z : hb.w;
     const uint32_t padded = (cnt + group - 1) / group * group;
@@ -1286,10 +1287,10 @@ OCT_KERNEL(k_walk)(WalkParams w)
 // ------------------------------------------------------------------------------------------------------------------
 // epilogue: penalty -> ln likelihood, mapping-quality mixture, template sum
 // ------------------------------------------------------------------------------------------------------------------
-OCT_KERNEL(k_epilogue)(DevBatch b, double* out, uint64_t n_out)
+OCT_KERNEL(k_epilogue)(DevBatch b, double* out, uint64_t out0, uint64_t out1)
 {
-    const uint64_t o = (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
-    if (o >= n_out) return;
+    const uint64_t o = out0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (o >= out1) return;
     const uint32_t h = upper_bound_idx(b.hap_out_off, b.n_haps + 1, o);
     const uint32_t g = b.hap_region[h];
     const uint32_t row = b.reg_row0[g] + (uint32_t)(o - b.hap_out_off[h]);

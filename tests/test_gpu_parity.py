@@ -99,6 +99,16 @@ def test_gpu_config2_with_device_mapping_matches_oracle():
     assert stats["n_pairs"] == 64000
 
 
+def test_gpu_populate_in_slices(monkeypatch):
+    monkeypatch.setenv("OCT_PHMM_SLICES", "4")
+    cp.check_basic("gpu", TOL)
+    cp.check_templates_and_regions("gpu", TOL)
+    cp.check_device_kmer_mapper("gpu", TOL)
+    cp.check_ragged_and_edges("gpu", TOL)
+    batch = synth.config_batch("1kx64", seed=43, B=16, positions="none")
+    cp.compare("gpu", batch, TOL, max_indel_error=16)
+
+
 def test_gpu_config2_1k_by_64_matches_oracle():
     """BASELINE.json configs[1]: the 1k x 64 batch (150 bp reads, 300 bp haplotypes, B = 16, flank 40/40)."""
     batch = synth.config_batch("1kx64", seed=42, B=16)

@@ -40,3 +40,12 @@ def test_sim_populate_wide_bands_and_long_reads():
 def test_sim_big_haplotype_mapper_matches_reference_mapper(monkeypatch):
     monkeypatch.setenv("OCT_PHMM_BIG_MAPPER", "1")      # force the one-workgroup-per-pair mapper used for very long haplotypes
     cp.check_device_kmer_mapper("sim")
+
+
+def test_sim_populate_in_slices(monkeypatch):
+    """Large batches are cut into slices of whole haplotypes that run on separate streams; force 3 slices on small batches."""
+    monkeypatch.setenv("OCT_PHMM_SLICES", "3")
+    cp.check_basic("sim")
+    cp.check_templates_and_regions("sim")
+    cp.check_device_kmer_mapper("sim")
+    cp.check_ragged_and_edges("sim")
