@@ -23,7 +23,7 @@ struct oct_phmm_handle {
     int band = 0;
     bool wide = false;                                   // int32 lanes (Config::use_int_scores)
     int  lanes_c = 1;                                    // band diagonals per lane on the streaming path (band / 64) for bands 128, 256
-    static constexpr int kMaxSlices = 4;
+    static constexpr int kMaxSlices = 8;
     rt::Stream stream {};                                 // slice 0 / uploads / downloads
     rt::Stream extra_streams[kMaxSlices - 1] {};          // further slices run on their own streams so that latency-bound and VALU-bound kernels overlap
     rt::Event ev_ready {};
@@ -226,7 +226,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         const size_t per_group = (size_t)p.k_cap * 4096 * (b->stream ? C : 1);
         const size_t fit = std::max<size_t>(1, h->bp_budget / std::max<size_t>(1, b->slices.size()) / per_group);
         chunk_groups = (uint32_t)std::min<size_t>(n_groups, fit);
-        chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / p.groups_per_block * p.groups_per_block);
+        if (chunk_groups < n_groups) chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / p.groups_per_block * p.groups_per_block);   // several launches: whole workgroups each
         if (!ensure_bp(h, slice, (size_t)std::min(chunk_groups, n_groups) * per_group)) return fail(status, OCT_PHMM_EHIP, "traceback scratch allocation");
     }
     for (uint32_t g0 = 0; g0 < n_groups; g0 += chunk_groups) {
@@ -500,7 +500,7 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     {
         // Slices of whole haplotypes, each on its own stream: while slice i is in its VALU-bound DP kernels, slice i+1 runs its
         // latency-bound mapper/classifier and slice i-1 its latency-bound walk. Small batches stay in one slice.
-        int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / 1500000));
+        int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / 1000000));
         if (const char* e = getenv("OCT_PHMM_SLICES")) n_slices = std::max(1, std::min(oct_phmm_handle::kMaxSlices, atoi(e)));
         n_slices = (int)std::min<uint32_t>((uint32_t)n_slices, std::max<uint32_t>(1, H->n_haps));
         uint4* totals = nullptr; RT(dalloc(bp, &totals, (size_t)n_slices));
