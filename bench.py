@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
 # VALU wave-instructions per DP iteration per wave (8 tasks at B = 16), counted in the ISA of this build
 VALU_PER_ITER = {"score": 31.3, "trace": 53.0}
-PMC_SUMMARY = ROOT / "profiles" / "r01_step4_pmc_summary.json"
+PMC_SUMMARY = ROOT / "profiles" / "r01_step8_pmc_summary.json"
 
 
 def algorithmic_bytes_per_task(T: int, B: int) -> int:
@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="100kx128")
     ap.add_argument("--band", type=int, default=16)
+    ap.add_argument("--regions", type=int, default=2000, help="--workload stream: active regions per rank per step (BASELINE configs[3] stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -104,7 +105,10 @@ def main():
     T, LH = 150, 300
     cfg = abi.Config.default(max_indel_error=B, device_id=local_rank)
     eng = engine.Engine(cfg)                      # fails loudly if liboct_phmm.so / a gfx950 device is missing
-    batch = synth.config_batch(args.workload, seed=42 + rank, B=B, positions="none")   # candidate positions come from the device k-mer mapper
+    if args.workload == "stream":                 # configs[3]: a stream of independent active regions, region i -> rank i mod N, one flat batch per rank
+        batch = synth.batch_from_regions(synth.region_stream(seed=42 + rank, n_regions=args.regions, B=B, positions="none"))
+    else:
+        batch = synth.config_batch(args.workload, seed=42 + rank, B=B, positions="none")   # candidate positions come from the device k-mer mapper
     rb = eng.upload(batch)                        # inputs resident in HBM before the timed region
 
     def sync_all():
@@ -117,11 +121,8 @@ def main():
         rb.run(); rb.wait()
     sync_all()
     t0 = time.perf_counter()
-    dp_ms, dp_launches = 0.0, 0
     for _ in range(args.steps):
         rb.run(); rb.wait()
-        ms, n = rb.kernel_time()
-        dp_ms += ms; dp_launches += n
     sync_all()
     elapsed = time.perf_counter() - t0
     stats = rb.stats()
@@ -138,38 +139,60 @@ def main():
 
     if rank == 0:
         per_step = elapsed / args.steps
-        # dominant kernel = the DP launches (HIP events on the library's own stream around each k_dp launch)
-        avg_launch_s = (dp_ms / 1e3) / max(dp_launches, 1)
-        tasks_per_launch = n_tasks * args.steps / max(dp_launches, 1)
+        # Roofline leg (outside the timed region): the pipeline above overlaps launches of different slices, so per-launch
+        # durations are taken from a single-slice run of the same batch, where every launch has the device to itself.
+        # Dominant kernel = k_dp<B, TRACE=true, fast cost, FASTADD> (the traceback DP); HIP events on the library's stream.
+        os.environ["OCT_PHMM_SLICES"] = "1"
+        rb1 = eng.upload(batch)
+        del os.environ["OCT_PHMM_SLICES"]
+        rb1.run(); rb1.wait()
+        kind_ms = {k: [0.0, 0] for k in ("score_fast", "trace_fast", "score_generic", "trace_generic")}
+        for _ in range(3):
+            rb1.run(); rb1.wait()
+            for k, (ms, n) in rb1.kernel_time_by_kind().items():
+                kind_ms[k][0] += ms; kind_ms[k][1] += n
+        rb1.free()
+        tr_ms, tr_n = kind_ms["trace_fast"]
+        sc_ms, sc_n = kind_ms["score_fast"]
+        avg_launch_s = (tr_ms / 1e3) / max(tr_n, 1)
+        tasks_per_launch = stats["n_dp_traceback"] * 3 / max(tr_n, 1)
         alg_bytes = algorithmic_bytes_per_task(T, B) * tasks_per_launch
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # VALU view (what actually binds): wave-instructions the DP launches issued per second vs the 4-cycle issue peak
         groups = lambda n: n / (2 * (64 // B))
         valu_instr = (groups(stats["n_dp_score_only"]) * VALU_PER_ITER["score"] + groups(stats["n_dp_traceback"]) * VALU_PER_ITER["trace"]) * (T + B)
-        dp_s_per_step = (dp_ms / 1e3) / args.steps
+        dp_s_per_step = ((tr_ms + sc_ms + kind_ms["score_generic"][0] + kind_ms["trace_generic"][0]) / 1e3) / 3
         traffic = None
         if PMC_SUMMARY.exists():        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-            pm = json.loads(PMC_SUMMARY.read_text()).get("octphmm::k_dp<16, true, false>", {})
+            pm = json.loads(PMC_SUMMARY.read_text()).get(f"octphmm::k_dp<{B}, true, false, true>", {})
             if "hbm_read_bytes_corrected" in pm and "hbm_write_bytes" in pm:
                 traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
         out = {
             "metric": "pair-HMM band cell-updates/s", "value": cells / per_step / 1e9, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: Illumina-like 150 bp reads x 300 bp haplotypes per region, band {B}, "
-                                   f"int16 lanes, flank 40/40, device k-mer mapping, one region per GPU", "band": B, "read_len": T, "hap_len": LH,
+            "config": {"workload": (f"{args.workload}: Illumina-like 150 bp reads x 300 bp haplotypes per region, band {B}, "
+                                    f"int16 lanes, flank 40/40, device k-mer mapping, one region per GPU") if args.workload != "stream" else
+                                   (f"stream: {args.regions} synthetic active regions per GPU per step (R ~ lognormal(300, 0.8) in [20, 5000], H ~ min(200, geometric(24)), "
+                                    f"Lh 300-500, T 150), band {B}, int16 lanes, flank 40/40, device k-mer mapping"), "band": B, "read_len": T, "hap_len": LH,
                        "pairs_per_step": pairs, "dp_tasks_per_step": n_tasks, "parallelism": f"regions sharded over {world} GPU(s), no collective"},
             "loglik_per_s": pairs / per_step,
+            **({"regions_per_s": args.regions * world / per_step} if args.workload == "stream" else {}),
             "stats": stats,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_note": "bytes per launch of k_dp<16,true,false> from profiles/r01_step4_pmc_summary.json "
-                                                             "(FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE), measured with host-provided positions",
-                         "kernel": "k_dp (score-only + traceback launches, HIP-event timed on the library stream)",
-                         "avg_launch_ms": avg_launch_s * 1e3, "launches_per_step": dp_launches / args.steps,
+                         "traffic": traffic,
+                         "traffic_note": f"HBM bytes per launch of k_dp<{B},true,false,true> from {PMC_SUMMARY.relative_to(ROOT)} (FETCH_SIZE x 2 per the gfx950 "
+                                         "correction + WRITE_SIZE, separate --pmc passes of this workload, single slice = one launch per step); "
+                                         "~94 % of it is the 5.3 KB/task backpointer tile stream the walk kernel consumes, which SURVEY 8d's per-task figure does not count",
+                         "kernel": f"k_dp<{B}, TRACE, fast cost, FASTADD> (traceback DP), single-slice run, HIP events on the library stream",
+                         "avg_launch_ms": avg_launch_s * 1e3, "tasks_per_launch": tasks_per_launch,
+                         "algorithmic_bytes_per_task": algorithmic_bytes_per_task(T, B),
+                         "score_only_kernel_avg_launch_ms": (sc_ms / max(sc_n, 1)),
                          "valu": {"achieved_wave_instr_per_s": valu_instr / dp_s_per_step if dp_s_per_step > 0 else 0.0,
                                   "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
                                   "frac": (valu_instr / dp_s_per_step / VALU_PEAK_WAVE_INSTR) if dp_s_per_step > 0 else 0.0,
-                                  "note": "the DP is integer-VALU bound, not HBM bound (SURVEY.md 8d); PMC: SQ_ACTIVE_INST_VALU = 93-100 % of kernel cycles"}},
+                                  "note": "the DP is integer-VALU issue bound, not HBM bound (SURVEY.md 8d): loop-body wave-instructions (ISA count) x iterations "
+                                          "/ DP kernel time vs 256 CU x 4 SIMD x 2.4 GHz / 4 cycles; PMC: SQ_ACTIVE_INST_VALU x 4 / (CU x SIMD) = 91-93 % of kernel cycles"}},
         }
         if world == 1:
             small = eng.upload(synth.config_batch("1kx64", seed=42, B=B, positions="none"))

@@ -61,7 +61,9 @@ struct oct_phmm_batch {
     bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
     uint32_t* d_blk_hap = nullptr; uint32_t* d_blk_read0 = nullptr; uint32_t n_map_blocks = 0;
     double dp_ms = 0; uint32_t dp_launches = 0;
-    std::vector<std::pair<rt::Event, rt::Event>> timers;
+    std::vector<std::pair<rt::Event, rt::Event>> timers;       // one (start, stop) pair per DP launch
+    std::vector<int> timer_kind;
+    double kind_ms[kNumKinds] = {0, 0, 0, 0}; uint32_t kind_launches[kNumKinds] = {0, 0, 0, 0};
     oct_phmm_handle* owner = nullptr;
 };
 
@@ -241,7 +243,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
                         : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         RT(rt::event_record(e1, st));
-        b->timers.emplace_back(e0, e1);
+        b->timers.emplace_back(e0, e1); b->timer_kind.push_back(kind);
         if (tr) {
             WalkParams w {};
             if (seam_walk) w = *seam_walk;
@@ -545,7 +547,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     rt::Stream s0 = h->stream;
     DevBatch& d = b->d;
     for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
-    b->timers.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
+    b->timers.clear(); b->timer_kind.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
     const uint32_t G = b->stream ? 1u : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
     const int S = (int)b->slices.size();
     RT(rt::dev_memset(d.stats, 0, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s0));
@@ -646,7 +648,11 @@ extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_ph
     RT(rt::stream_sync(h->stream));
     for (int k = 0; k < 6; ++k) { b->h_stats[k] = 0; for (uint32_t sl = 0; sl < kStatSlots; ++sl) b->h_stats[k] += b->h_stat_stripes[(size_t)sl * 8 + k]; }
     b->dp_ms = 0; b->dp_launches = 0;
-    for (auto& t : b->timers) { float ms = 0; RT(rt::event_elapsed_ms(&ms, t.first, t.second)); b->dp_ms += ms; ++b->dp_launches; }
+    for (int k = 0; k < kNumKinds; ++k) { b->kind_ms[k] = 0; b->kind_launches[k] = 0; }
+    for (size_t i = 0; i < b->timers.size(); ++i) {
+        float ms = 0; RT(rt::event_elapsed_ms(&ms, b->timers[i].first, b->timers[i].second));
+        b->dp_ms += ms; ++b->dp_launches; b->kind_ms[b->timer_kind[i]] += ms; ++b->kind_launches[b->timer_kind[i]];
+    }
     if (b->h_err_key != ~0ull) {
         // ShortHaplotypeError: recompute required_extension for the first offending (haplotype, read) — model.cpp:238-253
         const uint32_t hp = (uint32_t)(b->h_err_key >> 32), r = (uint32_t)b->h_err_key;
@@ -689,6 +695,13 @@ extern "C" int oct_phmm_batch_kernel_time(const oct_phmm_batch* b, double* ms, u
     if (!b) return OCT_PHMM_EINVAL;
     if (ms) *ms = b->dp_ms;
     if (launches) *launches = b->dp_launches;
+    return OCT_PHMM_OK;
+}
+
+extern "C" int oct_phmm_batch_kernel_time_by_kind(const oct_phmm_batch* b, double ms[4], uint32_t launches[4])
+{
+    if (!b) return OCT_PHMM_EINVAL;
+    for (int k = 0; k < kNumKinds; ++k) { if (ms) ms[k] = b->kind_ms[k]; if (launches) launches[k] = b->kind_launches[k]; }
     return OCT_PHMM_OK;
 }
 

@@ -63,6 +63,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_out_size.argtypes = [pv]
         lib.oct_phmm_batch_out_size.restype = C.c_size_t
         lib.oct_phmm_batch_kernel_time.argtypes = [pv, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        lib.oct_phmm_batch_kernel_time_by_kind.argtypes = [pv, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32 * 4)]
         lib.oct_phmm_batch_free.argtypes = [pv, pv]
         _LIBS[key] = lib
     return _LIBS[key]
@@ -122,6 +123,12 @@ class ResidentBatch:
         ms, n = C.c_double(0), C.c_uint32(0)
         self.engine.lib.oct_phmm_batch_kernel_time(self.ptr, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    def kernel_time_by_kind(self) -> dict:
+        """{kind: (ms, launches)} of the last run's DP launches; kinds as in oct_phmm.h."""
+        ms, n = (C.c_double * 4)(), (C.c_uint32 * 4)()
+        self.engine.lib.oct_phmm_batch_kernel_time_by_kind(self.ptr, C.byref(ms), C.byref(n))
+        return {k: (ms[i], n[i]) for i, k in enumerate(("score_fast", "trace_fast", "score_generic", "trace_generic"))}
 
     def free(self):
         if self.ptr:
