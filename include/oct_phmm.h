@@ -185,6 +185,28 @@ int  oct_phmm_batch_kernel_time(const oct_phmm_batch* b, double* dp_kernel_ms, u
 int  oct_phmm_batch_kernel_time_by_kind(const oct_phmm_batch* b, double dp_kernel_ms[4], uint32_t dp_launches[4]);
 void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b);
 
+/* ---- genotype read-out on the resident matrix ---------------------------------- */
+/* ConstantMixtureGenotypeLikelihoodModel::evaluate (core/models/genotype/constant_mixture_genotype_likelihood_model.cpp:29-330)
+ * for whole genotype vectors (the `evaluate(genotypes, model)` helper, constant_mixture_genotype_likelihood_model.hpp:58-75)
+ * on the likelihood matrix the last run left in HBM, so that only one double per genotype returns to the host:
+ *   ln p(reads | genotype) = sum over primed rows [ ln sum_{h in genotype} p(row | h) - ln ploidy ].
+ * One "set" = one such call: genotypes of one ploidy over haplotypes of ONE region, evaluated over the rows
+ * [row_begin, row_end) of that region (HaplotypeLikelihoodArray::prime(sample): a sample's rows are contiguous).
+ * A genotype is `ploidy` batch haplotype indices in non-decreasing order (Genotype<> keeps its haplotypes sorted,
+ * which the reference's zygosity case analysis relies on). ploidy 1 also gives haplotype_filter.cpp's LikelihoodSum. */
+#define OCT_PHMM_MAX_PLOIDY 16
+typedef struct oct_phmm_genotype_sets {
+    uint32_t        n_sets;
+    const uint32_t* ploidy;           /* [n_sets] 1..OCT_PHMM_MAX_PLOIDY */
+    const uint32_t* gt_offsets;       /* [n_sets + 1] genotypes [gt_offsets[s], gt_offsets[s+1]) belong to set s; gt_offsets[0] == 0 */
+    const uint32_t* hap_indices;      /* concatenated over genotypes: ploidy[s] haplotype indices each */
+    const uint32_t* row_begin;        /* [n_sets] or NULL (= 0) */
+    const uint32_t* row_end;          /* [n_sets] or NULL (= all rows of the region) */
+} oct_phmm_genotype_sets;
+/* out: gt_offsets[n_sets] doubles. The batch must have been run; blocks until the result is on the host. */
+int  oct_phmm_batch_genotype_likelihoods(oct_phmm_handle* h, oct_phmm_batch* b, const oct_phmm_genotype_sets* sets,
+                                         double* out, oct_phmm_status* status);
+
 /* ---- test seam: the raw band kernel ------------------------------------------------------------ */
 /* simd::PairHMM::align on explicit windows (simd_pair_hmm.hpp:438-509): what the reference's golden tests
  * drive (test/unit/core/models/pair_hmm_tests.cpp:63-85). Window i has truth_len = target_len + 2B - 1.

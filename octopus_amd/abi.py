@@ -209,6 +209,12 @@ class Batch:
             return np.array([0, self.n_rows], np.uint32), np.array([0, self.n_haps], np.uint32)
         return self.region_row_offsets, self.region_hap_offsets
 
+    def hap_out_offsets(self) -> np.ndarray:
+        """Offset of every haplotype's likelihood column in the flat output (column = the region's rows)."""
+        ro, ho = self.region_tables()
+        rows = np.repeat((ro[1:] - ro[:-1]).astype(np.uint64), (ho[1:] - ho[:-1]).astype(np.int64))
+        return np.concatenate([np.zeros(1, np.uint64), np.cumsum(rows, dtype=np.uint64)])
+
     def out_size(self) -> int:
         ro, ho = self.region_tables()
         return int(np.sum((ro[1:] - ro[:-1]).astype(np.int64) * (ho[1:] - ho[:-1]).astype(np.int64)))
@@ -264,3 +270,27 @@ class Batch:
         self._keep = [r, h, g, f, p]
         byref = lambda s: None if s is None else C.byref(s)
         return byref(r), byref(h), byref(g), byref(f), byref(p)
+
+
+class GenotypeSets(C.Structure):
+    """oct_phmm_genotype_sets: genotype vectors to read out of a resident likelihood matrix."""
+    _fields_ = [("n_sets", C.c_uint32), ("ploidy", C.c_void_p), ("gt_offsets", C.c_void_p), ("hap_indices", C.c_void_p),
+                ("row_begin", C.c_void_p), ("row_end", C.c_void_p)]
+
+    @staticmethod
+    def make(sets):
+        """sets: list of dict(genotypes = [n, ploidy] array of batch haplotype indices, rows = (begin, end) or None).
+        Returns (struct, keep-alive arrays, total genotypes)."""
+        ploidy = np.asarray([np.asarray(s["genotypes"]).reshape(len(s["genotypes"]), -1).shape[1] if len(s["genotypes"]) else s.get("ploidy", 1)
+                             for s in sets], np.uint32)
+        counts = [len(s["genotypes"]) for s in sets]
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+        idx = np.concatenate([np.asarray(s["genotypes"], np.uint32).reshape(-1) for s in sets] + [np.zeros(0, np.uint32)]).astype(np.uint32)
+        keep = [ploidy, offs, idx]
+        rb = re = None
+        if any(s.get("rows") is not None for s in sets):
+            if not all(s.get("rows") is not None for s in sets):
+                raise ValueError("give rows for every set or for none")
+            rb = np.asarray([s["rows"][0] for s in sets], np.uint32); re = np.asarray([s["rows"][1] for s in sets], np.uint32)
+            keep += [rb, re]
+        return GenotypeSets(len(sets), _ptr(ploidy), _ptr(offs), _ptr(idx), _ptr(rb), _ptr(re)), keep, int(offs[-1])

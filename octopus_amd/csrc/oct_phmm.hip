@@ -12,6 +12,7 @@
 
 #include "phmm_rt.hpp"
 #include "phmm_kernels.hpp"
+#include "phmm_readout.hpp"
 
 using namespace octphmm;
 
@@ -41,6 +42,7 @@ struct oct_phmm_batch {
     uint32_t n_reads = 0, n_haps = 0, n_rows = 0, n_regions = 0, t_cap = 0, lh_cap = 0, n_hap_bases = 0;
     uint64_t n_pairs = 0, n_out = 0;
     std::vector<uint32_t> h_roff, h_hoff, h_blk_hap; std::vector<int64_t> h_rbegin, h_hbegin;
+    std::vector<uint32_t> h_hap_region, h_reg_hap0; std::vector<uint64_t> h_hap_out_off;      // for the genotype read-out
     // run state
     struct Slice {                     // whole haplotypes [hap0, hap1) = pairs [pair0, pair1) = outputs [out0, out1)
         uint32_t hap0 = 0, hap1 = 0, blk0 = 0, blk1 = 0, n_tiles = 0; uint64_t pair0 = 0, pair1 = 0, out0 = 0, out1 = 0;
@@ -393,6 +395,7 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
         }
     }
     reg_row0[G] = g_row[G]; reg_read0[G] = first_read(g_row[G]);
+    b->h_hap_region = hap_region; b->h_hap_out_off = hap_out_off; b->h_reg_hap0.assign(g_hap, g_hap + G + 1);
     b->n_out = hap_out_off[H->n_haps]; b->n_pairs = hap_pair_off[H->n_haps];
     if (b->n_pairs >= 0xffffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "more than 2^32-1 pairs in one batch");
     for (uint32_t r = 0; r < R->n_reads; ++r) b->t_cap = std::max(b->t_cap, R->offsets[r + 1] - R->offsets[r]);
@@ -703,6 +706,97 @@ extern "C" int oct_phmm_batch_kernel_time_by_kind(const oct_phmm_batch* b, doubl
     if (!b) return OCT_PHMM_EINVAL;
     for (int k = 0; k < kNumKinds; ++k) { if (ms) ms[k] = b->kind_ms[k]; if (launches) launches[k] = b->kind_launches[k]; }
     return OCT_PHMM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// genotype read-out (phmm_readout.hpp)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int oct_phmm_batch_genotype_likelihoods(oct_phmm_handle* h, oct_phmm_batch* b, const oct_phmm_genotype_sets* gs,
+                                                   double* out, oct_phmm_status* status)
+{
+    if (!h || !b || b->owner != h || !gs) return fail(status, OCT_PHMM_EINVAL, "null argument");
+    if (!b->ran) return fail(status, OCT_PHMM_EINVAL, "batch was not run");
+    if (gs->n_sets == 0) return ok(status);
+    if (!gs->ploidy || !gs->gt_offsets || gs->gt_offsets[0] != 0) return fail(status, OCT_PHMM_EINVAL, "genotype set tables");
+    const uint32_t n_gt = gs->gt_offsets[gs->n_sets];
+    if (n_gt == 0) return ok(status);
+    if (!gs->hap_indices || !out) return fail(status, OCT_PHMM_EINVAL, "null genotype indices or output");
+    const int rc = oct_phmm_batch_wait(h, b, status);
+    if (rc != OCT_PHMM_OK) return rc;
+
+    constexpr uint32_t kTargetBlocks = 2048;                     // >= 8 workgroups per CU before rows are split
+    constexpr size_t kTileBytes = 96 * 1024;
+    std::vector<ReadoutSet> sets(gs->n_sets);
+    std::vector<uint4> blocks, sum_blocks;
+    uint64_t idx_off = 0, partial_off = 0; size_t lds = 0;
+    uint64_t total_blocks_unsplit = 0;
+    for (uint32_t s = 0; s < gs->n_sets; ++s) total_blocks_unsplit += (gs->gt_offsets[s + 1] - gs->gt_offsets[s] + kReadoutThreads - 1) / kReadoutThreads;
+    for (uint32_t s = 0; s < gs->n_sets; ++s) {
+        ReadoutSet& q = sets[s];
+        if (gs->gt_offsets[s + 1] < gs->gt_offsets[s]) return fail(status, OCT_PHMM_EINVAL, "genotype offsets must not decrease");
+        q.gt0 = gs->gt_offsets[s]; q.n_genotypes = gs->gt_offsets[s + 1] - q.gt0; q.ploidy = gs->ploidy[s];
+        q.gt_idx_off = idx_off; q.partial_off = partial_off;
+        if (q.ploidy < 1 || q.ploidy > OCT_PHMM_MAX_PLOIDY) return fail(status, OCT_PHMM_EUNSUPPORTED, "ploidy outside 1..16");
+        const uint32_t* gi = gs->hap_indices + idx_off;
+        idx_off += (uint64_t)q.n_genotypes * q.ploidy;
+        if (q.n_genotypes == 0) { q.n_splits = 1; continue; }
+        if (gi[0] >= b->n_haps) return fail(status, OCT_PHMM_EINVAL, "haplotype index out of range");
+        const uint32_t reg = b->h_hap_region[gi[0]];
+        q.hap0 = b->h_reg_hap0[reg]; q.n_haps = b->h_reg_hap0[reg + 1] - q.hap0;
+        for (uint64_t i = 0; i < (uint64_t)q.n_genotypes * q.ploidy; ++i) {
+            if (gi[i] < q.hap0 || gi[i] >= q.hap0 + q.n_haps) return fail(status, OCT_PHMM_EINVAL, "genotypes of one set must use haplotypes of one region");
+            if (i % q.ploidy && gi[i] < gi[i - 1]) return fail(status, OCT_PHMM_EINVAL, "genotype haplotype indices must be sorted");
+        }
+        const uint32_t rows = (uint32_t)(b->h_hap_out_off[q.hap0 + 1] - b->h_hap_out_off[q.hap0]);
+        q.row_begin = gs->row_begin ? gs->row_begin[s] : 0; q.row_end = gs->row_end ? gs->row_end[s] : rows;
+        if (q.row_begin > q.row_end || q.row_end > rows) return fail(status, OCT_PHMM_EINVAL, "row range outside the region");
+        const uint32_t nrows = q.row_end - q.row_begin;
+        const size_t fit = kTileBytes / (8 * (size_t)q.n_haps);
+        if (fit < 3) return fail(status, OCT_PHMM_EUNSUPPORTED, "too many haplotypes in one region for the read-out tile");
+        q.tile_rows = (uint32_t)std::min<size_t>(32, fit - 1);
+        lds = std::max(lds, (size_t)q.n_haps * (q.tile_rows + 1) * 8);
+        const uint32_t n_chunks = (q.n_genotypes + kReadoutThreads - 1) / kReadoutThreads;
+        const uint32_t n_tiles = std::max(1u, (nrows + q.tile_rows - 1) / q.tile_rows);
+        uint32_t want = total_blocks_unsplit >= kTargetBlocks ? 1 : (uint32_t)((kTargetBlocks + total_blocks_unsplit - 1) / total_blocks_unsplit);
+        want = std::min(want, n_tiles);
+        const uint32_t tiles_per_split = (n_tiles + want - 1) / want;
+        q.rows_per_split = tiles_per_split * q.tile_rows;
+        q.n_splits = (n_tiles + tiles_per_split - 1) / tiles_per_split;
+        if (q.n_splits > 1) partial_off += (uint64_t)q.n_splits * q.n_genotypes;
+        for (uint32_t sp = 0; sp < q.n_splits; ++sp)
+            for (uint32_t c = 0; c < n_chunks; ++c) blocks.push_back(uint4{s, c, sp, 0});
+        if (q.n_splits > 1) for (uint32_t c = 0; c < n_chunks; ++c) sum_blocks.push_back(uint4{s, c, 0, 0});
+    }
+    if (blocks.empty()) return ok(status);
+    if (blocks.size() > 0x7fffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "too many genotypes in one call");
+
+    RT(rt::set_device(h->cfg.device_id));
+    rt::Stream st = h->stream;
+    struct Tmp { std::vector<void*> v; ~Tmp() { for (void* p : v) rt::dev_free(p); } } tmp;
+    auto put = [&](const void* host, size_t bytes, void** dev) {
+        if (!rt::dev_malloc(dev, bytes)) return false;
+        tmp.v.push_back(*dev);
+        return host ? rt::h2d(*dev, host, bytes, st) : true;
+    };
+    void *d_gt = nullptr, *d_sets = nullptr, *d_blocks = nullptr, *d_sum = nullptr, *d_partial = nullptr, *d_res = nullptr;
+    RT(put(gs->hap_indices, idx_off * sizeof(uint32_t), &d_gt));
+    RT(put(sets.data(), sets.size() * sizeof(ReadoutSet), &d_sets));
+    RT(put(blocks.data(), blocks.size() * sizeof(uint4), &d_blocks));
+    if (!sum_blocks.empty()) { RT(put(sum_blocks.data(), sum_blocks.size() * sizeof(uint4), &d_sum)); RT(put(nullptr, partial_off * sizeof(double), &d_partial)); }
+    RT(put(nullptr, (size_t)n_gt * sizeof(double), &d_res));
+    ReadoutParams p {};
+    p.lik = b->d_out; p.hap_out_off = b->d.hap_out_off; p.gt = (const uint32_t*)d_gt; p.sets = (const ReadoutSet*)d_sets;
+    p.blocks = (const uint4*)d_blocks; p.partial = (double*)d_partial; p.out = (double*)d_res;
+    if (lds > 64 * 1024) RT(rt::allow_lds(k_genotype_lik, lds));
+    OCT_LAUNCH(k_genotype_lik, (uint32_t)blocks.size(), kReadoutThreads, lds, st, p);
+    RT(rt::launch_ok());
+    if (!sum_blocks.empty()) {
+        OCT_LAUNCH(k_genotype_sum, (uint32_t)sum_blocks.size(), kReadoutThreads, 0, st, p, (const uint4*)d_sum);
+        RT(rt::launch_ok());
+    }
+    RT(rt::d2h(out, d_res, (size_t)n_gt * sizeof(double), st));
+    RT(rt::stream_sync(st));
+    return ok(status);
 }
 
 extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,

@@ -28,7 +28,7 @@ class EngineError(RuntimeError):
 
 def build(force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 the kernels + host API into octopus_amd/liboct_phmm.so (in-tree)."""
-    srcs = [PKG_DIR / "csrc" / n for n in ("oct_phmm.hip", "phmm_kernels.hpp", "phmm_device.hpp", "phmm_hw.hpp", "phmm_rt.hpp")]
+    srcs = [PKG_DIR / "csrc" / n for n in ("oct_phmm.hip", "phmm_kernels.hpp", "phmm_readout.hpp", "phmm_device.hpp", "phmm_hw.hpp", "phmm_rt.hpp")]
     srcs.append(PKG_DIR.parent / "include" / "oct_phmm.h")
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH
@@ -64,6 +64,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_out_size.restype = C.c_size_t
         lib.oct_phmm_batch_kernel_time.argtypes = [pv, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         lib.oct_phmm_batch_kernel_time_by_kind.argtypes = [pv, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32 * 4)]
+        lib.oct_phmm_batch_genotype_likelihoods.argtypes = [pv, pv, pv, pv, pv]
         lib.oct_phmm_batch_free.argtypes = [pv, pv]
         _LIBS[key] = lib
     return _LIBS[key]
@@ -112,6 +113,17 @@ class ResidentBatch:
         code = self.engine.lib.oct_phmm_batch_download(self.engine.handle, self.ptr, _ptr(out), C.byref(st))
         if code != abi.OK:
             raise EngineError(code, st, "download")
+        return out[:n]
+
+    def genotype_likelihoods(self, sets) -> np.ndarray:
+        """ConstantMixtureGenotypeLikelihoodModel::evaluate for vectors of genotypes on the resident matrix
+        (oct_phmm_batch_genotype_likelihoods). sets: see abi.GenotypeSets.make."""
+        gs, keep, n = abi.GenotypeSets.make(sets)
+        out = np.empty(max(n, 1), dtype=np.float64)
+        st = abi.Status()
+        code = self.engine.lib.oct_phmm_batch_genotype_likelihoods(self.engine.handle, self.ptr, C.byref(gs), _ptr(out), C.byref(st))
+        if code != abi.OK:
+            raise EngineError(code, st, "genotype_likelihoods")
         return out[:n]
 
     def stats(self) -> dict:

@@ -162,6 +162,20 @@ def populate(cfg: abi.Config, batch: abi.Batch, n_threads: int = 1):
     return out[:batch.out_size()], st, stats.as_dict()
 
 
+def genotype_likelihoods(lik, hap_out_off, genotypes, rows=None):
+    """ConstantMixtureGenotypeLikelihoodModel::evaluate for an [n, ploidy] array of sorted haplotype indices over the
+    flat matrix `lik` (populate's output); rows = (begin, end) within the region, default all."""
+    g = np.ascontiguousarray(np.asarray(genotypes, np.uint32).reshape(len(genotypes), -1))
+    off = np.ascontiguousarray(hap_out_off, dtype=np.uint64)
+    if rows is None:
+        rows = (0, int(off[int(g[0, 0]) + 1] - off[int(g[0, 0])])) if len(g) else (0, 0)
+    out = np.empty(max(len(g), 1), np.float64)
+    code = lib().oracle_genotype_likelihoods(_p(np.ascontiguousarray(lik, dtype=np.float64)), _p(off), len(g), g.shape[1] if len(g) else 1,
+                                             _p(g), int(rows[0]), int(rows[1]), _p(out))
+    assert code == 0, code
+    return out[:len(g)]
+
+
 def time_align_windows(band, score_bits, truth, truth_offsets, target, quals, target_offsets, gap_open, gap_extend,
                        snv_mask, snv_prior, nuc_prior=2, traceback=False, reps=1, n_threads=1):
     """Seconds to run the current L1 backend over all windows `reps` times (CPU baseline leg of bench.py)."""

@@ -822,3 +822,77 @@ double oracle_time_align_windows(int band, int score_bits, uint32_t n,
     free(cs); free(th);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Genotype read-out: ConstantMixtureGenotypeLikelihoodModel (constant_mixture_genotype_likelihood_model.cpp)
+ * ---------------------------------------------------------------------------------------------------------------- */
+static const double LN2 = 0.693147180559945309417232121458176568075500134360255254120;   /* :46-63 */
+static const double LN3 = 1.098612288668109691395245236922525704647490557822749451734;
+static const double LN4 = 1.386294361119890618834464242916353136151000268720510508241;
+
+static double lse_2(double a, double b)              /* utils/maths.hpp:294-298 */
+{
+    const double lo = b < a ? b : a, hi = b < a ? a : b;
+    return hi + log1p(exp(lo - hi));
+}
+static double lse_3(double a, double b, double c)    /* utils/maths.hpp:302-306 */
+{
+    double mx = a; if (mx < b) mx = b; if (mx < c) mx = c;
+    return mx + log(exp(a - mx) + exp(b - mx) + exp(c - mx));
+}
+static double lse_n(const double* x, uint32_t n)     /* utils/maths.hpp:310-330 */
+{
+    double mx = x[0], s = 0;
+    for (uint32_t i = 1; i < n; ++i) if (mx < x[i]) mx = x[i];
+    for (uint32_t i = 0; i < n; ++i) s = s + exp(x[i] - mx);
+    return mx + log(s);
+}
+
+int oracle_genotype_likelihoods(const double* lik, const uint64_t* hap_out_off, uint32_t n_genotypes, uint32_t ploidy,
+        const uint32_t* hap_indices, uint32_t row_begin, uint32_t row_end, double* out)
+{
+    if (ploidy > 16) return OCT_PHMM_EUNSUPPORTED;
+    for (uint32_t gi = 0; gi < n_genotypes; ++gi) {
+        const uint32_t* g = hap_indices + (size_t)gi * ploidy;
+        const double* L[16];
+        for (uint32_t j = 0; j < ploidy; ++j) L[j] = lik + hap_out_off[g[j]];
+        double result = 0;
+        for (uint32_t r = row_begin; r < row_end; ++r) {
+            double v;
+            switch (ploidy) {
+                case 0: v = 0; break;
+                case 1: v = L[0][r]; break;                                                     /* evaluate_haploid :164-169 */
+                case 2:                                                                         /* evaluate_diploid :171-188 */
+                    v = g[0] == g[1] ? L[0][r] : lse_2(L[0][r], L[1][r]) - LN2; break;
+                case 3:                                                                         /* evaluate_triploid :190-226 */
+                    if (g[0] == g[1]) v = g[1] == g[2] ? L[0][r] : lse_2(LN2 + L[0][r], L[2][r]) - LN3;
+                    else if (g[1] == g[2]) v = lse_2(L[0][r], LN2 + L[1][r]) - LN3;
+                    else v = lse_3(L[0][r], L[1][r], L[2][r]) - LN3;
+                    break;
+                case 4:                                                                         /* evaluate_tetraploid :228-313 */
+                    if (g[0] == g[1]) {
+                        if (g[1] == g[2]) v = g[2] == g[3] ? L[0][r] : lse_2(LN3 + L[0][r], L[3][r]) - LN4;
+                        else if (g[2] == g[3]) v = lse_2(L[0][r], L[2][r]) - LN2;
+                        else v = lse_3(LN2 + L[0][r], L[2][r], L[3][r]) - LN4;
+                    } else if (g[1] == g[2]) {
+                        if (g[2] == g[3]) v = lse_2(L[0][r], LN3 + L[1][r]) - LN4;
+                        else v = lse_3(L[0][r], LN2 + L[1][r], L[3][r]) - LN4;
+                    } else if (g[2] == g[3]) {
+                        v = lse_3(L[0][r], L[1][r], LN2 + L[2][r]) - LN4;
+                    } else {
+                        const double x[4] = {L[0][r], L[1][r], L[2][r], L[3][r]};
+                        v = lse_n(x, 4) - LN4;
+                    }
+                    break;
+                default: {                                                                      /* evaluate_polyploid :315-329 */
+                    double x[16];
+                    for (uint32_t j = 0; j < ploidy; ++j) x[j] = L[j][r];
+                    v = lse_n(x, ploidy) - log((double)ploidy);
+                }
+            }
+            result += v;
+        }
+        out[gi] = result;
+    }
+    return OCT_PHMM_OK;
+}

@@ -92,6 +92,13 @@ double oracle_time_align_windows(int band, int score_bits, uint32_t n,
         const int8_t* gap_open, const int8_t* gap_extend, const char* snv_mask, const int8_t* snv_prior,
         int nuc_prior, int traceback, int reps, int n_threads, int64_t* checksum);
 
+/* ConstantMixtureGenotypeLikelihoodModel::evaluate(const Genotype<IndexedHaplotype<>>&)
+ * (core/models/genotype/constant_mixture_genotype_likelihood_model.cpp:65-330) for n_genotypes genotypes of `ploidy`
+ * sorted haplotype indices each, over rows [row_begin, row_end) of the columns lik[hap_out_off[h] + row].
+ * PARITY UNPINNED: the reference holds no test for this class and maths.hpp needs Boost to compile. */
+int oracle_genotype_likelihoods(const double* lik, const uint64_t* hap_out_off, uint32_t n_genotypes, uint32_t ploidy,
+        const uint32_t* hap_indices, uint32_t row_begin, uint32_t row_end, double* out);
+
 #ifdef __cplusplus
 }
 #endif

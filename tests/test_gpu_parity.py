@@ -142,3 +142,15 @@ def test_gpu_large_batch_properties():
     want, _, _ = oracle.populate(abi.Config.default(max_indel_error=16), synth.batch_from_regions([sub]), n_threads=4)
     assert np.max(np.abs(want - small)) <= TOL
     eng.close()
+
+
+def test_gpu_genotype_readout_all_ploidies_and_zygosities():
+    import check_readout as cr
+    cr.check_readout("gpu")
+    cr.check_readout_errors("gpu")
+
+
+def test_gpu_genotype_readout_large_region_row_splits():
+    """6,000 rows x 40 haplotypes: every genotype chunk is split over many row ranges and recombined in a fixed order."""
+    import check_readout as cr
+    cr.check_readout("gpu", seed=11, big=True)
