@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
 #include <memory>
+#include <unordered_map>
 #include <new>
 #include <vector>
 
@@ -19,8 +21,51 @@ using namespace octphmm;
 // ---------------------------------------------------------------------------------------------------------------
 // handle / batch objects
 // ---------------------------------------------------------------------------------------------------------------
+// Size-class cache of device allocations, one per handle: a populate call per active region makes dozens of small allocations, and
+// hipMalloc / hipFree take a process-wide lock and synchronise the device, which serialises the caller's region threads. Blocks are
+// returned here instead and handed out again; everything goes back to the runtime when the handle is destroyed (or past the cap).
+struct DevPool {
+    std::multimap<size_t, void*> free_blocks;
+    std::unordered_map<void*, size_t> live;
+    size_t cached = 0;
+    static constexpr size_t kCacheCap = (size_t)16 << 30;
+    static size_t size_class(size_t n)
+    {
+        if (n < 512) return 512;
+        if (n <= ((size_t)1 << 20)) { size_t c = 512; while (c < n) c <<= 1; return c; }
+        return (n + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    }
+    bool alloc(void** p, size_t n)
+    {
+        const size_t c = size_class(n);
+        auto it = free_blocks.find(c);
+        if (it != free_blocks.end()) { *p = it->second; free_blocks.erase(it); cached -= c; live[*p] = c; return true; }
+        if (!rt::dev_malloc(p, c)) {
+            trim();                                     // give cached blocks back and retry once
+            if (!rt::dev_malloc(p, c)) return false;
+        }
+        live[*p] = c;
+        return true;
+    }
+    void release(void* p)
+    {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) { rt::dev_free(p); return; }
+        const size_t c = it->second; live.erase(it);
+        if (cached + c > kCacheCap) { rt::dev_free(p); return; }
+        free_blocks.emplace(c, p); cached += c;
+    }
+    void trim() { for (auto& kv : free_blocks) rt::dev_free(kv.second); free_blocks.clear(); cached = 0; }
+};
+
 struct oct_phmm_handle {
     oct_phmm_config cfg;
+    DevPool pool;
+    void* stage = nullptr; size_t stage_bytes = 0;       // pinned host staging: all input arrays of a batch go up in ONE copy
+    std::vector<rt::Event> ev_pool;                      // recycled timing / completion events
+    bool get_event(rt::Event* e) { if (!ev_pool.empty()) { *e = ev_pool.back(); ev_pool.pop_back(); return true; } return rt::event_create(e); }
+    void put_event(rt::Event e) { ev_pool.push_back(e); }
     int band = 0;
     bool wide = false;                                   // int32 lanes (Config::use_int_scores)
     int  lanes_c = 1;                                    // band diagonals per lane on the streaming path (band / 64) for bands 128, 256
@@ -41,7 +86,7 @@ struct oct_phmm_batch {
     // host-side shape + small copies needed for error reporting
     uint32_t n_reads = 0, n_haps = 0, n_rows = 0, n_regions = 0, t_cap = 0, lh_cap = 0, n_hap_bases = 0;
     uint64_t n_pairs = 0, n_out = 0;
-    std::vector<uint32_t> h_roff, h_hoff, h_blk_hap; std::vector<int64_t> h_rbegin, h_hbegin;
+    std::vector<uint32_t> h_roff, h_hoff, h_blk_hap, h_blk_read0; std::vector<int64_t> h_rbegin, h_hbegin;
     std::vector<uint32_t> h_hap_region, h_reg_hap0; std::vector<uint64_t> h_hap_out_off;      // for the genotype read-out
     // run state
     struct Slice {                     // whole haplotypes [hap0, hap1) = pairs [pair0, pair1) = outputs [out0, out1)
@@ -51,7 +96,7 @@ struct oct_phmm_batch {
         rt::Event done {};
     };
     std::vector<Slice> slices;
-    uint4* d_hap_base = nullptr;
+    uint4* d_hap_base = nullptr; uint4* d_totals = nullptr;
     double* d_out = nullptr;
     uint32_t n_tasks[kNumKinds] = {0, 0, 0, 0};
     unsigned long long h_stats[6] = {0, 0, 0, 0, 0, 0};
@@ -91,24 +136,49 @@ int band_for(int max_indel_error)   // simd_pair_hmm_wrapper.hpp:219-241
 
 #define RT(expr) do { if (!(expr)) return fail(status, OCT_PHMM_EHIP, #expr); } while (0)
 
-template <class T>
-bool upload(oct_phmm_batch* b, rt::Stream s, const T* host, size_t n, const T** dev, size_t pad = 16)
+// All device memory of a batch is ONE pool block: `upload` / `dalloc` only record what is needed, `commit` allocates, fills in the
+// pointers and sends every input array up in a single copy out of the handle's pinned staging buffer (each array keeps a zeroed
+// 16-byte tail pad, as the kernels' vector loads expect).
+struct Packer {
+    struct Item { const void* src; size_t bytes; size_t off; void** dst; };
+    std::vector<Item> items;
+    size_t in_bytes = 0, total = 0;
+    static size_t aligned(size_t n) { return (n + 16 + 255) & ~(size_t)255; }
+    template <class T> void upload(const T* host, size_t n, const T** dev) { items.push_back({host, n * sizeof(T), 0, (void**)dev}); }
+    template <class T> void dalloc(T** dev, size_t n) { items.push_back({nullptr, n * sizeof(T), 0, (void**)dev}); }
+    bool commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s);
+};
+constexpr size_t kStageMax = (size_t)64 << 20;
+
+bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
 {
-    void* p = nullptr;
-    if (!rt::dev_malloc(&p, n * sizeof(T) + pad)) return false;
-    b->allocs.push_back(p);
-    if (!rt::dev_memset((char*)p + n * sizeof(T), 0, pad, s)) return false;
-    if (!rt::h2d(p, host, n * sizeof(T), s)) return false;
-    *dev = (const T*)p;
-    return true;
-}
-template <class T>
-bool dalloc(oct_phmm_batch* b, T** dev, size_t n)
-{
-    void* p = nullptr;
-    if (!rt::dev_malloc(&p, n * sizeof(T) + 16)) return false;
-    b->allocs.push_back(p);
-    *dev = (T*)p;
+    std::stable_partition(items.begin(), items.end(), [](const Item& it) { return it.src != nullptr; });   // inputs first, contiguous
+    total = 0;
+    for (auto& it : items) { it.off = total; total += aligned(it.bytes); if (it.src) in_bytes = total; }
+    void* base = nullptr;
+    if (!h->pool.alloc(&base, total)) return false;
+    b->allocs.push_back(base);
+    for (auto& it : items) *it.dst = (char*)base + it.off;
+    if (!in_bytes) return true;
+    if (in_bytes <= kStageMax) {
+        if (h->stage_bytes < in_bytes) {
+            rt::host_pinned_free(h->stage); h->stage = nullptr; h->stage_bytes = 0;
+            size_t want = (size_t)1 << 20; while (want < in_bytes) want <<= 1;
+            if (!rt::host_pinned_malloc(&h->stage, want)) return false;
+            h->stage_bytes = want;
+        }
+        for (auto& it : items) {
+            if (!it.src) break;
+            if (it.bytes) memcpy((char*)h->stage + it.off, it.src, it.bytes);
+            memset((char*)h->stage + it.off + it.bytes, 0, aligned(it.bytes) - it.bytes);
+        }
+        return rt::h2d(base, h->stage, in_bytes, s);
+    }
+    for (auto& it : items) {                               // big batch: straight from the caller's arrays
+        if (!it.src) break;
+        if (!rt::dev_memset((char*)base + it.off + it.bytes, 0, 16, s)) return false;
+        if (!rt::h2d((char*)base + it.off, it.src, it.bytes, s)) return false;
+    }
     return true;
 }
 
@@ -223,8 +293,10 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     p.k_cap = bp_tiles(b->t_cap, (uint32_t)B); p.t_cap = b->t_cap; p.lh_cap = b->lh_cap;
     const uint32_t n4 = ((uint32_t)(int8_t)nuc_prior << 2) & 0xffffu;       // vectorise_left_shift_bits(int8_t), simd_pair_hmm.hpp:74-78,257
     p.nuc4 = n4 | n4 << 16;
-    p.groups_per_block = kBlockWaves * kGroupsPerWave;
     const uint32_t n_groups = n_tasks / G;
+    // workgroups walk kGroupsPerWave groups per wave to amortise the haplotype-table staging; a small launch (one active region) instead
+    // spreads over the chip: one group per wave until there are enough workgroups for every CU
+    p.groups_per_block = kBlockWaves * std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerWave, n_groups / (kBlockWaves * 2048)));
     uint32_t chunk_groups = n_groups;
     if (tr) {
         const size_t per_group = (size_t)p.k_cap * 4096 * (b->stream ? C : 1);
@@ -239,7 +311,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         p.bp = h->bp[slice]; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
         const uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
         rt::Event e0, e1;
-        RT(rt::event_create(&e0)); RT(rt::event_create(&e1));
+        RT(h->get_event(&e0)); RT(h->get_event(&e1));
         RT(rt::event_record(e0, st));
         if (!(b->stream ? launch_dp_wide((int)C, tr, !h->wide, p, st)
                         : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
@@ -325,6 +397,10 @@ extern "C" void oct_phmm_destroy(oct_phmm_handle* h)
     rt::set_device(h->cfg.device_id);
     for (int i = 0; i < oct_phmm_handle::kMaxSlices; ++i) { rt::stream_sync(h->slice_stream(i)); rt::dev_free(h->bp[i]); }
     for (int i = 1; i < oct_phmm_handle::kMaxSlices; ++i) rt::stream_destroy(h->slice_stream(i));
+    for (auto& kv : h->pool.live) rt::dev_free(kv.first);
+    h->pool.live.clear(); h->pool.trim();
+    rt::host_pinned_free(h->stage);
+    for (rt::Event e : h->ev_pool) rt::event_destroy(e);
     rt::event_destroy(h->ev_ready);
     rt::stream_destroy(h->stream);
     delete h;
@@ -339,9 +415,10 @@ extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
 {
     if (!b) return;
     if (h) { rt::set_device(h->cfg.device_id); for (int i = 0; i < oct_phmm_handle::kMaxSlices; ++i) rt::stream_sync(h->slice_stream(i)); }
-    for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
-    for (void* p : b->allocs) rt::dev_free(p);
-    for (auto& sl : b->slices) { rt::dev_free(sl.d_tasks); rt::dev_free(sl.d_ends); rt::event_destroy(sl.done); }
+    if (!h) h = b->owner;
+    for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
+    for (void* p : b->allocs) h->pool.release(p);
+    for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_ends); h->put_event(sl.done); }
     delete b;
 }
 
@@ -388,10 +465,11 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
         reg_row0[g] = g_row[g]; reg_read0[g] = first_read(g_row[g]);
         const uint32_t rows = g_row[g + 1] - g_row[g], nreads = first_read(g_row[g + 1]) - first_read(g_row[g]);
         if (h->cfg.use_flank_state && g_hf && g_hf[g]) { reg_lhs[g] = g_fl[g].lhs_flank; reg_rhs[g] = g_fl[g].rhs_flank; }   // model.cpp:276-282
+        int64_t first_begin = INT64_MAX;
+        for (uint32_t r = reg_read0[g]; r < reg_read0[g] + nreads; ++r) first_begin = std::min(first_begin, R->ref_begin[r]);
         for (uint32_t hp = g_hap[g]; hp < g_hap[g + 1]; ++hp) {
             hap_region[hp] = g; hap_out_off[hp + 1] = hap_out_off[hp] + rows; hap_pair_off[hp + 1] = hap_pair_off[hp] + nreads;
-            for (uint32_t r = reg_read0[g]; r < reg_read0[g] + nreads; ++r)
-                if (R->ref_begin[r] < H->ref_begin[hp]) return fail(status, OCT_PHMM_EINVAL, "read begins before its haplotype (contains() violated)");
+            if (first_begin < H->ref_begin[hp]) return fail(status, OCT_PHMM_EINVAL, "read begins before its haplotype (contains() violated)");
         }
     }
     reg_row0[G] = g_row[G]; reg_read0[G] = first_read(g_row[G]);
@@ -451,38 +529,36 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions; d.wide = (h->wide || b->stream) ? 1 : 0;
     d.use_mapq = h->cfg.use_mapping_quality; d.mapq_cap = h->cfg.mapping_quality_cap; d.mapq_trigger = h->cfg.mapping_quality_cap_trigger;
     oct_phmm_batch* bp = b.get();
-    RT(upload(bp, s, (const uint8_t*)R->bases, n_read_bases, &d.rbases));
-    RT(upload(bp, s, R->qualities, n_read_bases, &d.rquals));
-    RT(upload(bp, s, R->offsets, (size_t)R->n_reads + 1, &d.roff));
-    RT(upload(bp, s, R->mapping_quality, R->n_reads, &d.rmapq));
-    RT(upload(bp, s, R->reverse_strand, R->n_reads, &d.rrev));
-    RT(upload(bp, s, R->ref_begin, R->n_reads, &d.rbegin));
+    Packer pk;
+    pk.upload((const uint8_t*)R->bases, n_read_bases, &d.rbases);
+    pk.upload(R->qualities, n_read_bases, &d.rquals);
+    pk.upload(R->offsets, (size_t)R->n_reads + 1, &d.roff);
+    pk.upload(R->mapping_quality, R->n_reads, &d.rmapq);
+    pk.upload(R->reverse_strand, R->n_reads, &d.rrev);
+    pk.upload(R->ref_begin, R->n_reads, &d.rbegin);
     d.row_off = nullptr;
-    if (R->row_offsets) RT(upload(bp, s, R->row_offsets, (size_t)n_rows + 1, &d.row_off));
-    RT(upload(bp, s, (const uint8_t*)H->bases, n_hap_bases, &d.hbases));
-    RT(upload(bp, s, H->offsets, (size_t)H->n_haps + 1, &d.hoff));
-    RT(upload(bp, s, H->ref_begin, H->n_haps, &d.hbegin));
-    RT(upload(bp, s, H->gap_open, n_hap_bases, &d.go));
-    RT(upload(bp, s, H->gap_extend, n_hap_bases, &d.ge));
-    RT(upload(bp, s, (const uint8_t*)H->snv_mask_fwd, n_hap_bases, &d.maskF));
-    RT(upload(bp, s, H->snv_prior_fwd, n_hap_bases, &d.priorF));
-    RT(upload(bp, s, (const uint8_t*)H->snv_mask_rev, n_hap_bases, &d.maskR));
-    RT(upload(bp, s, H->snv_prior_rev, n_hap_bases, &d.priorR));
-    RT(upload(bp, s, hap_region.data(), hap_region.size(), &d.hap_region));
-    RT(upload(bp, s, hap_out_off.data(), hap_out_off.size(), &d.hap_out_off));
-    RT(upload(bp, s, hap_pair_off.data(), hap_pair_off.size(), &d.hap_pair_off));
-    RT(upload(bp, s, reg_row0.data(), reg_row0.size(), &d.reg_row0));
-    RT(upload(bp, s, reg_read0.data(), reg_read0.size(), &d.reg_read0));
-    RT(upload(bp, s, reg_lhs.data(), reg_lhs.size(), &d.reg_lhs));
-    RT(upload(bp, s, reg_rhs.data(), reg_rhs.size(), &d.reg_rhs));
-    RT(dalloc(bp, &d.pos, (size_t)b->n_pairs * S + 1)); RT(dalloc(bp, &d.npos, (size_t)b->n_pairs + 1));
+    if (R->row_offsets) pk.upload(R->row_offsets, (size_t)n_rows + 1, &d.row_off);
+    pk.upload((const uint8_t*)H->bases, n_hap_bases, &d.hbases);
+    pk.upload(H->offsets, (size_t)H->n_haps + 1, &d.hoff);
+    pk.upload(H->ref_begin, H->n_haps, &d.hbegin);
+    pk.upload(H->gap_open, n_hap_bases, &d.go);
+    pk.upload(H->gap_extend, n_hap_bases, &d.ge);
+    pk.upload((const uint8_t*)H->snv_mask_fwd, n_hap_bases, &d.maskF);
+    pk.upload(H->snv_prior_fwd, n_hap_bases, &d.priorF);
+    pk.upload((const uint8_t*)H->snv_mask_rev, n_hap_bases, &d.maskR);
+    pk.upload(H->snv_prior_rev, n_hap_bases, &d.priorR);
+    pk.upload(hap_region.data(), hap_region.size(), &d.hap_region);
+    pk.upload(hap_out_off.data(), hap_out_off.size(), &d.hap_out_off);
+    pk.upload(hap_pair_off.data(), hap_pair_off.size(), &d.hap_pair_off);
+    pk.upload(reg_row0.data(), reg_row0.size(), &d.reg_row0);
+    pk.upload(reg_read0.data(), reg_read0.size(), &d.reg_read0);
+    pk.upload(reg_lhs.data(), reg_lhs.size(), &d.reg_lhs);
+    pk.upload(reg_rhs.data(), reg_rhs.size(), &d.reg_rhs);
+    pk.dalloc(&d.pos, (size_t)b->n_pairs * S + 1); pk.dalloc(&d.npos, (size_t)b->n_pairs + 1);
     d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr;
-    if (positions) {
-        RT(rt::h2d(d.pos, h_pos.data(), (size_t)b->n_pairs * S * sizeof(uint32_t), s));
-        RT(rt::h2d(d.npos, h_npos.data(), (size_t)b->n_pairs, s));
-    } else {
-        RT(dalloc(bp, &d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1)); RT(dalloc(bp, &d.bin_idx, (size_t)n_hap_bases + 1));
-        RT(dalloc(bp, &d.rhash, (size_t)n_read_bases + 1));
+    if (!positions) {
+        pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1); pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
+        pk.dalloc(&d.rhash, (size_t)n_read_bases + 1);
         std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, 64-read chunk of its region)
         for (uint32_t hp = 0; hp < H->n_haps; ++hp) {
             const uint32_t g = hap_region[hp];
@@ -490,26 +566,26 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
         }
         b->n_map_blocks = (uint32_t)blk_hap.size();
         b->h_blk_hap = blk_hap;
-        const uint32_t* dh = nullptr; const uint32_t* dr = nullptr;
-        RT(upload(bp, s, blk_hap.data(), blk_hap.size(), &dh)); RT(upload(bp, s, blk_read0.data(), blk_read0.size(), &dr));
-        b->d_blk_hap = const_cast<uint32_t*>(dh); b->d_blk_read0 = const_cast<uint32_t*>(dr);
+        b->h_blk_read0 = blk_read0;
+        pk.upload(b->h_blk_hap.data(), b->h_blk_hap.size(), (const uint32_t**)&b->d_blk_hap);
+        pk.upload(b->h_blk_read0.data(), b->h_blk_read0.size(), (const uint32_t**)&b->d_blk_read0);
     }
-    RT(dalloc(bp, &d.racgt, (size_t)R->n_reads));
-    RT(dalloc(bp, &d.tabFastF, (size_t)n_hap_bases)); RT(dalloc(bp, &d.tabFastR, (size_t)n_hap_bases));
-    RT(dalloc(bp, &d.tabGenF, (size_t)n_hap_bases));  RT(dalloc(bp, &d.tabGenR, (size_t)n_hap_bases));
-    RT(dalloc(bp, &d.hclean, (size_t)H->n_haps));
-    RT(dalloc(bp, &d.pair_best, (size_t)b->n_pairs)); RT(dalloc(bp, &d.pair_cls, (size_t)b->n_pairs));
-    RT(dalloc(bp, &d.pair_extra, (size_t)b->n_pairs)); RT(dalloc(bp, &d.pair_cnt, (size_t)b->n_pairs + oct_phmm_handle::kMaxSlices + 1));
-    RT(dalloc(bp, &d.stats, (size_t)kStatSlots * 8 + 8)); d.err_key = d.stats + (size_t)kStatSlots * 8;
-    RT(dalloc(bp, &b->d_hap_base, (size_t)H->n_haps + 1));
+    pk.dalloc(&d.racgt, (size_t)R->n_reads);
+    pk.dalloc(&d.tabFastF, (size_t)n_hap_bases); pk.dalloc(&d.tabFastR, (size_t)n_hap_bases);
+    pk.dalloc(&d.tabGenF, (size_t)n_hap_bases);  pk.dalloc(&d.tabGenR, (size_t)n_hap_bases);
+    pk.dalloc(&d.pair_best, (size_t)b->n_pairs); pk.dalloc(&d.pair_cls, (size_t)b->n_pairs);
+    pk.dalloc(&d.pair_extra, (size_t)b->n_pairs); pk.dalloc(&d.pair_cnt, (size_t)b->n_pairs + oct_phmm_handle::kMaxSlices + 1);
+    pk.dalloc(&d.stats, (size_t)kStatSlots * 8 + 8);
+    pk.dalloc(&b->d_hap_base, (size_t)H->n_haps + 1);
     {
         // Slices of whole haplotypes, each on its own stream: while slice i is in its VALU-bound DP kernels, slice i+1 runs its
         // latency-bound mapper/classifier and slice i-1 its latency-bound walk. Small batches stay in one slice.
         int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / 1000000));
         if (const char* e = getenv("OCT_PHMM_SLICES")) n_slices = std::max(1, std::min(oct_phmm_handle::kMaxSlices, atoi(e)));
         n_slices = (int)std::min<uint32_t>((uint32_t)n_slices, std::max<uint32_t>(1, H->n_haps));
-        uint4* totals = nullptr; RT(dalloc(bp, &totals, (size_t)n_slices));
-        uint32_t hap = 0, blk = 0;
+        pk.dalloc(&b->d_totals, (size_t)n_slices);
+        b->slices.reserve((size_t)n_slices);                   // the packer keeps addresses of the slices' pointers
+        uint32_t hap = 0;
         for (int i = 0; i < n_slices; ++i) {
             oct_phmm_batch::Slice sl;
             sl.hap0 = hap;
@@ -518,21 +594,28 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
             if (i == n_slices - 1) hap = H->n_haps;
             sl.hap1 = hap;
             sl.pair0 = hap_pair_off[sl.hap0]; sl.pair1 = hap_pair_off[sl.hap1]; sl.out0 = hap_out_off[sl.hap0]; sl.out1 = hap_out_off[sl.hap1];
-            sl.cnt = d.pair_cnt + sl.pair0 + i;                      // each slice owns pair1 - pair0 + 1 scan entries
             sl.n_tiles = (uint32_t)((sl.pair1 - sl.pair0 + 1 + kScanTile - 1) / kScanTile);
-            RT(dalloc(bp, &sl.tile_sums, (size_t)sl.n_tiles + 1));
-            sl.d_totals = totals + i;
-            RT(rt::event_create(&sl.done));
+            RT(h->get_event(&sl.done));
             sl.blk0 = (uint32_t)(std::lower_bound(b->h_blk_hap.begin(), b->h_blk_hap.end(), sl.hap0) - b->h_blk_hap.begin());
             sl.blk1 = (uint32_t)(std::lower_bound(b->h_blk_hap.begin(), b->h_blk_hap.end(), sl.hap1) - b->h_blk_hap.begin());
             b->slices.push_back(sl);
+            pk.dalloc(&b->slices.back().tile_sums, (size_t)sl.n_tiles + 1);
         }
-        (void)blk;
     }
-    RT(dalloc(bp, &b->d_out, (size_t)b->n_out));
-    // per-read flags and per-base DP tables (once per batch; HaplotypeLikelihoodModel::reset analogue)
+    pk.dalloc(&b->d_out, (size_t)b->n_out);
     std::vector<uint32_t> ones(H->n_haps + 1, 1u);
-    RT(rt::h2d(d.hclean, ones.data(), (size_t)H->n_haps * sizeof(uint32_t), s));
+    pk.upload(ones.data(), (size_t)H->n_haps, (const uint32_t**)&d.hclean);
+    RT(pk.commit(h, bp, s));
+    d.err_key = d.stats + (size_t)kStatSlots * 8;
+    for (size_t i = 0; i < b->slices.size(); ++i) {
+        b->slices[i].cnt = d.pair_cnt + b->slices[i].pair0 + i;      // each slice owns pair1 - pair0 + 1 scan entries
+        b->slices[i].d_totals = b->d_totals + i;
+    }
+    if (positions) {
+        RT(rt::h2d(d.pos, h_pos.data(), (size_t)b->n_pairs * S * sizeof(uint32_t), s));
+        RT(rt::h2d(d.npos, h_npos.data(), (size_t)b->n_pairs, s));
+    }
+    // per-read flags and per-base DP tables (once per batch; HaplotypeLikelihoodModel::reset analogue)
     if (R->n_reads) { OCT_LAUNCH(k_read_flags, (R->n_reads + 255) / 256, 256, 0, s, d); RT(rt::launch_ok()); }
     if (n_hap_bases) { OCT_LAUNCH(k_hap_tables, (n_hap_bases + 255) / 256, 256, 0, s, d, n_hap_bases); RT(rt::launch_ok()); }
     RT(rt::stream_sync(s));
@@ -549,7 +632,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     RT(rt::set_device(h->cfg.device_id));
     rt::Stream s0 = h->stream;
     DevBatch& d = b->d;
-    for (auto& t : b->timers) { rt::event_destroy(t.first); rt::event_destroy(t.second); }
+    for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
     b->timers.clear(); b->timer_kind.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
     const uint32_t G = b->stream ? 1u : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
     const int S = (int)b->slices.size();
@@ -603,13 +686,13 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         b->n_tasks[0] += totals.x; b->n_tasks[1] += totals.y; b->n_tasks[2] += totals.z; b->n_tasks[3] += totals.w;
         const size_t total = (size_t)totals.x + totals.y + totals.z + totals.w;
         if (total > sl.tasks_cap) {
-            rt::dev_free(sl.d_tasks); sl.d_tasks = nullptr; sl.tasks_cap = 0;
-            void* p = nullptr; RT(rt::dev_malloc(&p, (total + total / 8) * sizeof(DevTask))); sl.d_tasks = (DevTask*)p; sl.tasks_cap = total + total / 8;
+            h->pool.release(sl.d_tasks); sl.d_tasks = nullptr; sl.tasks_cap = 0;
+            void* p = nullptr; RT(h->pool.alloc(&p, (total + total / 8) * sizeof(DevTask))); sl.d_tasks = (DevTask*)p; sl.tasks_cap = total + total / 8;
         }
         const size_t n_trace = (size_t)std::max(totals.y, totals.w);
         if (n_trace > sl.ends_cap) {
-            rt::dev_free(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
-            void* p = nullptr; RT(rt::dev_malloc(&p, (n_trace + n_trace / 8) * sizeof(TraceEnd))); sl.d_ends = (TraceEnd*)p; sl.ends_cap = n_trace + n_trace / 8;
+            h->pool.release(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
+            void* p = nullptr; RT(h->pool.alloc(&p, (n_trace + n_trace / 8) * sizeof(TraceEnd))); sl.d_ends = (TraceEnd*)p; sl.ends_cap = n_trace + n_trace / 8;
         }
         if (total) {
             TaskArrays ta;
@@ -772,9 +855,9 @@ extern "C" int oct_phmm_batch_genotype_likelihoods(oct_phmm_handle* h, oct_phmm_
 
     RT(rt::set_device(h->cfg.device_id));
     rt::Stream st = h->stream;
-    struct Tmp { std::vector<void*> v; ~Tmp() { for (void* p : v) rt::dev_free(p); } } tmp;
+    struct Tmp { oct_phmm_handle* h; std::vector<void*> v; ~Tmp() { for (void* p : v) h->pool.release(p); } } tmp {h, {}};
     auto put = [&](const void* host, size_t bytes, void** dev) {
-        if (!rt::dev_malloc(dev, bytes)) return false;
+        if (!h->pool.alloc(dev, bytes)) return false;
         tmp.v.push_back(*dev);
         return host ? rt::h2d(*dev, host, bytes, st) : true;
     };
@@ -855,7 +938,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
     oct_phmm_batch* b = nullptr;
     int rc = oct_phmm_batch_upload(h, &R, &H, &RG, nullptr, &P, &b, status);
     if (rc != OCT_PHMM_OK) return rc;
-    struct Guard { oct_phmm_handle* h; oct_phmm_batch* b; std::vector<void*> extra; ~Guard() { rt::stream_sync(h->stream); for (void* p : extra) rt::dev_free(p); oct_phmm_batch_free(h, b); } } guard {h, b, {}};
+    struct Guard { oct_phmm_handle* h; oct_phmm_batch* b; std::vector<void*> extra; ~Guard() { rt::stream_sync(h->stream); for (void* p : extra) h->pool.release(p); oct_phmm_batch_free(h, b); } } guard {h, b, {}};
     rt::Stream s = h->stream;
     const uint32_t G = b->stream ? 1u : (h->wide ? 1u : 2u) * (64 / B);
     // route each window to the fast or generic kernel exactly as k_classify would
@@ -875,9 +958,9 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
         std::vector<DevTask>& t = tasks[gen];
         if (t.empty()) continue;
         const uint32_t nt = (uint32_t)t.size(), real = nt / G;
-        void* d_tasks = nullptr; RT(rt::dev_malloc(&d_tasks, nt * sizeof(DevTask))); guard.extra.push_back(d_tasks);
+        void* d_tasks = nullptr; RT(h->pool.alloc(&d_tasks, nt * sizeof(DevTask))); guard.extra.push_back(d_tasks);
         RT(rt::h2d(d_tasks, t.data(), nt * sizeof(DevTask), s));
-        void* d_ends = nullptr; RT(rt::dev_malloc(&d_ends, nt * sizeof(TraceEnd))); guard.extra.push_back(d_ends);
+        void* d_ends = nullptr; RT(h->pool.alloc(&d_ends, nt * sizeof(TraceEnd))); guard.extra.push_back(d_ends);
         WalkParams w {}; std::vector<uint32_t> aoff(nt + 1, 0); std::vector<int32_t> l(nt, 0), r(nt, 0);
         void *d_fp = nullptr, *d_a1 = nullptr, *d_a2 = nullptr, *d_aoff = nullptr, *d_l = nullptr, *d_r = nullptr, *d_fl = nullptr, *d_ms = nullptr;
         size_t aln_bytes = 0;
@@ -888,15 +971,15 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
                 if (lhs_flank) { l[j] = lhs_flank[i]; r[j] = rhs_flank[i]; }
             }
             aln_bytes = aoff[nt];
-            RT(rt::dev_malloc(&d_fp, nt * sizeof(int32_t))); guard.extra.push_back(d_fp);
-            RT(rt::dev_malloc(&d_a1, aln_bytes)); guard.extra.push_back(d_a1); RT(rt::dev_malloc(&d_a2, aln_bytes)); guard.extra.push_back(d_a2);
+            RT(h->pool.alloc(&d_fp, nt * sizeof(int32_t))); guard.extra.push_back(d_fp);
+            RT(h->pool.alloc(&d_a1, aln_bytes)); guard.extra.push_back(d_a1); RT(h->pool.alloc(&d_a2, aln_bytes)); guard.extra.push_back(d_a2);
             RT(rt::dev_memset(d_a1, 0, aln_bytes, s)); RT(rt::dev_memset(d_a2, 0, aln_bytes, s));
-            RT(rt::dev_malloc(&d_aoff, (nt + 1) * sizeof(uint32_t))); guard.extra.push_back(d_aoff);
+            RT(h->pool.alloc(&d_aoff, (nt + 1) * sizeof(uint32_t))); guard.extra.push_back(d_aoff);
             RT(rt::h2d(d_aoff, aoff.data(), (nt + 1) * sizeof(uint32_t), s));
             w.out_first_pos = (int32_t*)d_fp; w.out_align1 = (char*)d_a1; w.out_align2 = (char*)d_a2; w.out_align_off = (const uint32_t*)d_aoff;
             if (lhs_flank) {
-                RT(rt::dev_malloc(&d_l, nt * 4)); guard.extra.push_back(d_l); RT(rt::dev_malloc(&d_r, nt * 4)); guard.extra.push_back(d_r);
-                RT(rt::dev_malloc(&d_fl, nt * 4)); guard.extra.push_back(d_fl); RT(rt::dev_malloc(&d_ms, nt * 4)); guard.extra.push_back(d_ms);
+                RT(h->pool.alloc(&d_l, nt * 4)); guard.extra.push_back(d_l); RT(h->pool.alloc(&d_r, nt * 4)); guard.extra.push_back(d_r);
+                RT(h->pool.alloc(&d_fl, nt * 4)); guard.extra.push_back(d_fl); RT(h->pool.alloc(&d_ms, nt * 4)); guard.extra.push_back(d_ms);
                 RT(rt::h2d(d_l, l.data(), nt * 4, s)); RT(rt::h2d(d_r, r.data(), nt * 4, s));
                 w.seam_lhs = (const int32_t*)d_l; w.seam_rhs = (const int32_t*)d_r; w.out_flank = (int32_t*)d_fl; w.out_mask_size = (int32_t*)d_ms;
             }

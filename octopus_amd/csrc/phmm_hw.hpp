@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #define OCT_DEVICE __device__ __forceinline__
+#define OCT_DEVICE_NOINLINE __device__ __noinline__
 #define OCT_HD __host__ __device__ __forceinline__
 #define OCT_KERNEL(name) __global__ void name
 #define OCT_DYN_SMEM(ptr) extern __shared__ __attribute__((aligned(16))) unsigned char ptr[]

@@ -1138,6 +1138,27 @@ OCT_KERNEL(k_walk_strings)(WalkParams w)   // test seam only: emits the gapped s
     hw::atomic_min_i32(w.pair_best + t.pair, pen);
 }
 
+// Penalty of one in-flank alignment column (calculate_flank_score_helper, simd_pair_hmm.hpp:383-424). Deliberately NOT inlined: the
+// unrolled sweep of k_walk has 32 call sites on its rare event-buffer-overflow path and must stay inside the instruction cache.
+struct WalkPricing {
+    const uint8_t* rbases; const int8_t* rquals; const uint8_t* hbases; const uint8_t* mask; const int8_t* prior;
+    const int8_t* go; const int8_t* ge;       // rbases/rquals at the read's first base, the haplotype arrays at the window's first base
+};
+OCT_DEVICE_NOINLINE int32_t walk_price_event(WalkPricing p, uint32_t e)
+{
+    const uint32_t kind = e >> 30, ex = e & 0x7fffu, ey = (e >> 15) & 0x7fffu;
+    if (kind == 0) {
+        const uint32_t hc = p.hbases[ex], rc = p.rbases[ey];
+        if (hc == rc) return 0;
+        if (hc == 'N') return 2;
+        int32_t q = p.rquals[ey];
+        const int32_t pr = p.prior[ex];
+        if (p.mask[ex] == rc && pr < q) q = pr;
+        return q;
+    }
+    return (kind == 1 ? p.go : p.ge)[ex];
+}
+
 // Production walk: one thread per traceback task, all 64 tasks of a wave sweep the band iterations k from the top tile down IN
 // LOCKSTEP. Per 16-iteration tile every lane holds its own 64-byte backpointer line in registers (statically indexed in the
 // unrolled sweep), so a tile costs one batch of line loads for the whole wave instead of a memory round trip per step. In-flank
@@ -1181,50 +1202,47 @@ OCT_KERNEL(k_walk)(WalkParams w)
     // walker state (set_alignments :180-193)
     int32_t sidx = end.sidx, i = sidx / 2 - T, y = T, x = sidx - T;
     int32_t flank = 0, msz = 0; uint32_t nev = 0, state = 0;
-    bool ok = active && sidx >= 0, fin = !ok, started = false;
-    if (ok) { const int64_t f0 = (int64_t)sidx * B + i; if (f0 < 0 || f0 >= n_flat) { ok = false; fin = true; } }   // :186-190
+    // walker flags in ONE register word (separate bools ended up in scratch memory: the compiler merged their stores through a pointer select)
+    constexpr uint32_t kOk = 1u, kFin = 2u, kStarted = 4u;
+    uint32_t fl = (active && sidx >= 0) ? kOk : kFin;
+    if (fl & kOk) { const int64_t f0 = (int64_t)sidx * B + i; if (f0 < 0 || f0 >= n_flat) fl = kFin; }   // :186-190
 
-    auto price_event = [&](uint32_t e) {                                  // calculate_flank_score_helper :383-424, for one alignment column
-        const uint32_t kind = e >> 30; const int32_t ex = (int32_t)(e & 0x7fffu), ey = (int32_t)((e >> 15) & 0x7fffu);
-        const uint32_t hb = ho + (uint32_t)off + (uint32_t)ex;
-        if (kind == 0) {
-            const bool fwd = !w.rrev[t.read];
-            const uint32_t hc = w.hbases[hb], rc = w.rbases[ro + ey];
-            if (hc != rc) {
-                if (hc != 'N') {
-                    int32_t q = ((const int8_t*)w.rquals)[ro + ey];
-                    const uint32_t m = (fwd ? w.maskF : w.maskR)[hb]; const int32_t pr = (fwd ? w.priorF : w.priorR)[hb];
-                    if (m == rc && pr < q) q = pr;
-                    flank += q;
-                } else flank += 2;
-            }
-        } else flank += (kind == 1 ? w.go : w.ge)[hb];
-    };
+    WalkPricing pricing;
+    {
+        const bool fwd = !w.rrev[t.read];
+        const size_t hb0 = (size_t)ho + (uint32_t)off;
+        pricing.rbases = w.rbases + ro; pricing.rquals = (const int8_t*)w.rquals + ro; pricing.hbases = w.hbases + hb0;
+        pricing.mask = (fwd ? w.maskF : w.maskR) + hb0; pricing.prior = (fwd ? w.priorF : w.priorR) + hb0;
+        pricing.go = w.go + hb0; pricing.ge = w.ge + hb0;
+    }
+    auto price_event = [&](uint32_t e) { flank += walk_price_event(pricing, e); };
     auto push_event = [&](uint32_t kind, int32_t ex, int32_t ey) {
         const uint32_t e = kind << 30 | (uint32_t)ey << 15 | (uint32_t)ex;
         if (nev < kWalkEvents) evbuf[nev++] = e; else price_event(e);
     };
-    // one alignment column from backpointer word `wv` of cell (sidx, i)
+    // one alignment column from backpointer word `wv` of cell (sidx, i). Written with selects instead of a three-way branch (the
+    // unrolled sweep below instantiates it 32 times per tile; the branchy form overflowed the instruction cache); only the rare
+    // in-flank event push is a branch.
     auto step = [&](uint32_t wv) {
         const uint32_t par = (uint32_t)sidx & 1u;
         const uint32_t bits = (wv >> (hshift + 6 * par)) & 63u, mism = (wv >> (hshift + 15 - par)) & 1u;
-        if (!started) { state = bits & 3u; sidx -= 2; started = true; return; }                 // :191-192
+        if (!(fl & kStarted)) { state = bits & 3u; sidx -= 2; fl |= kStarted; return; }          // :191-192
         const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;                 // :200
-        if (state == 0) {                                                                       // match :201-204, :383-397
-            sidx -= 2; --x; --y;
-            if (want_flank && (x < lhs || x >= rhs_begin)) { ++msz; if (mism) push_event(0, x, y); }
-        } else if (state == 1) {                                                                // insert :205-209, :399-411
-            i += sidx & 1; sidx -= 1; --y;
-            if (want_flank && (x < lhs || x >= rhs_begin)) {
-                ++msz; flank += w.nuc_prior;
-                push_event((y != 0 && new_state == 1) ? 2u : 1u, x - 1 < 0 ? 0 : x - 1, 0);     // x-1 == -1 is out of bounds in the reference (UB): clamp
-            }
-        } else {                                                                                // delete :210-215, :413-424
-            sidx -= 1; i -= sidx & 1; --x;
-            if (want_flank && (x < lhs || x >= rhs_begin)) push_event(new_state == 3 ? 2u : 1u, x, 0);
+        const bool isM = state == 0, isI = state == 1, isD = !isM && !isI;
+        i += isI ? (sidx & 1) : 0;                                                              // insert :205-209
+        sidx -= isM ? 2 : 1;                                                                    // match :201-204
+        i -= isD ? (sidx & 1) : 0;                                                              // delete :210-215
+        x -= isI ? 0 : 1; y -= isD ? 0 : 1;
+        const bool in_flank = want_flank && (x < lhs || x >= rhs_begin);                        // calculate_flank_score_helper :383-424
+        msz += (in_flank && !isD) ? 1 : 0;
+        flank += (in_flank && isI) ? w.nuc_prior : 0;
+        if (in_flank && (!isM || mism)) {
+            const bool ext = isI ? (y != 0 && new_state == 1) : new_state == 3;                 // first alignment column has prev_state = match (:369)
+            const int32_t xi = x - 1 < 0 ? 0 : x - 1;                                           // x-1 == -1 is out of bounds in the reference (UB): clamp
+            push_event(isM ? 0u : (ext ? 2u : 1u), isI ? xi : x, isM ? y : 0);
         }
         state = new_state;
-        if (y <= 0) fin = true;                                                                 // :194
+        if (y <= 0) fl |= kFin;                                                                 // :194
     };
     auto slow_word = [&](int64_t flat) -> uint32_t {                                            // any cell by flat index = diagonal * B + lane
         const int32_t s = (int32_t)(flat / B), li = (int32_t)(flat % B);
@@ -1234,7 +1252,7 @@ OCT_KERNEL(k_walk)(WalkParams w)
         return w.bp[(size_t)group * w.k_cap * C * 1024 + line * 16 + (k & 15)];
     };
 
-    uint32_t kmax = ok ? (uint32_t)(sidx >> 1) : 0;
+    uint32_t kmax = (fl & kOk) ? (uint32_t)(sidx >> 1) : 0;
     for (int m = 1; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(kmax, m); kmax = o > kmax ? o : kmax; }
     kmax = hw::readfirstlane(kmax);
     for (int32_t kt = (int32_t)(kmax >> 4); kt >= 0; --kt) {
@@ -1248,17 +1266,17 @@ OCT_KERNEL(k_walk)(WalkParams w)
             c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w; c[12] = q3.x; c[13] = q3.y; c[14] = q3.z; c[15] = q3.w;
             line_i = i;
         };
-        if (!fin && i >= 0 && i < B) load_line(); else { for (int q = 0; q < 16; ++q) c[q] = 0; }
-#pragma unroll
-        for (int kk = 15; kk >= 0; --kk) {
-            const int32_t k = kt * 16 + kk;
+        if (!(fl & kFin) && i >= 0 && i < B) load_line(); else { for (int q = 0; q < 16; ++q) c[q] = 0; }
+#pragma nounroll
+        for (int kk = 15; kk >= 0; --kk) {                                                      // kk is wave-uniform: c[kk] is an indexed register read (M0), and
+            const int32_t k = kt * 16 + kk;                                                     // the loop body stays small enough for the instruction cache
 #pragma unroll
             for (int rep = 0; rep < 2; ++rep) {                                                 // an insertion/deletion can add a second step at the same k
-                if (!fin && (sidx >> 1) == k && sidx >= 0) {
-                    if (i < 0) { ok = false; fin = true; }                                      // :195-199
+                if (!(fl & kFin) && (sidx >> 1) == k && sidx >= 0) {
+                    if (i < 0) fl = (fl & ~kOk) | kFin;                                         // :195-199
                     else if (i >= B) {                                                          // the reference indexes its array flat: lane overflow reads the next diagonal
                         const int64_t f = (int64_t)sidx * B + i;
-                        if (f >= n_flat) { ok = false; fin = true; } else step(slow_word(f));
+                        if (f >= n_flat) fl = (fl & ~kOk) | kFin; else step(slow_word(f));
                     } else {
                         if (i != line_i) load_line();
                         step(c[kk]);
@@ -1267,7 +1285,8 @@ OCT_KERNEL(k_walk)(WalkParams w)
             }
         }
     }
-    if (!fin) ok = false;                                                                       // ran off the first diagonal with target bases left (:195-199)
+    if (!(fl & kFin)) fl &= ~kOk;                                                               // ran off the first diagonal with target bases left (:195-199)
+    const bool ok = (fl & kOk) != 0;
     const int32_t first_pos = ok ? x : -1;
     if (ok) for (uint32_t e = 0; e < nev; ++e) price_event(evbuf[e]);
     if (seam) {

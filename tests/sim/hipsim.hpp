@@ -13,6 +13,7 @@
 #include <vector>
 
 #define OCT_DEVICE inline
+#define OCT_DEVICE_NOINLINE inline
 #define OCT_HD inline
 #define OCT_KERNEL(name) inline void name
 #define OCT_DYN_SMEM(ptr) unsigned char* ptr = hipsim::S().smem

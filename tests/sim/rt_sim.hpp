@@ -19,6 +19,8 @@ inline void stream_destroy(Stream) {}
 inline bool stream_sync(Stream) { return true; }
 inline bool dev_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); if (*p) memset(*p, 0xCD, n ? n : 16); return *p != nullptr; }
 inline void dev_free(void* p) { free(p); }
+inline bool host_pinned_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); return *p != nullptr; }
+inline void host_pinned_free(void* p) { free(p); }
 inline bool h2d(void* d, const void* h, size_t n, Stream) { if (n) memcpy(d, h, n); return true; }
 inline bool d2h(void* h, const void* d, size_t n, Stream) { if (n) memcpy(h, d, n); return true; }
 inline bool dev_memset(void* d, int v, size_t n, Stream) { if (n) memset(d, v, n); return true; }

@@ -154,3 +154,36 @@ def test_gpu_genotype_readout_large_region_row_splits():
     """6,000 rows x 40 haplotypes: every genotype chunk is split over many row ranges and recombined in a fixed order."""
     import check_readout as cr
     cr.check_readout("gpu", seed=11, big=True)
+
+
+def test_gpu_concurrent_handles_from_host_threads():
+    """The reference calls populate from many region-task threads at once (caller.cpp:475, octopus.cpp:867): distinct handles must
+    be usable concurrently from distinct host threads (ctypes releases the GIL during the call) and give the serial answers."""
+    import threading
+    n_threads, per_thread = 4, 6
+    rng = np.random.default_rng(77)
+    batches = [[synth.batch_from_regions([synth.make_region(rng, int(rng.integers(100, 600)), int(rng.integers(4, 20)), B=16, positions="none")])
+                for _ in range(per_thread)] for _ in range(n_threads)]
+    ref_eng = make_engine("gpu", max_indel_error=16)
+    want = [[ref_eng.populate(b)[0].copy() for b in bs] for bs in batches]
+    ref_eng.close()
+    got = [[None] * per_thread for _ in range(n_threads)]
+    errors = []
+
+    def worker(t):
+        try:
+            eng = make_engine("gpu", max_indel_error=16)
+            for rep in range(3):
+                for i, b in enumerate(batches[t]):
+                    got[t][i] = eng.populate(b)[0].copy()
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors
+    for t in range(n_threads):
+        for i in range(per_thread):
+            assert np.array_equal(got[t][i], want[t][i])
