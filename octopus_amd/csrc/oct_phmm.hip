@@ -63,6 +63,7 @@ struct oct_phmm_handle {
     oct_phmm_config cfg;
     DevPool pool;
     void* stage = nullptr; size_t stage_bytes = 0;       // pinned host staging: all input arrays of a batch go up in ONE copy
+    void* out_stage = nullptr; size_t out_stage_bytes = 0;   // pinned landing zone for slice-wise result copies (oct_phmm_populate)
     std::vector<rt::Event> ev_pool;                      // recycled timing / completion events
     bool get_event(rt::Event* e) { if (!ev_pool.empty()) { *e = ev_pool.back(); ev_pool.pop_back(); return true; } return rt::event_create(e); }
     void put_event(rt::Event e) { ev_pool.push_back(e); }
@@ -103,6 +104,7 @@ struct oct_phmm_batch {
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
+    double* early_out = nullptr;  // oct_phmm_populate: copy every slice's rows to the caller as soon as its epilogue is done
     bool stream = false;          // streaming DP path (k_dp_wide): band 128/256, or band 64 with reads/haplotypes too long for LDS
     bool map_big = false;         // haplotypes too long for the LDS-resident k-mer mapper
     bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
@@ -162,7 +164,7 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
     if (!in_bytes) return true;
     if (in_bytes <= kStageMax) {
         if (h->stage_bytes < in_bytes) {
-            rt::host_pinned_free(h->stage); h->stage = nullptr; h->stage_bytes = 0;
+            rt::host_pinned_free(h->stage); rt::host_pinned_free(h->out_stage); h->stage = nullptr; h->stage_bytes = 0;
             size_t want = (size_t)1 << 20; while (want < in_bytes) want <<= 1;
             if (!rt::host_pinned_malloc(&h->stage, want)) return false;
             h->stage_bytes = want;
@@ -438,10 +440,14 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     if (R->row_offsets && (!monotone(R->row_offsets, n_rows) || R->row_offsets[0] != 0 || R->row_offsets[n_rows] != R->n_reads))
         return fail(status, OCT_PHMM_EINVAL, "row_offsets must partition the reads");
     const uint32_t n_read_bases = R->offsets[R->n_reads], n_hap_bases = H->offsets[H->n_haps];
-    for (uint32_t i = 0; i < n_read_bases; ++i) if (R->qualities[i] > 127) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
-    for (uint32_t i = 0; i < n_hap_bases; ++i)
-        if (H->gap_open[i] < 0 || H->gap_extend[i] < 0 || H->snv_prior_fwd[i] < 0 || H->snv_prior_rev[i] < 0)
-            return fail(status, OCT_PHMM_EINVAL, "negative penalty");
+    {   // branch-free reductions (these loops run over every base of the batch and must vectorise)
+        uint32_t qor = 0, por = 0;
+        for (uint32_t i = 0; i < n_read_bases; ++i) qor |= R->qualities[i];
+        if (qor & 0x80u) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
+        for (uint32_t i = 0; i < n_hap_bases; ++i)
+            por |= (uint32_t)(uint8_t)H->gap_open[i] | (uint8_t)H->gap_extend[i] | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
+        if (por & 0x80u) return fail(status, OCT_PHMM_EINVAL, "negative penalty");
+    }
 
     // regions
     uint32_t one_row[2] = {0, n_rows}, one_hap[2] = {0, H->n_haps};
@@ -491,9 +497,10 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
         // halves never carries between them and k_dp uses v_add_u32 (FASTADD); otherwise it keeps v_pk_add_u16. Results are identical.
         uint64_t sum_q_max = 0; uint32_t gomax = 0, gemax = 0;
         for (uint32_t r = 0; r < R->n_reads; ++r) {
-            uint64_t sq = 0;
-            for (uint32_t i = R->offsets[r]; i < R->offsets[r + 1]; ++i) sq += R->qualities[i];
-            sum_q_max = std::max(sum_q_max, sq);
+            uint32_t sq = 0;                                   // reads are < 32,768 bases of quality <= 127
+            const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
+            for (uint32_t i = 0; i < n; ++i) sq += q[i];
+            sum_q_max = std::max<uint64_t>(sum_q_max, sq);
         }
         for (uint32_t i = 0; i < n_hap_bases; ++i) { gomax = std::max<uint32_t>(gomax, (uint32_t)H->gap_open[i]); gemax = std::max<uint32_t>(gemax, (uint32_t)H->gap_extend[i]); }
         const uint64_t B64 = (uint64_t)h->band, nuc = (uint64_t)std::max(0, h->cfg.nuc_prior);
@@ -707,7 +714,16 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             }
         }
         if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
+        if (b->early_out && sl.out1 > sl.out0)
+            RT(rt::d2h((double*)h->out_stage + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
         RT(rt::event_record(sl.done, s));
+        return OCT_PHMM_OK;
+    };
+    auto deliver = [&](int i) -> int {                        // finished slice -> the caller's buffer (host copy overlaps the later slices' kernels)
+        const oct_phmm_batch::Slice& sl = b->slices[i];
+        if (!b->early_out || sl.out1 <= sl.out0) return OCT_PHMM_OK;
+        RT(rt::event_sync(sl.done));
+        memcpy(b->early_out + sl.out0, (const double*)h->out_stage + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double));
         return OCT_PHMM_OK;
     };
     // software pipeline over slices: phase 1 of slice i+1 is enqueued before the host waits for slice i's task counts
@@ -717,8 +733,10 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         if (rc != OCT_PHMM_OK) break;
         RT(rt::stream_sync(h->slice_stream(i)));              // the host read-back that sizes this slice's launches
         rc = phase2(i);
+        if (rc == OCT_PHMM_OK && i >= 2) rc = deliver(i - 2);
     }
     if (rc != OCT_PHMM_OK) return rc;
+    for (int i = std::max(0, S - 2); i < S; ++i) { rc = deliver(i); if (rc != OCT_PHMM_OK) return rc; }
     for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(s0, b->slices[i].done));
     b->h_stat_stripes.assign((size_t)kStatSlots * 8, 0);
     RT(rt::d2h(b->h_stat_stripes.data(), d.stats, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s0));
@@ -888,8 +906,17 @@ extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads
 {
     oct_phmm_batch* b = nullptr;
     int rc = oct_phmm_batch_upload(h, reads, haps, regions, flank, positions, &b, status);
+    bool early = false;
+    if (rc == OCT_PHMM_OK && b->slices.size() > 1 && out) {   // big batch: results stream back slice by slice through a pinned landing zone
+        const size_t bytes = (size_t)b->n_out * sizeof(double);
+        if (h->out_stage_bytes < bytes) {
+            rt::host_pinned_free(h->out_stage); h->out_stage = nullptr; h->out_stage_bytes = 0;
+            if (rt::host_pinned_malloc(&h->out_stage, bytes)) h->out_stage_bytes = bytes;
+        }
+        if (h->out_stage_bytes >= bytes) { b->early_out = out; early = true; }
+    }
     if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_run(h, b, status);
-    if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_download(h, b, out, status);
+    if (rc == OCT_PHMM_OK) rc = early ? oct_phmm_batch_wait(h, b, status) : oct_phmm_batch_download(h, b, out, status);
     oct_phmm_batch_free(h, b);
     return rc;
 }

@@ -39,6 +39,7 @@ inline bool dev_memset(void* d, int v, size_t n, Stream s) { if (n) OCT_RT_CHECK
 inline bool event_create(Event* e) { OCT_RT_CHECK(hipEventCreate(e)); return true; }
 inline void event_destroy(Event e) { (void)hipEventDestroy(e); }
 inline bool event_record(Event e, Stream s) { OCT_RT_CHECK(hipEventRecord(e, s)); return true; }
+inline bool event_sync(Event e) { OCT_RT_CHECK(hipEventSynchronize(e)); return true; }
 inline bool stream_wait_event(Stream s, Event e) { OCT_RT_CHECK(hipStreamWaitEvent(s, e, 0)); return true; }
 inline bool event_elapsed_ms(float* ms, Event a, Event b) { OCT_RT_CHECK(hipEventElapsedTime(ms, a, b)); return true; }
 inline bool launch_ok() { OCT_RT_CHECK(hipGetLastError()); return true; }

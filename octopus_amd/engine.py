@@ -180,9 +180,11 @@ class Engine:
         except Exception:
             pass
 
-    def populate(self, batch: abi.Batch, raise_on_error: bool = True):
-        """HaplotypeLikelihoodArray::populate. Returns (out, status)."""
-        out = np.full(max(batch.out_size(), 1), np.nan, dtype=np.float64)
+    def populate(self, batch: abi.Batch, raise_on_error: bool = True, out: Optional[np.ndarray] = None):
+        """HaplotypeLikelihoodArray::populate. Returns (out, status). `out`: optional preallocated float64 buffer."""
+        if out is None:
+            out = np.full(max(batch.out_size(), 1), np.nan, dtype=np.float64)
+        assert out.dtype == np.float64 and out.size >= batch.out_size() and out.flags.c_contiguous
         st = abi.Status()
         r, h, g, f, p = batch.c_args()
         code = self.lib.oct_phmm_populate(self.handle, _vp(r), _vp(h), _vp(g), _vp(f), _vp(p), _ptr(out), C.byref(st))

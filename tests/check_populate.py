@@ -200,3 +200,19 @@ def check_wide_and_long(backend, tol=0.0, long_T=300, long_Lh=1000, n_reads=6):
     g["quals"][:] = np.clip(g["quals"], 5, 15)            # PacBio-like low qualities -> many differences
     b = compare(backend, synth.batch_from_regions([g]), tol, max_indel_error=256, use_int_scores=1)
     return a, b
+
+
+def check_one_shot_populate_streams_slices_back(backend):
+    """oct_phmm_populate on a multi-slice batch delivers each slice's rows through the pinned landing zone as soon as its epilogue is
+    done; the result must equal the resident path's download (and the oracle)."""
+    rng = np.random.default_rng(21)
+    batch = synth.batch_from_regions([synth.make_region(rng, 70, 7, B=16, positions="none"),
+                                      synth.make_region(rng, 40, 5, B=16, positions="none")])
+    cfg = abi.Config.default(max_indel_error=16)
+    want, _, _ = oracle.populate(cfg, batch, n_threads=2)
+    eng = make_engine(backend, max_indel_error=16)
+    got, st = eng.populate(batch)
+    assert st.code == abi.OK and np.array_equal(got, want)
+    rb = eng.upload(batch); rb.run()
+    assert np.array_equal(rb.download(), want)
+    rb.free(); eng.close()

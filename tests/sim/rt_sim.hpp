@@ -27,6 +27,7 @@ inline bool dev_memset(void* d, int v, size_t n, Stream) { if (n) memset(d, v, n
 inline bool event_create(Event* e) { *e = 0; return true; }
 inline void event_destroy(Event) {}
 inline bool event_record(Event, Stream) { return true; }
+inline bool event_sync(Event) { return true; }
 inline bool stream_wait_event(Stream, Event) { return true; }
 inline bool event_elapsed_ms(float* ms, Event, Event) { *ms = 0.f; return true; }
 inline bool launch_ok() { return true; }

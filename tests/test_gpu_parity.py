@@ -107,6 +107,7 @@ def test_gpu_populate_in_slices(monkeypatch):
     cp.check_ragged_and_edges("gpu", TOL)
     batch = synth.config_batch("1kx64", seed=43, B=16, positions="none")
     cp.compare("gpu", batch, TOL, max_indel_error=16)
+    cp.check_one_shot_populate_streams_slices_back("gpu")
 
 
 def test_gpu_config2_1k_by_64_matches_oracle():

@@ -17,6 +17,7 @@ def test_sim_populate_templates_and_regions():
 
 def test_sim_populate_ragged_reads_edges_and_short_haplotype():
     cp.check_ragged_and_edges("sim")
+    cp.check_one_shot_populate_streams_slices_back("sim")
 
 
 def test_sim_populate_mapping_quality_and_flank_options():

@@ -28,10 +28,11 @@ res = {}
 if not a.skip_big:
     eng = engine.Engine(cfg)
     big = synth.config_batch("100kx128", seed=42, B=16, positions="none")
-    eng.populate(big)
+    outbuf = np.empty(big.out_size())
+    eng.populate(big, out=outbuf)
     t0 = time.perf_counter()
     for _ in range(3):
-        eng.populate(big)
+        eng.populate(big, out=outbuf)
     dt = (time.perf_counter() - t0) / 3
     rb = eng.upload(big); rb.run(); rb.wait()
     t0 = time.perf_counter()
