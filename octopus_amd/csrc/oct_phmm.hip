@@ -104,6 +104,7 @@ struct oct_phmm_batch {
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
+    rt::Event ev_fork {}, ev_join {};
     double* early_out = nullptr;  // oct_phmm_populate: copy every slice's rows to the caller as soon as its epilogue is done
     bool stream = false;          // streaming DP path (k_dp_wide): band 128/256, or band 64 with reads/haplotypes too long for LDS
     bool map_big = false;         // haplotypes too long for the LDS-resident k-mer mapper
@@ -190,7 +191,7 @@ bool monotone(const uint32_t* off, uint32_t n) { for (uint32_t i = 0; i < n; ++i
 template <int B, bool TR, bool GEN, bool FA>
 bool launch_dp_inst(const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
 {
-    if (!rt::allow_lds((k_dp<B, TR, GEN, FA>), lds)) return false;
+    if (lds > 64 * 1024 && !rt::allow_lds((k_dp<B, TR, GEN, FA>), lds)) return false;    // up to 64 KB needs no opt-in (and the call is a driver round trip)
     OCT_LAUNCH((k_dp<B, TR, GEN, FA>), n_blocks, kBlockWaves * 64, lds, s, p);
     return rt::launch_ok();
 }
@@ -213,7 +214,7 @@ bool launch_dp(int band, bool tr, bool gen, bool fa, const DpParams& p, uint32_t
 template <int B, bool TR>
 bool launch_dp32_inst(const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
 {
-    if (!rt::allow_lds((k_dp32<B, TR>), lds)) return false;
+    if (lds > 64 * 1024 && !rt::allow_lds((k_dp32<B, TR>), lds)) return false;
     OCT_LAUNCH((k_dp32<B, TR>), n_blocks, kBlockWaves * 64, lds, s, p);
     return rt::launch_ok();
 }
@@ -278,10 +279,10 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 
 // Run one kind's task list through the DP kernel (+ walk for traceback kinds), chunked so the traceback scratch fits.
 int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
-                int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status)
+                int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr)
 {
     if (!n_tasks) return OCT_PHMM_OK;
-    rt::Stream st = h->slice_stream(slice);
+    rt::Stream st = on_stream ? *on_stream : h->slice_stream(slice);
     const int B = h->band;
     const uint32_t C = (uint32_t)h->lanes_c;
     const uint32_t G = b->stream ? 1u : (h->wide ? 1 : 2) * (64 / B);
@@ -421,6 +422,7 @@ extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
     for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
     for (void* p : b->allocs) h->pool.release(p);
     for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_ends); h->put_event(sl.done); }
+    if (b->ev_fork) { h->put_event(b->ev_fork); h->put_event(b->ev_join); }
     delete b;
 }
 
@@ -462,7 +464,8 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     }
     auto first_read = [&](uint32_t row) { return R->row_offsets ? R->row_offsets[row] : row; };
 
-    std::unique_ptr<oct_phmm_batch> b(new (std::nothrow) oct_phmm_batch());
+    struct BatchDel { void operator()(oct_phmm_batch* p) const { oct_phmm_batch_free(p->owner, p); } };   // a failed upload returns its blocks and events to the handle
+    std::unique_ptr<oct_phmm_batch, BatchDel> b(new (std::nothrow) oct_phmm_batch());
     if (!b) return fail(status, OCT_PHMM_EHIP, "host allocation");
     b->owner = h; b->n_reads = R->n_reads; b->n_haps = H->n_haps; b->n_rows = n_rows; b->n_regions = G; b->n_hap_bases = n_hap_bases;
     std::vector<uint32_t> hap_region(H->n_haps + 1, 0), reg_row0(G + 1), reg_read0(G + 1), reg_lhs(G + 1, 0), reg_rhs(G + 1, 0);
@@ -612,6 +615,7 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     pk.dalloc(&b->d_out, (size_t)b->n_out);
     std::vector<uint32_t> ones(H->n_haps + 1, 1u);
     pk.upload(ones.data(), (size_t)H->n_haps, (const uint32_t**)&d.hclean);
+    RT(h->get_event(&b->ev_fork)); RT(h->get_event(&b->ev_join));
     RT(pk.commit(h, bp, s));
     d.err_key = d.stats + (size_t)kStatSlots * 8;
     for (size_t i = 0; i < b->slices.size(); ++i) {
@@ -664,11 +668,11 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             OCT_LAUNCH(k_kmer_tables, sl.hap1 - sl.hap0, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d, sl.hap0); RT(rt::launch_ok());
             if (b->map_big) {
                 const size_t lds = (size_t)b->lh_cap * 4 + 64;
-                RT(rt::allow_lds(k_kmer_map_big, lds));
+                if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_big, lds));
                 OCT_LAUNCH(k_kmer_map_big, (uint32_t)np, 256, lds, s, d, sl.pair0); RT(rt::launch_ok());
             } else if (sl.blk1 > sl.blk0) {
                 const size_t lds = kmer_map_lds_bytes(b->lh_cap);
-                RT(rt::allow_lds(k_kmer_map, lds));
+                if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map, lds));
                 OCT_LAUNCH(k_kmer_map, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
                            (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap); RT(rt::launch_ok());
             }
@@ -708,10 +712,17 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             const uint32_t pad_threads = (sl.hap1 - sl.hap0) * kNumKinds * G;
             OCT_LAUNCH(k_emit_pad, (pad_threads + 255) / 256, 256, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, (const uint4*)b->d_hap_base, ta, G); RT(rt::launch_ok());
             static const int order[kNumKinds] = {kTraceFast, kTraceGen, kScoreFast, kScoreGen};   // traceback first: its walk then overlaps the score-only DP of the next slice
+            // A single-slice (region-sized) batch is latency-bound: its score-only DP runs beside the traceback DP + walk on a second stream.
+            const bool side = S == 1 && (totals.x + totals.z) > 0 && (totals.y + totals.w) > 0;
+            rt::Stream aux = h->slice_stream(1);
+            if (side) { RT(rt::event_record(b->ev_fork, s)); RT(rt::stream_wait_event(aux, b->ev_fork)); }
             for (int k : order) {
-                const int rc = run_dp_kind(h, b, i, k, ta.t[k], (k == 0 ? totals.x : k == 1 ? totals.y : k == 2 ? totals.z : totals.w), sl.d_ends, h->cfg.nuc_prior, nullptr, status);
+                const bool score_kind = k == kScoreFast || k == kScoreGen;
+                const int rc = run_dp_kind(h, b, i, k, ta.t[k], (k == 0 ? totals.x : k == 1 ? totals.y : k == 2 ? totals.z : totals.w), sl.d_ends, h->cfg.nuc_prior, nullptr, status,
+                                           side && score_kind ? &aux : nullptr);
                 if (rc != OCT_PHMM_OK) return rc;
             }
+            if (side) { RT(rt::event_record(b->ev_join, aux)); RT(rt::stream_wait_event(s, b->ev_join)); }
         }
         if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
         if (b->early_out && sl.out1 > sl.out0)
