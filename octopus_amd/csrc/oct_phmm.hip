@@ -713,7 +713,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             OCT_LAUNCH(k_emit_pad, (pad_threads + 255) / 256, 256, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, (const uint4*)b->d_hap_base, ta, G); RT(rt::launch_ok());
             static const int order[kNumKinds] = {kTraceFast, kTraceGen, kScoreFast, kScoreGen};   // traceback first: its walk then overlaps the score-only DP of the next slice
             // A single-slice (region-sized) batch is latency-bound: its score-only DP runs beside the traceback DP + walk on a second stream.
-            const bool side = S == 1 && (totals.x + totals.z) > 0 && (totals.y + totals.w) > 0;
+            const bool side = S == 1 && total < 200000 && (totals.x + totals.z) > 0 && (totals.y + totals.w) > 0;   // big launches fill the chip on their own
             rt::Stream aux = h->slice_stream(1);
             if (side) { RT(rt::event_record(b->ev_fork, s)); RT(rt::stream_wait_event(aux, b->ev_fork)); }
             for (int k : order) {
