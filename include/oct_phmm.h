@@ -207,6 +207,31 @@ typedef struct oct_phmm_genotype_sets {
 int  oct_phmm_batch_genotype_likelihoods(oct_phmm_handle* h, oct_phmm_batch* b, const oct_phmm_genotype_sets* sets,
                                          double* out, oct_phmm_status* status);
 
+/* ---- realignment: best alignment per (read, haplotype) pair ---------------------- */
+/* HaplotypeLikelihoodModel::align (haplotype_likelihood_model.cpp:322-431; compute_optimal_alignment :335-395,
+ * hmm::align pair_hmm.hpp:861-872, try_naive_align :321-341, simd_align :788-823, make_cigar :152-188) for every
+ * (haplotype, read) pair of the batch - what read_realigner.cpp:114-139 calls per read. Same inputs as
+ * oct_phmm_populate (row_offsets must be NULL: alignments are per read). Pairs are ordered haplotype-major, reads
+ * of the haplotype's region in batch order: pair = sum over earlier haplotypes of their region's reads + read index.
+ * CIGAR operations use the BAM encoding length << 4 | op with op I = 1, D = 2, '=' = 7, X = 8
+ * (CigarOperation::Flag insertion, deletion, sequenceMatch, substitution). */
+#define OCT_PHMM_CIGAR_INS 1u
+#define OCT_PHMM_CIGAR_DEL 2u
+#define OCT_PHMM_CIGAR_EQ  7u
+#define OCT_PHMM_CIGAR_X   8u
+typedef struct oct_phmm_alignments {
+    uint32_t  max_cigar_ops;          /* capacity of `cigar` per pair; too small -> OCT_PHMM_EINVAL, status.required_extension = needed */
+    uint32_t* mapping_position;       /* [n_pairs] Alignment::mapping_position (haplotype offset of the first aligned base) */
+    double*   likelihood;             /* [n_pairs] Alignment::likelihood (after the mapping-quality mixture) */
+    uint32_t* n_cigar_ops;            /* [n_pairs] */
+    uint32_t* cigar;                  /* [n_pairs * max_cigar_ops] */
+} oct_phmm_alignments;
+/* OCT_PHMM_EOVERFLOW <-> hmm::HMMOverflow (a traceback that left the band, pair_hmm.hpp:811-813);
+ * OCT_PHMM_ESHORT_HAPLOTYPE as for populate. */
+int  oct_phmm_align(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
+                    const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                    const oct_phmm_positions* positions, oct_phmm_alignments* out, oct_phmm_status* status);
+
 /* ---- test seam: the raw band kernel ------------------------------------------------------------ */
 /* simd::PairHMM::align on explicit windows (simd_pair_hmm.hpp:438-509): what the reference's golden tests
  * drive (test/unit/core/models/pair_hmm_tests.cpp:63-85). Window i has truth_len = target_len + 2B - 1.

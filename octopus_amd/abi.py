@@ -294,3 +294,28 @@ class GenotypeSets(C.Structure):
             rb = np.asarray([s["rows"][0] for s in sets], np.uint32); re = np.asarray([s["rows"][1] for s in sets], np.uint32)
             keep += [rb, re]
         return GenotypeSets(len(sets), _ptr(ploidy), _ptr(offs), _ptr(idx), _ptr(rb), _ptr(re)), keep, int(offs[-1])
+
+
+CIGAR_OPS = {1: "I", 2: "D", 7: "=", 8: "X"}
+
+
+class Alignments(C.Structure):
+    """oct_phmm_alignments: caller-owned outputs of oct_phmm_align."""
+    _fields_ = [("max_cigar_ops", C.c_uint32), ("mapping_position", C.c_void_p), ("likelihood", C.c_void_p),
+                ("n_cigar_ops", C.c_void_p), ("cigar", C.c_void_p)]
+
+    @staticmethod
+    def make(n_pairs: int, max_cigar_ops: int):
+        arrays = dict(mapping_position=np.zeros(max(n_pairs, 1), np.uint32), likelihood=np.zeros(max(n_pairs, 1), np.float64),
+                      n_cigar_ops=np.zeros(max(n_pairs, 1), np.uint32), cigar=np.zeros(max(n_pairs * max_cigar_ops, 1), np.uint32))
+        st = Alignments(max_cigar_ops, _ptr(arrays["mapping_position"]), _ptr(arrays["likelihood"]), _ptr(arrays["n_cigar_ops"]), _ptr(arrays["cigar"]))
+        return st, arrays
+
+
+def alignments_result(arrays: dict, n_pairs: int, max_cigar_ops: int) -> dict:
+    """Trim the output arrays and decode every CIGAR to its string form."""
+    n = arrays["n_cigar_ops"][:n_pairs]
+    cig = arrays["cigar"][:n_pairs * max_cigar_ops].reshape(n_pairs, max_cigar_ops) if n_pairs else np.zeros((0, max_cigar_ops), np.uint32)
+    strings = ["".join(f"{int(v) >> 4}{CIGAR_OPS.get(int(v) & 15, '?')}" for v in cig[e, :min(int(n[e]), max_cigar_ops)]) for e in range(n_pairs)]
+    return dict(mapping_position=arrays["mapping_position"][:n_pairs].copy(), likelihood=arrays["likelihood"][:n_pairs].copy(),
+                n_cigar_ops=n.copy(), cigar=cig.copy(), cigar_strings=strings)

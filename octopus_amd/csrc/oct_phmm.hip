@@ -94,6 +94,7 @@ struct oct_phmm_batch {
         uint32_t hap0 = 0, hap1 = 0, blk0 = 0, blk1 = 0, n_tiles = 0; uint64_t pair0 = 0, pair1 = 0, out0 = 0, out1 = 0;
         uint4* cnt = nullptr; uint4* tile_sums = nullptr; uint4* d_totals = nullptr; uint4 totals {};
         DevTask* d_tasks = nullptr; size_t tasks_cap = 0; TraceEnd* d_ends = nullptr; size_t ends_cap = 0;
+        unsigned long long* d_keys = nullptr; size_t keys_cap = 0;   // align mode: per traceback task
         rt::Event done {};
     };
     std::vector<Slice> slices;
@@ -105,6 +106,9 @@ struct oct_phmm_batch {
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
     rt::Event ev_fork {}, ev_join {};
+    // align mode (oct_phmm_align)
+    bool align_mode = false; uint32_t cig_cap = 0;
+    double* d_aln_lik = nullptr; uint32_t* d_aln_mpos = nullptr; uint32_t* d_aln_n = nullptr; uint32_t* d_aln_ops = nullptr; uint32_t* d_err_flags = nullptr;
     double* early_out = nullptr;  // oct_phmm_populate: copy every slice's rows to the caller as soon as its epilogue is done
     bool stream = false;          // streaming DP path (k_dp_wide): band 128/256, or band 64 with reads/haplotypes too long for LDS
     bool map_big = false;         // haplotypes too long for the LDS-resident k-mer mapper
@@ -235,6 +239,7 @@ bool launch_walk_inst(const WalkParams& w, rt::Stream s)
     const size_t lds = 256 * kWalkEvents * sizeof(uint32_t);
     OCT_LAUNCH((k_walk<B, TPR, C>), blocks, 256, lds, s, w);
     if (w.out_align1 != nullptr) OCT_LAUNCH((k_walk_strings<B, TPR, C>), blocks, 256, 0, s, w);   // test seam: gapped strings from the simple per-step walker
+    if (w.pair_key != nullptr) OCT_LAUNCH((k_walk_cigar<B, TPR, C>), blocks, 256, 0, s, w);       // align mode: the pairs' winning tasks write their CIGARs
     return rt::launch_ok();
 }
 bool launch_walk(int band, bool one_per_row, const WalkParams& w, rt::Stream s)
@@ -335,6 +340,11 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
                 w.out_first_pos += o; w.out_align_off += o;
                 if (w.seam_lhs) { w.seam_lhs += o; w.seam_rhs += o; w.out_flank += o; w.out_mask_size += o; }
             }
+            if (b->align_mode) {
+                if (ng != n_groups) return fail(status, OCT_PHMM_EUNSUPPORTED, "alignment batch too large for the traceback scratch (raise OCT_PHMM_BP_BUDGET_GB or split the batch)");
+                w.pair_key = b->d.pair_key; w.task_key = b->slices[slice].d_keys; w.pos = b->d.pos; w.npos = b->d.npos; w.max_pos = b->d.max_pos;
+                w.err_flags = b->d_err_flags; w.cig_ops = b->d_aln_ops; w.cig_n = b->d_aln_n; w.cig_mpos = b->d_aln_mpos; w.cig_cap = b->cig_cap;
+            }
             if (!launch_walk(B, h->wide || b->stream, w, st)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
         }
     }
@@ -421,14 +431,25 @@ extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
     if (!h) h = b->owner;
     for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
     for (void* p : b->allocs) h->pool.release(p);
-    for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_ends); h->put_event(sl.done); }
+    for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_ends); h->pool.release(sl.d_keys); h->put_event(sl.done); }
     if (b->ev_fork) { h->put_event(b->ev_fork); h->put_event(b->ev_join); }
     delete b;
 }
 
+static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
+                       const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                       const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops);
+
 extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
                                      const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                                      const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status)
+{
+    return upload_impl(h, R, H, regions, flank, positions, out, status, false, 0);
+}
+
+static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
+                       const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                       const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops)
 {
     if (!h || !R || !H || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
     *out = nullptr;
@@ -613,6 +634,14 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
         }
     }
     pk.dalloc(&b->d_out, (size_t)b->n_out);
+    d.align_mode = align_mode ? 1 : 0; d.pair_key = nullptr;
+    if (align_mode) {
+        if (R->row_offsets) return fail(status, OCT_PHMM_EINVAL, "alignments are per read: row_offsets must be NULL");
+        b->align_mode = true;
+        b->cig_cap = (uint32_t)std::min<uint64_t>(max_cigar_ops, 2ull * (b->t_cap + (uint32_t)h->band) + 1);   // an alignment has at most 2 (T + B) columns
+        pk.dalloc(&d.pair_key, (size_t)b->n_pairs); pk.dalloc(&b->d_aln_lik, (size_t)b->n_pairs); pk.dalloc(&b->d_aln_mpos, (size_t)b->n_pairs);
+        pk.dalloc(&b->d_aln_n, (size_t)b->n_pairs); pk.dalloc(&b->d_aln_ops, (size_t)b->n_pairs * b->cig_cap); pk.dalloc(&b->d_err_flags, 4);
+    }
     std::vector<uint32_t> ones(H->n_haps + 1, 1u);
     pk.upload(ones.data(), (size_t)H->n_haps, (const uint32_t**)&d.hclean);
     RT(h->get_event(&b->ev_fork)); RT(h->get_event(&b->ev_join));
@@ -649,6 +678,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     const int S = (int)b->slices.size();
     RT(rt::dev_memset(d.stats, 0, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s0));
     RT(rt::dev_memset(d.err_key, 0xff, sizeof(unsigned long long), s0));
+    if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
     if (b->n_pairs && b->device_map) {
         const uint32_t n_rb = b->h_roff[b->n_reads];      // compute_kmer_hashes once per read (array.cpp:118-131)
@@ -705,6 +735,10 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             h->pool.release(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
             void* p = nullptr; RT(h->pool.alloc(&p, (n_trace + n_trace / 8) * sizeof(TraceEnd))); sl.d_ends = (TraceEnd*)p; sl.ends_cap = n_trace + n_trace / 8;
         }
+        if (b->align_mode && n_trace > sl.keys_cap) {
+            h->pool.release(sl.d_keys); sl.d_keys = nullptr; sl.keys_cap = 0;
+            void* p = nullptr; RT(h->pool.alloc(&p, (n_trace + n_trace / 8) * sizeof(unsigned long long))); sl.d_keys = (unsigned long long*)p; sl.keys_cap = n_trace + n_trace / 8;
+        }
         if (total) {
             TaskArrays ta;
             ta.t[0] = sl.d_tasks; ta.t[1] = ta.t[0] + totals.x; ta.t[2] = ta.t[1] + totals.y; ta.t[3] = ta.t[2] + totals.z;
@@ -724,7 +758,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             }
             if (side) { RT(rt::event_record(b->ev_join, aux)); RT(rt::stream_wait_event(s, b->ev_join)); }
         }
-        if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
+        if (b->align_mode) {
+            if (np) { OCT_LAUNCH(k_epilogue_align, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, b->d_aln_lik, b->d_aln_mpos, b->d_aln_n, b->d_aln_ops, b->cig_cap); RT(rt::launch_ok()); }
+        } else if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
         if (b->early_out && sl.out1 > sl.out0)
             RT(rt::d2h((double*)h->out_stage + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
         RT(rt::event_record(sl.done, s));
@@ -930,6 +966,42 @@ extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads
     if (rc == OCT_PHMM_OK) rc = early ? oct_phmm_batch_wait(h, b, status) : oct_phmm_batch_download(h, b, out, status);
     oct_phmm_batch_free(h, b);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// realignment: best alignment per (read, haplotype) pair
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int oct_phmm_align(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
+                              const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                              const oct_phmm_positions* positions, oct_phmm_alignments* out, oct_phmm_status* status)
+{
+    if (!out || !out->mapping_position || !out->likelihood || !out->n_cigar_ops || (!out->cigar && out->max_cigar_ops))
+        return fail(status, OCT_PHMM_EINVAL, "null output");
+    oct_phmm_batch* b = nullptr;
+    int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, true, out->max_cigar_ops);
+    struct Guard { oct_phmm_handle* h; oct_phmm_batch*& b; ~Guard() { oct_phmm_batch_free(h, b); } } guard {h, b};
+    if (rc != OCT_PHMM_OK) return rc;
+    rc = oct_phmm_batch_run(h, b, status);
+    if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_wait(h, b, status);
+    if (rc != OCT_PHMM_OK) return rc;
+    const size_t np = (size_t)b->n_pairs, cap = b->cig_cap;
+    uint32_t flags = 0;
+    std::vector<uint32_t> ops(np * cap + 1);
+    RT(rt::d2h(&flags, b->d_err_flags, sizeof(flags), h->stream));
+    RT(rt::d2h(out->likelihood, b->d_aln_lik, np * sizeof(double), h->stream));
+    RT(rt::d2h(out->mapping_position, b->d_aln_mpos, np * sizeof(uint32_t), h->stream));
+    RT(rt::d2h(out->n_cigar_ops, b->d_aln_n, np * sizeof(uint32_t), h->stream));
+    RT(rt::d2h(ops.data(), b->d_aln_ops, np * cap * sizeof(uint32_t), h->stream));
+    RT(rt::stream_sync(h->stream));
+    if (flags & 1u) return fail(status, OCT_PHMM_EOVERFLOW, "Pair HMM alignment overflowed");
+    uint32_t needed = 0;
+    for (size_t e = 0; e < np; ++e) {                       // the device wrote each alignment last column first
+        const uint32_t n = out->n_cigar_ops[e];
+        if (n > out->max_cigar_ops) { needed = std::max(needed, n); continue; }
+        for (uint32_t k = 0; k < n; ++k) out->cigar[e * (size_t)out->max_cigar_ops + k] = ops[e * cap + (n - 1 - k)];
+    }
+    if (needed) { fail(status, OCT_PHMM_EINVAL, "max_cigar_ops too small"); if (status) status->required_extension = needed; return OCT_PHMM_EINVAL; }
+    return ok(status);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -61,6 +61,10 @@ struct DevBatch {
     uint4*    pair_cnt;       // [n_pairs + 1] per-kind task counts, exclusive-scanned in place
     // configuration
     int band, nuc_prior, max_pos, use_mapq, mapq_cap, mapq_trigger, wide;   // wide = int32 lanes (Config::use_int_scores)
+    // HaplotypeLikelihoodModel::align mode (oct_phmm_align): every candidate is aligned with traceback and the best one per pair is kept
+    // under key = penalty << 32 | order << 8 | naive, order = 0 for the read's original position (it wins ties, model.cpp:365), 1 + j for
+    // mapped position j (the first maximum wins, :355)
+    int align_mode; unsigned long long* pair_key;
     // counters, kStatSlots stripes of 8: [0] candidates [1] fast path [2] score-only DP [3] traceback DP [4] band cells [5] pairs
     unsigned long long* stats;
     unsigned long long* err_key;                      // min over failing pairs of (hap << 32 | read); ~0 = none
@@ -90,6 +94,10 @@ struct WalkParams {
     // test seam outputs (null on the populate path)
     int32_t* out_first_pos; char* out_align1; char* out_align2; const uint32_t* out_align_off;
     const int32_t* seam_lhs; const int32_t* seam_rhs; int32_t* out_flank; int32_t* out_mask_size;
+    // align mode (null / 0 otherwise)
+    unsigned long long* pair_key; unsigned long long* task_key; const uint32_t* pos; const uint8_t* npos; int max_pos;
+    uint32_t* err_flags;                              // bit 0: a traceback left the band (hmm::HMMOverflow)
+    uint32_t* cig_ops; uint32_t* cig_n; uint32_t* cig_mpos; uint32_t cig_cap;   // per pair, operations in REVERSE order
 };
 
 } // namespace octphmm

@@ -344,8 +344,18 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt)
         const uint32_t* P = b.pos + e * (uint64_t)b.max_pos; const uint32_t npos = b.npos[e];
         int32_t best = kNoScore; uint32_t cls = 0, n_score = 0, n_trace = 0, extra = 0;
         bool orig_mapped = false, any = false;
+        unsigned long long key = ~0ull;
         auto visit = [&](uint32_t slot, uint32_t p) {
             ++st_cand;
+            if (b.align_mode) {                                                                     // hmm::align, pair_hmm.hpp:861-872
+                bool same = true;                                                                   // try_naive_align :321-341
+                for (uint32_t tt = 0; tt < T; ++tt) if (target[tt] != truth[p + tt]) { same = false; break; }
+                const unsigned long long order = slot == (uint32_t)b.max_pos ? 0ull : (unsigned long long)slot + 1;
+                if (same) { ++st_fast; const unsigned long long k = order << 8 | 1ull; if (k < key) key = k; return; }
+                st_cells += 2ull * B * (T + B);                                                     // simd_align always tracebacks (:806-810)
+                cls |= 2u << (2 * slot); ++n_trace; ++st_trace;
+                return;
+            }
             int32_t pen;
             if (try_naive(truth, Lh, target, T, quals, p, go, ge, mask, prior, lhs, rhs, &pen)) { ++st_fast; if (pen < best) best = pen; return; }
             const uint32_t off = p > B ? p - B : 0;                                                 // pair_hmm.hpp:735
@@ -369,6 +379,7 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt)
             else { extra = (uint32_t)fin; visit((uint32_t)b.max_pos, extra); }
         }
         b.pair_best[e] = best; b.pair_cls[e] = cls; b.pair_extra[e] = extra;
+        if (b.align_mode) b.pair_key[e] = key;
         const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
         cnt[e - pair0] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
         st_pairs = 1;
@@ -1296,11 +1307,75 @@ OCT_KERNEL(k_walk)(WalkParams w)
         }
         return;
     }
-    if (!ok) return;                                        // lowest(): contributes nothing to the max (pair_hmm.hpp:750-752)
-    if (T - msz < 2) flank = 0;                             // :757-759
+    if (!ok) {
+        if (w.pair_key && active) { w.task_key[ti] = ~0ull; hw::atomic_or_u32(w.err_flags, 1u); }   // simd_align throws HMMOverflow (:811-813)
+        return;                                             // populate: lowest(), contributes nothing to the max (pair_hmm.hpp:750-752)
+    }
+    if (T - msz < 2) flank = 0;                             // :757-759 / :664-665
     const int32_t score = end.score;
-    const int32_t pen = flank <= score ? score - flank : flank + score;   // :760-764
+    const int32_t pen = flank <= score ? score - flank : flank + score;   // :760-764 / :666-670
+    if (w.pair_key) {                                       // align mode: compete for the pair under the reference's tie rules
+        const uint32_t p = t.off + (uint32_t)B;             // in-range positions are >= B, so alignment_offset = position - B
+        const uint32_t* P = w.pos + (size_t)t.pair * (uint32_t)w.max_pos; const uint32_t np = w.npos[t.pair];
+        unsigned long long order = 0;                       // not in the mapped list: the original (or shifted original) position
+        for (uint32_t j = 0; j < np; ++j) if (P[j] == p) { order = j + 1; break; }
+        const unsigned long long key = (unsigned long long)(uint32_t)pen << 32 | order << 8;
+        w.task_key[ti] = key;
+        hw::atomic_min_u64(w.pair_key + t.pair, key);
+        return;
+    }
     hw::atomic_min_i32(w.pair_best + t.pair, pen);
+}
+
+// Align mode, second pass: the task that won its pair walks its backpointers once more (simple per-step walker) and writes the
+// alignment as run-length classes of its columns = make_cigar (pair_hmm.hpp:152-188), last column first, plus the mapping position
+// target_offset - pad + first_pos (simd_align :817).
+template <int B, int TPR, int C>
+OCT_KERNEL(k_walk_cigar)(WalkParams w)
+{
+    constexpr uint32_t ROWS = 64 * C / B, G = TPR * ROWS;
+    const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (ti >= w.n_tasks) return;
+    const DevTask t = w.tasks[ti];
+    if (t.pair == kPadTask) return;
+    const unsigned long long key = w.task_key[ti];
+    if (key == ~0ull || key != w.pair_key[t.pair]) return;
+    const TraceEnd end = w.ends[ti];
+    const uint32_t group = ti / G, slot = ti % G, row = slot / TPR, half = slot % TPR;
+    const uint32_t ro = w.roff[t.read]; const int32_t T = (int32_t)(w.roff[t.read + 1] - ro);
+    const uint8_t* target = w.rbases + ro; const uint8_t* truth = w.hbases + w.hoff[t.hap] + t.off;
+    const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
+    const uint32_t* bpg = w.bp + (size_t)group * w.k_cap * C * 1024;
+    auto bits_at = [&](int64_t flat) -> uint32_t {          // 6 backpointer bits of band cell `flat` = diagonal * B + lane
+        const int32_t s = (int32_t)(flat / B), i = (int32_t)(flat % B);
+        if (s >= 2 * (T + B)) return 0;
+        const uint32_t k = (uint32_t)s >> 1;
+        const size_t line = C == 1 ? (size_t)(k >> 4) * 64 + row * B + (uint32_t)i : ((size_t)(k >> 4) * C + (uint32_t)i % C) * 64 + (uint32_t)i / C;
+        return (bpg[line * 16 + (k & 15)] >> (16 * half + 6 * (s & 1))) & 63u;
+    };
+    uint32_t* ops = w.cig_ops + (size_t)t.pair * w.cig_cap;
+    uint32_t n_ops = 0, cur = 0, run = 0;
+    auto column = [&](uint32_t op) {
+        if (op == cur) { ++run; return; }
+        if (run) { if (n_ops < w.cig_cap) ops[n_ops] = run << 4 | cur; ++n_ops; }
+        cur = op; run = 1;
+    };
+    int32_t sidx = end.sidx, i = sidx / 2 - T, y = T, x = sidx - y;
+    uint32_t state = bits_at((int64_t)sidx * B + i) & 3u;   // set_alignments :191 (this task's walk succeeded in k_walk)
+    sidx -= 2;
+    while (y > 0) {
+        const int64_t f = (int64_t)sidx * B + i;
+        if (sidx < 0 || i < 0 || f >= n_flat) break;
+        const uint32_t bits = bits_at(f);
+        const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;
+        if (state == 0) { sidx -= 2; --x; --y; column(truth[x] == target[y] ? 7u : 8u); }          // '=' / X
+        else if (state == 1) { i += sidx & 1; sidx -= 1; --y; column(1u); }                         // I
+        else { sidx -= 1; i -= sidx & 1; --x; column(2u); }                                         // D
+        state = new_state;
+    }
+    if (run) { if (n_ops < w.cig_cap) ops[n_ops] = run << 4 | cur; ++n_ops; }
+    w.cig_n[t.pair] = n_ops;
+    w.cig_mpos[t.pair] = t.off + (uint32_t)x;               // first_pos = x
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1335,6 +1410,36 @@ OCT_KERNEL(k_epilogue)(DevBatch b, double* out, uint64_t out0, uint64_t out1)
         acc = acc + res;
     }
     out[o] = acc;
+}
+
+// Align mode: Alignment::likelihood per pair (mapping-quality mixture, model.cpp:416-429) and the alignment itself where the winner
+// was an exact match found by the classifier (try_naive_align: the whole read as one '=' run at its position).
+OCT_KERNEL(k_epilogue_align)(DevBatch b, uint64_t pair0, uint64_t pair1, double* lik, uint32_t* mpos, uint32_t* n_ops, uint32_t* ops, uint32_t cap)
+{
+    const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (e >= pair1) return;
+    const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
+    const uint32_t g = b.hap_region[h];
+    const uint32_t r = b.reg_read0[g] + (uint32_t)(e - b.hap_pair_off[h]);
+    const unsigned long long key = b.pair_key[e];
+    const double ln_given_mapped = key == ~0ull ? kLowest : -kLn10Div10 * (double)(uint32_t)(key >> 32);
+    double res = ln_given_mapped;
+    if (b.use_mapq) {
+        int32_t mq = b.rmapq[r];
+        if (b.mapq_trigger >= 0 && mq >= b.mapq_trigger) mq = b.mapq_cap & 0xff;
+        const double ln_miss = -kLn10Div10 * mq;
+        const double ln_mapped = log(1.0 - exp(ln_miss));
+        const double x = ln_mapped + ln_given_mapped, y = ln_miss;
+        const double lo = x < y ? x : y, hi = x < y ? y : x;
+        res = hi + log1p(exp(lo - hi));
+    }
+    lik[e] = res > -1e-15 ? 0.0 : res;
+    if (key != ~0ull && (key & 1ull)) {
+        const uint32_t order = (uint32_t)(key >> 8) & 0xffu;
+        mpos[e] = order == 0 ? b.pair_extra[e] : b.pos[e * (uint64_t)b.max_pos + (order - 1)];
+        n_ops[e] = 1;
+        if (cap) ops[e * (uint64_t)cap] = (b.roff[r + 1] - b.roff[r]) << 4 | 7u;
+    }
 }
 
 } // namespace octphmm

@@ -65,6 +65,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_kernel_time.argtypes = [pv, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         lib.oct_phmm_batch_kernel_time_by_kind.argtypes = [pv, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32 * 4)]
         lib.oct_phmm_batch_genotype_likelihoods.argtypes = [pv, pv, pv, pv, pv]
+        lib.oct_phmm_align.argtypes = [pv, pv, pv, pv, pv, pv, pv, pv]
         lib.oct_phmm_batch_free.argtypes = [pv, pv]
         _LIBS[key] = lib
     return _LIBS[key]
@@ -191,6 +192,17 @@ class Engine:
         if code != abi.OK and raise_on_error:
             raise EngineError(code, st, "populate")
         return out[:batch.out_size()], st
+
+    def align(self, batch: abi.Batch, max_cigar_ops: int = 64, raise_on_error: bool = True):
+        """HaplotypeLikelihoodModel::align for every (haplotype, read) pair (oct_phmm_align). Returns (result dict, status)."""
+        n = batch.n_read_pairs()
+        out, arrays = abi.Alignments.make(n, max_cigar_ops)
+        st = abi.Status()
+        r, h, g, f, p = batch.c_args()
+        code = self.lib.oct_phmm_align(self.handle, _vp(r), _vp(h), _vp(g), _vp(f), _vp(p), C.byref(out), C.byref(st))
+        if code != abi.OK and raise_on_error:
+            raise EngineError(code, st, "align")
+        return abi.alignments_result(arrays, n, max_cigar_ops), st
 
     def upload(self, batch: abi.Batch) -> ResidentBatch:
         return ResidentBatch(self, batch)

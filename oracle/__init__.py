@@ -162,6 +162,17 @@ def populate(cfg: abi.Config, batch: abi.Batch, n_threads: int = 1):
     return out[:batch.out_size()], st, stats.as_dict()
 
 
+def align_batch(cfg: abi.Config, batch: abi.Batch, max_cigar_ops: int = 64, n_threads: int = 1):
+    """HaplotypeLikelihoodModel::align for every (haplotype, read) pair on the CPU oracle. Returns (result dict, status)."""
+    n = batch.n_read_pairs()
+    out, arrays = abi.Alignments.make(n, max_cigar_ops)
+    st = abi.Status()
+    r, h, g, f, p = batch.c_args()
+    code = lib().oracle_align_batch(C.byref(cfg), r, h, g, f, p, C.byref(out), C.byref(st), int(n_threads))
+    assert code == st.code
+    return abi.alignments_result(arrays, n, max_cigar_ops), st
+
+
 def genotype_likelihoods(lik, hap_out_off, genotypes, rows=None):
     """ConstantMixtureGenotypeLikelihoodModel::evaluate for an [n, ploidy] array of sorted haplotype indices over the
     flat matrix `lik` (populate's output); rows = (begin, end) within the region, default all."""

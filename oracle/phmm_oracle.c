@@ -532,6 +532,8 @@ typedef struct {
     uint64_t* hap_pair_off;       /* [n_haps+1] reads */
     uint16_t* read_hashes;        /* concatenated per read, offset = reads->offsets[r] */
     double* out;
+    const oct_phmm_alignments* aln;   /* non-NULL: HaplotypeLikelihoodModel::align mode (oracle_align_batch) */
+    int aln_error; uint32_t aln_needed_ops;   /* 1 = HMMOverflow, 2 = cigar capacity */
     /* per-haplotype error records (ShortHaplotypeError) */
     uint8_t* hap_err; uint32_t* hap_err_read; uint32_t* hap_err_ext;
     volatile uint32_t next_hap; uint32_t n_items; uint32_t* hap_item_off;   /* work items = (haplotype, ROW_CHUNK rows) */
@@ -625,6 +627,143 @@ static int evaluate_read(pop_ctx* c, worker_state* w, uint32_t h, uint32_t r, ui
     return 0;
 }
 
+/* make_cigar, pair_hmm.hpp:152-188: run-length classes of the alignment columns. Returns the number of operations (they are
+ * written while they fit in cap). */
+static uint32_t make_cigar(const char* a1, const char* a2, uint32_t* ops, uint32_t cap)
+{
+    size_t n = strlen(a1);                                 /* last non-zero char of align1 (:157) */
+    uint32_t k = 0; size_t i = 0;
+    while (i < n) {
+        uint32_t op; size_t j = i;
+        if (a1[i] == a2[i]) { while (j < n && a1[j] == a2[j]) ++j; op = OCT_PHMM_CIGAR_EQ; }                   /* std::mismatch :162-166 */
+        else if (a1[i] == '-') { while (j < n && a1[j] == '-') ++j; op = OCT_PHMM_CIGAR_INS; }                 /* :168-173 */
+        else if (a2[i] == '-') { while (j < n && a2[j] == '-') ++j; op = OCT_PHMM_CIGAR_DEL; }                 /* :174-179 */
+        else { ++j; while (j < n && a1[j] != a2[j] && a1[j] != '-' && a2[j] != '-') ++j; op = OCT_PHMM_CIGAR_X; }   /* :180-185 */
+        if (k < cap) ops[k] = (uint32_t)(j - i) << 4 | op;
+        ++k; i = j;
+    }
+    return k;
+}
+
+typedef struct { double likelihood; uint32_t target_offset; uint32_t n_ops; int overflow; } one_alignment;
+
+/* hmm::align, pair_hmm.hpp:861-872 = try_naive_align :321-341, else simd_align :788-823 */
+static one_alignment hmm_align(pop_ctx* c, worker_state* w, const char* truth, int Lh, const char* target, int T, const uint8_t* quals,
+                               uint32_t target_offset, const int8_t* go, const int8_t* ge, const char* mask, const int8_t* prior,
+                               uint32_t lhs_flank, uint32_t rhs_flank, uint32_t* ops, uint32_t cap)
+{
+    one_alignment r; memset(&r, 0, sizeof(r));
+    if (memcmp(target, truth + target_offset, (size_t)T) == 0) {            /* try_naive_align */
+        r.likelihood = 0; r.target_offset = target_offset; r.n_ops = 1;
+        if (cap) ops[0] = (uint32_t)T << 4 | OCT_PHMM_CIGAR_EQ;
+        return r;
+    }
+    const int pad = c->band, L = T + 2 * pad - 1;
+    int alignment_offset = (int)target_offset - pad; if (alignment_offset < 0) alignment_offset = 0;   /* :799 */
+    if (alignment_offset + L > Lh) { r.likelihood = OCT_PHMM_LOWEST; return r; }                      /* :800-805 */
+    const size_t need = (size_t)(2 * (T + pad)) + 1;
+    aln_scratch* scr = &w->scr;
+    if (scr->cap < need) { scr->a1 = (char*)realloc(scr->a1, need); scr->a2 = (char*)realloc(scr->a2, need); scr->cap = need; }
+    memset(scr->a1, 0, need); memset(scr->a2, 0, need);
+    int first_pos = 0, st = 0;
+    const int8_t* q8 = (const int8_t*)quals;
+    int score = g_align(c->band, c->score_bits, truth + alignment_offset, target, q8, L, T, mask + alignment_offset, prior + alignment_offset,
+                        go + alignment_offset, ge + alignment_offset, 0, c->cfg->nuc_prior, 1, &first_pos, scr->a1, scr->a2, &st);
+    if (first_pos == -1) { r.overflow = 1; return r; }                                                /* throw HMMOverflow :811-813 */
+    /* discount_flank_score :646-673 */
+    const int adjusted = (uint64_t)target_offset < ((uint64_t)lhs_flank + (uint64_t)pad)
+        || ((uint64_t)target_offset + (uint64_t)T + (uint64_t)pad) > ((uint64_t)Lh - (uint64_t)rhs_flank);
+    if (adjusted) {
+        int lhs = (int)lhs_flank;
+        if (lhs < alignment_offset) lhs = 0; else { lhs -= alignment_offset; if (lhs < 0) lhs = 0; }
+        int rhs = (int)rhs_flank;
+        if (alignment_offset + L < Lh - rhs) rhs = 0; else { rhs += alignment_offset + L; rhs -= Lh; if (rhs < 0) rhs = 0; }
+        int target_mask_size = 0;
+        int flank_score = g_flank(c->band, c->score_bits, L, lhs, rhs, target, q8, mask + alignment_offset, prior + alignment_offset,
+                                  go + alignment_offset, ge + alignment_offset, c->cfg->nuc_prior, first_pos, scr->a1, scr->a2,
+                                  &target_mask_size, &st);
+        if (T - target_mask_size < 2) flank_score = 0;
+        if (flank_score <= score) score -= flank_score; else score += flank_score;
+    }
+    r.target_offset = target_offset - (uint32_t)pad + (uint32_t)first_pos;                            /* :817 */
+    r.likelihood = -LN10_DIV_10 * (double)score;
+    r.n_ops = make_cigar(scr->a1, scr->a2, ops, cap);
+    return r;
+}
+
+/* HaplotypeLikelihoodModel::align(read, first, last), haplotype_likelihood_model.cpp:397-431 with compute_optimal_alignment :335-395.
+ * Returns 0 ok, 1 ShortHaplotypeError (ext filled), 2 HMMOverflow. */
+static int align_read(pop_ctx* c, worker_state* w, uint32_t h, uint32_t r, uint32_t lhs, uint32_t rhs, const uint32_t* pos, int npos,
+                      uint64_t pair, uint32_t* ext)
+{
+    const oct_phmm_reads* R = c->reads; const oct_phmm_haplotypes* H = c->haps;
+    const uint32_t ro = R->offsets[r], T = R->offsets[r + 1] - ro;
+    const uint32_t ho = H->offsets[h], Lh = H->offsets[h + 1] - ho;
+    const char* target = R->bases + ro; const uint8_t* quals = R->qualities + ro; const char* truth = H->bases + ho;
+    const int is_forward = !R->reverse_strand[r];
+    const char* mask = (is_forward ? H->snv_mask_fwd : H->snv_mask_rev) + ho;
+    const int8_t* prior = (is_forward ? H->snv_prior_fwd : H->snv_prior_rev) + ho;
+    const int8_t* go = H->gap_open + ho; const int8_t* ge = H->gap_extend + ho;
+    const unsigned pad = (unsigned)c->band;
+    const uint64_t original = (uint64_t)(R->ref_begin[r] - H->ref_begin[h]);
+    const uint32_t cap = c->aln->max_cigar_ops;
+    uint32_t* best_ops = c->aln->cigar + pair * cap;
+    uint32_t* tmp = (uint32_t*)malloc(((size_t)cap + 1) * sizeof(uint32_t));
+    one_alignment best; memset(&best, 0, sizeof(best)); best.likelihood = OCT_PHMM_LOWEST;
+    int orig_mapped = 0, has_in_range = 0, rc = 0;
+#define ALIGN_AT(p, accept_equal) do { \
+        one_alignment a_ = hmm_align(c, w, truth, (int)Lh, target, (int)T, quals, (uint32_t)(p), go, ge, mask, prior, lhs, rhs, tmp, cap); \
+        if (a_.overflow) { rc = 2; goto done; } \
+        if ((accept_equal) ? a_.likelihood >= best.likelihood : a_.likelihood > best.likelihood) { \
+            best = a_; memcpy(best_ops, tmp, (size_t)(a_.n_ops < cap ? a_.n_ops : cap) * sizeof(uint32_t)); } \
+    } while (0)
+    for (int j = 0; j < npos; ++j) {                                        /* :349-362 */
+        const uint64_t p = pos[j];
+        if (p == original) orig_mapped = 1;
+        if (num_out_of_range_bases(p, T, Lh, pad) == 0) { has_in_range = 1; ALIGN_AT(p, 0); }
+    }
+    if (!orig_mapped && num_out_of_range_bases(original, T, Lh, pad) == 0) { has_in_range = 1; ALIGN_AT(original, 1); }   /* :363-371 */
+    if (!has_in_range) {                                                    /* :372-392 */
+        const int min_shift = num_out_of_range_bases(original, T, Lh, pad);
+        uint64_t final_pos = original;
+        if (min_shift > 0) {
+            final_pos += (uint64_t)min_shift;
+            if (num_out_of_range_bases(final_pos, T, Lh, pad) != 0) { *ext = (unsigned)min_shift; rc = 1; goto done; }
+        } else {
+            const unsigned min_left_shift = (unsigned)(-min_shift);
+            if (original >= min_left_shift) final_pos -= min_left_shift;
+            else { *ext = (uint32_t)(min_left_shift - original); rc = 1; goto done; }
+        }
+        best.likelihood = OCT_PHMM_LOWEST;
+        ALIGN_AT(final_pos, 1);                                             /* assigned unconditionally :388-391 */
+    }
+#undef ALIGN_AT
+    {
+        double res = best.likelihood;
+        if (c->cfg->use_mapping_quality) {                                  /* :416-427 */
+            int mq = R->mapping_quality[r];
+            if (c->cfg->mapping_quality_cap_trigger >= 0 && c->cfg->mapping_quality_cap_trigger < c->cfg->mapping_quality_cap
+                && mq >= c->cfg->mapping_quality_cap_trigger) mq = c->cfg->mapping_quality_cap;
+            mq &= 0xFF;
+            const double ln_missmapped = -LN10_DIV_10 * mq, ln_mapped = log(1.0 - exp(ln_missmapped));
+            const double a = ln_mapped + res, b = ln_missmapped;
+            const double lo = a < b ? a : b, hi = a < b ? b : a;
+            res = hi + log1p(exp(lo - hi));
+        }
+        res = res > -1e-15 ? 0.0 : res;
+        c->aln->likelihood[pair] = res; c->aln->mapping_position[pair] = best.target_offset; c->aln->n_cigar_ops[pair] = best.n_ops;
+        if (best.n_ops > cap) {
+            pthread_mutex_lock(&c->mu);
+            if (c->aln_error == 0) c->aln_error = 3;
+            if (best.n_ops > c->aln_needed_ops) c->aln_needed_ops = best.n_ops;
+            pthread_mutex_unlock(&c->mu);
+        }
+    }
+done:
+    free(tmp);
+    return rc;
+}
+
 #define ROW_CHUNK 128   /* rows per work item: (haplotype, row chunk) items keep every host core busy even with few haplotypes */
 
 static void populate_haplotype(pop_ctx* c, worker_state* w, uint32_t h, uint32_t chunk)
@@ -656,7 +795,12 @@ static void populate_haplotype(pop_ctx* c, worker_state* w, uint32_t h, uint32_t
             }
             double v = 0; uint32_t ext = 0;
             ++w->st.n_pairs;
-            if (evaluate_read(c, w, h, r, lhs, rhs, pos, npos, &v, &ext)) {
+            int erc;
+            if (c->aln) {
+                erc = align_read(c, w, h, r, lhs, rhs, pos, npos, c->hap_pair_off[h] + (r - first_read), &ext);
+                if (erc == 2) { pthread_mutex_lock(&c->mu); c->aln_error = 2; pthread_mutex_unlock(&c->mu); erc = 0; }
+            } else erc = evaluate_read(c, w, h, r, lhs, rhs, pos, npos, &v, &ext);
+            if (erc) {
                 pthread_mutex_lock(&c->mu);                                 /* keep the first failing read of this haplotype in serial order */
                 if (!c->hap_err[h] || r < c->hap_err_read[h]) { c->hap_err[h] = 1; c->hap_err_read[h] = r; c->hap_err_ext[h] = ext; }
                 pthread_mutex_unlock(&c->mu);
@@ -664,7 +808,7 @@ static void populate_haplotype(pop_ctx* c, worker_state* w, uint32_t h, uint32_t
             }
             acc = acc + v;
         }
-        c->out[c->hap_out_off[h] + (row - reg_row0)] = acc;
+        if (!c->aln) c->out[c->hap_out_off[h] + (row - reg_row0)] = acc;
     }
 }
 
@@ -694,15 +838,16 @@ static int set_status(oct_phmm_status* st, int code, const char* msg)
     return code;
 }
 
-int oracle_populate(const oct_phmm_config* cfg,
+static int populate_impl(const oct_phmm_config* cfg,
         const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
         const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
         const oct_phmm_positions* positions,
-        double* out, oct_phmm_status* status, oct_phmm_stats* stats, int n_threads)
+        double* out, const oct_phmm_alignments* aln, oct_phmm_status* status, oct_phmm_stats* stats, int n_threads)
 {
-    if (!cfg || !reads || !haps || !out) return set_status(status, OCT_PHMM_EINVAL, "null argument");
+    if (!cfg || !reads || !haps || (!out && !aln)) return set_status(status, OCT_PHMM_EINVAL, "null argument");
+    if (aln && reads->row_offsets) return set_status(status, OCT_PHMM_EINVAL, "alignments are per read: row_offsets must be NULL");
     pop_ctx c; memset(&c, 0, sizeof(c));
-    c.cfg = cfg; c.reads = reads; c.haps = haps; c.positions = positions; c.out = out;
+    c.cfg = cfg; c.reads = reads; c.haps = haps; c.positions = positions; c.out = out; c.aln = aln;
     c.band = oracle_band_size(cfg->max_indel_error);
     if (c.band < 0) return set_status(status, OCT_PHMM_EBAND, "requested band size is too large");
     c.score_bits = cfg->use_int_scores ? 32 : 16;
@@ -759,9 +904,35 @@ int oracle_populate(const oct_phmm_config* cfg,
         if (status) { status->hap_index = h; status->read_index = c.hap_err_read[h]; status->required_extension = c.hap_err_ext[h]; }
         break;
     }
+    if (code == OCT_PHMM_OK && c.aln_error == 2) code = set_status(status, OCT_PHMM_EOVERFLOW, "Pair HMM alignment overflowed");
+    if (code == OCT_PHMM_OK && c.aln_error == 3) {
+        code = set_status(status, OCT_PHMM_EINVAL, "max_cigar_ops too small");
+        if (status) status->required_extension = c.aln_needed_ops;
+    }
     if (stats) *stats = c.stats;
     free(c.hap_item_off); free(c.hap_region); free(c.hap_out_off); free(c.hap_pair_off); free(c.hap_err); free(c.hap_err_read); free(c.hap_err_ext); free(c.read_hashes);
     return code;
+}
+
+int oracle_populate(const oct_phmm_config* cfg,
+        const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
+        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+        const oct_phmm_positions* positions,
+        double* out, oct_phmm_status* status, oct_phmm_stats* stats, int n_threads)
+{
+    if (!out) return set_status(status, OCT_PHMM_EINVAL, "null argument");
+    return populate_impl(cfg, reads, haps, regions, flank, positions, out, NULL, status, stats, n_threads);
+}
+
+int oracle_align_batch(const oct_phmm_config* cfg,
+        const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
+        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+        const oct_phmm_positions* positions,
+        const oct_phmm_alignments* out, oct_phmm_status* status, int n_threads)
+{
+    if (!out || !out->mapping_position || !out->likelihood || !out->n_cigar_ops || !out->cigar)
+        return set_status(status, OCT_PHMM_EINVAL, "null argument");
+    return populate_impl(cfg, reads, haps, regions, flank, positions, NULL, out, status, NULL, n_threads);
 }
 
 /* ------------------------------------------------------------------------------------------------ */

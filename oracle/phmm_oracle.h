@@ -84,6 +84,15 @@ int oracle_populate(const oct_phmm_config* cfg,
         const oct_phmm_positions* positions,
         double* out, oct_phmm_status* status, oct_phmm_stats* stats, int n_threads);
 
+/* HaplotypeLikelihoodModel::align (haplotype_likelihood_model.cpp:322-431) for every (haplotype, read) pair of the flat batch:
+ * compute_optimal_alignment :335-395 over hmm::align (pair_hmm.hpp:861-872 = try_naive_align :321-341 | simd_align :788-823,
+ * make_cigar :152-188, discount_flank_score :646-673). Same conventions as oct_phmm_align. PARITY UNPINNED above L1 (no reference test). */
+int oracle_align_batch(const oct_phmm_config* cfg,
+        const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
+        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+        const oct_phmm_positions* positions,
+        const oct_phmm_alignments* out, oct_phmm_status* status, int n_threads);
+
 /* Raw-kernel timing loop for the CPU baseline: runs the current L1 backend's score-only or traceback align over
  * n windows `reps` times with n_threads threads; returns seconds. */
 double oracle_time_align_windows(int band, int score_bits, uint32_t n,

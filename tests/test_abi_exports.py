@@ -26,7 +26,8 @@ def lib():
 def test_header_declares_the_boundary():
     names = declared_functions()
     for need in ("oct_phmm_create", "oct_phmm_destroy", "oct_phmm_populate", "oct_phmm_batch_upload", "oct_phmm_batch_run",
-                 "oct_phmm_batch_wait", "oct_phmm_batch_download", "oct_phmm_align_windows"):
+                 "oct_phmm_batch_wait", "oct_phmm_batch_download", "oct_phmm_align_windows", "oct_phmm_align",
+                 "oct_phmm_batch_genotype_likelihoods"):
         assert need in names
 
 

@@ -188,3 +188,19 @@ def test_gpu_concurrent_handles_from_host_threads():
     for t in range(n_threads):
         for i in range(per_thread):
             assert np.array_equal(got[t][i], want[t][i])
+
+
+def test_gpu_align_best_alignment_and_cigar_per_pair():
+    import check_align as ca
+    ca.check_align_basic("gpu")
+    ca.check_align_positions_and_options("gpu")
+    ca.check_align_errors("gpu")
+
+
+def test_gpu_align_realigner_sized_batch():
+    """read_realigner's shape: many reads against few haplotypes, device mapping; vs the oracle on all pairs."""
+    import check_align as ca
+    rng = np.random.default_rng(41)
+    batch = synth.batch_from_regions([synth.make_region(rng, 3000, 4, B=16, positions="none")])
+    got = ca.compare_align("gpu", batch, max_indel_error=16)
+    assert len(got["cigar_strings"]) == 12000

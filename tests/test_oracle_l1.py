@@ -90,3 +90,23 @@ def test_oracle_matches_reference_on_int16_overflow():
             b = oracle.align(band, 16, c["truth"], c["target"], c["quals"], c["gap_open"], c["gap_extend"], 1,
                              snv_mask=c["mask"], snv_prior=c["prior"], traceback=tb, backend="sse2")
             assert a == b, (it, tb, a["score"], b["score"])
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="reference build absent")
+def test_oracle_align_batch_is_the_same_on_reference_kernels():
+    """The align path (best position, CIGAR, likelihood) restated above L1 gives identical answers whether its band kernel is the
+    restatement or the reference's own SIMD build."""
+    import numpy as np
+    from octopus_amd import abi, synth
+    rng = np.random.default_rng(8)
+    batch = synth.batch_from_regions([synth.make_region(rng, 60, 5, B=16, positions="none", indels_per_read=1)])
+    cfg = abi.Config.default(max_indel_error=16)
+    a, sa = oracle.align_batch(cfg, batch, 64)
+    oracle.set_l1_backend("sse2")
+    try:
+        b, sb = oracle.align_batch(cfg, batch, 64)
+    finally:
+        oracle.set_l1_backend("oracle")
+    assert sa.code == sb.code == abi.OK
+    assert a["cigar_strings"] == b["cigar_strings"]
+    assert np.array_equal(a["mapping_position"], b["mapping_position"]) and np.array_equal(a["likelihood"], b["likelihood"])
