@@ -187,6 +187,50 @@ def genotype_likelihoods(lik, hap_out_off, genotypes, rows=None):
     return out[:len(g)]
 
 
+class ErrorModel(C.Structure):
+    """oct_phmm_error_model (oracle/error_model_oracle.h): the model tables as the reference's constructors expand them."""
+    _fields_ = [(n, C.c_int8 * 50) for n in ("at_homopolymer_open", "cg_homopolymer_open", "dinucleotide_open", "trinucleotide_open",
+                                            "homopolymer_extend", "dinucleotide_extend", "trinucleotide_extend")] + \
+               [("snv_caps", (C.c_int8 * 51) * 3), ("use_snv_model", C.c_int32)]
+
+    @staticmethod
+    def make(at_open, cg_open, di_open, tri_open, snv_caps, homo_ext=(3, 3, 3, 3, 3, 3, 4, 5, 6, 6, 8, 8, 7, 6, 5, 4, 3),
+             di_ext=(3, 3, 5, 4, 3, 2), tri_ext=(3, 3, 5, 4, 3, 2)):
+        m = ErrorModel()
+        def fill(dst, src, n):                      # copy(): first min(size, N) entries, the rest = the last one
+            for i in range(n):
+                dst[i] = src[i] if i < len(src) else src[-1]
+        for name, src in (("at_homopolymer_open", at_open), ("cg_homopolymer_open", cg_open), ("dinucleotide_open", di_open),
+                          ("trinucleotide_open", tri_open), ("homopolymer_extend", homo_ext), ("dinucleotide_extend", di_ext),
+                          ("trinucleotide_extend", tri_ext)):
+            fill(getattr(m, name), src, 50)
+        for p in range(3):
+            fill(m.snv_caps[p], snv_caps[p], 51)
+        m.use_snv_model = 1
+        return m
+
+
+def tandem_repeats(seq, min_period=1, max_period=5, backend="oracle"):
+    """tandem::extract_exact_tandem_repeats -> [(pos, length, period)] from the restatement or the reference's library (oracle/_ref)."""
+    s = bytes(seq)
+    cap = 4 * len(s) + 64
+    out = (C.c_uint32 * (3 * cap))()
+    n = (lib().oracle_tandem_repeats if backend == "oracle" else ref().ref_tandem_repeats)(s, len(s), int(min_period), int(max_period), out, cap)
+    assert n <= cap
+    return [(out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i in range(n)]
+
+
+def penalty_vectors(model: "ErrorModel", seq, substitution_mask=None):
+    """HaplotypeLikelihoodModel::reset's six vectors for one haplotype sequence: (gap_open, gap_extend, mask_fwd, prior_fwd, mask_rev, prior_rev)."""
+    s = bytes(seq); n = len(s)
+    go, ge, pf, pr = (np.zeros(n, np.int8) for _ in range(4))
+    mf, mr = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    lib().oracle_indel_penalties(C.byref(model), s, n, _p(go), _p(ge))
+    lib().oracle_snv_priors(C.byref(model), s, n, _p(None if substitution_mask is None else np.asarray(substitution_mask, np.uint8)),
+                            _p(mf), _p(pf), _p(mr), _p(pr))
+    return go, ge, mf, pf, mr, pr
+
+
 def time_align_windows(band, score_bits, truth, truth_offsets, target, quals, target_offsets, gap_open, gap_extend,
                        snv_mask, snv_prior, nuc_prior=2, traceback=False, reps=1, n_threads=1):
     """Seconds to run the current L1 backend over all windows `reps` times (CPU baseline leg of bench.py)."""
