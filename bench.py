@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--band", type=int, default=16)
     ap.add_argument("--regions", type=int, default=2000, help="--workload stream: active regions per rank per step (BASELINE configs[3] stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the 1k x 64 latency leg (for rocprof runs: keeps every k_dp launch full-size)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -194,7 +195,7 @@ def main():
                                   "note": "the DP is integer-VALU issue bound, not HBM bound (SURVEY.md 8d): loop-body wave-instructions (ISA count) x iterations "
                                           "/ DP kernel time vs 256 CU x 4 SIMD x 2.4 GHz / 4 cycles; PMC: SQ_ACTIVE_INST_VALU x 4 / (CU x SIMD) = 91-93 % of kernel cycles"}},
         }
-        if world == 1:
+        if world == 1 and not args.no_small_batch:
             small = eng.upload(synth.config_batch("1kx64", seed=42, B=B, positions="none"))
             for _ in range(3):
                 small.run(); small.wait()
@@ -203,8 +204,8 @@ def main():
                 small.run(); small.wait()
             out["small_batch_ms"] = (time.perf_counter() - t1) / 10 * 1e3
             small.free()
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(B, seed=42)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, seed=42)
         print(json.dumps(out))
     rb.free()
     eng.close()
