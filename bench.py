@@ -144,6 +144,7 @@ def main():
         # durations are taken from a single-slice run of the same batch, where every launch has the device to itself.
         # Dominant kernel = k_dp<B, TRACE=true, fast cost, FASTADD> (the traceback DP); HIP events on the library's stream.
         os.environ["OCT_PHMM_SLICES"] = "1"
+        eng.set_timing(True)
         rb1 = eng.upload(batch)
         del os.environ["OCT_PHMM_SLICES"]
         rb1.run(); rb1.wait()

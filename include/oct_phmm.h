@@ -179,6 +179,9 @@ size_t oct_phmm_batch_out_size(const oct_phmm_batch* b); /* number of doubles `o
 /* Average device time (ms) of the last run's dominant DP kernel launches measured with HIP events on the
  * handle's stream, and the number of launches; for bench.py's roofline block. */
 int  oct_phmm_batch_kernel_time(const oct_phmm_batch* b, double* dp_kernel_ms, uint32_t* dp_launches);
+/* DP launches are bracketed with HIP events only while timing is enabled (off by default: four event records per
+ * region-sized call are measurable; also enabled by the environment variable OCT_PHMM_TIMING). */
+int  oct_phmm_set_timing(oct_phmm_handle* h, int enabled);
 /* The same, split by DP kernel kind: [0] score-only/fast-cost, [1] traceback/fast-cost, [2] score-only/generic,
  * [3] traceback/generic. With more than one slice the launches of different slices overlap on the device, so
  * per-launch durations are only meaningful for a single-slice run (OCT_PHMM_SLICES=1). */

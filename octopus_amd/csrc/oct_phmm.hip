@@ -65,6 +65,7 @@ struct oct_phmm_handle {
     void* stage = nullptr; size_t stage_bytes = 0;       // pinned host staging: all input arrays of a batch go up in ONE copy
     void* out_stage = nullptr; size_t out_stage_bytes = 0;   // pinned landing zone for slice-wise result copies (oct_phmm_populate)
     std::vector<rt::Event> ev_pool;                      // recycled timing / completion events
+    bool timing = false;                                 // HIP-event timing of the DP launches (oct_phmm_set_timing; bench.py's roofline leg)
     bool get_event(rt::Event* e) { if (!ev_pool.empty()) { *e = ev_pool.back(); ev_pool.pop_back(); return true; } return rt::event_create(e); }
     void put_event(rt::Event e) { ev_pool.push_back(e); }
     int band = 0;
@@ -105,7 +106,7 @@ struct oct_phmm_batch {
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
-    rt::Event ev_fork {}, ev_join {};
+    rt::Event ev_fork {}, ev_join {}, ev_hashes {};
     // align mode (oct_phmm_align)
     bool align_mode = false; uint32_t cig_cap = 0;
     double* d_aln_lik = nullptr; uint32_t* d_aln_mpos = nullptr; uint32_t* d_aln_n = nullptr; uint32_t* d_aln_ops = nullptr; uint32_t* d_err_flags = nullptr;
@@ -114,6 +115,7 @@ struct oct_phmm_batch {
     bool map_big = false;         // haplotypes too long for the LDS-resident k-mer mapper
     bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
     uint32_t* d_blk_hap = nullptr; uint32_t* d_blk_read0 = nullptr; uint32_t n_map_blocks = 0;
+    uint32_t map_reads_per_block = 64;   // reads one k_kmer_map workgroup walks with the haplotype's bins staged once; fewer for small batches (latency)
     double dp_ms = 0; uint32_t dp_launches = 0;
     std::vector<std::pair<rt::Event, rt::Event>> timers;       // one (start, stop) pair per DP launch
     std::vector<int> timer_kind;
@@ -318,14 +320,12 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         p.tasks = tasks + (size_t)g0 * G; p.n_tasks = ng * G;
         p.bp = h->bp[slice]; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
         const uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
-        rt::Event e0, e1;
-        RT(h->get_event(&e0)); RT(h->get_event(&e1));
-        RT(rt::event_record(e0, st));
+        rt::Event e0 {}, e1 {};
+        if (h->timing) { RT(h->get_event(&e0)); RT(h->get_event(&e1)); RT(rt::event_record(e0, st)); }
         if (!(b->stream ? launch_dp_wide((int)C, tr, !h->wide, p, st)
                         : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
-        RT(rt::event_record(e1, st));
-        b->timers.emplace_back(e0, e1); b->timer_kind.push_back(kind);
+        if (h->timing) { RT(rt::event_record(e1, st)); b->timers.emplace_back(e0, e1); b->timer_kind.push_back(kind); }
         if (tr) {
             WalkParams w {};
             if (seam_walk) w = *seam_walk;
@@ -396,6 +396,7 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     h->cfg = *cfg; h->band = band; h->wide = cfg->use_int_scores != 0; h->lanes_c = band > 64 ? band / 64 : 1;
     if (h->cfg.mapping_quality_cap_trigger >= 0 && h->cfg.mapping_quality_cap_trigger >= h->cfg.mapping_quality_cap)
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
+    h->timing = getenv("OCT_PHMM_TIMING") != nullptr;
     if (const char* e = getenv("OCT_PHMM_BP_BUDGET_GB")) { const long gb = atol(e); if (gb > 0) h->bp_budget = (size_t)gb << 30; }
     if (!rt::stream_create(&h->stream)) return OCT_PHMM_EHIP;
     for (auto& es : h->extra_streams) if (!rt::stream_create(&es)) return OCT_PHMM_EHIP;
@@ -421,6 +422,13 @@ extern "C" void oct_phmm_destroy(oct_phmm_handle* h)
 
 extern "C" int oct_phmm_band_size(const oct_phmm_handle* h) { return h ? h->band : -1; }
 
+extern "C" int oct_phmm_set_timing(oct_phmm_handle* h, int enabled)
+{
+    if (!h) return OCT_PHMM_EINVAL;
+    h->timing = enabled != 0;
+    return OCT_PHMM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // upload
 // ---------------------------------------------------------------------------------------------------------------
@@ -432,7 +440,7 @@ extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
     for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
     for (void* p : b->allocs) h->pool.release(p);
     for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_ends); h->pool.release(sl.d_keys); h->put_event(sl.done); }
-    if (b->ev_fork) { h->put_event(b->ev_fork); h->put_event(b->ev_join); }
+    if (b->ev_fork) { h->put_event(b->ev_fork); h->put_event(b->ev_join); h->put_event(b->ev_hashes); }
     delete b;
 }
 
@@ -590,10 +598,11 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     if (!positions) {
         pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1); pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
         pk.dalloc(&d.rhash, (size_t)n_read_bases + 1);
-        std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, 64-read chunk of its region)
+        b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 64;
+        std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, read chunk of its region)
         for (uint32_t hp = 0; hp < H->n_haps; ++hp) {
             const uint32_t g = hap_region[hp];
-            for (uint32_t r = reg_read0[g]; r < first_read(g_row[g + 1]); r += kMapReadsPerBlock) { blk_hap.push_back(hp); blk_read0.push_back(r); }
+            for (uint32_t r = reg_read0[g]; r < first_read(g_row[g + 1]); r += b->map_reads_per_block) { blk_hap.push_back(hp); blk_read0.push_back(r); }
         }
         b->n_map_blocks = (uint32_t)blk_hap.size();
         b->h_blk_hap = blk_hap;
@@ -644,7 +653,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     }
     std::vector<uint32_t> ones(H->n_haps + 1, 1u);
     pk.upload(ones.data(), (size_t)H->n_haps, (const uint32_t**)&d.hclean);
-    RT(h->get_event(&b->ev_fork)); RT(h->get_event(&b->ev_join));
+    RT(h->get_event(&b->ev_fork)); RT(h->get_event(&b->ev_join)); RT(h->get_event(&b->ev_hashes));
     RT(pk.commit(h, bp, s));
     d.err_key = d.stats + (size_t)kStatSlots * 8;
     for (size_t i = 0; i < b->slices.size(); ++i) {
@@ -656,8 +665,10 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         RT(rt::h2d(d.npos, h_npos.data(), (size_t)b->n_pairs, s));
     }
     // per-read flags and per-base DP tables (once per batch; HaplotypeLikelihoodModel::reset analogue)
-    if (R->n_reads) { OCT_LAUNCH(k_read_flags, (R->n_reads + 255) / 256, 256, 0, s, d); RT(rt::launch_ok()); }
-    if (n_hap_bases) { OCT_LAUNCH(k_hap_tables, (n_hap_bases + 255) / 256, 256, 0, s, d, n_hap_bases); RT(rt::launch_ok()); }
+    {
+        const uint32_t table_blocks = (n_hap_bases + 255) / 256, flag_blocks = (R->n_reads + 255) / 256;
+        if (table_blocks + flag_blocks) { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks, 256, 0, s, d, n_hap_bases, table_blocks); RT(rt::launch_ok()); }
+    }
     RT(rt::stream_sync(s));
     *out = b.release();
     return ok(status);
@@ -676,16 +687,13 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     b->timers.clear(); b->timer_kind.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
     const uint32_t G = b->stream ? 1u : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
     const int S = (int)b->slices.size();
-    RT(rt::dev_memset(d.stats, 0, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s0));
-    RT(rt::dev_memset(d.err_key, 0xff, sizeof(unsigned long long), s0));
+    RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * 8 + 1) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key behind them
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
-    if (b->n_pairs && b->device_map) {
-        const uint32_t n_rb = b->h_roff[b->n_reads];      // compute_kmer_hashes once per read (array.cpp:118-131)
-        OCT_LAUNCH(k_read_hashes, (n_rb + 255) / 256, 256, 0, s0, d, n_rb); RT(rt::launch_ok());
+    if (S > 1) {
+        RT(rt::event_record(h->ev_ready, s0));
+        for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(h->slice_stream(i), h->ev_ready));
     }
-    RT(rt::event_record(h->ev_ready, s0));
-    for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(h->slice_stream(i), h->ev_ready));
 
     // phase 1 of a slice: candidate mapping, classification + scalar fast path, task counts -> slot offsets (everything up to the one
     // host read-back that sizes the DP launches)
@@ -695,7 +703,11 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         const uint64_t np = sl.pair1 - sl.pair0;
         if (!np) { sl.totals = make_uint4(0, 0, 0, 0); return OCT_PHMM_OK; }
         if (b->device_map) {                              // HaplotypeLikelihoodArray::populate maps per haplotype (array.cpp:118-158)
-            OCT_LAUNCH(k_kmer_tables, sl.hap1 - sl.hap0, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d, sl.hap0); RT(rt::launch_ok());
+            // slice 0's launch also hashes every read of the batch once (array.cpp:118-131); the other slices' mappers wait for it
+            const uint32_t n_rb = b->h_roff[b->n_reads], hash_blocks = i == 0 ? (n_rb + 255) / 256 : 0;
+            OCT_LAUNCH(k_kmer_tables, sl.hap1 - sl.hap0 + hash_blocks, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d, sl.hap0, sl.hap1 - sl.hap0, n_rb); RT(rt::launch_ok());
+            if (i == 0 && S > 1) RT(rt::event_record(b->ev_hashes, s));
+            if (i > 0) RT(rt::stream_wait_event(s, b->ev_hashes));
             if (b->map_big) {
                 const size_t lds = (size_t)b->lh_cap * 4 + 64;
                 if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_big, lds));
@@ -704,16 +716,19 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 const size_t lds = kmer_map_lds_bytes(b->lh_cap);
                 if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map, lds));
                 OCT_LAUNCH(k_kmer_map, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
-                           (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap); RT(rt::launch_ok());
+                           (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block); RT(rt::launch_ok());
             }
         }
-        RT(rt::dev_memset(sl.cnt + np, 0, sizeof(uint4), s));
         const uint32_t pair_blocks = (uint32_t)((np + 255) / 256);
         OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt); RT(rt::launch_ok());
         const uint64_t n_scan = np + 1;
-        OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 0); RT(rt::launch_ok());
-        OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.tile_sums, sl.n_tiles); RT(rt::launch_ok());
-        OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 1); RT(rt::launch_ok());
+        if (sl.n_tiles == 1) {
+            OCT_LAUNCH(k_scan_tiles, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 2); RT(rt::launch_ok());
+        } else {
+            OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 0); RT(rt::launch_ok());
+            OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.tile_sums, sl.n_tiles); RT(rt::launch_ok());
+            OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 1); RT(rt::launch_ok());
+        }
         OCT_LAUNCH(k_hap_bases, 1, 64, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, b->d_hap_base, sl.d_totals, G); RT(rt::launch_ok());
         RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s));
         return OCT_PHMM_OK;
@@ -785,9 +800,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     if (rc != OCT_PHMM_OK) return rc;
     for (int i = std::max(0, S - 2); i < S; ++i) { rc = deliver(i); if (rc != OCT_PHMM_OK) return rc; }
     for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(s0, b->slices[i].done));
-    b->h_stat_stripes.assign((size_t)kStatSlots * 8, 0);
-    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, (size_t)kStatSlots * 8 * sizeof(unsigned long long), s0));
-    RT(rt::d2h(&b->h_err_key, d.err_key, sizeof(unsigned long long), s0));
+    b->h_stat_stripes.assign((size_t)kStatSlots * 8 + 1, 0);  // counters + the inverted error key, one copy
+    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, ((size_t)kStatSlots * 8 + 1) * sizeof(unsigned long long), s0));
     b->ran = true;
     return ok(status);
 }
@@ -798,6 +812,7 @@ extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_ph
     RT(rt::set_device(h->cfg.device_id));
     RT(rt::stream_sync(h->stream));
     for (int k = 0; k < 6; ++k) { b->h_stats[k] = 0; for (uint32_t sl = 0; sl < kStatSlots; ++sl) b->h_stats[k] += b->h_stat_stripes[(size_t)sl * 8 + k]; }
+    b->h_err_key = ~b->h_stat_stripes[(size_t)kStatSlots * 8];
     b->dp_ms = 0; b->dp_launches = 0;
     for (int k = 0; k < kNumKinds; ++k) { b->kind_ms[k] = 0; b->kind_launches[k] = 0; }
     for (size_t i = 0; i < b->timers.size(); ++i) {

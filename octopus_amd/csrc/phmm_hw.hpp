@@ -75,6 +75,7 @@ OCT_DEVICE void block_sync() { __syncthreads(); }
 OCT_DEVICE int  atomic_min_i32(int32_t* p, int32_t v) { return atomicMin(p, v); }
 OCT_DEVICE unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
 OCT_DEVICE uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+OCT_DEVICE unsigned long long atomic_max_u64(unsigned long long* p, unsigned long long v) { return atomicMax(p, v); }
 OCT_DEVICE unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 OCT_DEVICE uint32_t atomic_and_u32(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
 OCT_DEVICE uint32_t thread_idx() { return threadIdx.x; }

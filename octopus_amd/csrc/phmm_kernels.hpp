@@ -41,9 +41,8 @@ OCT_DEVICE uint32_t upper_bound_idx(const T* a, uint32_t n, T v)   // largest i 
 // ------------------------------------------------------------------------------------------------------------------
 // per-read flags, per-haplotype-base DP tables
 // ------------------------------------------------------------------------------------------------------------------
-OCT_KERNEL(k_read_flags)(DevBatch b)
+OCT_DEVICE void read_flags_thread(const DevBatch& b, uint32_t r)
 {
-    const uint32_t r = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (r >= b.n_reads) return;
     uint32_t ok = 1;
     for (uint32_t i = b.roff[r]; i < b.roff[r + 1]; ++i) ok &= is_acgt(b.rbases[i]) ? 1u : 0u;
@@ -58,8 +57,11 @@ OCT_DEVICE uint32_t cap_of(uint32_t r, uint32_t h, uint32_t m, uint32_t p)
     return r == m ? p : 255u;
 }
 
-OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases)
+// Once per batch (HaplotypeLikelihoodModel::reset analogue): the per-base DP tables; the workgroups past `table_blocks` set the per-read
+// "pure ACGT" flags in the same launch.
+OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks)
 {
+    if (hw::block_idx() >= table_blocks) { read_flags_thread(b, (hw::block_idx() - table_blocks) * hw::block_dim() + hw::thread_idx()); return; }
     const uint32_t g = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (g >= n_bases) return;
     const uint32_t h = b.hbases[g], mf = b.maskF[g], mr = b.maskR[g];
@@ -92,8 +94,17 @@ OCT_DEVICE uint32_t kmer_hash6(const uint8_t* s)               // perfect_kmer_h
 
 // make_kmer_hash_table (:85-106) for every haplotype: one workgroup per haplotype, CSR bins (order inside a bin does not
 // affect the vote counts). LDS: 4096 counters + 256 scan slots.
-OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0)
+OCT_DEVICE void read_hash_thread(const DevBatch& b, uint32_t g, uint32_t n_bases)   // compute_kmer_hashes<6> (:57-69), once per read base
 {
+    if (g >= n_bases) return;
+    const uint32_t r = upper_bound_idx(b.roff, b.n_reads + 1, g);
+    if (g + kKmer <= b.roff[r + 1]) b.rhash[g] = (uint16_t)kmer_hash6(b.rbases + g);
+}
+
+// The workgroups past `n_hap_blocks` (slice 0 only) compute the read hashes of the whole batch in the same launch.
+OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint32_t n_read_bases)
+{
+    if (hw::block_idx() >= n_hap_blocks) { read_hash_thread(b, (hw::block_idx() - n_hap_blocks) * hw::block_dim() + hw::thread_idx(), n_read_bases); return; }
     OCT_DYN_SMEM(smem);
     uint32_t* hist = (uint32_t*)smem;            // [4096]
     uint32_t* part = hist + kKmerBins;           // [256]
@@ -130,21 +141,12 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0)
 
 // compute_kmer_hashes<6> (:57-69) for every read, once per batch like the reference (haplotype_likelihood_array.cpp:118-131):
 // rhash[roff[r] + q] for q <= T - 6.
-OCT_KERNEL(k_read_hashes)(DevBatch b, uint32_t n_bases)
-{
-    const uint32_t g = hw::block_idx() * hw::block_dim() + hw::thread_idx();
-    if (g >= n_bases) return;
-    const uint32_t r = upper_bound_idx(b.roff, b.n_reads + 1, g);
-    if (g + kKmer <= b.roff[r + 1]) b.rhash[g] = (uint16_t)kmer_hash6(b.rbases + g);
-}
-
 // map_query_to_target (:120-159): one wave per (haplotype, read) pair; the workgroup keeps the haplotype's bins in LDS and its
 // four waves stride over a chunk of the region's reads. Votes go to per-wave LDS counters; a 64-lane batch whose votes all fall on
 // one diagonal (the normal case: the read's true offset) is merged into a single add.
-constexpr uint32_t kMapReadsPerBlock = 64;
 inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + ((lh_cap + 1) & ~1u) * 2 + kBlockWaves * (lh_cap + 64) * 4; }
 
-OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap)
+OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap, uint32_t reads_per_block)
 {
     OCT_DYN_SMEM(smem);
     uint16_t* bins = (uint16_t*)smem;                                  // [4097]
@@ -154,7 +156,7 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
     const uint32_t h = blk_hap[hw::block_idx()], r_first = blk_read0[hw::block_idx()];
     const uint32_t g = b.hap_region[h];
     const uint32_t reg_r0 = b.reg_read0[g], reg_r1 = b.reg_read0[g + 1];
-    const uint32_t r_end = r_first + kMapReadsPerBlock < reg_r1 ? r_first + kMapReadsPerBlock : reg_r1;
+    const uint32_t r_end = r_first + reads_per_block < reg_r1 ? r_first + reads_per_block : reg_r1;
     const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;   // table.second
     for (uint32_t i = tid; i <= kKmerBins; i += kBlockWaves * 64) bins[i] = b.bin_start[(size_t)h * (kKmerBins + 1) + i];
     for (uint32_t i = tid; i < nk; i += kBlockWaves * 64) idx[i] = b.bin_idx[ho + i];
@@ -375,13 +377,14 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt)
             uint64_t fin = orig; bool err = false;
             if (min_shift > 0) { fin += (uint64_t)min_shift; if (!pos_in_range(fin, T, Lh, B)) err = true; }
             else { const uint32_t left = (uint32_t)(-min_shift); if (orig >= left) fin -= left; else err = true; }
-            if (err) hw::atomic_min_u64(b.err_key, ((unsigned long long)h << 32) | r);
+            if (err) hw::atomic_max_u64(b.err_key, ~(((unsigned long long)h << 32) | r));   // stored inverted: the first failing pair is the maximum, 0 = none
             else { extra = (uint32_t)fin; visit((uint32_t)b.max_pos, extra); }
         }
         b.pair_best[e] = best; b.pair_cls[e] = cls; b.pair_extra[e] = extra;
         if (b.align_mode) b.pair_key[e] = key;
         const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
         cnt[e - pair0] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
+        if (e + 1 == pair1) cnt[pair1 - pair0] = make_uint4(0, 0, 0, 0);                               // the scan's extra entry (totals land here)
         st_pairs = 1;
     }
     st_cand = wave_sum(st_cand); st_fast = wave_sum(st_fast); st_score = wave_sum(st_score);
@@ -426,7 +429,8 @@ OCT_KERNEL(k_scan_tiles)(uint4* data, uint64_t n, uint4* tile_sums, int apply)
         if (tid == kScanThreads - 1) tile_sums[hw::block_idx()] = sh[tid];
         return;
     }
-    uint4 run = add4(tile_sums[hw::block_idx()], tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0));
+    // apply == 2: the whole array is this one tile (a region-sized batch): no tile offsets to add, one launch instead of three
+    uint4 run = add4(apply == 2 ? make_uint4(0, 0, 0, 0) : tile_sums[hw::block_idx()], tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0));
     for (uint32_t i = 0; i < kScanItems; ++i) if (base + i < n) { data[base + i] = run; run = add4(run, v[i]); }
 }
 

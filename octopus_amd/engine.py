@@ -66,6 +66,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_kernel_time_by_kind.argtypes = [pv, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32 * 4)]
         lib.oct_phmm_batch_genotype_likelihoods.argtypes = [pv, pv, pv, pv, pv]
         lib.oct_phmm_align.argtypes = [pv, pv, pv, pv, pv, pv, pv, pv]
+        lib.oct_phmm_set_timing.argtypes = [pv, C.c_int]
         lib.oct_phmm_batch_free.argtypes = [pv, pv]
         _LIBS[key] = lib
     return _LIBS[key]
@@ -203,6 +204,10 @@ class Engine:
         if code != abi.OK and raise_on_error:
             raise EngineError(code, st, "align")
         return abi.alignments_result(arrays, n, max_cigar_ops), st
+
+    def set_timing(self, enabled: bool = True):
+        """Bracket the DP launches with HIP events (ResidentBatch.kernel_time*); off by default."""
+        self.lib.oct_phmm_set_timing(self.handle, 1 if enabled else 0)
 
     def upload(self, batch: abi.Batch) -> ResidentBatch:
         return ResidentBatch(self, batch)

@@ -183,6 +183,7 @@ inline void block_sync() { hipsim::block_sync_impl(); }
 inline int atomic_min_i32(int32_t* p, int32_t v) { const int32_t o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { const auto o = *p; if (v < o) *p = v; return o; }
 inline uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { const auto o = *p; *p = o | v; return o; }
+inline unsigned long long atomic_max_u64(unsigned long long* p, unsigned long long v) { const auto o = *p; if (v > o) *p = v; return o; }
 inline unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { const auto o = *p; *p = o + v; return o; }
 inline uint32_t atomic_and_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o & v; return o; }
 inline uint32_t thread_idx() { return hipsim::S().cur; }
