@@ -279,7 +279,10 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
     if (h->bp_bytes[slice] >= bytes) return true;
     rt::dev_free(h->bp[slice]); h->bp[slice] = nullptr; h->bp_bytes[slice] = 0;
     void* p = nullptr;
-    if (!rt::dev_malloc(&p, bytes)) return false;
+    if (!rt::dev_malloc(&p, bytes)) {
+        h->pool.trim();                                 // cached blocks of earlier batches may be in the way
+        if (!rt::dev_malloc(&p, bytes)) return false;
+    }
     h->bp[slice] = (uint32_t*)p; h->bp_bytes[slice] = bytes;
     return true;
 }
