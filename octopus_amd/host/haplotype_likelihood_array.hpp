@@ -15,6 +15,7 @@
 #include <functional>
 #include <memory>
 #include <stdexcept>
+#include <cmath>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -125,6 +126,47 @@ public:
         if (rc != OCT_PHMM_OK) throw DeviceError {std::string {"oct_phmm_create: "} + oct_phmm_strerror(rc)};
         handle_.reset(h, [] (oct_phmm_handle* p) { oct_phmm_destroy(p); });
     }
+    struct Alignment { std::size_t mapping_position; std::string cigar; double likelihood; };   // ref: haplotype_likelihood_model.hpp:57-62 (CigarString as text)
+    class HMMOverflow : public std::runtime_error { public: HMMOverflow() : std::runtime_error {"Pair HMM alignment overflowed"} {} };   // ref: pair_hmm.hpp:47-64
+
+    // ref: HaplotypeLikelihoodModel::align(read) after reset(haplotype, flank_state), model.cpp:322-431 - here for a whole vector of reads
+    // against one haplotype, as read_realigner.cpp:114-139 needs it; candidate positions come from the device k-mer mapper.
+    std::vector<Alignment> align(const std::vector<AlignedRead>& reads, const Haplotype& haplotype, const FlankState* flank_state = nullptr) const
+    {
+        std::string rb; std::vector<std::uint8_t> q, mq, rev; std::vector<std::uint32_t> off {0}; std::vector<std::int64_t> beg;
+        for (const AlignedRead& r : reads) {
+            rb += r.sequence(); q.insert(q.end(), r.base_qualities().begin(), r.base_qualities().end()); off.push_back(static_cast<std::uint32_t>(rb.size()));
+            mq.push_back(r.mapping_quality()); rev.push_back(r.is_marked_reverse_mapped() ? 1 : 0); beg.push_back(r.begin_);
+        }
+        const PenaltyVectors v = penalties_(haplotype);
+        const std::uint32_t hoff[2] = {0, static_cast<std::uint32_t>(haplotype.sequence().size())}; const std::int64_t hbeg[1] = {haplotype.begin_};
+        oct_phmm_reads R {static_cast<std::uint32_t>(reads.size()), rb.data(), q.data(), off.data(), mq.data(), rev.data(), beg.data(), 0, nullptr};
+        oct_phmm_haplotypes H {1, haplotype.sequence().data(), hoff, hbeg, v.gap_open.data(), v.gap_extend.data(), v.snv_forward_mask.data(),
+                               v.snv_forward_priors.data(), v.snv_reverse_mask.data(), v.snv_reverse_priors.data()};
+        oct_phmm_flank_state fs {0, 0}; if (flank_state) fs = {flank_state->lhs_flank, flank_state->rhs_flank};
+        std::uint32_t cap = 32;
+        for (;;) {
+            std::vector<std::uint32_t> mpos(reads.size() + 1), n_ops(reads.size() + 1), ops(reads.size() * cap + 1); std::vector<double> lik(reads.size() + 1);
+            oct_phmm_alignments out {cap, mpos.data(), lik.data(), n_ops.data(), ops.data()};
+            oct_phmm_status st;
+            const int rc = oct_phmm_align(handle_.get(), &R, &H, nullptr, flank_state ? &fs : nullptr, nullptr, &out, &st);
+            if (rc == OCT_PHMM_EINVAL && st.required_extension > cap) { cap = st.required_extension; continue; }   // CIGARs longer than guessed: once more with room
+            if (rc == OCT_PHMM_ESHORT_HAPLOTYPE) throw ShortHaplotypeError {st.hap_index, st.required_extension};
+            if (rc == OCT_PHMM_EOVERFLOW) throw HMMOverflow {};
+            if (rc != OCT_PHMM_OK) throw DeviceError {std::string {"oct_phmm_align: "} + oct_phmm_strerror(rc) + " (" + st.message + ")"};
+            std::vector<Alignment> result(reads.size());
+            for (std::size_t i = 0; i < reads.size(); ++i) {
+                result[i].mapping_position = mpos[i]; result[i].likelihood = lik[i];
+                for (std::uint32_t k = 0; k < n_ops[i]; ++k) {
+                    const std::uint32_t op = ops[i * cap + k];
+                    result[i].cigar += std::to_string(op >> 4);
+                    result[i].cigar += (op & 15u) == OCT_PHMM_CIGAR_EQ ? '=' : (op & 15u) == OCT_PHMM_CIGAR_X ? 'X' : (op & 15u) == OCT_PHMM_CIGAR_INS ? 'I' : 'D';
+                }
+            }
+            return result;
+        }
+    }
+
     const Config& config() const noexcept { return config_; }
     unsigned pad_requirement() const noexcept { return static_cast<unsigned>(oct_phmm_band_size(handle_.get())); }   // ref: model.cpp:55-58
     bool can_use_flank_state() const noexcept { return config_.use_flank_state; }
@@ -185,7 +227,11 @@ public:
     const std::vector<Haplotype>& haplotypes() const noexcept { return haplotypes_; }
     bool contains(const Haplotype& haplotype) const noexcept { return haplotype_indices_.count(haplotype) == 1; }
     bool is_empty() const noexcept { return likelihoods_.empty(); }
-    void clear() noexcept { likelihoods_.clear(); haplotype_indices_.clear(); sample_indices_.clear(); haplotypes_.clear(); unprime(); }
+    void clear() noexcept { likelihoods_.clear(); haplotype_indices_.clear(); sample_indices_.clear(); haplotypes_.clear(); resident_.reset(); unprime(); }
+    // the device-resident matrix of the last populate (null after reset()/merge_samples(), whose row layout it no longer matches)
+    oct_phmm_batch* resident_batch() const noexcept { return resident_.get(); }
+    oct_phmm_handle* handle() const noexcept { return likelihood_model_.handle(); }
+    std::pair<std::uint32_t, std::uint32_t> primed_rows() const { return {sample_row_begin_.at(primed_sample_), sample_row_begin_.at(primed_sample_ + 1)}; }
     bool is_primed() const noexcept { return primed_; }
     void prime(const SampleName& sample) const { primed_sample_ = sample_indices_.at(sample); primed_ = true; }
     void unprime() const noexcept { primed_ = false; }
@@ -198,7 +244,7 @@ public:
         std::vector<std::vector<LikelihoodVector>> kept; kept.reserve(keep.size());
         std::unordered_map<Haplotype, std::size_t, HaplotypeHash> idx;
         for (std::size_t i = 0; i < keep.size(); ++i) { kept.push_back(std::move(likelihoods_[haplotype_indices_.at(keep[i])])); idx.emplace(keep[i], i); }
-        likelihoods_ = std::move(kept); haplotype_indices_ = std::move(idx); haplotypes_ = keep;
+        likelihoods_ = std::move(kept); haplotype_indices_ = std::move(idx); haplotypes_ = keep; resident_.reset();
     }
     // ref: :357-409 — concatenate the samples' likelihood vectors under one new sample
     HaplotypeLikelihoodArray merge_samples(const std::vector<SampleName>& which, SampleName new_sample = {}) const
@@ -247,7 +293,17 @@ private:
         if (flank_state) fs = {flank_state->lhs_flank, flank_state->rhs_flank};
         std::vector<double> out(haplotypes.size() * static_cast<std::size_t>(n_rows) + 1);
         oct_phmm_status st;
-        const int rc = oct_phmm_populate(likelihood_model_.handle(), &R, &H, nullptr, flank_state ? &fs : nullptr, nullptr, out.data(), &st);
+        // upload + run + download instead of the one-shot oct_phmm_populate: the matrix stays in HBM behind the array so that the genotype
+        // models can read it out there (ConstantMixtureGenotypeLikelihoodModel below)
+        resident_.reset(); sample_row_begin_.assign(1, 0);
+        for (std::size_t n : rows_per_sample) sample_row_begin_.push_back(sample_row_begin_.back() + static_cast<std::uint32_t>(n));
+        oct_phmm_handle* hd = likelihood_model_.handle();
+        oct_phmm_batch* batch = nullptr;
+        int rc = oct_phmm_batch_upload(hd, &R, &H, nullptr, flank_state ? &fs : nullptr, nullptr, &batch, &st);
+        if (batch) resident_.reset(batch, [hd] (oct_phmm_batch* b) { oct_phmm_batch_free(hd, b); });
+        if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_run(hd, batch, &st);
+        if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_download(hd, batch, out.data(), &st);
+        if (rc != OCT_PHMM_OK) resident_.reset();
         if (rc == OCT_PHMM_ESHORT_HAPLOTYPE) throw HaplotypeLikelihoodModel::ShortHaplotypeError {st.hap_index, st.required_extension};
         if (rc != OCT_PHMM_OK) throw HaplotypeLikelihoodModel::DeviceError {std::string {"oct_phmm_populate: "} + oct_phmm_strerror(rc) + " (" + st.message + ")"};
         likelihoods_.assign(haplotypes.size(), std::vector<LikelihoodVector>(rows_per_sample.size()));
@@ -267,6 +323,46 @@ private:
     std::vector<Haplotype> haplotypes_;
     mutable std::size_t primed_sample_ = 0;
     mutable bool primed_ = false;
+    std::shared_ptr<oct_phmm_batch> resident_;
+    std::vector<std::uint32_t> sample_row_begin_ {0};
+};
+
+// ref: core/models/genotype/constant_mixture_genotype_likelihood_model.hpp:16-76. A genotype is its haplotypes' indices in the array
+// (IndexedHaplotype<>), sorted. evaluate(genotypes) = the free evaluate(genotypes, model) helper (:58-75): with the matrix still on the
+// device it is one oct_phmm_batch_genotype_likelihoods call.
+class ConstantMixtureGenotypeLikelihoodModel
+{
+public:
+    using LogProbability = double;
+    using Genotype = std::vector<std::size_t>;
+    explicit ConstantMixtureGenotypeLikelihoodModel(const HaplotypeLikelihoodArray& likelihoods) : likelihoods_ {likelihoods} {}
+    const HaplotypeLikelihoodArray& cache() const noexcept { return likelihoods_; }
+
+    std::vector<LogProbability> evaluate(const std::vector<Genotype>& genotypes) const
+    {
+        std::vector<LogProbability> result(genotypes.size(), 0.0);
+        if (genotypes.empty()) return result;
+        const std::size_t ploidy = genotypes.front().size();
+        if (ploidy == 0) return result;                                     // :36
+        if (oct_phmm_batch* batch = likelihoods_.resident_batch()) {
+            std::vector<std::uint32_t> idx; idx.reserve(genotypes.size() * ploidy);
+            for (const Genotype& g : genotypes) { if (g.size() != ploidy) throw std::invalid_argument {"mixed ploidies in one evaluate call"}; for (std::size_t h : g) idx.push_back(static_cast<std::uint32_t>(h)); }
+            const std::uint32_t pl = static_cast<std::uint32_t>(ploidy), offs[2] = {0, static_cast<std::uint32_t>(genotypes.size())};
+            const auto rows = likelihoods_.primed_rows();
+            oct_phmm_genotype_sets sets {1, &pl, offs, idx.data(), &rows.first, &rows.second};
+            oct_phmm_status st;
+            const int rc = oct_phmm_batch_genotype_likelihoods(likelihoods_.handle(), batch, &sets, result.data(), &st);
+            if (rc != OCT_PHMM_OK) throw HaplotypeLikelihoodModel::DeviceError {std::string {"oct_phmm_batch_genotype_likelihoods: "} + oct_phmm_strerror(rc) + " (" + st.message + ")"};
+            return result;
+        }
+        // reset()/merge_samples() changed the row layout on the host only: there is no device matrix to read out (and no host
+        // re-implementation here) - the reference's own genotype models keep working on the array's accessors
+        throw HaplotypeLikelihoodModel::DeviceError {"ConstantMixtureGenotypeLikelihoodModel: the array has no device-resident matrix (populate it again)"};
+    }
+    LogProbability evaluate(const Genotype& genotype) const { return evaluate(std::vector<Genotype> {genotype}).front(); }
+
+private:
+    const HaplotypeLikelihoodArray& likelihoods_;
 };
 
 } // namespace octopus_amd

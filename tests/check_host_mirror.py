@@ -87,6 +87,32 @@ def check(backend, tol=0.0):
         for h in range(want.shape[0]):
             row = np.concatenate([got[(h, "S1")], got[(h, "S2")]])
             assert row.shape == want[h].shape and np.max(np.abs(row - want[h])) <= tol, (seed, h, row, want[h])
+        # genotype read-out through the mirror of ConstantMixtureGenotypeLikelihoodModel (primed sample S1 = the first `split` rows)
+        import itertools
+        nh = want.shape[0]
+        gts = np.asarray(list(itertools.combinations_with_replacement(range(nh), 2)), np.uint32)
+        off = np.arange(nh + 1, dtype=np.uint64) * want.shape[1]
+        gl_want = oracle.genotype_likelihoods(want.reshape(-1), off, gts, (0, split))
+        gl_got = {(int(p[1]), int(p[2])): float(p[3]) for p in (ln.split() for ln in lines if ln.startswith("G "))}
+        for (a, b), w in zip(gts.tolist(), gl_want):
+            assert abs(gl_got[(a, b)] - w) <= 1e-9 * max(1.0, abs(w)), (seed, a, b, gl_got[(a, b)], w)
+        g3 = [float(ln.split()[1]) for ln in lines if ln.startswith("G3 ")]
+        w3 = oracle.genotype_likelihoods(want.reshape(-1), off, np.asarray([[0, 1, 2]], np.uint32), (0, split))[0]
+        assert len(g3) == 1 and abs(g3[0] - w3) <= 1e-9 * max(1.0, abs(w3))
+        assert "Ghost refused" in lines                       # after reset() there is no device matrix and no host re-implementation
+        # realignment through the mirror of HaplotypeLikelihoodModel::align: sample S1's reads against haplotype 0
+        n1 = rows[split]
+        hap0 = dict(seq=bytes(g["haps"][0]), begin=0, gap_open=np.full(len(g["haps"][0]), 45, np.int8), gap_extend=np.full(len(g["haps"][0]), 3, np.int8),
+                    mask_fwd=g["haps"][0], prior_fwd=np.full(len(g["haps"][0]), 100, np.int8), mask_rev=g["haps"][0], prior_rev=np.full(len(g["haps"][0]), 100, np.int8))
+        rd = [dict(seq=bytes(g["reads"][r]), quals=g["quals"][r], mapq=int(g["mapq"][r]), reverse=bool(g["reverse"][r]), begin=int(g["begin"][r])) for r in range(n1)]
+        ab = abi.Batch.from_lists(rd, [hap0], flank=g["flank"])
+        aw, ast = oracle.align_batch(abi.Config.default(max_indel_error=band, use_mapping_quality=int(use_mapq)), ab, 64)
+        assert ast.code == abi.OK
+        al = [ln.split() for ln in lines if ln.startswith("A ")]
+        assert len(al) == n1
+        for p in al:
+            i = int(p[1])
+            assert int(p[2]) == int(aw["mapping_position"][i]) and p[3] == aw["cigar_strings"][i] and abs(float(p[4]) - aw["likelihood"][i]) <= 1e-9, (seed, p, aw["cigar_strings"][i])
         assert any(ln.startswith("primed %d contains 1" % split) for ln in lines)
         assert any(ln == "merged %d" % (len(rows) - 1) for ln in lines)
         assert any(ln == "reset 1 0" for ln in lines)

@@ -44,9 +44,24 @@ int main()
             for (const auto& n : names) { std::printf("L %zu %s", h, n.c_str()); for (double v : arr(n, haps[h])) std::printf(" %.17g", v); std::printf("\n"); }
         arr.prime(names.front());
         std::printf("primed %zu contains %d\n", arr.num_likelihoods(), arr.contains(haps.front()) ? 1 : 0);
+        {   // genotype read-out on the resident matrix (primed sample) and realignment of the first sample's reads against haplotype 0
+            ConstantMixtureGenotypeLikelihoodModel gm {arr};
+            std::vector<ConstantMixtureGenotypeLikelihoodModel::Genotype> gts;
+            for (std::size_t a = 0; a < haps.size(); ++a) for (std::size_t b = a; b < haps.size(); ++b) gts.push_back({a, b});
+            const auto gl = gm.evaluate(gts);
+            for (std::size_t i = 0; i < gts.size(); ++i) std::printf("G %zu %zu %.17g\n", gts[i][0], gts[i][1], gl[i]);
+            if (haps.size() >= 3) std::printf("G3 %.17g\n", gm.evaluate({0, 1, 2}));
+            const auto alns = model.align(rm.front().second, haps.front(), has_flank ? &fs : nullptr);
+            for (std::size_t i = 0; i < alns.size(); ++i) std::printf("A %zu %zu %s %.17g\n", i, alns[i].mapping_position, alns[i].cigar.c_str(), alns[i].likelihood);
+        }
         const auto merged = arr.merge_samples(names);
         std::printf("merged %zu\n", merged[0].size());
-        if (haps.size() > 1) { arr.reset({haps.back()}); std::printf("reset %zu %d\n", arr.haplotypes().size(), arr.contains(haps.front()) ? 1 : 0); }
+        if (haps.size() > 1) {
+            arr.reset({haps.back()}); std::printf("reset %zu %d\n", arr.haplotypes().size(), arr.contains(haps.front()) ? 1 : 0);
+            arr.prime(names.front());                           // no device matrix any more: the mirror says so instead of computing on the host
+            try { ConstantMixtureGenotypeLikelihoodModel {arr}.evaluate({0, 0}); std::printf("Ghost computed\n"); }
+            catch (const HaplotypeLikelihoodModel::DeviceError&) { std::printf("Ghost refused\n"); }
+        }
     } catch (const HaplotypeLikelihoodModel::ShortHaplotypeError& e) {
         std::printf("ShortHaplotypeError %zu %zu\n", e.haplotype_index(), e.required_extension());
     } catch (const HaplotypeLikelihoodModel::TooLargeBandSizeError& e) {
