@@ -256,20 +256,24 @@ bool launch_walk(int band, bool one_per_row, const WalkParams& w, rt::Stream s)
         default: return false;
     }
 }
-template <int C, bool TR>
+template <int B, bool TR>
 bool launch_dp_wide_inst(bool w16, const DpParams& p, rt::Stream s)
 {
-    const uint32_t blocks = (p.n_tasks + kBlockWaves - 1) / kBlockWaves;
-    if (w16) OCT_LAUNCH((k_dp_wide<C, TR, true>), blocks, kBlockWaves * 64, 0, s, p);
-    else     OCT_LAUNCH((k_dp_wide<C, TR, false>), blocks, kBlockWaves * 64, 0, s, p);
+    constexpr uint32_t ROWS = B < 64 ? 64 / B : 1;                       // tasks per wave
+    const uint32_t waves = (p.n_tasks + ROWS - 1) / ROWS, blocks = (waves + kBlockWaves - 1) / kBlockWaves;
+    if (w16) OCT_LAUNCH((k_dp_wide<B, TR, true>), blocks, kBlockWaves * 64, 0, s, p);
+    else     OCT_LAUNCH((k_dp_wide<B, TR, false>), blocks, kBlockWaves * 64, 0, s, p);
     return rt::launch_ok();
 }
-bool launch_dp_wide(int c, bool tr, bool w16, const DpParams& p, rt::Stream s)
+bool launch_dp_wide(int band, bool tr, bool w16, const DpParams& p, rt::Stream s)
 {
-    switch (c) {
-        case 1: return tr ? launch_dp_wide_inst<1, true>(w16, p, s) : launch_dp_wide_inst<1, false>(w16, p, s);
-        case 2: return tr ? launch_dp_wide_inst<2, true>(w16, p, s) : launch_dp_wide_inst<2, false>(w16, p, s);
-        case 4: return tr ? launch_dp_wide_inst<4, true>(w16, p, s) : launch_dp_wide_inst<4, false>(w16, p, s);
+    switch (band) {
+        case 8:   return tr ? launch_dp_wide_inst<8, true>(w16, p, s) : launch_dp_wide_inst<8, false>(w16, p, s);
+        case 16:  return tr ? launch_dp_wide_inst<16, true>(w16, p, s) : launch_dp_wide_inst<16, false>(w16, p, s);
+        case 32:  return tr ? launch_dp_wide_inst<32, true>(w16, p, s) : launch_dp_wide_inst<32, false>(w16, p, s);
+        case 64:  return tr ? launch_dp_wide_inst<64, true>(w16, p, s) : launch_dp_wide_inst<64, false>(w16, p, s);
+        case 128: return tr ? launch_dp_wide_inst<128, true>(w16, p, s) : launch_dp_wide_inst<128, false>(w16, p, s);
+        case 256: return tr ? launch_dp_wide_inst<256, true>(w16, p, s) : launch_dp_wide_inst<256, false>(w16, p, s);
         default: return false;
     }
 }
@@ -295,7 +299,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     rt::Stream st = on_stream ? *on_stream : h->slice_stream(slice);
     const int B = h->band;
     const uint32_t C = (uint32_t)h->lanes_c;
-    const uint32_t G = b->stream ? 1u : (h->wide ? 1 : 2) * (64 / B);
+    const uint32_t G = b->stream ? (B < 64 ? 64u / (uint32_t)B : 1u) : (h->wide ? 1 : 2) * (64 / B);
     const bool tr = kind == kTraceFast || kind == kTraceGen, gen = kind == kScoreGen || kind == kTraceGen;
     const size_t lds = b->stream ? 0 : dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr);
     if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
@@ -325,7 +329,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         const uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
         rt::Event e0 {}, e1 {};
         if (h->timing) { RT(h->get_event(&e0)); RT(h->get_event(&e1)); RT(rt::event_record(e0, st)); }
-        if (!(b->stream ? launch_dp_wide((int)C, tr, !h->wide, p, st)
+        if (!(b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
                         : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         if (h->timing) { RT(rt::event_record(e1, st)); b->timers.emplace_back(e0, e1); b->timer_kind.push_back(kind); }
@@ -521,8 +525,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     for (uint32_t hp = 0; hp < H->n_haps; ++hp) b->lh_cap = std::max(b->lh_cap, H->offsets[hp + 1] - H->offsets[hp]);
     {
         const bool fits = h->band <= 64 && dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)h->band, true) <= rt::kMaxLdsBytes;
-        b->stream = h->band > 64 || (h->band == 64 && !fits);
-        if (!b->stream && !fits) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident kernels at this band (use band >= 64)");
+        b->stream = h->band > 64 || !fits;      // long reads at any band stream their operands (PacBioCCS.config: max-indel-errors=16 with 10-20 kb reads)
         if (b->t_cap + 2 * (uint32_t)h->band >= 32768) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long (walk events hold 15-bit coordinates)");
     }
     {
@@ -688,7 +691,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     DevBatch& d = b->d;
     for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
     b->timers.clear(); b->timer_kind.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
-    const uint32_t G = b->stream ? 1u : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
+    const uint32_t G = b->stream ? (h->band < 64 ? 64u / (uint32_t)h->band : 1u) : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
     const int S = (int)b->slices.size();
     RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * 8 + 1) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key behind them
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
@@ -1068,7 +1071,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
     if (rc != OCT_PHMM_OK) return rc;
     struct Guard { oct_phmm_handle* h; oct_phmm_batch* b; std::vector<void*> extra; ~Guard() { rt::stream_sync(h->stream); for (void* p : extra) h->pool.release(p); oct_phmm_batch_free(h, b); } } guard {h, b, {}};
     rt::Stream s = h->stream;
-    const uint32_t G = b->stream ? 1u : (h->wide ? 1u : 2u) * (64 / B);
+    const uint32_t G = b->stream ? (B < 64 ? 64u / (uint32_t)B : 1u) : (h->wide ? 1u : 2u) * (64 / B);
     // route each window to the fast or generic kernel exactly as k_classify would
     std::vector<uint8_t> racgt(n); std::vector<uint32_t> hclean(n);
     RT(rt::d2h(racgt.data(), b->d.racgt, n, s)); RT(rt::d2h(hclean.data(), b->d.hclean, n * sizeof(uint32_t), s)); RT(rt::stream_sync(s));

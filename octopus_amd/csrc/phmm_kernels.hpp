@@ -924,20 +924,26 @@ template <bool W16> OCT_DEVICE uint32_t wadd(uint32_t a, uint32_t b)
     if constexpr (W16) return (uint32_t)(int32_t)(int16_t)(uint16_t)(a + b); else return a + b;
 }
 
-template <int C, bool TRACE, bool W16>
+template <int B, bool TRACE, bool W16>
 OCT_KERNEL(k_dp_wide)(DpParams p)
 {
-    constexpr int B = 64 * C;
+    // B >= 64: one task per wave, C = B / 64 adjacent diagonals per lane. B < 64 (long reads at a narrow band - the reference's PacBio
+    // configuration runs band 16): 64 / B tasks per wave, one per row of B lanes, exactly the task-group layout of the LDS-resident kernels.
+    constexpr int C = B > 64 ? B / 64 : 1, BL = B < 64 ? B : 64, ROWS = 64 / BL;
     constexpr uint32_t INFW = W16 ? 0x00007800u : INF32;
     constexpr uint32_t NULW = W16 ? 0xffff8000u : NUL32;
     const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
-    const uint32_t task = hw::block_idx() * kBlockWaves + wave;
-    if (task >= p.n_tasks) return;                                      // whole waves only
+    const uint32_t row = lane / BL, li = lane % BL;
+    const uint32_t group = hw::block_idx() * kBlockWaves + wave;           // = the wave's task group (ROWS tasks)
+    if (group * ROWS >= p.n_tasks) return;                                 // whole waves only (n_tasks is a multiple of ROWS)
+    const uint32_t task = group * ROWS + row;
     const DevTask t = p.tasks[task];
     const uint32_t ro = p.roff[t.read], T = p.roff[t.read + 1] - ro;
-    const uint32_t K = T + B;
+    uint32_t K = T + B;
+    if (ROWS > 1) { for (int m = BL; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(K, m); K = o > K ? o : K; } K = hw::readfirstlane(K); }   // the rows iterate together
+    const uint32_t last_rec = T + 2 * B;                                   // operand index one past this task's window (already read by the B >= 64 form)
     const uint2* tab = (p.rrev[t.read] ? p.tabR : p.tabF) + p.hoff[t.hap] + t.off;   // generic table of the band window
-    const uint32_t i0 = lane * C;                                       // this lane's first band diagonal
+    const uint32_t i0 = li * C;                                            // this lane's first band diagonal
     const uint32_t NUCW = (uint32_t)(int32_t)(int16_t)(p.nuc4 & 0xffffu);
     uint32_t M1[C], I1[C], D1[C], M2[C], I2[C], D2[C];
     for (int c = 0; c < C; ++c) M1[c] = I1[c] = D1[c] = M2[c] = I2[c] = D2[c] = INFW;
@@ -960,7 +966,7 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
         *mism = r2.x != h ? 1u : 0u;
         return min_i32(c, isn ? 8u : INFW);
     };
-    uint32_t* bpt = TRACE ? p.bp + (size_t)task * p.k_cap * C * 1024 : nullptr;
+    uint32_t* bpt = TRACE ? p.bp + (size_t)group * p.k_cap * C * 1024 : nullptr;
     for (uint32_t k = 0; k < K; ++k) {
         uint32_t dsh[C], ish[C], bpe[C];
         for (int c = 0; c < C; ++c) {
@@ -978,8 +984,9 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
             bpe[c] = mE << 15;
             (void)mO;
         }
-        {   // :294 D1 <- shifted one diagonal up, infinity_ into diagonal 0
-            const uint32_t from_below = hw::dpp_wave_shr1(INFW, dsh[C - 1]);
+        {   // :294 D1 <- shifted one diagonal up, infinity_ into diagonal 0 (of every row)
+            uint32_t from_below = hw::dpp_wave_shr1(INFW, dsh[C - 1]);
+            if (ROWS > 1 && li == 0) from_below = INFW;
             for (int c = C - 1; c >= 1; --c) D1[c] = dsh[c - 1];
             D1[0] = from_below;
         }
@@ -1003,8 +1010,9 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
             ish[c] = wadd<W16>(min_i32(wadd<W16>(I1[c], GE), wadd<W16>(M1[c], GO)), NUCW);  // :318 (shifted below)
             bpe[c] |= mO << 14;
         }
-        {   // :318-319 I2 <- shifted one diagonal down, infinity_ into the last diagonal
-            const uint32_t from_above = hw::dpp_wave_shl1(INFW, ish[0]);
+        {   // :318-319 I2 <- shifted one diagonal down, infinity_ into the last diagonal (of every row)
+            uint32_t from_above = hw::dpp_wave_shl1(INFW, ish[0]);
+            if (ROWS > 1 && li == (uint32_t)BL - 1) from_above = INFW;
             for (int c = 0; c < C - 1; ++c) I2[c] = ish[c + 1];
             I2[C - 1] = from_above;
         }
@@ -1015,20 +1023,20 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
                 bpt[(((size_t)(k >> 4) * C + c) * 64 + lane) * 16 + (k & 15)] = bpe[c] | (tm | ti << 2 | td << 4) << 6;
             }
         }
-        // slide the operand windows by one position
+        // slide the operand windows by one position (a row that has finished its own T + B iterations re-reads its last record)
         for (int c = 0; c < C; ++c) hw_[c] = hw_[c + 1];
-        hw_[C] = tab[k + 1 + i0 + C];
+        { const uint32_t nx = k + 1 + i0 + C; hw_[C] = tab[ROWS > 1 && nx > last_rec ? last_rec : nx]; }
         for (int c = C - 1; c >= 1; --c) rw[c] = rw[c - 1];
         rw[0] = read_rec((int32_t)(k + 1) - (int32_t)i0);
     }
     // first minimum over the end cells: per lane the candidates were visited in increasing diagonal order, so strict < kept the first
     uint32_t kv = have ? (W16 ? ((best + 0x8000u) & 0xffffu) : (best ^ 0x80000000u)) : 0xffffffffu, ks = best_s;
     if (!have) ks = 0xffffffffu;
-    for (int m = 1; m < 64; m <<= 1) {
+    for (int m = 1; m < BL; m <<= 1) {
         const uint32_t ov = hw::shfl_xor(kv, m), os = hw::shfl_xor(ks, m);
         if (ov < kv || (ov == kv && os < ks)) { kv = ov; ks = os; }
     }
-    if (lane == 0) {
+    if (li == 0) {
         // no end cell below infinity_: minscore stays infinity_, minscoreidx -1 (:269-270)
         const bool none = kv == 0xffffffffu;
         const uint32_t biased = none ? (W16 ? ((INFW + 0x8000u) & 0xffffu) : (INFW ^ 0x80000000u)) : kv;

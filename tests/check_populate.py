@@ -216,3 +216,15 @@ def check_one_shot_populate_streams_slices_back(backend):
     rb = eng.upload(batch); rb.run()
     assert np.array_equal(rb.download(), want)
     rb.free(); eng.close()
+
+
+def check_long_reads_at_narrow_bands(backend, tol=0.0, T=1400, Lh=3600, n_reads=5):
+    """The reference's PacBio configuration keeps band 16 for 10-20 kb reads (resources/configs/PacBioCCS.config: max-indel-errors=16):
+    reads and haplotypes far too long for the LDS-resident kernels at bands 8/16/32 go through the streaming kernel with one task per row
+    of B lanes, int16 and int32 lanes, score-only and traceback, plus the align path."""
+    out = []
+    for band, bits, seed in ((16, 1, 71), (16, 0, 72), (8, 1, 73), (32, 0, 74)):
+        g, rng = small_region(seed, R=n_reads, H=2, T=T, Lh=Lh, B=band, flank=(Lh // 3, Lh // 3))      # wide inactive flanks: most candidates need the traceback
+        g["quals"][:] = np.clip(g["quals"], 5, 20)
+        out.append(compare(backend, synth.batch_from_regions([g]), tol, max_indel_error=band, use_int_scores=bits))
+    return out

@@ -204,3 +204,15 @@ def test_gpu_align_realigner_sized_batch():
     batch = synth.batch_from_regions([synth.make_region(rng, 3000, 4, B=16, positions="none")])
     got = ca.compare_align("gpu", batch, max_indel_error=16)
     assert len(got["cigar_strings"]) == 12000
+
+
+def test_gpu_long_reads_at_narrow_bands_stream():
+    stats = cp.check_long_reads_at_narrow_bands("gpu", TOL)
+    assert all(s["n_dp_score_only"] + s["n_dp_traceback"] > 0 for s in stats) and any(s["n_dp_traceback"] > 0 for s in stats)
+    # full PacBio-CCS-like shape: 10 kb reads, 14 kb haplotypes, band 16, int32 lanes
+    import check_align as ca
+    rng = np.random.default_rng(75)
+    g = synth.make_region(rng, 12, 3, T=10_000, Lh=14_000, B=16, flank=(200, 200), positions="none", q_values=(20, 40), indels_per_read=3)
+    batch = synth.batch_from_regions([g])
+    cp.compare("gpu", batch, TOL, max_indel_error=16, use_int_scores=1)
+    ca.compare_align("gpu", batch, max_cigar_ops=256, max_indel_error=16, use_int_scores=1)

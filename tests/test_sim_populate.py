@@ -50,3 +50,8 @@ def test_sim_populate_in_slices(monkeypatch):
     cp.check_templates_and_regions("sim")
     cp.check_device_kmer_mapper("sim")
     cp.check_ragged_and_edges("sim")
+
+
+def test_sim_long_reads_at_narrow_bands_stream():
+    stats = cp.check_long_reads_at_narrow_bands("sim", T=700, Lh=1900, n_reads=3)
+    assert all(s["n_dp_score_only"] + s["n_dp_traceback"] > 0 for s in stats) and any(s["n_dp_traceback"] > 0 for s in stats)
