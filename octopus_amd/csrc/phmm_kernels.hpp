@@ -958,6 +958,26 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
     };
     uint2 rw[C];
     for (int c = 0; c < C; ++c) rw[c] = read_rec(-(int32_t)i0 - c);
+    // Operand prefetch: a lone wave per SIMD cannot hide a memory round trip per iteration, so the haplotype records and read bytes of the
+    // NEXT 8 iterations are fetched while the current 8 compute (registers: 8 table entries + 8 read bases + 8 qualities per lane).
+    constexpr int CH = 8;
+    struct Chunk { uint2 tab[CH]; uint64_t rb, rq; int32_t tt0, start; };
+    auto fetch = [&](uint32_t k0) -> Chunk {                             // operands consumed at the END of iterations k0 .. k0 + 7
+        Chunk ch;
+        for (int e = 0; e < CH; ++e) { const uint32_t nx = k0 + e + 1 + i0 + C; ch.tab[e] = tab[nx > last_rec ? last_rec : nx]; }
+        ch.tt0 = (int32_t)(k0 + 1) - (int32_t)i0;                         // read position of element 0
+        const int32_t hi = (int32_t)T > CH ? (int32_t)T - CH : 0;
+        ch.start = ch.tt0 < 0 ? 0 : (ch.tt0 > hi ? hi : ch.tt0);          // 8 bytes from a position inside the read (the batch's arrays carry a 16-byte tail pad)
+        ch.rb = ld64u(p.rbases + ro + ch.start); ch.rq = ld64u(p.rquals + ro + ch.start);
+        return ch;
+    };
+    auto chunk_read_rec = [&](const Chunk& ch, int e) -> uint2 {
+        const int32_t tt = ch.tt0 + e;
+        if (tt < 0) return make_uint2(0x100u, 64u << 2);
+        if ((uint32_t)tt >= T) return make_uint2((uint32_t)'0', 64u << 2);
+        const uint32_t sh = 8u * (uint32_t)(tt - ch.start);
+        return make_uint2((uint32_t)(ch.rb >> sh) & 0xffu, ((uint32_t)(ch.rq >> sh) & 0xffu) << 2);
+    };
     auto cost = [&](const uint2 r2, const uint2 a, uint32_t* mism) -> uint32_t {           // update_match_state :121-132
         const uint32_t h = a.x & 0xffu, m = (a.x >> 8) & 0xffu, p4 = ((a.x >> 16) & 0xffu) << 2, isn = a.x >> 24;
         const uint32_t inner = r2.x == m ? p4 : r2.y;
@@ -967,7 +987,13 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
         return min_i32(c, isn ? 8u : INFW);
     };
     uint32_t* bpt = TRACE ? p.bp + (size_t)group * p.k_cap * C * 1024 : nullptr;
-    for (uint32_t k = 0; k < K; ++k) {
+    Chunk nxt = fetch(0);
+    for (uint32_t k0 = 0; k0 < K; k0 += CH) {
+      const Chunk cur = nxt;
+      if (k0 + CH < K) nxt = fetch(k0 + CH);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const uint32_t k = k0 + (uint32_t)e;                              // iterations past K (K is not a multiple of 8) only touch spare traceback words
         uint32_t dsh[C], ish[C], bpe[C];
         for (int c = 0; c < C; ++c) {
             const uint32_t i = i0 + c;
@@ -1023,11 +1049,12 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
                 bpt[(((size_t)(k >> 4) * C + c) * 64 + lane) * 16 + (k & 15)] = bpe[c] | (tm | ti << 2 | td << 4) << 6;
             }
         }
-        // slide the operand windows by one position (a row that has finished its own T + B iterations re-reads its last record)
+        // slide the operand windows by one position (past its own window a task re-reads its last record)
         for (int c = 0; c < C; ++c) hw_[c] = hw_[c + 1];
-        { const uint32_t nx = k + 1 + i0 + C; hw_[C] = tab[ROWS > 1 && nx > last_rec ? last_rec : nx]; }
+        hw_[C] = cur.tab[e];
         for (int c = C - 1; c >= 1; --c) rw[c] = rw[c - 1];
-        rw[0] = read_rec((int32_t)(k + 1) - (int32_t)i0);
+        rw[0] = chunk_read_rec(cur, e);
+      }
     }
     // first minimum over the end cells: per lane the candidates were visited in increasing diagonal order, so strict < kept the first
     uint32_t kv = have ? (W16 ? ((best + 0x8000u) & 0xffffu) : (best ^ 0x80000000u)) : 0xffffffffu, ks = best_s;

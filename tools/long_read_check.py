@@ -6,8 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle
 from octopus_amd import abi, engine, synth
-t0 = time.time(); batch = synth.config_batch("long64x8", seed=42, B=256, positions="none"); print("generated in %.1fs" % (time.time() - t0), flush=True)
-cfg = abi.Config.default(max_indel_error=256, use_int_scores=1)
+# default: BASELINE configs[4] (band 256). "ccs": the reference's PacBioCCS.config shape - band 16, int32 lanes, 10 kb reads x 14 kb haplotypes
+if len(sys.argv) > 1 and sys.argv[1] == "ccs":
+    rng = np.random.default_rng(42)
+    t0 = time.time(); batch = synth.batch_from_regions([synth.make_region(rng, 256, 12, T=10_000, Lh=14_000, B=16, flank=(400, 400), positions="none",
+                                                                          q_values=(20, 40), indels_per_read=4)])
+    cfg = abi.Config.default(max_indel_error=16, use_int_scores=1)
+else:
+    t0 = time.time(); batch = synth.config_batch("long64x8", seed=42, B=256, positions="none")
+    cfg = abi.Config.default(max_indel_error=256, use_int_scores=1)
+print("generated in %.1fs" % (time.time() - t0), flush=True)
 eng = engine.Engine(cfg)
 rb = eng.upload(batch)
 rb.run(); got = rb.download().copy()
