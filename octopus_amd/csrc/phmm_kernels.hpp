@@ -256,13 +256,19 @@ OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
     if (mx) hw::atomic_max_lds_u32(&s_max, mx);
     hw::block_sync();
     mx = s_max;
-    if (tid == 0 && mx > 0) {                                          // ascending scan by one thread: this path serves a few hundred pairs
-        uint32_t n = 0;
-        for (uint32_t d = 0; d < nk && n < (uint32_t)b.max_pos; ++d) if (counts[d] == mx) b.pos[e * (uint64_t)b.max_pos + n++] = d;
-        s_nout = n;
-    }
+    // the ascending offsets that reach the maximum, at most max_pos of them (:145-157): every thread owns a contiguous stretch of
+    // diagonals, the stretches' match counts are prefix-summed, and a thread writes its matches while their rank is below max_pos
+    __shared__ uint32_t s_cnt[256];
+    const uint32_t per = (nk + nt - 1) / nt, d0 = tid * per, d1 = d0 + per < nk ? d0 + per : nk;
+    uint32_t mine = 0;
+    if (mx > 0) for (uint32_t d = d0; d < d1; ++d) mine += counts[d] == mx ? 1u : 0u;
+    s_cnt[tid] = mine;
     hw::block_sync();
-    if (tid == 0) b.npos[e] = (uint8_t)s_nout;
+    if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < nt; ++i) { const uint32_t c = s_cnt[i]; s_cnt[i] = run; run += c; } s_nout = run; }
+    hw::block_sync();
+    uint32_t rank = s_cnt[tid];
+    if (mine) for (uint32_t d = d0; d < d1 && rank < (uint32_t)b.max_pos; ++d) if (counts[d] == mx) b.pos[e * (uint64_t)b.max_pos + rank++] = d;
+    if (tid == 0) b.npos[e] = (uint8_t)(s_nout < (uint32_t)b.max_pos ? s_nout : (uint32_t)b.max_pos);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
