@@ -216,3 +216,8 @@ def test_gpu_long_reads_at_narrow_bands_stream():
     batch = synth.batch_from_regions([g])
     cp.compare("gpu", batch, TOL, max_indel_error=16, use_int_scores=1)
     ca.compare_align("gpu", batch, max_cigar_ops=256, max_indel_error=16, use_int_scores=1)
+
+
+def test_gpu_random_scenarios():
+    import check_fuzz
+    assert check_fuzz.check_fuzz("gpu", seed=7, n=120, tol=TOL) == 120
