@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
 # VALU wave-instructions per DP iteration per wave (8 tasks at B = 16), counted in the ISA of this build
 VALU_PER_ITER = {"score": 31.3, "trace": 53.0}
-PMC_SUMMARY = ROOT / "profiles" / "r01_step8_pmc_summary.json"
+PMC_SUMMARY = ROOT / "profiles" / "r01_step11_pmc_summary.json"
 
 
 def algorithmic_bytes_per_task(T: int, B: int) -> int:
