@@ -5,12 +5,15 @@
  * luntergroup/octopus v0.7.4. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this; the product library (octopus_amd/csrc) never links, imports or executes it.
  *
- * Parity pinning: L1 (align / traceback / flank score) is checked against every golden vector of the
- * reference's own test/unit/core/models/pair_hmm_tests.cpp (tests/golden/pair_hmm_tests.json) and
- * against the reference's own SIMD headers compiled in place (oracle/_ref/libref_phmm.so) on random
- * inputs. L2/L3 (fast path, flank-adjusted evaluate, max over mapping positions, mapping-quality mix,
- * k-mer mapper, populate) have NO reference tests (their test files are empty stubs) and cannot be
- * compiled here (Boost/HTSlib absent): those layers are "parity unpinned" and follow the cited lines.
+ * Parity pinning (everything below is compiled in place from /root/reference into oracle/_ref/libref_phmm.so):
+ *   L1  align / traceback / flank score: every golden vector of the reference's own test/unit/core/models/pair_hmm_tests.cpp
+ *       (tests/golden/pair_hmm_tests.json) and the reference's SIMD headers (SSE2 / AVX2 / AVX-512) on random inputs.
+ *   L2  hmm::evaluate (fast path, score-only, flank-adjusted traceback) and hmm::align (exact-match shortcut, simd_align,
+ *       make_cigar, flank discount): the reference's own core/models/pairhmm/pair_hmm.hpp, hmm::PairHMM<hmm::MutationModel>
+ *       (tests/test_oracle_l2.py; Boost and maths.hpp replaced by the few-line shims in oracle/ref_shim).
+ *   k-mer mapper: the reference's own utils/kmer_mapper.hpp (tests/test_oracle_mapper.py).
+ * Still "parity unpinned" (the classes need Haplotype / AlignedRead / HTSlib and cannot be compiled here; they follow the cited
+ * lines): the loop over candidate positions and the mapping-quality mixture of HaplotypeLikelihoodModel (L3), the populate driver.
  */
 #ifndef PHMM_ORACLE_H
 #define PHMM_ORACLE_H
@@ -86,7 +89,7 @@ int oracle_populate(const oct_phmm_config* cfg,
 
 /* HaplotypeLikelihoodModel::align (haplotype_likelihood_model.cpp:322-431) for every (haplotype, read) pair of the flat batch:
  * compute_optimal_alignment :335-395 over hmm::align (pair_hmm.hpp:861-872 = try_naive_align :321-341 | simd_align :788-823,
- * make_cigar :152-188, discount_flank_score :646-673). Same conventions as oct_phmm_align. PARITY UNPINNED above L1 (no reference test). */
+ * make_cigar :152-188, discount_flank_score :646-673). Same conventions as oct_phmm_align. The per-position hmm::align is pinned on the reference's pair_hmm.hpp; the loop over positions is not. */
 int oracle_align_batch(const oct_phmm_config* cfg,
         const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
         const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
