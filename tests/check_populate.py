@@ -228,3 +228,28 @@ def check_long_reads_at_narrow_bands(backend, tol=0.0, T=1400, Lh=3600, n_reads=
         g["quals"][:] = np.clip(g["quals"], 5, 20)
         out.append(compare(backend, synth.batch_from_regions([g]), tol, max_indel_error=band, use_int_scores=bits))
     return out
+
+
+def check_empty_batches(backend):
+    """No reads, no haplotypes, neither: every entry point returns OK with empty outputs (and a 1 x 1 batch still works after them)."""
+    rng = np.random.default_rng(1)
+    g = synth.make_region(rng, 6, 2, T=40, Lh=120, B=8, positions="none")
+    reads = [dict(seq=bytes(g["reads"][r]), quals=g["quals"][r], mapq=60, reverse=False, begin=int(g["begin"][r])) for r in range(6)]
+    haps = []
+    for h in g["haps"]:
+        go, ge, mf, pf, mr, pr = synth._penalties(h)
+        haps.append(dict(seq=bytes(h), begin=0, gap_open=go, gap_extend=ge, mask_fwd=mf, prior_fwd=pf, mask_rev=mr, prior_rev=pr))
+    eng = make_engine(backend, max_indel_error=8)
+    cfg = abi.Config.default(max_indel_error=8)
+    for rr, hh in (([], haps), (reads, []), ([], []), (reads[:1], haps[:1])):
+        batch = abi.Batch.from_lists(rr, hh, flank=(5, 5))
+        out, st = eng.populate(batch, raise_on_error=False)
+        want, wst, _ = oracle.populate(cfg, batch)
+        assert st.code == wst.code == abi.OK and np.array_equal(out, want) and len(out) == len(rr) * len(hh)
+        aln, ast = eng.align(batch, raise_on_error=False)
+        assert ast.code == abi.OK and len(aln["cigar_strings"]) == len(rr) * len(hh)
+        rb = eng.upload(batch); rb.run()
+        assert len(rb.download()) == len(rr) * len(hh)
+        assert len(rb.genotype_likelihoods([])) == 0
+        rb.free()
+    eng.close()

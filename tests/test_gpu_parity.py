@@ -221,3 +221,7 @@ def test_gpu_long_reads_at_narrow_bands_stream():
 def test_gpu_random_scenarios():
     import check_fuzz
     assert check_fuzz.check_fuzz("gpu", seed=7, n=120, tol=TOL) == 120
+
+
+def test_gpu_empty_batches():
+    cp.check_empty_batches("gpu")

@@ -55,3 +55,7 @@ def test_sim_populate_in_slices(monkeypatch):
 def test_sim_long_reads_at_narrow_bands_stream():
     stats = cp.check_long_reads_at_narrow_bands("sim", T=700, Lh=1900, n_reads=3)
     assert all(s["n_dp_score_only"] + s["n_dp_traceback"] > 0 for s in stats) and any(s["n_dp_traceback"] > 0 for s in stats)
+
+
+def test_sim_empty_batches():
+    cp.check_empty_batches("sim")
