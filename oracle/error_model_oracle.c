@@ -10,9 +10,9 @@
  * PINNED: the repeat extraction is checked list-for-list against the reference's own tandem library compiled in place
  * (oracle/_ref, ref_tandem_repeats) - including that library's quirks (runs touching the end of the string, period == max_period,
  * the duplicated suffix-array entry), which the error models inherit. UNPINNED: the two model classes (they need Haplotype / Boost
- * to compile); they follow the cited lines. One documented divergence: sort_by_length uses std::sort (unstable); we order equal
- * lengths by their extraction order (stable), which can only differ where two equal-length repeats with different extension
- * penalties overlap.
+ * to compile on their own) - ALSO PINNED: oracle/_ref compiles the reference's BasicRepeatBasedIndelErrorModel and BasicRepeatBasedSNVErrorModel
+ * in place on a stand-in Haplotype (oracle/ref_errmodel_bridge.cpp); all six vectors are compared for equality, including the order
+ * std::sort leaves equal-length repeats in (restated below).
  */
 #include "error_model_oracle.h"
 
@@ -246,6 +246,95 @@ int oracle_tandem_repeats(const char* str, uint32_t n, uint32_t min_period, uint
     return k;
 }
 
+/* sort_by_length (repeat_based_indel_error_model.cpp:20-23) is std::sort on `length` alone: NOT stable, and which of two equal-length
+ * repeats ends up later decides the extension penalty where they overlap. The reference is built with libstdc++, so this is its
+ * std::sort, step for step (bits/stl_algo.h: __introsort_loop with median-of-three pivot to *first, __unguarded_partition, depth limit
+ * 2 * floor(log2 n) with the heap-sort fallback, then __final_insertion_sort with threshold 16); pinned against the real std::sort in
+ * oracle/_ref (ref_sort_by_length) and through the gap_extend vectors of the reference's model class. */
+static int len_less(const rep_t* a, const rep_t* b) { return a->length < b->length; }
+static void rep_swap(rep_t* a, rep_t* b) { const rep_t t = *a; *a = *b; *b = t; }
+static void unguarded_linear_insert(rep_t* last)
+{
+    const rep_t val = *last; rep_t* next = last - 1;
+    while (len_less(&val, next)) { *last = *next; last = next; --next; }
+    *last = val;
+}
+static void insertion_sort(rep_t* first, rep_t* last)
+{
+    if (first == last) return;
+    for (rep_t* i = first + 1; i != last; ++i) {
+        if (len_less(i, first)) { const rep_t val = *i; memmove(first + 1, first, (size_t)(i - first) * sizeof(rep_t)); *first = val; }
+        else unguarded_linear_insert(i);
+    }
+}
+static void adjust_heap(rep_t* first, long hole, long len, rep_t value)      /* std::__adjust_heap + __push_heap */
+{
+    const long top = hole; long child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (len_less(first + child, first + (child - 1))) --child;
+        first[hole] = first[child]; hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); first[hole] = first[child - 1]; hole = child - 1; }
+    long parent = (hole - 1) / 2;
+    while (hole > top && len_less(first + parent, &value)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
+    first[hole] = value;
+}
+static void heap_sort_range(rep_t* first, rep_t* last)                       /* std::__partial_sort(first, last, last): make_heap + sort_heap */
+{
+    const long len = last - first;
+    if (len >= 2) for (long parent = (len - 2) / 2; ; --parent) { adjust_heap(first, parent, len, first[parent]); if (parent == 0) break; }
+    while (last - first > 1) { --last; const rep_t value = *last; *last = *first; adjust_heap(first, 0, last - first, value); }
+}
+static void move_median_to_first(rep_t* result, rep_t* a, rep_t* b, rep_t* c)
+{
+    if (len_less(a, b)) { if (len_less(b, c)) rep_swap(result, b); else if (len_less(a, c)) rep_swap(result, c); else rep_swap(result, a); }
+    else if (len_less(a, c)) rep_swap(result, a);
+    else if (len_less(b, c)) rep_swap(result, c);
+    else rep_swap(result, b);
+}
+static rep_t* unguarded_partition(rep_t* first, rep_t* last, rep_t* pivot)
+{
+    for (;;) {
+        while (len_less(first, pivot)) ++first;
+        --last;
+        while (len_less(pivot, last)) --last;
+        if (!(first < last)) return first;
+        rep_swap(first, last);
+        ++first;
+    }
+}
+static void introsort_loop(rep_t* first, rep_t* last, long depth_limit)
+{
+    while (last - first > 16) {
+        if (depth_limit == 0) { heap_sort_range(first, last); return; }
+        --depth_limit;
+        rep_t* mid = first + (last - first) / 2;
+        move_median_to_first(first, first + 1, mid, last - 1);
+        rep_t* cut = unguarded_partition(first + 1, last, first);
+        introsort_loop(cut, last, depth_limit);
+        last = cut;
+    }
+}
+static void sort_by_length_like_libstdcxx(rep_t* v, uint32_t n)
+{
+    if (n < 2) return;
+    long lg = 0; for (uint32_t m = n; m > 1; m >>= 1) ++lg;                  /* std::__lg */
+    introsort_loop(v, v + n, 2 * lg);
+    if (n > 16) { insertion_sort(v, v + 16); for (rep_t* i = v + 16; i != v + n; ++i) unguarded_linear_insert(i); }
+    else insertion_sort(v, v + n);
+}
+
+/* test hook: the permutation sort_by_length produces for the given lengths (ids 0..n-1 in `period`) */
+void oracle_sort_by_length(const uint32_t* lengths, uint32_t n, uint32_t* out_ids)
+{
+    rep_t* v = (rep_t*)malloc((n ? n : 1) * sizeof(rep_t));
+    for (uint32_t i = 0; i < n; ++i) v[i] = (rep_t){i, lengths[i], i};
+    sort_by_length_like_libstdcxx(v, n);
+    for (uint32_t i = 0; i < n; ++i) out_ids[i] = v[i].period;
+    free(v);
+}
+
 /* ---- indel error model --------------------------------------------------------------------------------------------- */
 static int8_t table_at(const int8_t* t, uint32_t periodicity) { return t[periodicity < OCT_PHMM_INDEL_TABLE ? periodicity : OCT_PHMM_INDEL_TABLE - 1]; }   /* get_min_penalty :44-47 on the 50-entry arrays (:23-28) */
 static int8_t cap_at(const int8_t* t, uint32_t run) { return t[run < OCT_PHMM_SNV_TABLE ? run : OCT_PHMM_SNV_TABLE - 1]; }                          /* get_penalty :115-119 on the 51-entry arrays */
@@ -279,12 +368,7 @@ void oracle_indel_penalties(const oct_phmm_error_model* m, const char* seq, uint
     memset(gap_open, m->dinucleotide_open[0], n); memset(gap_extend, m->dinucleotide_extend[0], n);
     vec_t r = {0};
     extract_repeats(seq, n, 1, 5, &r);                                  /* :15-18 */
-    /* sort_by_length :20-23 (see the header comment: stable here) */
-    for (uint32_t i = 1; i < r.n; ++i) {
-        const rep_t x = r.v[i]; uint32_t j = i;
-        while (j > 0 && x.length < r.v[j - 1].length) { r.v[j] = r.v[j - 1]; --j; }
-        r.v[j] = x;
-    }
+    sort_by_length_like_libstdcxx(r.v, r.n);                             /* sort_by_length :20-23 */
     for (uint32_t i = 0; i < r.n; ++i) {
         const rep_t* q = &r.v[i];
         const int8_t op = open_penalty(m, seq + q->pos, q->period, q->length);

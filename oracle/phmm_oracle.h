@@ -12,8 +12,11 @@
  *       make_cigar, flank discount): the reference's own core/models/pairhmm/pair_hmm.hpp, hmm::PairHMM<hmm::MutationModel>
  *       (tests/test_oracle_l2.py; Boost and maths.hpp replaced by the few-line shims in oracle/ref_shim).
  *   k-mer mapper: the reference's own utils/kmer_mapper.hpp (tests/test_oracle_mapper.py).
- * Still "parity unpinned" (the classes need Haplotype / AlignedRead / HTSlib and cannot be compiled here; they follow the cited
- * lines): the loop over candidate positions and the mapping-quality mixture of HaplotypeLikelihoodModel (L3), the populate driver.
+ *   L3  HaplotypeLikelihoodModel::evaluate / align over candidate positions (in-range test, original-position rule, shifted fallback,
+ *       ShortHaplotypeError, mapping-quality mixture): the reference's own core/models/haplotype_likelihood_model.cpp on stand-in
+ *       Haplotype / AlignedRead types (tests/test_oracle_l3.py).
+ * Still "parity unpinned" (HaplotypeLikelihoodArray / Genotype<> cannot be compiled here; they follow the cited lines): the populate
+ * driver loop (rows x haplotypes, template sums) and the genotype read-out.
  */
 #ifndef PHMM_ORACLE_H
 #define PHMM_ORACLE_H

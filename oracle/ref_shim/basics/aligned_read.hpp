@@ -1,0 +1,22 @@
+// TEST INFRASTRUCTURE ONLY: stand-in for the reference's basics/aligned_read.hpp (which pulls in HTSlib-facing types) exposing exactly the
+// members core/models/haplotype_likelihood_model.cpp touches; shadows the real header when that file is compiled in place for oracle/_ref.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+namespace octopus {
+class AlignedRead
+{
+public:
+    using NucleotideSequence = std::string;
+    using MappingQuality = std::uint8_t;
+    using BaseQuality = std::uint8_t;
+    using BaseQualityVector = std::vector<BaseQuality>;
+    NucleotideSequence sequence_; BaseQualityVector base_qualities_; MappingQuality mapping_quality_ = 0; bool reverse_ = false; std::int64_t begin_ = 0;
+    const NucleotideSequence& sequence() const noexcept { return sequence_; }
+    const BaseQualityVector& base_qualities() const noexcept { return base_qualities_; }
+    MappingQuality mapping_quality() const noexcept { return mapping_quality_; }
+    bool is_marked_reverse_mapped() const noexcept { return reverse_; }
+};
+inline std::size_t sequence_size(const AlignedRead& r) noexcept { return r.sequence_.size(); }
+} // namespace octopus

@@ -1,0 +1,3 @@
+// TEST INFRASTRUCTURE ONLY: see ../stubs.hpp
+#pragma once
+#include "boost/math/stubs.hpp"

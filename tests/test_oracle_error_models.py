@@ -74,3 +74,58 @@ def test_snv_model_masks_priors_and_substitution_mask():
     *_, pf2, _, pr2 = oracle.penalty_vectors(m, seq, sub)
     assert set(pf2[20:36].tolist()) == {125} and set(pr2[20:36].tolist()) == {125}  # haplotype's own substitutions are never down-weighted (:168-172)
     assert np.array_equal(pf2[:20], pf[:20]) and np.array_equal(pf2[36:], pf[36:])
+
+
+def ref_penalty_vectors(seq, substitution_mask=None):
+    """The reference's own BasicRepeatBasedIndelErrorModel + BasicRepeatBasedSNVErrorModel (oracle/_ref) on the default tables."""
+    import ctypes as C
+    tabs = [AT, CG, DI, TRI, [3, 3, 3, 3, 3, 3, 4, 5, 6, 6, 8, 8, 7, 6, 5, 4, 3], [3, 3, 5, 4, 3, 2], [3, 3, 5, 4, 3, 2]] + SNV
+    flat = np.asarray([v for t in tabs for v in t], np.int8); lens = np.asarray([len(t) for t in tabs], np.uint32)
+    n = len(seq)
+    go, ge, pf, pr = (np.zeros(n, np.int8) for _ in range(4)); mf, mr = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    p = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    sub = None if substitution_mask is None else np.ascontiguousarray(substitution_mask, dtype=np.uint8)
+    oracle.ref().ref_error_models(p(flat), p(lens), bytes(seq), n, p(sub), p(go), p(ge), p(mf), p(pf), p(mr), p(pr))
+    return go, ge, mf, pf, mr, pr
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="reference build absent")
+def test_error_model_restatement_equals_the_reference_classes():
+    """All six vectors of HaplotypeLikelihoodModel::reset: the restatement vs the reference's own model classes compiled in place
+    (default PCR-free tables), on random haplotypes with planted repeats and random substitution masks."""
+    rng = np.random.default_rng(77)
+    m = model()
+    names = ("gap_open", "gap_extend", "mask_fwd", "prior_fwd", "mask_rev", "prior_rev")
+    for it in range(600):
+        seq = random_sequence(rng, int(rng.integers(2, 420)), b"ACGT" if it % 6 else b"ACGTN")
+        sub = None
+        if it % 3 == 0:
+            sub = np.zeros(len(seq), np.uint8)
+            for _ in range(int(rng.integers(0, 4))):
+                a = int(rng.integers(0, len(seq))); sub[a:a + int(rng.integers(1, 6))] = 1
+        got, want = oracle.penalty_vectors(m, seq, sub), ref_penalty_vectors(seq, sub)
+        for name, g, w in zip(names, got, want):
+            assert np.array_equal(g, w), (name, seq, np.flatnonzero(g != w)[:5])
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="reference build absent")
+def test_sort_by_length_restatement_equals_std_sort():
+    """gap_extend depends on the order std::sort (unstable) leaves equal-length repeats in: the restated libstdc++ introsort against the real one,
+    including inputs that reach its heap-sort fallback."""
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    def run(lib, fn, a):
+        out = np.zeros(len(a), np.uint32)
+        getattr(lib, fn)(a.ctypes.data_as(C.c_void_p), len(a), out.ctypes.data_as(C.c_void_p))
+        return out
+    cases = []
+    for it in range(1500):
+        a = rng.integers(2, 2 + int(rng.choice([2, 3, 5, 20, 1000])), int(rng.integers(0, 300))).astype(np.uint32)
+        cases.append(np.sort(a) if it % 7 == 0 else (np.sort(a)[::-1].copy() if it % 11 == 0 else a))
+    for n in (64, 128, 500, 1000, 4000):                                   # alternating low / high halves: deep recursion
+        k = n // 2; a = np.zeros(n, np.uint32)
+        a[0::2] = [i + 1 if i % 2 == 0 else k + i + 1 for i in range(k)]
+        a[1::2] = [k + i + 1 if i % 2 == 0 else i + 1 for i in range(k)]
+        cases.append(a)
+    for a in cases:
+        assert np.array_equal(run(oracle.ref(), "ref_sort_by_length", a), run(oracle.lib(), "oracle_sort_by_length", a))
