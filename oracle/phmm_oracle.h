@@ -15,8 +15,8 @@
  *   L3  HaplotypeLikelihoodModel::evaluate / align over candidate positions (in-range test, original-position rule, shifted fallback,
  *       ShortHaplotypeError, mapping-quality mixture): the reference's own core/models/haplotype_likelihood_model.cpp on stand-in
  *       Haplotype / AlignedRead types (tests/test_oracle_l3.py).
- * Still "parity unpinned" (HaplotypeLikelihoodArray / Genotype<> cannot be compiled here; they follow the cited lines): the populate
- * driver loop (rows x haplotypes, template sums) and the genotype read-out.
+ *   Genotype read-out: the reference's own constant_mixture_genotype_likelihood_model.cpp on stand-in array / genotype types.
+ * Still "parity unpinned" (follows the cited lines): only the populate driver loop (rows x haplotypes, template sums).
  */
 #ifndef PHMM_ORACLE_H
 #define PHMM_ORACLE_H
@@ -110,7 +110,7 @@ double oracle_time_align_windows(int band, int score_bits, uint32_t n,
 /* ConstantMixtureGenotypeLikelihoodModel::evaluate(const Genotype<IndexedHaplotype<>>&)
  * (core/models/genotype/constant_mixture_genotype_likelihood_model.cpp:65-330) for n_genotypes genotypes of `ploidy`
  * sorted haplotype indices each, over rows [row_begin, row_end) of the columns lik[hap_out_off[h] + row].
- * PARITY UNPINNED: the reference holds no test for this class and maths.hpp needs Boost to compile. */
+ * Pinned on the reference's own constant_mixture_genotype_likelihood_model.cpp built in place (tests/test_oracle_l3.py). */
 int oracle_genotype_likelihoods(const double* lik, const uint64_t* hap_out_off, uint32_t n_genotypes, uint32_t ploidy,
         const uint32_t* hap_indices, uint32_t row_begin, uint32_t row_end, double* out);
 

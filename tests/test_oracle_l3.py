@@ -118,3 +118,26 @@ def test_align_over_positions_equals_the_reference_model(band):
             assert (got["cigar_strings"][0], int(got["mapping_position"][0]), float(got["likelihood"][0])) == (cig, mp.value, lik.value), (kw, c["begin"], c["pos"])
             seen += 1
     assert seen > 300
+
+
+@pytest.mark.parametrize("indexed", [1, 0])
+def test_genotype_model_restatement_equals_the_reference_class(indexed):
+    """oracle_genotype_likelihoods vs the reference's own constant_mixture_genotype_likelihood_model.cpp (every ploidy 1-7 and every
+    zygosity pattern; both the IndexedHaplotype overloads the callers use and the Haplotype ones)."""
+    import itertools
+    rng = np.random.default_rng(500 + indexed)
+    H, Rr = 6, 57
+    lik = -np.abs(rng.normal(3, 6, (H, Rr))); lik[rng.random((H, Rr)) < 0.1] = 0.0; lik[2, 5] = -1.7976931348623157e308
+    off = np.arange(H + 1, dtype=np.uint64) * Rr
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    for ploidy in range(1, 8):
+        gts = np.asarray(list(itertools.combinations_with_replacement(range(H), ploidy)), np.uint32)
+        if len(gts) > 400:
+            gts = gts[rng.choice(len(gts), 400, replace=False)]
+        want = np.zeros(len(gts)); cols = np.ascontiguousarray(lik)
+        oracle.ref().ref_genotype_likelihoods(p(cols), H, Rr, p(gts), len(gts), ploidy, indexed, p(want))
+        got = oracle.genotype_likelihoods(lik.reshape(-1), off, gts, (0, Rr))
+        if indexed:
+            assert np.array_equal(got, want), (ploidy, np.flatnonzero(got != want)[:5])
+        else:   # the Haplotype overloads group the same cases slightly differently (e.g. no tetraploid special cases): same value to rounding
+            assert np.allclose(got, want, rtol=1e-13, atol=0), ploidy
