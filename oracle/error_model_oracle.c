@@ -9,8 +9,7 @@
  *
  * PINNED: the repeat extraction is checked list-for-list against the reference's own tandem library compiled in place
  * (oracle/_ref, ref_tandem_repeats) - including that library's quirks (runs touching the end of the string, period == max_period,
- * the duplicated suffix-array entry), which the error models inherit. UNPINNED: the two model classes (they need Haplotype / Boost
- * to compile on their own) - ALSO PINNED: oracle/_ref compiles the reference's BasicRepeatBasedIndelErrorModel and BasicRepeatBasedSNVErrorModel
+ * the duplicated suffix-array entry), which the error models inherit. The two model classes are pinned too: oracle/_ref compiles the reference's BasicRepeatBasedIndelErrorModel and BasicRepeatBasedSNVErrorModel
  * in place on a stand-in Haplotype (oracle/ref_errmodel_bridge.cpp); all six vectors are compared for equality, including the order
  * std::sort leaves equal-length repeats in (restated below).
  */
