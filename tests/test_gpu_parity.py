@@ -225,3 +225,11 @@ def test_gpu_random_scenarios():
 
 def test_gpu_empty_batches():
     cp.check_empty_batches("gpu")
+
+
+def test_gpu_matrix_equals_the_reference_composed_piece_by_piece():
+    """The reference's own error models, k-mer mapper and likelihood model (oracle/_ref) produce the matrix; the GPU must reproduce it."""
+    if not oracle.have_ref():
+        pytest.skip("reference build absent")
+    from test_oracle_l3 import check_populate_composed_from_the_reference_pieces
+    check_populate_composed_from_the_reference_pieces("gpu", TOL)

@@ -141,3 +141,46 @@ def test_genotype_model_restatement_equals_the_reference_class(indexed):
             assert np.array_equal(got, want), (ploidy, np.flatnonzero(got != want)[:5])
         else:   # the Haplotype overloads group the same cases slightly differently (e.g. no tetraploid special cases): same value to rounding
             assert np.allclose(got, want, rtol=1e-13, atol=0), ploidy
+
+
+def check_populate_composed_from_the_reference_pieces(backend, tol=0.0):
+    """A whole region through the REFERENCE's own code, piece by piece (its error models -> six vectors, its k-mer mapper -> candidate
+    positions, its HaplotypeLikelihoodModel::evaluate per read and haplotype), against the oracle's populate with device-style mapping and
+    against the product pipeline on the wave simulator: the matrix the caller would see, from nothing but bases, qualities and positions."""
+    from test_oracle_error_models import ref_penalty_vectors
+    from backends import make_engine
+    from octopus_amd import synth
+    rng = np.random.default_rng(9)
+    band = 8
+    g = synth.make_region(rng, 14, 4, T=60, Lh=200, B=band, flank=(30, 25), positions="none", indels_per_read=0)
+    g["mapq"] = rng.integers(5, 70, 14).astype(np.uint8)
+    vec = [ref_penalty_vectors(bytes(h)) for h in g["haps"]]                   # reference error models
+    haps = [dict(seq=bytes(h), begin=0, gap_open=v[0], gap_extend=v[1], mask_fwd=v[2], prior_fwd=v[3], mask_rev=v[4], prior_rev=v[5])
+            for h, v in zip(g["haps"], vec)]
+    reads = [dict(seq=bytes(g["reads"][r]), quals=g["quals"][r], mapq=int(g["mapq"][r]), reverse=bool(g["reverse"][r]), begin=int(g["begin"][r]))
+             for r in range(14)]
+    batch = abi.Batch.from_lists(reads, haps, flank=g["flank"])
+    kw = dict(max_indel_error=band)
+    R = oracle.ref(); out = (C.c_uint32 * 32)()
+    want = np.zeros((4, 14))
+    for h in range(4):
+        for r in range(14):
+            hs, rs = bytes(g["haps"][h]), bytes(g["reads"][r])
+            n = R.ref_kmer_map(rs, len(rs), hs, len(hs), 10, out)              # reference k-mer mapper
+            c = dict(hap=g["haps"][h], read=g["reads"][r], quals=g["quals"][r], begin=int(g["begin"][r]), pos=np.asarray([out[i] for i in range(n)], np.uint32),
+                     reverse=bool(g["reverse"][r]), mapq=int(g["mapq"][r]), go=vec[h][0], ge=vec[h][1], mask_f=vec[h][2], prior_f=vec[h][3],
+                     mask_r=vec[h][4], prior_r=vec[h][5], flank=g["flank"])
+            a, keep = to_args(c, kw)
+            v, ext = C.c_double(0), C.c_uint32(0)
+            assert R.ref_model_evaluate(C.byref(a), C.byref(v), C.byref(ext)) == 0   # reference likelihood model
+            want[h, r] = v.value
+    got, st, _ = oracle.populate(abi.Config.default(**kw), batch)
+    assert st.code == abi.OK and np.array_equal(got.reshape(4, 14), want)
+    eng = make_engine(backend, **kw)
+    dev, dst = eng.populate(batch)
+    eng.close()
+    assert dst.code == abi.OK and np.max(np.abs(dev.reshape(4, 14) - want)) <= tol
+
+
+def test_populate_composed_from_the_reference_pieces():
+    check_populate_composed_from_the_reference_pieces("sim")
