@@ -6,7 +6,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <memory>
 #include <unordered_map>
 #include <new>
@@ -987,6 +992,151 @@ extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads
     if (rc == OCT_PHMM_OK) rc = early ? oct_phmm_batch_wait(h, b, status) : oct_phmm_batch_download(h, b, out, status);
     oct_phmm_batch_free(h, b);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// region server: calls from many threads -> multi-region batches on one handle
+// ---------------------------------------------------------------------------------------------------------------
+struct oct_phmm_server {
+    struct Request {
+        const oct_phmm_reads* R; const oct_phmm_haplotypes* H; const oct_phmm_flank_state* flank; const oct_phmm_positions* pos;
+        double* out; oct_phmm_status st; int rc = OCT_PHMM_OK; bool done = false;
+    };
+#if defined(OCTPHMM_SIM)
+    static constexpr int kWorkers = 1;                   // the CPU wave simulator is single-threaded
+#else
+    static constexpr int kWorkers = 2;                   // two device queues: while one worker's batch computes, the other gathers and uploads the calls that arrived since
+#endif
+    oct_phmm_handle* hs[kWorkers] = {};
+    uint32_t max_regions = 256;
+    std::mutex mu; std::condition_variable cv_work, cv_done;
+    std::deque<Request*> queue;
+    bool stop = false;
+    std::thread workers[kWorkers];
+    uint64_t n_calls = 0, n_batches = 0;
+
+    static uint32_t rows_of(const oct_phmm_reads* R) { return R->row_offsets ? R->n_rows : R->n_reads; }
+
+    void serve_one(oct_phmm_handle* h, Request* q) { q->rc = oct_phmm_populate(h, q->R, q->H, nullptr, q->flank, q->pos, q->out, &q->st); }
+
+    // concatenate the calls' arrays into one flat batch with one region per call
+    void serve_many(oct_phmm_handle* h, std::vector<Request*>& qs)
+    {
+        std::string rb, hb, mf, mr; std::vector<uint8_t> rq, mq, rv, has_flank; std::vector<uint32_t> roff {0}, hoff {0}, row_off {0}, reg_rows {0}, reg_haps {0};
+        std::vector<int64_t> rbeg, hbeg; std::vector<int8_t> go, ge, pf, pr; std::vector<oct_phmm_flank_state> fl;
+        bool templates = false;
+        for (Request* q : qs) if (q->R->row_offsets) templates = true;
+        size_t n_out = 0;
+        for (Request* q : qs) {
+            const oct_phmm_reads* R = q->R; const oct_phmm_haplotypes* H = q->H;
+            const uint32_t nb = R->n_reads ? R->offsets[R->n_reads] : 0, hn = H->n_haps ? H->offsets[H->n_haps] : 0;
+            rb.append(R->bases, nb); rq.insert(rq.end(), R->qualities, R->qualities + nb);
+            for (uint32_t r = 0; r < R->n_reads; ++r) roff.push_back(roff.back() + (R->offsets[r + 1] - R->offsets[r]));
+            mq.insert(mq.end(), R->mapping_quality, R->mapping_quality + R->n_reads); rv.insert(rv.end(), R->reverse_strand, R->reverse_strand + R->n_reads);
+            rbeg.insert(rbeg.end(), R->ref_begin, R->ref_begin + R->n_reads);
+            const uint32_t read0 = (uint32_t)mq.size() - R->n_reads;
+            if (templates) for (uint32_t row = 0; row < rows_of(R); ++row) row_off.push_back(read0 + (R->row_offsets ? R->row_offsets[row + 1] : row + 1));
+            hb.append(H->bases, hn);
+            for (uint32_t k = 0; k < H->n_haps; ++k) hoff.push_back(hoff.back() + (H->offsets[k + 1] - H->offsets[k]));
+            hbeg.insert(hbeg.end(), H->ref_begin, H->ref_begin + H->n_haps);
+            go.insert(go.end(), H->gap_open, H->gap_open + hn); ge.insert(ge.end(), H->gap_extend, H->gap_extend + hn);
+            mf.append(H->snv_mask_fwd, hn); mr.append(H->snv_mask_rev, hn);
+            pf.insert(pf.end(), H->snv_prior_fwd, H->snv_prior_fwd + hn); pr.insert(pr.end(), H->snv_prior_rev, H->snv_prior_rev + hn);
+            reg_rows.push_back(reg_rows.back() + rows_of(R)); reg_haps.push_back(reg_haps.back() + H->n_haps);
+            has_flank.push_back(q->flank ? 1 : 0); fl.push_back(q->flank ? *q->flank : oct_phmm_flank_state {0, 0});
+            n_out += (size_t)rows_of(R) * H->n_haps;
+        }
+        const uint32_t n_reads = (uint32_t)mq.size(), n_rows = reg_rows.back();
+        oct_phmm_reads R {n_reads, rb.data(), rq.data(), roff.data(), mq.data(), rv.data(), rbeg.data(), templates ? n_rows : 0, templates ? row_off.data() : nullptr};
+        oct_phmm_haplotypes H {(uint32_t)hbeg.size(), hb.data(), hoff.data(), hbeg.data(), go.data(), ge.data(), mf.data(), pf.data(), mr.data(), pr.data()};
+        oct_phmm_regions G {(uint32_t)qs.size(), reg_rows.data(), reg_haps.data(), has_flank.data(), fl.data()};
+        std::vector<double> out(n_out + 1);
+        oct_phmm_status st;
+        const int rc = oct_phmm_populate(h, &R, &H, &G, nullptr, nullptr, out.data(), &st);
+        if (rc != OCT_PHMM_OK) { for (Request* q : qs) serve_one(h, q); return; }      // one region's error must not reach the others: answer each on its own
+        const double* p = out.data();
+        for (Request* q : qs) {
+            const size_t n = (size_t)rows_of(q->R) * q->H->n_haps;
+            if (n) memcpy(q->out, p, n * sizeof(double));
+            p += n; q->rc = OCT_PHMM_OK; memset(&q->st, 0, sizeof(q->st));
+        }
+    }
+
+    void run(int w)
+    {
+        oct_phmm_handle* h = hs[w];
+        for (;;) {
+            std::vector<Request*> take;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+                if (queue.empty() && stop) return;
+                while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
+            }
+            std::vector<Request*> batchable, single;
+            for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : batchable).push_back(q);
+            if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
+            if (!batchable.empty()) serve_many(h, batchable);
+            for (Request* q : single) serve_one(h, q);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (Request* q : take) q->done = true;
+                n_calls += take.size(); n_batches += (batchable.empty() ? 0 : 1) + single.size();
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+extern "C" int oct_phmm_server_create(const oct_phmm_config* cfg, uint32_t max_regions_per_batch, oct_phmm_server** out)
+{
+    if (!out) return OCT_PHMM_EINVAL;
+    *out = nullptr;
+    oct_phmm_server* s = new (std::nothrow) oct_phmm_server();
+    if (!s) return OCT_PHMM_EHIP;
+    for (int w = 0; w < oct_phmm_server::kWorkers; ++w) {
+        const int rc = oct_phmm_create(cfg, &s->hs[w]);
+        if (rc != OCT_PHMM_OK) { for (int k = 0; k < w; ++k) oct_phmm_destroy(s->hs[k]); delete s; return rc; }
+    }
+    if (max_regions_per_batch) s->max_regions = max_regions_per_batch;
+    for (int w = 0; w < oct_phmm_server::kWorkers; ++w) s->workers[w] = std::thread([s, w] { s->run(w); });
+    *out = s;
+    return OCT_PHMM_OK;
+}
+
+extern "C" void oct_phmm_server_destroy(oct_phmm_server* s)
+{
+    if (!s) return;
+    { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
+    s->cv_work.notify_all();
+    for (auto& t : s->workers) if (t.joinable()) t.join();
+    for (auto* h : s->hs) oct_phmm_destroy(h);
+    delete s;
+}
+
+extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
+                                        const oct_phmm_flank_state* flank, const oct_phmm_positions* positions, double* out, oct_phmm_status* status)
+{
+    if (!s || !reads || !haps) return fail(status, OCT_PHMM_EINVAL, "null argument");
+    oct_phmm_server::Request q; q.R = reads; q.H = haps; q.flank = flank; q.pos = positions; q.out = out; memset(&q.st, 0, sizeof(q.st));
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        if (s->stop) return fail(status, OCT_PHMM_EINVAL, "server is shutting down");
+        s->queue.push_back(&q);
+        s->cv_work.notify_one();
+        s->cv_done.wait(lk, [&] { return q.done; });
+    }
+    if (status) *status = q.st;
+    return q.rc;
+}
+
+extern "C" int oct_phmm_server_stats(const oct_phmm_server* s, uint64_t* n_calls, uint64_t* n_batches)
+{
+    if (!s) return OCT_PHMM_EINVAL;
+    std::lock_guard<std::mutex> lk(const_cast<oct_phmm_server*>(s)->mu);
+    if (n_calls) *n_calls = s->n_calls;
+    if (n_batches) *n_batches = s->n_batches;
+    return OCT_PHMM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -67,6 +67,10 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_genotype_likelihoods.argtypes = [pv, pv, pv, pv, pv]
         lib.oct_phmm_align.argtypes = [pv, pv, pv, pv, pv, pv, pv, pv]
         lib.oct_phmm_set_timing.argtypes = [pv, C.c_int]
+        lib.oct_phmm_server_create.argtypes = [C.POINTER(abi.Config), C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.oct_phmm_server_destroy.argtypes = [pv]
+        lib.oct_phmm_server_populate.argtypes = [pv, pv, pv, pv, pv, pv, pv]
+        lib.oct_phmm_server_stats.argtypes = [pv, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.oct_phmm_batch_free.argtypes = [pv, pv]
         _LIBS[key] = lib
     return _LIBS[key]
@@ -255,3 +259,43 @@ class Engine:
                     d.update(flank_score=int(fl[i]), mask_size=int(ms[i]))
             res.append(d)
         return res
+
+
+class Server:
+    """oct_phmm_server: one device queue shared by many calling threads; concurrent single-region populate calls are answered by
+    multi-region batches. `populate` is thread-safe and blocks until its own result is ready."""
+
+    def __init__(self, cfg: Optional[abi.Config] = None, max_regions_per_batch: int = 0, lib_path: Optional[Path] = None):
+        self.lib = load(lib_path)
+        self.cfg = cfg if cfg is not None else abi.Config.default()
+        self.ptr = C.c_void_p()
+        code = self.lib.oct_phmm_server_create(C.byref(self.cfg), int(max_regions_per_batch), C.byref(self.ptr))
+        if code != abi.OK:
+            raise EngineError(code, None, "server_create")
+
+    def populate(self, batch: abi.Batch, raise_on_error: bool = True, out: Optional[np.ndarray] = None):
+        if out is None:
+            out = np.full(max(batch.out_size(), 1), np.nan, dtype=np.float64)
+        st = abi.Status()
+        r, h, g, f, p = batch.c_args()
+        assert g is None, "one region per call"
+        code = self.lib.oct_phmm_server_populate(self.ptr, _vp(r), _vp(h), _vp(f), _vp(p), _ptr(out), C.byref(st))
+        if code != abi.OK and raise_on_error:
+            raise EngineError(code, st, "server_populate")
+        return out[:batch.out_size()], st
+
+    def stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.lib.oct_phmm_server_stats(self.ptr, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        if self.ptr:
+            self.lib.oct_phmm_server_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

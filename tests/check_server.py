@@ -1,0 +1,71 @@
+"""oct_phmm_server: concurrent single-region calls from several threads are answered by multi-region batches; every caller must get exactly
+what its own oct_phmm_populate call would have returned (values, or its own error status)."""
+import threading
+
+import numpy as np
+
+import oracle
+from backends import build_sim, make_engine
+from check_populate import mapper_positions
+from octopus_amd import abi, engine, synth
+
+
+def make_requests(rng, n, band=8):
+    reqs = []
+    for i in range(n):
+        T, Lh = int(rng.integers(30, 70)), int(rng.integers(150, 260))
+        g = synth.make_region(rng, int(rng.integers(4, 30)), int(rng.integers(1, 6)), T=T, Lh=Lh, B=band,
+                              flank=None if i % 4 == 0 else (int(rng.integers(0, 40)), int(rng.integers(0, 40))), positions="none")
+        if i % 7 == 3:                                                 # a region whose haplotypes cannot hold its reads: ShortHaplotypeError for this caller only
+            g["haps"] = [h[:T + 2 * band - 4] for h in g["haps"]]
+            g["begin"] = np.minimum(g["begin"], 3)
+        b = synth.batch_from_regions([g])
+        if i % 5 == 1:                                                 # templates
+            R = g["reads"].shape[0]; rows, r = [0], 0
+            while r < R:
+                r += 2 if (R - r >= 2 and rng.random() < 0.5) else 1
+                rows.append(r)
+            b.row_offsets = np.asarray(rows, np.uint32)
+        if i % 6 == 2:                                                 # caller-provided candidate positions: served on its own
+            mapper_positions(b, rng=rng, junk=0.3)
+        reqs.append(b)
+    return reqs
+
+
+def check_server(backend, n_threads=5, per_thread=7, seed=17, band=8):
+    rng = np.random.default_rng(seed)
+    reqs = [make_requests(rng, per_thread, band) for _ in range(n_threads)]
+    cfg = abi.Config.default(max_indel_error=band)
+    lib_path = build_sim() if backend == "sim" else None
+    srv = engine.Server(cfg, lib_path=lib_path)
+    got = [[None] * per_thread for _ in range(n_threads)]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(2):
+                for i, b in enumerate(reqs[t]):
+                    out, st = srv.populate(b, raise_on_error=False)
+                    got[t][i] = (out.copy(), st.code, st.hap_index, st.read_index, st.required_extension)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    calls, batches = srv.stats()
+    srv.close()
+    assert not errors, errors
+    assert calls == 2 * n_threads * per_thread and 0 < batches <= calls
+    n_err = 0
+    for t in range(n_threads):
+        for i, b in enumerate(reqs[t]):
+            want, wst, _ = oracle.populate(cfg, b)
+            out, code, hi, ri, ext = got[t][i]
+            assert code == wst.code, (t, i, code, wst.code)
+            if code == abi.OK:
+                assert np.max(np.abs(out - want), initial=0.0) <= (0.0 if backend == "sim" else 1e-9)
+            else:
+                n_err += 1
+                assert (hi, ri, ext) == (wst.hap_index, wst.read_index, wst.required_extension)
+    assert n_err > 0
+    return calls, batches

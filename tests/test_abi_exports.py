@@ -27,7 +27,7 @@ def test_header_declares_the_boundary():
     names = declared_functions()
     for need in ("oct_phmm_create", "oct_phmm_destroy", "oct_phmm_populate", "oct_phmm_batch_upload", "oct_phmm_batch_run",
                  "oct_phmm_batch_wait", "oct_phmm_batch_download", "oct_phmm_align_windows", "oct_phmm_align",
-                 "oct_phmm_batch_genotype_likelihoods"):
+                 "oct_phmm_batch_genotype_likelihoods", "oct_phmm_server_create", "oct_phmm_server_populate"):
         assert need in names
 
 

@@ -233,3 +233,9 @@ def test_gpu_matrix_equals_the_reference_composed_piece_by_piece():
         pytest.skip("reference build absent")
     from test_oracle_l3 import check_populate_composed_from_the_reference_pieces
     check_populate_composed_from_the_reference_pieces("gpu", TOL)
+
+
+def test_gpu_server_batches_concurrent_region_calls():
+    import check_server
+    calls, batches = check_server.check_server("gpu", n_threads=8, per_thread=12, band=16)
+    assert calls == 192 and batches < calls            # some calls were answered together

@@ -51,7 +51,34 @@ int main(int argc, char** argv)
     if (threads.empty()) threads = {1, 2, 4, 8, 16};
     std::mt19937_64 rng(42);
     std::vector<Region> regions; for (int i = 0; i < n_regions; ++i) regions.push_back(make_region(rng, R, H));
-    for (int T : threads) {
+    for (int T : threads) {                                     // ---- one region server shared by T calling threads (oct_phmm_server) ----
+        oct_phmm_config c; oct_phmm_config_default(&c); c.max_indel_error = 16;
+        oct_phmm_server* srv = nullptr;
+        if (oct_phmm_server_create(&c, 0, &srv) != OCT_PHMM_OK) { fprintf(stderr, "no device\n"); return 1; }
+        int failures = 0;
+        auto work = [&](int t, int count) {
+            for (int i = t; i < count; i += T) {
+                Region& g = regions[i];
+                oct_phmm_reads rd {(uint32_t)g.mq.size(), g.rb.data(), g.q.data(), g.ro.data(), g.mq.data(), g.rev.data(), g.rbeg.data(), 0, nullptr};
+                oct_phmm_haplotypes hp {(uint32_t)g.hbeg.size(), g.hb.data(), g.ho.data(), g.hbeg.data(), g.go.data(), g.ge.data(), g.mf.data(), g.pf.data(), g.mr.data(), g.pr.data()};
+                oct_phmm_flank_state fl {40, 40}; oct_phmm_status st;
+                if (oct_phmm_server_populate(srv, &rd, &hp, &fl, nullptr, g.out.data(), &st) != OCT_PHMM_OK) ++failures;
+            }
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            const int count = pass ? n_regions : std::min(n_regions, 4 * T);
+            uint64_t c0 = 0, b0 = 0, c1 = 0, b1 = 0; oct_phmm_server_stats(srv, &c0, &b0);
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t, count);
+            for (auto& x : th) x.join();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            oct_phmm_server_stats(srv, &c1, &b1);
+            if (pass) printf("{\"mode\": \"server\", \"threads\": %d, \"regions_per_s\": %.1f, \"M_loglik_per_s\": %.2f, \"regions_per_device_batch\": %.2f, \"failures\": %d}\n",
+                             T, n_regions / dt, (double)n_regions * R * H / dt / 1e6, (double)(c1 - c0) / (double)std::max<uint64_t>(1, b1 - b0), failures);
+        }
+        oct_phmm_server_destroy(srv);
+    }
+    for (int T : threads) {                                     // ---- one handle per calling thread ----
         std::vector<oct_phmm_handle*> hs(T, nullptr);
         oct_phmm_config c; oct_phmm_config_default(&c); c.max_indel_error = 16;
         for (auto& h : hs) if (oct_phmm_create(&c, &h) != OCT_PHMM_OK) { fprintf(stderr, "no device\n"); return 1; }
@@ -71,7 +98,7 @@ int main(int argc, char** argv)
             std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t, count);
             for (auto& x : th) x.join();
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (pass) printf("{\"threads\": %d, \"regions_per_s\": %.1f, \"ms_per_call\": %.3f, \"M_loglik_per_s\": %.2f, \"failures\": %d}\n",
+            if (pass) printf("{\"mode\": \"handle per thread\", \"threads\": %d, \"regions_per_s\": %.1f, \"ms_per_call\": %.3f, \"M_loglik_per_s\": %.2f, \"failures\": %d}\n",
                              T, n_regions / dt, dt / n_regions * T * 1e3, (double)n_regions * R * H / dt / 1e6, failures);
         }
         for (auto h : hs) oct_phmm_destroy(h);
