@@ -34,17 +34,20 @@ struct DevPool {
     std::unordered_map<void*, size_t> live;
     size_t cached = 0;
     static constexpr size_t kCacheCap = (size_t)16 << 30;
-    static size_t size_class(size_t n)
+    static size_t size_class(size_t n)                  // powers of two up to 1 MB, then eight classes per octave: few distinct sizes, so blocks get reused
     {
         if (n < 512) return 512;
-        if (n <= ((size_t)1 << 20)) { size_t c = 512; while (c < n) c <<= 1; return c; }
-        return (n + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        size_t c = 512; while (c < n && c < ((size_t)1 << 20)) c <<= 1;
+        if (c >= n) return c;
+        size_t p2 = (size_t)1 << 20; while ((p2 << 1) <= n) p2 <<= 1;      // largest power of two <= n
+        const size_t step = p2 >> 3;
+        return (n + step - 1) / step * step;
     }
     bool alloc(void** p, size_t n)
     {
         const size_t c = size_class(n);
-        auto it = free_blocks.find(c);
-        if (it != free_blocks.end()) { *p = it->second; free_blocks.erase(it); cached -= c; live[*p] = c; return true; }
+        auto it = free_blocks.lower_bound(c);             // the smallest cached block that fits, if it is not wastefully large
+        if (it != free_blocks.end() && it->first <= c + c / 2) { *p = it->second; const size_t got = it->first; free_blocks.erase(it); cached -= got; live[*p] = got; return true; }
         if (!rt::dev_malloc(p, c)) {
             trim();                                     // give cached blocks back and retry once
             if (!rt::dev_malloc(p, c)) return false;
@@ -1001,6 +1004,7 @@ struct oct_phmm_server {
     struct Request {
         const oct_phmm_reads* R; const oct_phmm_haplotypes* H; const oct_phmm_flank_state* flank; const oct_phmm_positions* pos;
         double* out; oct_phmm_status st; int rc = OCT_PHMM_OK; bool done = false;
+        std::condition_variable cv;                       // one per call: finishing a batch wakes exactly its callers
     };
 #if defined(OCTPHMM_SIM)
     static constexpr int kWorkers = 1;                   // the CPU wave simulator is single-threaded
@@ -1009,7 +1013,7 @@ struct oct_phmm_server {
 #endif
     oct_phmm_handle* hs[kWorkers] = {};
     uint32_t max_regions = 256;
-    std::mutex mu; std::condition_variable cv_work, cv_done;
+    std::mutex mu; std::condition_variable cv_work;
     std::deque<Request*> queue;
     bool stop = false;
     std::thread workers[kWorkers];
@@ -1080,10 +1084,9 @@ struct oct_phmm_server {
             for (Request* q : single) serve_one(h, q);
             {
                 std::lock_guard<std::mutex> lk(mu);
-                for (Request* q : take) q->done = true;
                 n_calls += take.size(); n_batches += (batchable.empty() ? 0 : 1) + single.size();
+                for (Request* q : take) { q->done = true; q->cv.notify_one(); }     // under the lock: the request lives on its caller's stack
             }
-            cv_done.notify_all();
         }
     }
 };
@@ -1124,7 +1127,7 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
         if (s->stop) return fail(status, OCT_PHMM_EINVAL, "server is shutting down");
         s->queue.push_back(&q);
         s->cv_work.notify_one();
-        s->cv_done.wait(lk, [&] { return q.done; });
+        q.cv.wait(lk, [&] { return q.done; });
     }
     if (status) *status = q.st;
     return q.rc;
