@@ -211,6 +211,7 @@ def main():
     rb.free()
     eng.close()
     if dist is not None:
+        dist.barrier()                  # rank 0 reports (and runs its roofline leg) while the others wait: leave together
         dist.destroy_process_group()
 
 
