@@ -22,6 +22,9 @@ cp.check_int32_lanes("sim"); cp.check_wide_and_long("sim"); cp.check_long_reads_
 ca.check_align_basic("sim"); ca.check_align_errors("sim"); cr.check_readout("sim"); cr.check_readout_errors("sim")
 import check_fuzz
 check_fuzz.check_fuzz("sim", seed=5, n=6)
+import check_server
+check_server.check_server("sim", n_threads=3, per_thread=5)
+cp.check_empty_batches("sim")
 print("SANITIZED-OK")
 """
 
