@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
 # VALU wave-instructions per DP iteration per wave (8 tasks at B = 16), counted in the ISA of this build
 VALU_PER_ITER = {"score": 31.3, "trace": 53.0}
-PMC_SUMMARY = ROOT / "profiles" / "r01_step11_pmc_summary.json"
+PMC_SUMMARY = ROOT / "profiles" / "r01_step14_pmc_summary.json"
 
 
 def algorithmic_bytes_per_task(T: int, B: int) -> int:
@@ -165,10 +165,17 @@ def main():
         valu_instr = (groups(stats["n_dp_score_only"]) * VALU_PER_ITER["score"] + groups(stats["n_dp_traceback"]) * VALU_PER_ITER["trace"]) * (T + B)
         dp_s_per_step = ((tr_ms + sc_ms + kind_ms["score_generic"][0] + kind_ms["trace_generic"][0]) / 1e3) / 3
         traffic = None
+        valu_src = "loop-body wave-instructions (ISA count of the traceback form; an upper bound for late-start launches) x iterations"
         if PMC_SUMMARY.exists():        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-            pm = json.loads(PMC_SUMMARY.read_text()).get(f"octphmm::k_dp<{B}, true, false, true>", {})
+            pmc = json.loads(PMC_SUMMARY.read_text())
+            pm = pmc.get(f"octphmm::k_dp<{B}, true, false, true>", {})
             if "hbm_read_bytes_corrected" in pm and "hbm_write_bytes" in pm:
                 traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
+            ps = pmc.get(f"octphmm::k_dp<{B}, false, false, true>", {})
+            if args.workload == "100kx128" and B == 16 and "SQ_INSTS_VALU" in pm and "SQ_INSTS_VALU" in ps:
+                # the PMC passes ran this very workload: instructions actually issued per launch x launches per step
+                valu_instr = pm["SQ_INSTS_VALU"] * tr_n / 3 + ps["SQ_INSTS_VALU"] * sc_n / 3
+                valu_src = f"SQ_INSTS_VALU per launch ({PMC_SUMMARY.relative_to(ROOT)}) x launches per step"
         out = {
             "metric": "pair-HMM band cell-updates/s", "value": cells / per_step / 1e9, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
@@ -184,8 +191,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "traffic_note": f"HBM bytes per launch of k_dp<{B},true,false,true> from {PMC_SUMMARY.relative_to(ROOT)} (FETCH_SIZE x 2 per the gfx950 "
-                                         "correction + WRITE_SIZE, separate --pmc passes of this workload, single slice = one launch per step); "
-                                         "~94 % of it is the 5.3 KB/task backpointer tile stream the walk kernel consumes, which SURVEY 8d's per-task figure does not count",
+                                         "correction + WRITE_SIZE, separate --pmc passes of this workload, single slice = two launches per step: late-start and full traceback); "
+                                         "~90 % of it is the backpointer tile stream the walk kernel consumes, which SURVEY 8d's per-task figure does not count",
                          "kernel": f"k_dp<{B}, TRACE, fast cost, FASTADD> (traceback DP), single-slice run, HIP events on the library stream",
                          "avg_launch_ms": avg_launch_s * 1e3, "tasks_per_launch": tasks_per_launch,
                          "algorithmic_bytes_per_task": algorithmic_bytes_per_task(T, B),
@@ -193,8 +200,8 @@ def main():
                          "valu": {"achieved_wave_instr_per_s": valu_instr / dp_s_per_step if dp_s_per_step > 0 else 0.0,
                                   "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
                                   "frac": (valu_instr / dp_s_per_step / VALU_PEAK_WAVE_INSTR) if dp_s_per_step > 0 else 0.0,
-                                  "note": "the DP is integer-VALU issue bound, not HBM bound (SURVEY.md 8d): loop-body wave-instructions (ISA count) x iterations "
-                                          "/ DP kernel time vs 256 CU x 4 SIMD x 2.4 GHz / 4 cycles; PMC: SQ_ACTIVE_INST_VALU x 4 / (CU x SIMD) = 91-93 % of kernel cycles"}},
+                                  "note": "the DP is integer-VALU issue bound, not HBM bound (SURVEY.md 8d): " + valu_src +
+                                          " / DP kernel time vs 256 CU x 4 SIMD x 2.4 GHz / 4 cycles"}},
         }
         if world == 1 and not args.no_small_batch:
             small = eng.upload(synth.config_batch("1kx64", seed=42, B=B, positions="none"))

@@ -102,12 +102,14 @@ struct oct_phmm_batch {
     struct Slice {                     // whole haplotypes [hap0, hap1) = pairs [pair0, pair1) = outputs [out0, out1)
         uint32_t hap0 = 0, hap1 = 0, blk0 = 0, blk1 = 0, n_tiles = 0; uint64_t pair0 = 0, pair1 = 0, out0 = 0, out1 = 0;
         uint4* cnt = nullptr; uint4* tile_sums = nullptr; uint4* d_totals = nullptr; uint4 totals {};
+        uint4* cnt_late = nullptr; uint4* tile_sums_late = nullptr; uint4* d_totals_late = nullptr; uint4 totals_late {};   // right-flank-only traceback tasks (x fast, y generic)
         DevTask* d_tasks = nullptr; size_t tasks_cap = 0; TraceEnd* d_ends = nullptr; size_t ends_cap = 0;
         unsigned long long* d_keys = nullptr; size_t keys_cap = 0;   // align mode: per traceback task
         rt::Event done {};
     };
     std::vector<Slice> slices;
     uint4* d_hap_base = nullptr; uint4* d_totals = nullptr;
+    bool late_ok = false; uint4* d_pair_cnt_late = nullptr; uint4* d_hap_base_late = nullptr; uint4* d_totals_late = nullptr;
     double* d_out = nullptr;
     uint32_t n_tasks[kNumKinds] = {0, 0, 0, 0};
     unsigned long long h_stats[6] = {0, 0, 0, 0, 0, 0};
@@ -301,7 +303,7 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 
 // Run one kind's task list through the DP kernel (+ walk for traceback kinds), chunked so the traceback scratch fits.
 int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
-                int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr)
+                int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false)
 {
     if (!n_tasks) return OCT_PHMM_OK;
     rt::Stream st = on_stream ? *on_stream : h->slice_stream(slice);
@@ -322,6 +324,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     // workgroups walk kGroupsPerWave groups per wave to amortise the haplotype-table staging; a small launch (one active region) instead
     // spreads over the chip: one group per wave until there are enough workgroups for every CU
     p.groups_per_block = kBlockWaves * std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerWave, n_groups / (kBlockWaves * 2048)));
+    p.late = late ? 1 : 0; p.hap_region = b->d.hap_region; p.reg_rhs = b->d.reg_rhs;
     uint32_t chunk_groups = n_groups;
     if (tr) {
         const size_t per_group = (size_t)p.k_cap * 4096 * (b->stream ? C : 1);
@@ -350,6 +353,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
             w.maskF = b->d.maskF; w.priorF = b->d.priorF; w.maskR = b->d.maskR; w.priorR = b->d.priorR;
             w.hap_region = b->d.hap_region; w.reg_lhs = b->d.reg_lhs; w.reg_rhs = b->d.reg_rhs;
             w.nuc_prior = nuc_prior; w.pair_best = b->d.pair_best;
+            w.early_stop = (!seam_walk && !b->align_mode && b->fast_adds && !b->stream && !h->wide) ? 1 : 0;
             if (seam_walk) {   // seam outputs are indexed by task: advance to this chunk
                 const size_t o = (size_t)g0 * G;
                 w.out_first_pos += o; w.out_align_off += o;
@@ -631,6 +635,14 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     pk.dalloc(&d.pair_extra, (size_t)b->n_pairs); pk.dalloc(&d.pair_cnt, (size_t)b->n_pairs + oct_phmm_handle::kMaxSlices + 1);
     pk.dalloc(&d.stats, (size_t)kStatSlots * 8 + 8);
     pk.dalloc(&b->d_hap_base, (size_t)H->n_haps + 1);
+    // late traceback start (k_dp): packed int16 kernels only, no lane can wrap (a failed traceback is then impossible,
+    // so a walk may stop once it has left the right flank), populate only, and only where the three extra scan launches do not show
+    uint64_t late_min_pairs = 100000;
+    if (const char* e = getenv("OCT_PHMM_LATE_MIN_PAIRS")) late_min_pairs = (uint64_t)atoll(e);   // test hook (0 = always, a huge value = never)
+    b->late_ok = b->fast_adds && !align_mode && !b->stream && !h->wide && b->n_pairs >= late_min_pairs;
+    if (b->late_ok) {
+        pk.dalloc(&b->d_pair_cnt_late, (size_t)b->n_pairs + oct_phmm_handle::kMaxSlices + 1); pk.dalloc(&b->d_hap_base_late, (size_t)H->n_haps + 1);
+    }
     {
         // Slices of whole haplotypes, each on its own stream: while slice i is in its VALU-bound DP kernels, slice i+1 runs its
         // latency-bound mapper/classifier and slice i-1 its latency-bound walk. Small batches stay in one slice.
@@ -638,6 +650,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         if (const char* e = getenv("OCT_PHMM_SLICES")) n_slices = std::max(1, std::min(oct_phmm_handle::kMaxSlices, atoi(e)));
         n_slices = (int)std::min<uint32_t>((uint32_t)n_slices, std::max<uint32_t>(1, H->n_haps));
         pk.dalloc(&b->d_totals, (size_t)n_slices);
+        if (b->late_ok) pk.dalloc(&b->d_totals_late, (size_t)n_slices);
         b->slices.reserve((size_t)n_slices);                   // the packer keeps addresses of the slices' pointers
         uint32_t hap = 0;
         for (int i = 0; i < n_slices; ++i) {
@@ -654,6 +667,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             sl.blk1 = (uint32_t)(std::lower_bound(b->h_blk_hap.begin(), b->h_blk_hap.end(), sl.hap1) - b->h_blk_hap.begin());
             b->slices.push_back(sl);
             pk.dalloc(&b->slices.back().tile_sums, (size_t)sl.n_tiles + 1);
+            if (b->late_ok) pk.dalloc(&b->slices.back().tile_sums_late, (size_t)sl.n_tiles + 1);
         }
     }
     pk.dalloc(&b->d_out, (size_t)b->n_out);
@@ -673,6 +687,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     for (size_t i = 0; i < b->slices.size(); ++i) {
         b->slices[i].cnt = d.pair_cnt + b->slices[i].pair0 + i;      // each slice owns pair1 - pair0 + 1 scan entries
         b->slices[i].d_totals = b->d_totals + i;
+        if (b->late_ok) { b->slices[i].cnt_late = b->d_pair_cnt_late + b->slices[i].pair0 + i; b->slices[i].d_totals_late = b->d_totals_late + i; }
     }
     if (positions) {
         RT(rt::h2d(d.pos, h_pos.data(), (size_t)b->n_pairs * S * sizeof(uint32_t), s));
@@ -734,7 +749,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             }
         }
         const uint32_t pair_blocks = (uint32_t)((np + 255) / 256);
-        OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt); RT(rt::launch_ok());
+        OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late); RT(rt::launch_ok());
         const uint64_t n_scan = np + 1;
         if (sl.n_tiles == 1) {
             OCT_LAUNCH(k_scan_tiles, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 2); RT(rt::launch_ok());
@@ -743,8 +758,20 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.tile_sums, sl.n_tiles); RT(rt::launch_ok());
             OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 1); RT(rt::launch_ok());
         }
-        OCT_LAUNCH(k_hap_bases, 1, 64, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, b->d_hap_base, sl.d_totals, G); RT(rt::launch_ok());
+        OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, b->d_hap_base, sl.d_totals, G); RT(rt::launch_ok());
         RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s));
+        sl.totals_late = make_uint4(0, 0, 0, 0);
+        if (sl.cnt_late) {                                    // the same scan for the late-start traceback tasks
+            if (sl.n_tiles == 1) {
+                OCT_LAUNCH(k_scan_tiles, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt_late, n_scan, sl.tile_sums_late, 2); RT(rt::launch_ok());
+            } else {
+                OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt_late, n_scan, sl.tile_sums_late, 0); RT(rt::launch_ok());
+                OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.tile_sums_late, sl.n_tiles); RT(rt::launch_ok());
+                OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt_late, n_scan, sl.tile_sums_late, 1); RT(rt::launch_ok());
+            }
+            OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt_late, sl.pair0, b->d_hap_base_late, sl.d_totals_late, G); RT(rt::launch_ok());
+            RT(rt::d2h(&sl.totals_late, sl.d_totals_late, sizeof(uint4), s));
+        }
         return OCT_PHMM_OK;
     };
     // phase 2: task emission, the DP kernels (+ traceback walk), epilogue for the slice's rows
@@ -754,12 +781,13 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         const uint64_t np = sl.pair1 - sl.pair0;
         const uint4 totals = sl.totals;
         b->n_tasks[0] += totals.x; b->n_tasks[1] += totals.y; b->n_tasks[2] += totals.z; b->n_tasks[3] += totals.w;
-        const size_t total = (size_t)totals.x + totals.y + totals.z + totals.w;
+        const uint4 late = sl.totals_late;                      // x: fast-cost kernel, y: generic kernel
+        const size_t total = (size_t)totals.x + totals.y + totals.z + totals.w + late.x + late.y;
         if (total > sl.tasks_cap) {
             h->pool.release(sl.d_tasks); sl.d_tasks = nullptr; sl.tasks_cap = 0;
             void* p = nullptr; RT(h->pool.alloc(&p, (total + total / 8) * sizeof(DevTask))); sl.d_tasks = (DevTask*)p; sl.tasks_cap = total + total / 8;
         }
-        const size_t n_trace = (size_t)std::max(totals.y, totals.w);
+        const size_t n_trace = (size_t)std::max(std::max(totals.y, totals.w), std::max(late.x, late.y));
         if (n_trace > sl.ends_cap) {
             h->pool.release(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
             void* p = nullptr; RT(h->pool.alloc(&p, (n_trace + n_trace / 8) * sizeof(TraceEnd))); sl.d_ends = (TraceEnd*)p; sl.ends_cap = n_trace + n_trace / 8;
@@ -771,14 +799,23 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         if (total) {
             TaskArrays ta;
             ta.t[0] = sl.d_tasks; ta.t[1] = ta.t[0] + totals.x; ta.t[2] = ta.t[1] + totals.y; ta.t[3] = ta.t[2] + totals.z;
-            OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta); RT(rt::launch_ok());
+            TaskArrays tl;                                       // late-start traceback tasks: [0] fast-cost kernel, [1] generic
+            tl.t[0] = ta.t[3] + totals.w; tl.t[1] = tl.t[0] + late.x; tl.t[2] = tl.t[1] + late.y; tl.t[3] = tl.t[2];
+            OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
+                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl); RT(rt::launch_ok());
             const uint32_t pad_threads = (sl.hap1 - sl.hap0) * kNumKinds * G;
             OCT_LAUNCH(k_emit_pad, (pad_threads + 255) / 256, 256, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, (const uint4*)b->d_hap_base, ta, G); RT(rt::launch_ok());
+            if (late.x + late.y) { OCT_LAUNCH(k_emit_pad, (pad_threads + 255) / 256, 256, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt_late, sl.pair0, (const uint4*)b->d_hap_base_late, tl, G); RT(rt::launch_ok()); }
             static const int order[kNumKinds] = {kTraceFast, kTraceGen, kScoreFast, kScoreGen};   // traceback first: its walk then overlaps the score-only DP of the next slice
             // A single-slice (region-sized) batch is latency-bound: its score-only DP runs beside the traceback DP + walk on a second stream.
             const bool side = S == 1 && total < 200000 && (totals.x + totals.z) > 0 && (totals.y + totals.w) > 0;   // big launches fill the chip on their own
             rt::Stream aux = h->slice_stream(1);
             if (side) { RT(rt::event_record(b->ev_fork, s)); RT(rt::stream_wait_event(aux, b->ev_fork)); }
+            for (int lk = 0; lk < 2; ++lk) {                     // late-start traceback launches first (the longest walks of the slice start earliest)
+                const uint32_t n = lk ? late.y : late.x;
+                const int rc = run_dp_kind(h, b, i, lk ? kTraceGen : kTraceFast, tl.t[lk], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, nullptr, true);
+                if (rc != OCT_PHMM_OK) return rc;
+            }
             for (int k : order) {
                 const bool score_kind = k == kScoreFast || k == kScoreGen;
                 const int rc = run_dp_kind(h, b, i, k, ta.t[k], (k == 0 ? totals.x : k == 1 ? totals.y : k == 2 ? totals.z : totals.w), sl.d_ends, h->cfg.nuc_prior, nullptr, status,

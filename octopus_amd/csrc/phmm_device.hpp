@@ -81,6 +81,9 @@ struct DpParams {
     uint32_t  lh_cap;                                 // longest haplotype in the batch
     uint32_t  nuc4;                                   // packed {nuc_prior << 2, nuc_prior << 2}
     uint32_t  groups_per_block;
+    // late traceback start (tasks whose window touches only the RIGHT inactive flank): the traceback words are needed, and written, only for the
+    // last iterations; everything before runs the score-only recurrence. 0 = off.
+    int late; const uint32_t* hap_region; const uint32_t* reg_rhs;
 };
 
 struct WalkParams {
@@ -98,6 +101,7 @@ struct WalkParams {
     unsigned long long* pair_key; unsigned long long* task_key; const uint32_t* pos; const uint8_t* npos; int max_pos;
     uint32_t* err_flags;                              // bit 0: a traceback left the band (hmm::HMMOverflow)
     uint32_t* cig_ops; uint32_t* cig_n; uint32_t* cig_mpos; uint32_t cig_cap;   // per pair, operations in REVERSE order
+    int early_stop;                                   // populate only, no int16 lane can wrap: a walk that has left the right flank of a window without left flank is done
 };
 
 } // namespace octphmm

@@ -334,7 +334,7 @@ OCT_DEVICE uint64_t wave_sum(uint64_t v)
 // Pass 1: one thread per (read, haplotype) pair. Runs the candidate-position logic and the scalar fast path, leaves the
 // best fast-path penalty in pair_best, classifies every remaining candidate as score-only or traceback DP.
 // A batch is processed in slices of whole haplotypes (pairs [pair0, pair1)); `cnt` is the slice's own scan array (pair1 - pair0 + 1 entries).
-OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt)
+OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* cnt_late)
 {
     const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
     unsigned long long st_cand = 0, st_fast = 0, st_score = 0, st_trace = 0, st_cells = 0, st_pairs = 0;
@@ -350,7 +350,7 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt)
         const int8_t* go = b.go + ho; const int8_t* ge = b.ge + ho;
         const uint64_t orig = (uint64_t)(b.rbegin[r] - b.hbegin[h]);                               // begin_distance, model.cpp:220
         const uint32_t* P = b.pos + e * (uint64_t)b.max_pos; const uint32_t npos = b.npos[e];
-        int32_t best = kNoScore; uint32_t cls = 0, n_score = 0, n_trace = 0, extra = 0;
+        int32_t best = kNoScore; uint32_t cls = 0, n_score = 0, n_trace = 0, n_late = 0, extra = 0;
         bool orig_mapped = false, any = false;
         unsigned long long key = ~0ull;
         auto visit = [&](uint32_t slot, uint32_t p) {
@@ -370,7 +370,9 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt)
             if ((uint64_t)off + T + 2 * B - 1 > Lh) return;                                         // :736-738 -> lowest()
             const bool adjusted = (uint64_t)p < (uint64_t)lhs + B || (uint64_t)p + T + B > (uint64_t)Lh - (uint64_t)rhs;   // :123-137
             st_cells += 2ull * B * (T + B);
-            if (adjusted) { cls |= 2u << (2 * slot); ++n_trace; ++st_trace; } else { cls |= 1u << (2 * slot); ++n_score; ++st_score; }
+            // class 3 = traceback needed for the right flank only (the window starts at or after the left flank's end): late traceback start
+            if (adjusted && cnt_late && (uint64_t)lhs + B <= (uint64_t)p) { cls |= 3u << (2 * slot); ++n_late; ++st_trace; }
+            else if (adjusted) { cls |= 2u << (2 * slot); ++n_trace; ++st_trace; } else { cls |= 1u << (2 * slot); ++n_score; ++st_score; }
         };
         for (uint32_t j = 0; j < npos; ++j) {                                                       // model.cpp:223-232
             const uint32_t p = P[j];
@@ -391,6 +393,7 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt)
         const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
         cnt[e - pair0] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
         if (e + 1 == pair1) cnt[pair1 - pair0] = make_uint4(0, 0, 0, 0);                               // the scan's extra entry (totals land here)
+        if (cnt_late) { cnt_late[e - pair0] = generic ? make_uint4(0, n_late, 0, 0) : make_uint4(n_late, 0, 0, 0); if (e + 1 == pair1) cnt_late[pair1 - pair0] = make_uint4(0, 0, 0, 0); }
         st_pairs = 1;
     }
     st_cand = wave_sum(st_cand); st_fast = wave_sum(st_fast); st_score = wave_sum(st_score);
@@ -461,25 +464,44 @@ OCT_KERNEL(k_scan_tile_sums)(uint4* tile_sums, uint32_t n_tiles)   // one block 
     for (uint32_t i = lo; i < hi; ++i) { const uint4 v = tile_sums[i]; tile_sums[i] = run; run = add4(run, v); }
 }
 
+constexpr uint32_t kHapBaseThreads = 1024;
 // Per haplotype and kind: first task slot, with every haplotype's task run padded to a multiple of the group size so
 // that a DP task group never straddles two haplotypes. hap_base[n_haps] = padded totals.
 OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* cnt, uint64_t pair0, uint4* hap_base, uint4* totals, uint32_t group)
 {
-    if (hw::thread_idx() != 0 || hw::block_idx() != 0) return;
-    uint4 run = make_uint4(0, 0, 0, 0);
+    // one block of kHapBaseThreads threads: each sums a contiguous run of haplotypes, the block scans the thread sums, each writes its run
+    // (a slice of the many-region workload holds tens of thousands of haplotypes: one serial thread took 4.6 ms per launch)
+    OCT_DYN_SMEM(smem);
+    uint4* sh = (uint4*)smem;                                   // [kHapBaseThreads]
+    const uint32_t tid = hw::thread_idx(), n = hap1 - hap0;
+    const uint32_t per = (n + kHapBaseThreads - 1) / kHapBaseThreads;
+    const uint32_t lo = hap0 + (tid * per < n ? tid * per : n), hi = hap0 + ((tid + 1) * per < n ? (tid + 1) * per : n);
     auto up = [&](uint32_t c) { return (c + group - 1) / group * group; };
-    for (uint32_t h = hap0; h < hap1; ++h) {
+    auto padded = [&](uint32_t h) {
         const uint4 a = cnt[b.hap_pair_off[h] - pair0], z = cnt[b.hap_pair_off[h + 1] - pair0];
-        hap_base[h] = run;
-        run = add4(run, make_uint4(up(z.x - a.x), up(z.y - a.y), up(z.z - a.z), up(z.w - a.w)));
+        return make_uint4(up(z.x - a.x), up(z.y - a.y), up(z.z - a.z), up(z.w - a.w));
+    };
+    uint4 sum = make_uint4(0, 0, 0, 0);
+    for (uint32_t h = lo; h < hi; ++h) sum = add4(sum, padded(h));
+    sh[tid] = sum;
+    hw::block_sync();
+    for (uint32_t d = 1; d < kHapBaseThreads; d <<= 1) {
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (tid >= d) o = sh[tid - d];
+        hw::block_sync();
+        sh[tid] = add4(sh[tid], o);
+        hw::block_sync();
     }
-    *totals = run;
+    uint4 run = tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0);
+    for (uint32_t h = lo; h < hi; ++h) { hap_base[h] = run; run = add4(run, padded(h)); }
+    if (tid == kHapBaseThreads - 1) *totals = sh[tid];
 }
 
 struct TaskArrays { DevTask* t[kNumKinds]; };
 
 // Pass 2: write the DP tasks of every pair at hap_base + (scanned count - scanned count at the haplotype's first pair).
-OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt, const uint4* hap_base, TaskArrays out)
+OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt, const uint4* hap_base, TaskArrays out,
+                   const uint4* cnt_late, const uint4* hap_base_late, TaskArrays out_late)
 {
     const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (e >= pair1) return;
@@ -492,6 +514,11 @@ OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt,
     uint32_t at_score = generic ? hb.z + (s.z - s0.z) : hb.x + (s.x - s0.x);
     uint32_t at_trace = generic ? hb.w + (s.w - s0.w) : hb.y + (s.y - s0.y);
     DevTask* ts = out.t[generic ? kScoreGen : kScoreFast]; DevTask* tt = out.t[generic ? kTraceGen : kTraceFast];
+    uint32_t at_late = 0; DevTask* tl = nullptr;
+    if (cnt_late) {
+        const uint4 q = cnt_late[e - pair0], q0 = cnt_late[b.hap_pair_off[h] - pair0], qb = hap_base_late[h];
+        at_late = generic ? qb.y + (q.y - q0.y) : qb.x + (q.x - q0.x); tl = out_late.t[generic ? 1 : 0];
+    }
     const uint32_t* P = b.pos + e * (uint64_t)b.max_pos;
     const uint32_t B = (uint32_t)b.band;
     for (uint32_t slot = 0; slot <= (uint32_t)b.max_pos; ++slot) {
@@ -499,7 +526,7 @@ OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt,
         if (!k) continue;
         const uint32_t p = slot < (uint32_t)b.max_pos ? P[slot] : b.pair_extra[e];
         DevTask t; t.pair = (uint32_t)e; t.read = r; t.hap = h; t.off = p > B ? p - B : 0;
-        if (k == 1) ts[at_score++] = t; else tt[at_trace++] = t;
+        if (k == 1) ts[at_score++] = t; else if (k == 2) tt[at_trace++] = t; else tl[at_late++] = t;
     }
 }
 
@@ -687,8 +714,8 @@ OCT_KERNEL(k_dp)(DpParams p)
                 hw::wave_lds_fence();
             };
 
-            auto quad = [&](uint32_t k0, auto init_c, auto cap_c) {
-                constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value;
+            auto quad = [&](uint32_t k0, auto init_c, auto cap_c, auto tr_c) {
+                constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value, TR = TRACE && decltype(tr_c)::value;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t k = k0 + u;
@@ -708,7 +735,7 @@ OCT_KERNEL(k_dp)(DpParams p)
                     D1 = shift_up<B>(INFB, dsh, li);                                        // :293-294
                     I1 = sadd(hw::pk_min_u(sadd(I2, GE), sadd(M2, GO)), NUC);               // :295
                     uint32_t bpe = 0;
-                    if constexpr (TRACE) {                                                  // update_traceback :147-163
+                    if constexpr (TR) {                                                     // update_traceback :147-163
                         const uint32_t tm = M1 & 0x00030003u, ti = I1 & 0x00030003u, td = D1 & 0x00030003u;
                         M1 ^= tm; I1 = (I1 & ~0x00030003u) | 0x00010001u; D1 |= 0x00030003u;
                         bpe = hw_lshl_or(td, 4, hw_lshl_or(ti, 2, tm | flag_of(fe, 15)));   // + "this match cell costs something" flag
@@ -722,7 +749,7 @@ OCT_KERNEL(k_dp)(DpParams p)
                     D2 = hw::pk_min_u(sadd(D1, GEn), sadd(y1, GOn));                        // :317
                     const uint32_t ish = sadd(hw::pk_min_u(sadd(I1, GE), sadd(M1, GO)), NUC);
                     I2 = shift_down<B>(INFB, ish, li);                                      // :318-319
-                    if constexpr (TRACE) {
+                    if constexpr (TR) {
                         const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
                         M2 ^= tm; I2 = (I2 & ~0x00030003u) | 0x00010001u; D2 |= 0x00030003u;
                         const uint32_t bpo = hw_lshl_or(td, 4, hw_lshl_or(ti, 2, tm));
@@ -731,16 +758,40 @@ OCT_KERNEL(k_dp)(DpParams p)
                     rr = rr_nx; cA = nA; cB = nB; GO = GOn; GE = GEn; nA = nnA; nB = nnB;
                     GOn = hw::perm(nB.y, nA.y, 0x05040100u); GEn = hw::perm(nB.y, nA.y, 0x07060302u);
                 }
-                if constexpr (TRACE) {
+                if constexpr (TR) {
                     if (((k0 + 4) & 15) == 0) flush_tile(k0 >> 4);
                 }
             };
 
             const uint32_t kB = (Tmin & ~3u) > (uint32_t)B ? (Tmin & ~3u) : (uint32_t)B;   // no end cell before the shortest read is consumed
             uint32_t k = 0;
-            for (; k < (uint32_t)B; k += 4) quad(k, BoolC<true>{}, BoolC<true>{});         // rolling initialisation lasts B iterations
-            for (; k < kB; k += 4) quad(k, BoolC<false>{}, BoolC<false>{});
-            for (; k < K4; k += 4) quad(k, BoolC<false>{}, BoolC<true>{});
+            if constexpr (TRACE) {
+                // Late traceback start (p.late): every task of this launch needs its walk only inside the RIGHT inactive flank, i.e. only the
+                // traceback words of the last iterations. Until k_sw the wave runs the score-only recurrence (no label extraction, no tile
+                // writes); at k_sw the states get the labels they would carry (M 0, I 1, D 3, :63-65) and the traceback form takes over.
+                // Scores are the same in both forms (labels only break ties inside an iteration and are reset after it); k_sw is a tile
+                // boundary no later than the first possible end cell, so end-cell ties see their labels.
+                uint32_t k_sw = 0;
+                if (p.late) {
+                    auto first_needed = [&](const DevTask& t, uint32_t T) -> uint32_t {
+                        const uint32_t Lh = p.hoff[t.hap + 1] - p.hoff[t.hap], L = T + 2 * B - 1, rhs = p.reg_rhs[p.hap_region[t.hap]];
+                        const uint32_t rhs_w = t.off + L + rhs < Lh ? 0u : (t.off + L + rhs - Lh < L ? t.off + L + rhs - Lh : L);   // right flank in window coordinates (pair_hmm.hpp:580-587)
+                        const uint32_t rhs_begin = L - rhs_w;
+                        return rhs_begin > (uint32_t)B + 2 ? rhs_begin - B - 2 : 0u;        // cells with x >= rhs_begin - 2 lie on iterations k >= x - (B - 1) - 1
+                    };
+                    uint32_t ks = first_needed(tA, TA); const uint32_t kb2 = first_needed(tB, TB);
+                    ks = kb2 < ks ? kb2 : ks;
+                    for (int m = B; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(ks, m); ks = o < ks ? o : ks; }
+                    ks = hw::readfirstlane(ks);
+                    k_sw = (ks < Tmin ? ks : Tmin) & ~15u;
+                }
+                for (; k < (uint32_t)B && k < k_sw; k += 4) quad(k, BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
+                for (; k < k_sw; k += 4) quad(k, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
+                if (k_sw) { I1 |= 0x00010001u; D1 |= 0x00030003u; I2 |= 0x00010001u; D2 |= 0x00030003u; y1 = hw::pk_min_u(M1, I1); }
+            }
+            for (; k < (uint32_t)B; k += 4) quad(k, BoolC<true>{}, BoolC<true>{}, BoolC<true>{});         // rolling initialisation lasts B iterations
+            for (; k < kB; k += 4) quad(k, BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
+            for (; k < K4; k += 4) quad(k, BoolC<false>{}, BoolC<true>{}, BoolC<true>{});
             if constexpr (TRACE) { if (K4 & 15) flush_tile(K4 >> 4); }
 
             // ---- first minimum over the row's end cells, per packed task (:285-291,309-315,323) ----
@@ -1299,6 +1350,8 @@ OCT_KERNEL(k_walk)(WalkParams w)
         }
         state = new_state;
         if (y <= 0) fl |= kFin;                                                                 // :194
+        // nothing left to charge: no left flank in this window and the walk is past the right one (the traceback cannot fail when no lane wraps)
+        if (w.early_stop && lhs == 0 && x < rhs_begin) fl |= kFin;
     };
     auto slow_word = [&](int64_t flat) -> uint32_t {                                            // any cell by flat index = diagonal * B + lane
         const int32_t s = (int32_t)(flat / B), li = (int32_t)(flat % B);
@@ -1312,6 +1365,7 @@ OCT_KERNEL(k_walk)(WalkParams w)
     for (int m = 1; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(kmax, m); kmax = o > kmax ? o : kmax; }
     kmax = hw::readfirstlane(kmax);
     for (int32_t kt = (int32_t)(kmax >> 4); kt >= 0; --kt) {
+        if (hw::ballot(!(fl & kFin)) == 0) break;                                              // every walk of the wave is over (early stops)
         uint32_t c[16];
         int32_t line_i = -1;
         auto load_line = [&]() {

@@ -20,8 +20,22 @@ a = ap.parse_args()
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
 dur = collections.defaultdict(list)
+def rows_of(p):
+    """One dict per (dispatch, counter): rocprofv3's CSV output, or its default rocpd database (p_results.db)."""
+    f = Path(p) / "p_counter_collection.csv"
+    if f.exists():
+        yield from csv.DictReader(open(f))
+        return
+    import sqlite3
+    db = sqlite3.connect(str(Path(p) / "p_results.db"))
+    q = ("select grid_size, kernel_name, counter_name, sum(value), min(start), max(end) from counters_collection "
+         "group by dispatch_id, counter_name")
+    for g, k, n, v, t0, t1 in db.execute(q):
+        yield {"Grid_Size": g, "Kernel_Name": k, "Counter_Name": n, "Counter_Value": v, "Start_Timestamp": t0, "End_Timestamp": t1}
+
+
 for p in a.passes:
-    for r in csv.DictReader(open(Path(p) / "p_counter_collection.csv")):
+    for r in rows_of(p):
         g = int(r["Grid_Size"])
         if g < a.min_grid:
             continue
