@@ -253,3 +253,48 @@ def check_empty_batches(backend):
         assert len(rb.genotype_likelihoods([])) == 0
         rb.free()
     eng.close()
+
+
+def check_late_traceback_start(backend, tol=0.0):
+    """Windows that overlap only the RIGHT inactive flank run the score-only recurrence until the last tiles and their walk stops when it
+    leaves the flank (k_dp late start). Forced on for small batches through the test hook; every case must equal the
+    oracle, and the bytes of the same batch with the late start switched off."""
+    import os
+    rng = np.random.default_rng(1234)
+    out = []
+    old = os.environ.get("OCT_PHMM_LATE_MIN_PAIRS")
+    try:
+        for B, T, Lh, flank, with_n, ragged in ((16, 150, 300, (40, 40), False, False), (16, 120, 260, (0, 90), True, False),
+                                                (8, 70, 200, (15, 60), False, True), (16, 200, 420, (10, 150), False, True),
+                                                (32, 150, 400, (30, 120), False, False), (64, 100, 400, (0, 100), False, False)):
+            g = synth.make_region(rng, 20, 4, T=T, Lh=Lh, B=B, flank=flank, positions="none", indels_per_read=1)
+            if with_n:
+                g["reads"][rng.integers(0, 20, 4), rng.integers(0, T, 4)] = ord("N")
+            batch = synth.batch_from_regions([g])
+            if ragged:                                              # trim reads to different lengths (Tmin of a wave bounds the switch point)
+                rl, hl = [], []
+                for r in range(20):
+                    n = int(rng.integers(max(B + 4, T // 3), T + 1))
+                    rl.append(dict(seq=bytes(g["reads"][r][:n]), quals=g["quals"][r][:n], mapq=int(g["mapq"][r]), reverse=bool(g["reverse"][r]), begin=int(g["begin"][r])))
+                for h in g["haps"]:
+                    go, ge, mf, pf, mr, pr = synth._penalties(h)
+                    hl.append(dict(seq=bytes(h), begin=0, gap_open=go, gap_extend=ge, mask_fwd=mf, prior_fwd=pf, mask_rev=mr, prior_rev=pr))
+                batch = abi.Batch.from_lists(rl, hl, flank=flank)
+            batch = mapper_positions(batch, rng=rng, junk=0.3)
+            os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = "0"
+            stats = compare(backend, batch, tol, max_indel_error=B)
+            eng = make_engine(backend, max_indel_error=B)
+            late, _ = eng.populate(batch)
+            os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = "1000000000000"
+            plain, _ = eng.populate(batch)
+            eng.close()
+            assert np.array_equal(late, plain)
+            out.append(stats)
+    finally:
+        if old is None:
+            os.environ.pop("OCT_PHMM_LATE_MIN_PAIRS", None)
+        else:
+            os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = old
+    assert sum(s["n_dp_traceback"] for s in out) > 200
+    return out
+

@@ -223,6 +223,15 @@ def test_gpu_random_scenarios():
     assert check_fuzz.check_fuzz("gpu", seed=7, n=120, tol=TOL) == 120
 
 
+def test_gpu_late_traceback_start_equals_oracle_and_plain_path(monkeypatch):
+    cp.check_late_traceback_start("gpu", TOL)
+    import check_fuzz
+    monkeypatch.setenv("OCT_PHMM_LATE_MIN_PAIRS", "0")
+    assert check_fuzz.check_fuzz("gpu", seed=31, n=80, tol=TOL) == 80
+    batch = synth.config_batch("1kx64", seed=44, B=16, positions="none")
+    cp.compare("gpu", batch, TOL, max_indel_error=16)
+
+
 def test_gpu_empty_batches():
     cp.check_empty_batches("gpu")
 

@@ -59,3 +59,14 @@ def test_sim_long_reads_at_narrow_bands_stream():
 
 def test_sim_empty_batches():
     cp.check_empty_batches("sim")
+
+
+def test_sim_late_traceback_start_equals_oracle_and_plain_path():
+    cp.check_late_traceback_start("sim")
+
+
+def test_sim_random_scenarios_with_late_traceback_start(monkeypatch):
+    import check_fuzz
+    monkeypatch.setenv("OCT_PHMM_LATE_MIN_PAIRS", "0")
+    assert check_fuzz.check_fuzz("sim", seed=99, n=8) == 8
+
