@@ -417,6 +417,7 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
     h->timing = getenv("OCT_PHMM_TIMING") != nullptr;
     if (const char* e = getenv("OCT_PHMM_BP_BUDGET_GB")) { const long gb = atol(e); if (gb > 0) h->bp_budget = (size_t)gb << 30; }
+    if (const char* e = getenv("OCT_PHMM_BP_BUDGET_KB")) { const long kb = atol(e); if (kb > 0) h->bp_budget = (size_t)kb << 10; }   // test hook: forces chunked traceback launches on small batches
     if (!rt::stream_create(&h->stream)) return OCT_PHMM_EHIP;
     for (auto& es : h->extra_streams) if (!rt::stream_create(&es)) return OCT_PHMM_EHIP;
     if (!rt::event_create(&h->ev_ready)) return OCT_PHMM_EHIP;

@@ -298,3 +298,30 @@ def check_late_traceback_start(backend, tol=0.0):
     assert sum(s["n_dp_traceback"] for s in out) > 200
     return out
 
+
+def check_chunked_traceback(backend, tol=0.0):
+    """When a slice's traceback tasks do not fit the scratch budget the DP + walk pair runs in chunks of whole workgroups over the same
+    scratch. Forced here with a budget of a few task groups (test hook), with and without the late traceback start, populate and align."""
+    import os
+    keep = {k: os.environ.get(k) for k in ("OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_LATE_MIN_PAIRS")}
+    try:
+        for late in ("0", "1000000000000"):
+            os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = late
+            for B, kb in ((8, 100), (16, 200)):
+                os.environ["OCT_PHMM_BP_BUDGET_KB"] = str(kb)
+                g, rng = small_region(300 + B, R=40, H=6, T=90, Lh=220, B=B, flank=(25, 60))
+                batch = mapper_positions(synth.batch_from_regions([g]), rng=rng, junk=0.3)
+                stats = compare(backend, batch, tol, max_indel_error=B)
+                assert stats["n_dp_traceback"] > 64
+                if late == "0":                                     # align mode keeps every task's backpointers until the winners walk again: one chunk or a clean error
+                    eng = make_engine(backend, max_indel_error=B)
+                    _, st = eng.align(batch, 64, raise_on_error=False)
+                    eng.close()
+                    assert st.code == abi.EUNSUPPORTED and b"OCT_PHMM_BP_BUDGET_GB" in bytes(st.message)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+

@@ -232,6 +232,10 @@ def test_gpu_late_traceback_start_equals_oracle_and_plain_path(monkeypatch):
     cp.compare("gpu", batch, TOL, max_indel_error=16)
 
 
+def test_gpu_chunked_traceback_launches():
+    cp.check_chunked_traceback("gpu", TOL)
+
+
 def test_gpu_empty_batches():
     cp.check_empty_batches("gpu")
 

@@ -70,3 +70,7 @@ def test_sim_random_scenarios_with_late_traceback_start(monkeypatch):
     monkeypatch.setenv("OCT_PHMM_LATE_MIN_PAIRS", "0")
     assert check_fuzz.check_fuzz("sim", seed=99, n=8) == 8
 
+
+def test_sim_chunked_traceback_launches():
+    cp.check_chunked_traceback("sim")
+

@@ -60,10 +60,23 @@ for T in a.threads:
     res[f"per_region_calls_{T}_threads"] = {"regions_per_s": len(batches) / dt, "M_loglik_per_s": pairs / dt / 1e6, "ms_per_call": dt / len(batches) * T * 1e3}
 eng = engine.Engine(cfg)
 flat = synth.batch_from_regions(regions)
-eng.populate(flat)
+outbuf = np.empty(flat.out_size())
+eng.populate(flat, out=outbuf)
 t0 = time.perf_counter()
-eng.populate(flat)
-dt = time.perf_counter() - t0
+for _ in range(3):
+    eng.populate(flat, out=outbuf)
+dt = (time.perf_counter() - t0) / 3
+rb = eng.upload(flat); rb.run(); rb.wait()
+t0 = time.perf_counter()
+for _ in range(3):
+    rb.run(); rb.wait()
+dres = (time.perf_counter() - t0) / 3
+t0 = time.perf_counter()
+rb2 = eng.upload(flat)
+dup = time.perf_counter() - t0
+rb.free(); rb2.free()
 eng.close()
-res["flat_multi_region_batch"] = {"regions_per_s": len(regions) / dt, "M_loglik_per_s": pairs / dt / 1e6}
+res["flat_multi_region_batch"] = {"regions": len(regions), "regions_per_s": len(regions) / dt, "M_loglik_per_s": pairs / dt / 1e6, "populate_from_host_ms": dt * 1e3,
+                                  "resident_run_ms": dres * 1e3, "upload_ms": dup * 1e3,
+                                  "host_bytes_in": int(flat.read_bases.nbytes * 2 + flat.hap_bases.nbytes * 7), "host_bytes_out": flat.out_size() * 8}
 print(json.dumps(res))
