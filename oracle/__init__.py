@@ -57,6 +57,56 @@ def ref() -> C.CDLL:
     return _REF
 
 
+_REF_ARRAY: Optional[C.CDLL] = None
+
+
+def have_ref_array() -> bool:
+    return (_DIR / "_ref" / "libref_array.so").exists()
+
+
+class _RefArrayArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("max_indel_error", "use_int_scores", "use_mapping_quality", "mapping_quality_cap",
+                                         "mapping_quality_cap_trigger", "use_flank_state")] + [
+        ("n_haps", C.c_uint32), ("hap_bases", C.c_void_p), ("hap_off", C.c_void_p), ("hap_begin", C.c_void_p),
+        ("gap_open", C.c_void_p), ("gap_extend", C.c_void_p), ("mask_f", C.c_void_p), ("prior_f", C.c_void_p), ("mask_r", C.c_void_p), ("prior_r", C.c_void_p),
+        ("has_flank", C.c_int32), ("lhs_flank", C.c_uint32), ("rhs_flank", C.c_uint32),
+        ("n_reads", C.c_uint32), ("read_bases", C.c_void_p), ("quals", C.c_void_p), ("read_off", C.c_void_p), ("read_begin", C.c_void_p),
+        ("mapq", C.c_void_p), ("reverse", C.c_void_p),
+        ("n_rows", C.c_uint32), ("row_off", C.c_void_p), ("n_samples", C.c_uint32), ("sample_row_off", C.c_void_p), ("n_threads", C.c_int32)]
+
+
+def ref_array_populate(cfg: abi.Config, batch: abi.Batch, sample_rows=None, n_threads: int = 1, merged: bool = False):
+    """The REFERENCE's own HaplotypeLikelihoodArray::populate (haplotype_likelihood_array.cpp, built in place into
+    oracle/_ref/libref_array.so) on a single-region batch whose rows are split into samples at `sample_rows` (row offsets).
+    Mapping positions come from the reference's own k-mer mapper (the batch's are ignored), as in the reference.
+    Returns (code, out [H x rows] flat, merged or None, err_hap, required_extension): code 0 ok, 1 ShortHaplotypeError."""
+    global _REF_ARRAY
+    if _REF_ARRAY is None:
+        _REF_ARRAY = C.CDLL(str(_DIR / "_ref" / "libref_array.so"))
+    assert batch.region_row_offsets is None or len(batch.region_row_offsets) == 2, "one populate() call = one region"
+    n_reads = len(batch.read_offsets) - 1
+    n_rows = n_reads if batch.row_offsets is None else len(batch.row_offsets) - 1
+    n_haps = len(batch.hap_offsets) - 1
+    srows = np.asarray([0, n_rows] if sample_rows is None else sample_rows, dtype=np.uint32)
+    flank = batch.flank if batch.region_flank is None else (tuple(int(x) for x in batch.region_flank[0]) if batch.region_has_flank[0] else None)
+    keep = [np.ascontiguousarray(x) for x in (batch.hap_bases, batch.hap_offsets.astype(np.uint32), batch.hap_ref_begin.astype(np.int64),
+                                              batch.gap_open, batch.gap_extend, batch.snv_mask_fwd, batch.snv_prior_fwd, batch.snv_mask_rev,
+                                              batch.snv_prior_rev, batch.read_bases, batch.read_quals, batch.read_offsets.astype(np.uint32),
+                                              batch.read_ref_begin.astype(np.int64), batch.mapq, batch.reverse, srows)]
+    rows = None if batch.row_offsets is None else np.ascontiguousarray(batch.row_offsets.astype(np.uint32))
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    a = _RefArrayArgs(cfg.max_indel_error, cfg.use_int_scores, cfg.use_mapping_quality, cfg.mapping_quality_cap, cfg.mapping_quality_cap_trigger,
+                      cfg.use_flank_state, n_haps, vp(keep[0]), vp(keep[1]), vp(keep[2]), vp(keep[3]), vp(keep[4]), vp(keep[5]), vp(keep[6]),
+                      vp(keep[7]), vp(keep[8]), 1 if flank is not None else 0, int(flank[0]) if flank else 0, int(flank[1]) if flank else 0,
+                      n_reads, vp(keep[9]), vp(keep[10]), vp(keep[11]), vp(keep[12]), vp(keep[13]), vp(keep[14]),
+                      n_rows, vp(rows) if rows is not None else None, len(srows) - 1, vp(keep[15]), int(n_threads))
+    out = np.full(max(n_haps * n_rows, 1), np.nan)
+    mg = np.full(max(n_haps * n_rows, 1), np.nan) if merged else None
+    err_hap, ext = C.c_uint32(0), C.c_uint32(0)
+    code = _REF_ARRAY.ref_array_populate(C.byref(a), _p(out), _p(mg) if merged else None, C.byref(err_hap), C.byref(ext))
+    return code, out[:n_haps * n_rows], (mg[:n_haps * n_rows] if merged else None), err_hap.value, ext.value
+
+
 def ref_isa_supported(isa: str) -> bool:
     return have_ref() and bool(ref().ref_phmm_isa_supported(ISA[isa])) if isa != "native" else have_ref()
 

@@ -16,7 +16,10 @@
  *       ShortHaplotypeError, mapping-quality mixture): the reference's own core/models/haplotype_likelihood_model.cpp on stand-in
  *       Haplotype / AlignedRead types (tests/test_oracle_l3.py).
  *   Genotype read-out: the reference's own constant_mixture_genotype_likelihood_model.cpp on stand-in array / genotype types.
- * Still "parity unpinned" (follows the cited lines): only the populate driver loop (rows x haplotypes, template sums).
+ *   Populate driver (rows x haplotypes loop, read hashes once per batch, k-mer table + model reset per haplotype, template sums, sample
+ *       concatenation = merge_samples, ShortHaplotypeError): the reference's own core/models/haplotype_likelihood_array.cpp (both populate
+ *       overloads, with and without its thread pool) on stand-in containers, oracle/_ref/libref_array.so (tests/test_oracle_populate_driver.py).
+ * Nothing on the path is "parity unpinned" any more; oracle_align_batch's loop over pairs is the same loop as oracle_populate's.
  */
 #ifndef PHMM_ORACLE_H
 #define PHMM_ORACLE_H

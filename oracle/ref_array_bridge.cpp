@@ -1,0 +1,133 @@
+// TEST INFRASTRUCTURE ONLY — never linked into, imported by, or executed from the product path.
+//
+// extern "C" bridge over the REFERENCE's own batch driver, compiled in place from /root/reference/src:
+//   core/models/haplotype_likelihood_array.cpp   HaplotypeLikelihoodArray::populate(ReadMap ...) :51-103, populate(TemplateMap ...) :105-199
+//                                                (read hashes once per batch, k-mer table per haplotype, map_query_to_target per pair,
+//                                                model reset per haplotype, template sums, optional thread-pool fan-out), the read-back
+//                                                accessors operator()(sample, IndexedHaplotype) / operator[] when primed, merge_samples :357-409
+//   core/models/haplotype_likelihood_model.cpp, utils/kmer_mapper.hpp, utils/thread_pool.cpp, utils/parallel_transform.hpp
+// on stand-in Haplotype / AlignedRead / container types (oracle/ref_shim) and with every haplotype's six penalty vectors supplied through
+// two trivial error-model subclasses (the vectors are the C-ABI batch's). This pins the oracle's populate driver loop (oracle_populate).
+// Linked into its own library (_ref/libref_array.so): the genotype bridge in libref_phmm.so uses a stand-in class of the same name.
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+#include REF_ARRAY_HPP
+#include "core/models/error/error_model_factory.hpp"
+
+using namespace octopus;
+
+namespace octopus { namespace config { const std::string HelpForum {}, BugReport {"(bridge)"}; } }   // named by ProgramError::do_help only
+namespace octopus {
+std::unique_ptr<SnvErrorModel> make_snv_error_model() { return nullptr; }
+std::unique_ptr<IndelErrorModel> make_indel_error_model() { return nullptr; }
+ErrorModel make_error_model(const std::string&) { return {}; }
+}
+
+namespace {
+struct Vectors { std::vector<char> mask_f, mask_r; std::vector<std::int8_t> prior_f, prior_r, go, ge; };
+const Vectors& vectors_of(const Haplotype& h) { return *static_cast<const Vectors*>(h.payload_); }
+
+class GivenSnvModel : public SnvErrorModel
+{
+    std::unique_ptr<SnvErrorModel> do_clone() const override { return std::make_unique<GivenSnvModel>(*this); }
+    void do_evaluate(const Haplotype& h, MutationVector& fm, PenaltyVector& fp, MutationVector& rm, PenaltyVector& rp) const override
+    { const auto& v = vectors_of(h); fm = v.mask_f; fp = v.prior_f; rm = v.mask_r; rp = v.prior_r; }
+};
+class GivenIndelModel : public IndelErrorModel
+{
+    std::unique_ptr<IndelErrorModel> do_clone() const override { return std::make_unique<GivenIndelModel>(*this); }
+    void do_set_penalties(const Haplotype& h, PenaltyVector& go, PenaltyType& ge) const override { const auto& v = vectors_of(h); go = v.go; ge = v.ge.empty() ? 0 : v.ge.front(); }
+    void do_set_penalties(const Haplotype& h, PenaltyVector& go, PenaltyVector& ge) const override { const auto& v = vectors_of(h); go = v.go; ge = v.ge; }
+};
+} // namespace
+
+struct ref_array_args {
+    int32_t max_indel_error, use_int_scores, use_mapping_quality, mapping_quality_cap, mapping_quality_cap_trigger, use_flank_state;
+    uint32_t n_haps; const char* hap_bases; const uint32_t* hap_off; const int64_t* hap_begin;
+    const int8_t* gap_open; const int8_t* gap_extend; const char* mask_f; const int8_t* prior_f; const char* mask_r; const int8_t* prior_r;
+    int32_t has_flank; uint32_t lhs_flank, rhs_flank;
+    uint32_t n_reads; const char* read_bases; const uint8_t* quals; const uint32_t* read_off; const int64_t* read_begin; const uint8_t* mapq; const uint8_t* reverse;
+    uint32_t n_rows; const uint32_t* row_off;          // NULL: the ReadMap overload (a row per read); else the TemplateMap overload, row r = reads [row_off[r], row_off[r+1])
+    uint32_t n_samples; const uint32_t* sample_row_off;  // rows of sample s = [sample_row_off[s], sample_row_off[s+1])
+    int32_t n_threads;                                   // > 2: hand populate a ThreadPool of that size
+};
+
+// out[h * n_rows + row] read back through operator()(sample, IndexedHaplotype); merged (optional, same shape) through merge_samples() + operator[].
+// returns 0 ok, 1 ShortHaplotypeError (*err_hap = index of the haplotype it names, *ext = required_extension)
+extern "C" int ref_array_populate(const ref_array_args* a, double* out, double* merged, uint32_t* err_hap, uint32_t* ext)
+{
+    std::vector<Vectors> vecs(a->n_haps);
+    MappableBlock<Haplotype> haps(a->n_haps);
+    for (uint32_t h = 0; h < a->n_haps; ++h) {
+        const uint32_t o = a->hap_off[h], n = a->hap_off[h + 1] - o;
+        auto& v = vecs[h];
+        v.go.assign(a->gap_open + o, a->gap_open + o + n); v.ge.assign(a->gap_extend + o, a->gap_extend + o + n);
+        v.mask_f.assign(a->mask_f + o, a->mask_f + o + n); v.mask_r.assign(a->mask_r + o, a->mask_r + o + n);
+        v.prior_f.assign(a->prior_f + o, a->prior_f + o + n); v.prior_r.assign(a->prior_r + o, a->prior_r + o + n);
+        haps[h].sequence_.assign(a->hap_bases + o, a->hap_bases + o + n); haps[h].begin_ = a->hap_begin[h]; haps[h].payload_ = &v;
+    }
+    auto make_read = [&](uint32_t r) {
+        AlignedRead x; const uint32_t o = a->read_off[r], n = a->read_off[r + 1] - o;
+        x.sequence_.assign(a->read_bases + o, a->read_bases + o + n); x.base_qualities_.assign(a->quals + o, a->quals + o + n);
+        x.mapping_quality_ = a->mapq[r]; x.reverse_ = a->reverse[r] != 0; x.begin_ = a->read_begin[r];
+        return x;
+    };
+    std::vector<SampleName> samples;
+    for (uint32_t s = 0; s < a->n_samples; ++s) { char nm[16]; std::snprintf(nm, sizeof nm, "s%04u", s); samples.emplace_back(nm); }
+    HaplotypeLikelihoodModel::Config cfg;
+    cfg.use_mapping_quality = a->use_mapping_quality != 0; cfg.mapping_quality_cap = static_cast<std::uint8_t>(a->mapping_quality_cap);
+    if (a->mapping_quality_cap_trigger >= 0) cfg.mapping_quality_cap_trigger = static_cast<std::uint8_t>(a->mapping_quality_cap_trigger);
+    cfg.use_flank_state = a->use_flank_state != 0; cfg.max_indel_error = static_cast<unsigned>(a->max_indel_error); cfg.use_int_scores = a->use_int_scores != 0;
+    HaplotypeLikelihoodModel model {std::make_unique<GivenSnvModel>(), std::make_unique<GivenIndelModel>(), cfg};
+    const bool arr_can_use_flank = model.can_use_flank_state();
+    HaplotypeLikelihoodArray arr {std::move(model), a->n_haps, samples};
+    boost::optional<HaplotypeLikelihoodArray::FlankState> fs;
+    if (a->has_flank && arr_can_use_flank) fs = HaplotypeLikelihoodArray::FlankState {a->lhs_flank, a->rhs_flank};   // the caller's gate: Caller::compute_haplotype_likelihoods, caller.cpp:1172-1173
+    std::unique_ptr<ThreadPool> pool;
+    HaplotypeLikelihoodArray::OptionalThreadPool workers;
+    if (a->n_threads > 2) { pool = std::make_unique<ThreadPool>(static_cast<std::size_t>(a->n_threads)); workers = *pool; }
+    try {
+        if (!a->row_off) {
+            ReadMap reads;
+            for (uint32_t s = 0; s < a->n_samples; ++s) {
+                auto& dst = reads[samples[s]];
+                for (uint32_t r = a->sample_row_off[s]; r < a->sample_row_off[s + 1]; ++r) dst.push_back(make_read(r));
+            }
+            arr.populate(reads, haps, fs, workers);
+        } else {
+            TemplateMap reads;
+            for (uint32_t s = 0; s < a->n_samples; ++s) {
+                auto& dst = reads[samples[s]];
+                for (uint32_t row = a->sample_row_off[s]; row < a->sample_row_off[s + 1]; ++row) {
+                    AlignedTemplate t;
+                    for (uint32_t r = a->row_off[row]; r < a->row_off[row + 1]; ++r) t.push_back(make_read(r));
+                    dst.push_back(std::move(t));
+                }
+            }
+            arr.populate(reads, haps, fs, workers);
+        }
+    } catch (const HaplotypeLikelihoodModel::ShortHaplotypeError& e) {
+        *ext = static_cast<uint32_t>(e.required_extension()); *err_hap = ~0u;
+        for (uint32_t h = 0; h < a->n_haps; ++h) if (&e.haplotype() == &haps[h] || e.haplotype() == haps[h]) { *err_hap = h; break; }
+        return 1;
+    }
+    for (uint32_t h = 0; h < a->n_haps; ++h)
+        for (uint32_t s = 0; s < a->n_samples; ++s) {
+            const auto& v = arr(samples[s], IndexedHaplotype<> {h});
+            if (v.size() != a->sample_row_off[s + 1] - a->sample_row_off[s]) return 2;
+            for (std::size_t i = 0; i < v.size(); ++i) out[static_cast<std::size_t>(h) * a->n_rows + a->sample_row_off[s] + i] = v[i];
+        }
+    if (merged) {
+        const auto m = arr.merge_samples();
+        for (uint32_t h = 0; h < a->n_haps; ++h) {
+            const auto& v = m[IndexedHaplotype<> {h}];
+            if (v.size() != a->n_rows) return 3;
+            for (std::size_t i = 0; i < v.size(); ++i) merged[static_cast<std::size_t>(h) * a->n_rows + i] = v[i];
+        }
+    }
+    return 0;
+}

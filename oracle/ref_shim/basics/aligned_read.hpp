@@ -17,6 +17,9 @@ public:
     const BaseQualityVector& base_qualities() const noexcept { return base_qualities_; }
     MappingQuality mapping_quality() const noexcept { return mapping_quality_; }
     bool is_marked_reverse_mapped() const noexcept { return reverse_; }
+    std::string name() const { return {}; }                                        // debug printers of haplotype_likelihood_array.hpp only
+    std::string cigar() const { return {}; }
 };
+inline std::int64_t mapped_region(const AlignedRead& r) noexcept { return r.begin_; }
 inline std::size_t sequence_size(const AlignedRead& r) noexcept { return r.sequence_.size(); }
 } // namespace octopus

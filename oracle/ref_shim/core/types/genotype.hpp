@@ -6,7 +6,6 @@
 #include "core/types/haplotype.hpp"
 #include "core/types/indexed_haplotype.hpp"
 namespace octopus {
-inline bool operator==(const Haplotype& a, const Haplotype& b) noexcept { return a.begin_ == b.begin_ && a.sequence_ == b.sequence_; }
 inline bool operator!=(const Haplotype& a, const Haplotype& b) noexcept { return !(a == b); }
 template <typename T>
 class Genotype
