@@ -325,3 +325,31 @@ def check_chunked_traceback(backend, tol=0.0):
             else:
                 os.environ[k] = v
 
+
+def check_against_reference_array(backend, tol=0.0):
+    """The product pipeline against the REFERENCE's own HaplotypeLikelihoodArray::populate (haplotype_likelihood_array.cpp built in place,
+    oracle/_ref/libref_array.so): reads and templates, several samples' rows, device k-mer mapping, with no oracle restatement in between."""
+    rng = np.random.default_rng(515)
+    n_checked = 0
+    for B, R, H, T, Lh, flank, tmpl in ((8, 30, 5, 60, 170, (20, 25), False), (16, 40, 6, 100, 260, (40, 40), True), (16, 25, 4, 150, 300, None, False),
+                                        (32, 20, 3, 120, 330, (30, 60), True)):
+        g = synth.make_region(rng, R, H, T=T, Lh=Lh, B=B, flank=flank, positions="none", indels_per_read=1)
+        g["mapq"] = rng.integers(0, 70, R).astype(np.uint8)
+        batch = synth.batch_from_regions([g])
+        if tmpl:
+            rows, r = [0], 0
+            while r < R:
+                r += min(R - r, int(rng.integers(1, 4)))
+                rows.append(r)
+            batch.row_offsets = np.asarray(rows, np.uint32)
+        cfg = abi.Config.default(max_indel_error=B)
+        code, want, _, _, _ = oracle.ref_array_populate(cfg, batch, n_threads=4 if tmpl else 1)
+        assert code == 0
+        eng = make_engine(backend, max_indel_error=B)
+        got, _ = eng.populate(batch)
+        eng.close()
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want), initial=0.0) <= tol, (B, tmpl)
+        n_checked += got.size
+    return n_checked
+

@@ -236,6 +236,13 @@ def test_gpu_chunked_traceback_launches():
     cp.check_chunked_traceback("gpu", TOL)
 
 
+def test_gpu_matrix_equals_the_reference_array_populate():
+    """Device output against the reference's own HaplotypeLikelihoodArray::populate (prebuilt oracle/_ref/libref_array.so travels with the snapshot)."""
+    if not oracle.have_ref_array():
+        pytest.skip("oracle/_ref/libref_array.so not built")
+    assert cp.check_against_reference_array("gpu", TOL) > 400
+
+
 def test_gpu_empty_batches():
     cp.check_empty_batches("gpu")
 

@@ -74,3 +74,11 @@ def test_sim_random_scenarios_with_late_traceback_start(monkeypatch):
 def test_sim_chunked_traceback_launches():
     cp.check_chunked_traceback("sim")
 
+
+def test_sim_matrix_equals_the_reference_array_populate():
+    import oracle
+    import pytest
+    if not oracle.have_ref_array():
+        pytest.skip("oracle/_ref/libref_array.so not built (no /root/reference)")
+    assert cp.check_against_reference_array("sim") > 400
+
