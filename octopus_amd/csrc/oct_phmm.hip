@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -158,6 +159,18 @@ int band_for(int max_indel_error)   // simd_pair_hmm_wrapper.hpp:219-241
 // All device memory of a batch is ONE pool block: `upload` / `dalloc` only record what is needed, `commit` allocates, fills in the
 // pointers and sends every input array up in a single copy out of the handle's pinned staging buffer (each array keeps a zeroed
 // 16-byte tail pad, as the kernels' vector loads expect).
+// Run f(lo, hi) over [0, n) on a few host threads (memory-bound passes over a big batch's arrays); small n stays on the caller's thread.
+template <class F> void host_parallel(size_t n, size_t grain, F&& f)
+{
+    unsigned T = std::thread::hardware_concurrency(); T = T > 4 ? 4 : (T ? T : 1);
+    if (n / grain < T) T = (unsigned)(n / grain);
+    if (T <= 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th; th.reserve(T - 1);
+    for (unsigned t = 1; t < T; ++t) th.emplace_back([&f, n, t, T] { f(n * t / T, n * (t + 1) / T); });
+    f((size_t)0, n / T);
+    for (auto& x : th) x.join();
+}
+
 struct Packer {
     struct Item { const void* src; size_t bytes; size_t off; void** dst; };
     std::vector<Item> items;
@@ -167,7 +180,13 @@ struct Packer {
     template <class T> void dalloc(T** dev, size_t n) { items.push_back({nullptr, n * sizeof(T), 0, (void**)dev}); }
     bool commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s);
 };
-constexpr size_t kStageMax = (size_t)64 << 20;
+// Inputs up to this size are packed into the pinned staging buffer and copied in one piece; larger ones stream through its two halves.
+// OCT_PHMM_STAGE_MAX_KB: test hook (small batches through the streaming path).
+static size_t stage_max()
+{
+    if (const char* e = getenv("OCT_PHMM_STAGE_MAX_KB")) { const long kb = atol(e); if (kb >= 2) return (size_t)kb << 10; }
+    return (size_t)64 << 20;
+}
 
 bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
 {
@@ -179,9 +198,10 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
     b->allocs.push_back(base);
     for (auto& it : items) *it.dst = (char*)base + it.off;
     if (!in_bytes) return true;
+    const size_t kStageMax = stage_max();
     if (in_bytes <= kStageMax) {
         if (h->stage_bytes < in_bytes) {
-            rt::host_pinned_free(h->stage); rt::host_pinned_free(h->out_stage); h->stage = nullptr; h->stage_bytes = 0;
+            rt::host_pinned_free(h->stage); h->stage = nullptr; h->stage_bytes = 0;
             size_t want = (size_t)1 << 20; while (want < in_bytes) want <<= 1;
             if (!rt::host_pinned_malloc(&h->stage, want)) return false;
             h->stage_bytes = want;
@@ -193,12 +213,52 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
         }
         return rt::h2d(base, h->stage, in_bytes, s);
     }
-    for (auto& it : items) {                               // big batch: straight from the caller's arrays
-        if (!it.src) break;
-        if (!rt::dev_memset((char*)base + it.off + it.bytes, 0, 16, s)) return false;
-        if (!rt::h2d((char*)base + it.off, it.src, it.bytes, s)) return false;
+    if (getenv("OCT_PHMM_PAGEABLE_H2D")) {                 // A/B switch: straight from the caller's (pageable) arrays
+        for (auto& it : items) {
+            if (!it.src) break;
+            if (!rt::dev_memset((char*)base + it.off + it.bytes, 0, 16, s)) return false;
+            if (!rt::h2d((char*)base + it.off, it.src, it.bytes, s)) return false;
+        }
+        return true;
     }
-    return true;
+    // Big batch: the device image [0, in_bytes) goes through the two halves of the pinned staging buffer. While the DMA drains one half
+    // a few host threads fill the other (one thread copies at ~10 GB/s, a pageable hipMemcpy no faster; PCIe takes ~50 GB/s).
+    if (h->stage_bytes < kStageMax) {
+        rt::host_pinned_free(h->stage); h->stage = nullptr; h->stage_bytes = 0;
+        if (!rt::host_pinned_malloc(&h->stage, kStageMax)) return false;
+        h->stage_bytes = kStageMax;
+    }
+    size_t n_in = 0; while (n_in < items.size() && items[n_in].src) ++n_in;
+    const size_t half = (kStageMax / 2) & ~(size_t)255;
+    rt::Event ev[2] {}; bool used[2] = {false, false};
+    if (!h->get_event(&ev[0]) || !h->get_event(&ev[1])) return false;
+    auto fill = [&](char* dst, size_t lo, size_t hi) {       // image of device bytes [lo, hi): item payloads, zero padding between them
+        size_t i = (size_t)(std::upper_bound(items.begin(), items.begin() + n_in, lo, [](size_t v, const Item& it) { return v < it.off; }) - items.begin());
+        i = i ? i - 1 : 0;
+        for (size_t pos = lo; pos < hi; ) {
+            const Item& it = items[i];
+            const size_t end = i + 1 < n_in ? items[i + 1].off : in_bytes;      // this item's slot (payload + padding)
+            const size_t stop = end < hi ? end : hi;
+            if (pos < it.off + it.bytes) {
+                const size_t n = (it.off + it.bytes < stop ? it.off + it.bytes : stop) - pos;
+                memcpy(dst + (pos - lo), (const char*)it.src + (pos - it.off), n);
+                pos += n;
+            }
+            if (pos < stop) { memset(dst + (pos - lo), 0, stop - pos); pos = stop; }
+            if (pos >= end) ++i;
+        }
+    };
+    bool ok = true; int k = 0;
+    for (size_t lo = 0; lo < in_bytes && ok; lo += half, k ^= 1) {
+        const size_t len = in_bytes - lo < half ? in_bytes - lo : half;
+        char* buf = (char*)h->stage + (size_t)k * half;
+        if (used[k]) ok = rt::event_sync(ev[k]);
+        host_parallel(len, kStageMax >= ((size_t)32 << 20) ? (size_t)4 << 20 : 256, [&](size_t a, size_t z) { fill(buf + a, lo + a, lo + z); });
+        ok = ok && rt::h2d((char*)base + lo, buf, len, s) && rt::event_record(ev[k], s);
+        used[k] = true;
+    }
+    for (int i = 0; i < 2; ++i) { if (used[i]) ok = rt::event_sync(ev[i]) && ok; h->put_event(ev[i]); }   // the staging buffer is the handle's: drained before anyone reuses it
+    return ok;
 }
 
 bool monotone(const uint32_t* off, uint32_t n) { for (uint32_t i = 0; i < n; ++i) if (off[i + 1] < off[i]) return false; return true; }
@@ -492,12 +552,20 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         return fail(status, OCT_PHMM_EINVAL, "row_offsets must partition the reads");
     const uint32_t n_read_bases = R->offsets[R->n_reads], n_hap_bases = H->offsets[H->n_haps];
     {   // branch-free reductions (these loops run over every base of the batch and must vectorise)
-        uint32_t qor = 0, por = 0;
-        for (uint32_t i = 0; i < n_read_bases; ++i) qor |= R->qualities[i];
-        if (qor & 0x80u) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
-        for (uint32_t i = 0; i < n_hap_bases; ++i)
-            por |= (uint32_t)(uint8_t)H->gap_open[i] | (uint8_t)H->gap_extend[i] | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
-        if (por & 0x80u) return fail(status, OCT_PHMM_EINVAL, "negative penalty");
+        std::atomic<uint32_t> qor {0}, por {0};
+        host_parallel(n_read_bases, (size_t)8 << 20, [&](size_t lo, size_t hi) {
+            uint32_t v = 0;
+            for (size_t i = lo; i < hi; ++i) v |= R->qualities[i];
+            qor.fetch_or(v);
+        });
+        if (qor.load() & 0x80u) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
+        host_parallel(n_hap_bases, (size_t)4 << 20, [&](size_t lo, size_t hi) {
+            uint32_t v = 0;
+            for (size_t i = lo; i < hi; ++i)
+                v |= (uint32_t)(uint8_t)H->gap_open[i] | (uint8_t)H->gap_extend[i] | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
+            por.fetch_or(v);
+        });
+        if (por.load() & 0x80u) return fail(status, OCT_PHMM_EINVAL, "negative penalty");
     }
 
     // regions
@@ -546,14 +614,22 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         // path along its diagonal plus one gap opening, every not-yet-initialised ("infinite") cell by infinity_ plus the deletion chain's
         // growth (the 0x7FF tolerance the reference itself relies on, simd_pair_hmm.hpp:55). If neither can, a 32-bit add of two packed
         // halves never carries between them and k_dp uses v_add_u32 (FASTADD); otherwise it keeps v_pk_add_u16. Results are identical.
-        uint64_t sum_q_max = 0; uint32_t gomax = 0, gemax = 0;
-        for (uint32_t r = 0; r < R->n_reads; ++r) {
-            uint32_t sq = 0;                                   // reads are < 32,768 bases of quality <= 127
-            const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
-            for (uint32_t i = 0; i < n; ++i) sq += q[i];
-            sum_q_max = std::max<uint64_t>(sum_q_max, sq);
-        }
-        for (uint32_t i = 0; i < n_hap_bases; ++i) { gomax = std::max<uint32_t>(gomax, (uint32_t)H->gap_open[i]); gemax = std::max<uint32_t>(gemax, (uint32_t)H->gap_extend[i]); }
+        std::mutex mx; uint64_t sum_q_max = 0; uint32_t gomax = 0, gemax = 0;
+        host_parallel(R->n_reads, (size_t)50000, [&](size_t r0, size_t r1) {
+            uint64_t best = 0;
+            for (size_t r = r0; r < r1; ++r) {
+                uint32_t sq = 0;                               // reads are < 32,768 bases of quality <= 127
+                const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
+                for (uint32_t i = 0; i < n; ++i) sq += q[i];
+                best = std::max<uint64_t>(best, sq);
+            }
+            std::lock_guard<std::mutex> lk(mx); sum_q_max = std::max(sum_q_max, best);
+        });
+        host_parallel(n_hap_bases, (size_t)4 << 20, [&](size_t lo, size_t hi) {
+            uint32_t a = 0, e = 0;
+            for (size_t i = lo; i < hi; ++i) { a = std::max<uint32_t>(a, (uint32_t)H->gap_open[i]); e = std::max<uint32_t>(e, (uint32_t)H->gap_extend[i]); }
+            std::lock_guard<std::mutex> lk(mx); gomax = std::max(gomax, a); gemax = std::max(gemax, e);
+        });
         const uint64_t B64 = (uint64_t)h->band, nuc = (uint64_t)std::max(0, h->cfg.nuc_prior);
         const uint64_t finite = 4 * (sum_q_max + 2 * 64 * B64 + gomax + gemax + nuc) + 1024;
         const uint64_t garbage = 4 * (2 * B64 * gemax + 64 + gomax + gemax + nuc) + 64;

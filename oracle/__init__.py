@@ -75,11 +75,7 @@ class _RefArrayArgs(C.Structure):
         ("n_rows", C.c_uint32), ("row_off", C.c_void_p), ("n_samples", C.c_uint32), ("sample_row_off", C.c_void_p), ("n_threads", C.c_int32)]
 
 
-def ref_array_populate(cfg: abi.Config, batch: abi.Batch, sample_rows=None, n_threads: int = 1, merged: bool = False):
-    """The REFERENCE's own HaplotypeLikelihoodArray::populate (haplotype_likelihood_array.cpp, built in place into
-    oracle/_ref/libref_array.so) on a single-region batch whose rows are split into samples at `sample_rows` (row offsets).
-    Mapping positions come from the reference's own k-mer mapper (the batch's are ignored), as in the reference.
-    Returns (code, out [H x rows] flat, merged or None, err_hap, required_extension): code 0 ok, 1 ShortHaplotypeError."""
+def _ref_array_args(cfg, batch, sample_rows, n_threads):
     global _REF_ARRAY
     if _REF_ARRAY is None:
         _REF_ARRAY = C.CDLL(str(_DIR / "_ref" / "libref_array.so"))
@@ -100,6 +96,23 @@ def ref_array_populate(cfg: abi.Config, batch: abi.Batch, sample_rows=None, n_th
                       vp(keep[7]), vp(keep[8]), 1 if flank is not None else 0, int(flank[0]) if flank else 0, int(flank[1]) if flank else 0,
                       n_reads, vp(keep[9]), vp(keep[10]), vp(keep[11]), vp(keep[12]), vp(keep[13]), vp(keep[14]),
                       n_rows, vp(rows) if rows is not None else None, len(srows) - 1, vp(keep[15]), int(n_threads))
+    return a, (keep, rows, n_haps, n_rows)
+
+
+def ref_array_time_populate(cfg: abi.Config, batch: abi.Batch, n_threads: int, reps: int = 1) -> float:
+    """Seconds the REFERENCE's own HaplotypeLikelihoodArray::populate (TemplateMap overload, one read per template, its ThreadPool of
+    n_threads workers fanning out over haplotypes, array.cpp:167-184) spends on `reps` calls of this single-region batch."""
+    a, keep = _ref_array_args(cfg, batch, None, n_threads)
+    _REF_ARRAY.ref_array_time_populate.restype = C.c_double
+    return float(_REF_ARRAY.ref_array_time_populate(C.byref(a), int(reps)))
+
+
+def ref_array_populate(cfg: abi.Config, batch: abi.Batch, sample_rows=None, n_threads: int = 1, merged: bool = False):
+    """The REFERENCE's own HaplotypeLikelihoodArray::populate (haplotype_likelihood_array.cpp, built in place into
+    oracle/_ref/libref_array.so) on a single-region batch whose rows are split into samples at `sample_rows` (row offsets).
+    Mapping positions come from the reference's own k-mer mapper (the batch's are ignored), as in the reference.
+    Returns (code, out [H x rows] flat, merged or None, err_hap, required_extension): code 0 ok, 1 ShortHaplotypeError."""
+    a, (keep, rows, n_haps, n_rows) = _ref_array_args(cfg, batch, sample_rows, n_threads)
     out = np.full(max(n_haps * n_rows, 1), np.nan)
     mg = np.full(max(n_haps * n_rows, 1), np.nan) if merged else None
     err_hap, ext = C.c_uint32(0), C.c_uint32(0)

@@ -56,6 +56,10 @@ struct ref_array_args {
     int32_t n_threads;                                   // > 2: hand populate a ThreadPool of that size
 };
 
+// Timing entry for bench.py's cpu_baseline: `reps` populate() calls of the reference on the same inputs (containers built once, outside the
+// clock); returns the seconds spent inside populate(), or a negative value on ShortHaplotypeError.
+extern "C" double ref_array_time_populate(const ref_array_args* a, int reps);
+
 // out[h * n_rows + row] read back through operator()(sample, IndexedHaplotype); merged (optional, same shape) through merge_samples() + operator[].
 // returns 0 ok, 1 ShortHaplotypeError (*err_hap = index of the haplotype it names, *ext = required_extension)
 extern "C" int ref_array_populate(const ref_array_args* a, double* out, double* merged, uint32_t* err_hap, uint32_t* ext)
@@ -131,3 +135,46 @@ extern "C" int ref_array_populate(const ref_array_args* a, double* out, double* 
     }
     return 0;
 }
+
+#include <chrono>
+extern "C" double ref_array_time_populate(const ref_array_args* a, int reps)
+{
+    std::vector<Vectors> vecs(a->n_haps);
+    MappableBlock<Haplotype> haps(a->n_haps);
+    for (uint32_t h = 0; h < a->n_haps; ++h) {
+        const uint32_t o = a->hap_off[h], n = a->hap_off[h + 1] - o;
+        auto& v = vecs[h];
+        v.go.assign(a->gap_open + o, a->gap_open + o + n); v.ge.assign(a->gap_extend + o, a->gap_extend + o + n);
+        v.mask_f.assign(a->mask_f + o, a->mask_f + o + n); v.mask_r.assign(a->mask_r + o, a->mask_r + o + n);
+        v.prior_f.assign(a->prior_f + o, a->prior_f + o + n); v.prior_r.assign(a->prior_r + o, a->prior_r + o + n);
+        haps[h].sequence_.assign(a->hap_bases + o, a->hap_bases + o + n); haps[h].begin_ = a->hap_begin[h]; haps[h].payload_ = &v;
+    }
+    TemplateMap reads;                                   // one read per template: the overload that fans haplotypes out over the thread pool
+    auto& dst = reads["s0000"];
+    for (uint32_t r = 0; r < a->n_reads; ++r) {
+        AlignedRead x; const uint32_t o = a->read_off[r], n = a->read_off[r + 1] - o;
+        x.sequence_.assign(a->read_bases + o, a->read_bases + o + n); x.base_qualities_.assign(a->quals + o, a->quals + o + n);
+        x.mapping_quality_ = a->mapq[r]; x.reverse_ = a->reverse[r] != 0; x.begin_ = a->read_begin[r];
+        dst.push_back(AlignedTemplate {std::move(x)});
+    }
+    HaplotypeLikelihoodModel::Config cfg;
+    cfg.use_mapping_quality = a->use_mapping_quality != 0; cfg.mapping_quality_cap = static_cast<std::uint8_t>(a->mapping_quality_cap);
+    if (a->mapping_quality_cap_trigger >= 0) cfg.mapping_quality_cap_trigger = static_cast<std::uint8_t>(a->mapping_quality_cap_trigger);
+    cfg.use_flank_state = a->use_flank_state != 0; cfg.max_indel_error = static_cast<unsigned>(a->max_indel_error); cfg.use_int_scores = a->use_int_scores != 0;
+    boost::optional<HaplotypeLikelihoodArray::FlankState> fs;
+    if (a->has_flank && cfg.use_flank_state) fs = HaplotypeLikelihoodArray::FlankState {a->lhs_flank, a->rhs_flank};
+    std::unique_ptr<ThreadPool> pool;
+    HaplotypeLikelihoodArray::OptionalThreadPool workers;
+    if (a->n_threads > 2) { pool = std::make_unique<ThreadPool>(static_cast<std::size_t>(a->n_threads)); workers = *pool; }
+    double seconds = 0.0;
+    for (int rep = 0; rep < reps; ++rep) {
+        HaplotypeLikelihoodModel model {std::make_unique<GivenSnvModel>(), std::make_unique<GivenIndelModel>(), cfg};
+        HaplotypeLikelihoodArray arr {std::move(model), a->n_haps, {"s0000"}};
+        const auto t0 = std::chrono::steady_clock::now();
+        try { arr.populate(reads, haps, fs, workers); }
+        catch (const HaplotypeLikelihoodModel::ShortHaplotypeError&) { return -1.0; }
+        seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return seconds;
+}
+

@@ -353,3 +353,31 @@ def check_against_reference_array(backend, tol=0.0):
         n_checked += got.size
     return n_checked
 
+
+def check_streamed_upload_and_growing_calls(backend, tol=0.0):
+    """Inputs larger than the pinned staging buffer stream through its two halves (filled by a few host threads while the DMA drains the
+    other half). Forced here with a staging buffer of a few KB (test hook), so item boundaries, padding and the last partial chunk all fall
+    inside chunks. Then one handle serves calls of growing and shrinking size (the staging and landing buffers are re-sized independently)."""
+    import os
+    old = os.environ.get("OCT_PHMM_STAGE_MAX_KB")
+    try:
+        for kb in ("2", "5", "64"):
+            os.environ["OCT_PHMM_STAGE_MAX_KB"] = kb
+            check_basic(backend, tol)
+            check_templates_and_regions(backend, tol)
+            check_device_kmer_mapper(backend, tol)
+    finally:
+        if old is None:
+            os.environ.pop("OCT_PHMM_STAGE_MAX_KB", None)
+        else:
+            os.environ["OCT_PHMM_STAGE_MAX_KB"] = old
+    rng = np.random.default_rng(88)
+    cfg = abi.Config.default(max_indel_error=8)
+    eng = make_engine(backend, max_indel_error=8)
+    for R, H in ((6, 2), (60, 6), (9, 3), (90, 7), (5, 2)):
+        batch = synth.batch_from_regions([synth.make_region(rng, R, H, T=50, Lh=150, B=8, flank=(20, 20), positions="none")])
+        want, _, _ = oracle.populate(cfg, batch, n_threads=2)
+        got, st = eng.populate(batch)
+        assert st.code == abi.OK and np.max(np.abs(got - want), initial=0.0) <= tol, (R, H)
+    eng.close()
+

@@ -243,6 +243,10 @@ def test_gpu_matrix_equals_the_reference_array_populate():
     assert cp.check_against_reference_array("gpu", TOL) > 400
 
 
+def test_gpu_streamed_upload_and_growing_calls():
+    cp.check_streamed_upload_and_growing_calls("gpu", TOL)
+
+
 def test_gpu_empty_batches():
     cp.check_empty_batches("gpu")
 

@@ -82,3 +82,7 @@ def test_sim_matrix_equals_the_reference_array_populate():
         pytest.skip("oracle/_ref/libref_array.so not built (no /root/reference)")
     assert cp.check_against_reference_array("sim") > 400
 
+
+def test_sim_streamed_upload_and_growing_calls():
+    cp.check_streamed_upload_and_growing_calls("sim")
+
