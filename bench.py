@@ -81,18 +81,27 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
     oracle.set_l1_backend("oracle")
     if oracle.have_ref_array():
         # the reference's own populate(): one call, its ThreadPool of `cores` workers (array.cpp:167-184); the clock covers populate() only
-        secs = oracle.ref_array_time_populate(cfg, batch, cores, 1)
-        reps_a = 1
-        while secs * reps_a < 4.0 and reps_a < 32:
-            reps_a *= 2
-        if reps_a > 1:
-            secs = oracle.ref_array_time_populate(cfg, batch, cores, reps_a) / reps_a
+        def time_array(isa):
+            secs = oracle.ref_array_time_populate(cfg, batch, cores, 1, isa=isa)
+            reps_a = 1
+            while 0 < secs * reps_a < 4.0 and reps_a < 32:
+                reps_a *= 2
+            if reps_a > 1:
+                secs = oracle.ref_array_time_populate(cfg, batch, cores, reps_a, isa=isa) / reps_a
+            return secs, reps_a
+        secs, reps_a = time_array("sse2")
+        isa_used = "SSE2"
         if secs > 0:
             out["value_oracle_layers_over_reference_kernels"] = out["value"]
+            if oracle.have_ref_array("avx2"):             # what a -march=native build of the reference runs for B = 16 x int16
+                secs2, reps2 = time_array("avx2")
+                if secs2 > 0:
+                    out["value_sse2_build"] = cells / secs / 1e9
+                    secs, reps_a, isa_used = secs2, reps2, "AVX2"
             out["value"] = cells / secs / 1e9
             out["loglik_per_s"] = pairs / secs
             out["sample"] = (f"{R} reads x {H} haplotypes of the same generator, {reps_a} repetition(s) of the reference's own "
-                             f"HaplotypeLikelihoodArray::populate (built in place, SSE2 kernels, its thread pool of {cores} workers over haplotypes)")
+                             f"HaplotypeLikelihoodArray::populate (built in place, {isa_used} kernels, its thread pool of {cores} workers over haplotypes)")
     return out
 
 

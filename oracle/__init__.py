@@ -57,11 +57,21 @@ def ref() -> C.CDLL:
     return _REF
 
 
-_REF_ARRAY: Optional[C.CDLL] = None
+_REF_ARRAYS: dict = {}
 
 
-def have_ref_array() -> bool:
-    return (_DIR / "_ref" / "libref_array.so").exists()
+def have_ref_array(isa: str = "sse2") -> bool:
+    """oracle/_ref/libref_array.so (SSE2 kernels) or libref_array_avx2.so (the reference's AVX2 kernels; needs an AVX2 CPU)."""
+    name = "libref_array.so" if isa == "sse2" else "libref_array_avx2.so"
+    return (_DIR / "_ref" / name).exists() and (isa == "sse2" or ref_isa_supported("avx2"))
+
+
+def _ref_array_lib(isa: str = "sse2") -> C.CDLL:
+    if isa not in _REF_ARRAYS:
+        lib_ = C.CDLL(str(_DIR / "_ref" / ("libref_array.so" if isa == "sse2" else "libref_array_avx2.so")))
+        lib_.ref_array_time_populate.restype = C.c_double
+        _REF_ARRAYS[isa] = lib_
+    return _REF_ARRAYS[isa]
 
 
 class _RefArrayArgs(C.Structure):
@@ -76,9 +86,6 @@ class _RefArrayArgs(C.Structure):
 
 
 def _ref_array_args(cfg, batch, sample_rows, n_threads):
-    global _REF_ARRAY
-    if _REF_ARRAY is None:
-        _REF_ARRAY = C.CDLL(str(_DIR / "_ref" / "libref_array.so"))
     assert batch.region_row_offsets is None or len(batch.region_row_offsets) == 2, "one populate() call = one region"
     n_reads = len(batch.read_offsets) - 1
     n_rows = n_reads if batch.row_offsets is None else len(batch.row_offsets) - 1
@@ -99,15 +106,14 @@ def _ref_array_args(cfg, batch, sample_rows, n_threads):
     return a, (keep, rows, n_haps, n_rows)
 
 
-def ref_array_time_populate(cfg: abi.Config, batch: abi.Batch, n_threads: int, reps: int = 1) -> float:
+def ref_array_time_populate(cfg: abi.Config, batch: abi.Batch, n_threads: int, reps: int = 1, isa: str = "sse2") -> float:
     """Seconds the REFERENCE's own HaplotypeLikelihoodArray::populate (TemplateMap overload, one read per template, its ThreadPool of
     n_threads workers fanning out over haplotypes, array.cpp:167-184) spends on `reps` calls of this single-region batch."""
     a, keep = _ref_array_args(cfg, batch, None, n_threads)
-    _REF_ARRAY.ref_array_time_populate.restype = C.c_double
-    return float(_REF_ARRAY.ref_array_time_populate(C.byref(a), int(reps)))
+    return float(_ref_array_lib(isa).ref_array_time_populate(C.byref(a), int(reps)))
 
 
-def ref_array_populate(cfg: abi.Config, batch: abi.Batch, sample_rows=None, n_threads: int = 1, merged: bool = False):
+def ref_array_populate(cfg: abi.Config, batch: abi.Batch, sample_rows=None, n_threads: int = 1, merged: bool = False, isa: str = "sse2"):
     """The REFERENCE's own HaplotypeLikelihoodArray::populate (haplotype_likelihood_array.cpp, built in place into
     oracle/_ref/libref_array.so) on a single-region batch whose rows are split into samples at `sample_rows` (row offsets).
     Mapping positions come from the reference's own k-mer mapper (the batch's are ignored), as in the reference.
@@ -116,7 +122,7 @@ def ref_array_populate(cfg: abi.Config, batch: abi.Batch, sample_rows=None, n_th
     out = np.full(max(n_haps * n_rows, 1), np.nan)
     mg = np.full(max(n_haps * n_rows, 1), np.nan) if merged else None
     err_hap, ext = C.c_uint32(0), C.c_uint32(0)
-    code = _REF_ARRAY.ref_array_populate(C.byref(a), _p(out), _p(mg) if merged else None, C.byref(err_hap), C.byref(ext))
+    code = _ref_array_lib(isa).ref_array_populate(C.byref(a), _p(out), _p(mg) if merged else None, C.byref(err_hap), C.byref(ext))
     return code, out[:n_haps * n_rows], (mg[:n_haps * n_rows] if merged else None), err_hap.value, ext.value
 
 

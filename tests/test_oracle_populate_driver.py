@@ -142,3 +142,14 @@ def test_several_regions_in_one_call_equal_the_reference_called_once_per_region(
         assert code == 0
         parts.append(got)
     assert np.array_equal(want, np.concatenate(parts))
+
+
+@pytest.mark.skipif(not oracle.have_ref_array("avx2"), reason="no AVX2 build of the reference array (or no AVX2 CPU)")
+def test_avx2_build_of_the_reference_array_gives_the_same_matrix():
+    """bench.py's cpu_baseline times this build where the CPU allows (what -march=native makes of the reference for B = 16 x int16)."""
+    batch, _ = one_region(77, R=40, H=5, T=100, Lh=260, B=16, flank=(40, 40), indels=1)
+    cfg = abi.Config.default(max_indel_error=16)
+    want, st, _ = oracle.populate(cfg, batch, n_threads=2)
+    code, got, _, _, _ = oracle.ref_array_populate(cfg, batch, isa="avx2")
+    assert st.code == abi.OK and code == 0 and np.array_equal(want, got)
+
