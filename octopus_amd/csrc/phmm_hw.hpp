@@ -24,6 +24,11 @@ OCT_DEVICE uint32_t dpp_row_shr1(uint32_t fill, uint32_t v)  { return (uint32_t)
 // lane i <- lane i+1 within each 16-lane row; last lane of a row keeps `fill`
 OCT_DEVICE uint32_t dpp_row_shl1(uint32_t fill, uint32_t v)  { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xf, 0xf, false); }
 // same across the whole wave64 (gfx9 DPP wave_shr:1 / wave_shl:1)
+// the same shifts with zero in the lane that has no source (bound_ctrl): `shift | lane-constant fill` then folds into ONE v_or_b32_dpp
+OCT_DEVICE uint32_t dpp_row_shr1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+OCT_DEVICE uint32_t dpp_row_shl1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }
+OCT_DEVICE uint32_t dpp_wave_shr1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+OCT_DEVICE uint32_t dpp_wave_shl1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 OCT_DEVICE uint32_t dpp_wave_shr1(uint32_t fill, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false); }
 OCT_DEVICE uint32_t dpp_wave_shl1(uint32_t fill, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false); }
 

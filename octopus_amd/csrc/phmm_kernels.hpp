@@ -548,19 +548,23 @@ OCT_KERNEL(k_emit_pad)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* sc
 // ------------------------------------------------------------------------------------------------------------------
 // the banded min-plus DP
 // ------------------------------------------------------------------------------------------------------------------
+// Both shifts are ONE v_or_b32_dpp (B = 16, 64) or v_and_b32_dpp + v_or_b32 (B = 8, 32): the DPP move zeroes the lane that has no source
+// (bound_ctrl), and the fill arrives through a loop-invariant lane constant instead of a v_mov of the fill before every shift.
 template <int B> OCT_DEVICE uint32_t shift_up(uint32_t fill, uint32_t v, uint32_t li)     // lane i <- lane i-1, first lane of a task row <- fill
 {
-    if constexpr (B == 16) return hw::dpp_row_shr1(fill, v);
-    else if constexpr (B == 64) return hw::dpp_wave_shr1(fill, v);
-    else if constexpr (B == 8) { const uint32_t r = hw::dpp_row_shr1(fill, v); return li == 0 ? fill : r; }
-    else { const uint32_t r = hw::dpp_wave_shr1(fill, v); return li == 0 ? fill : r; }
+    const uint32_t fw = li == 0 ? fill : 0u;
+    if constexpr (B == 16) return hw::dpp_row_shr1_z(v) | fw;
+    else if constexpr (B == 64) return hw::dpp_wave_shr1_z(v) | fw;
+    else if constexpr (B == 8) return (hw::dpp_row_shr1_z(v) & (li == 0 ? 0u : ~0u)) | fw;
+    else return (hw::dpp_wave_shr1_z(v) & (li == 0 ? 0u : ~0u)) | fw;
 }
 template <int B> OCT_DEVICE uint32_t shift_down(uint32_t fill, uint32_t v, uint32_t li)   // lane i <- lane i+1, last lane of a task row <- fill
 {
-    if constexpr (B == 16) return hw::dpp_row_shl1(fill, v);
-    else if constexpr (B == 64) return hw::dpp_wave_shl1(fill, v);
-    else if constexpr (B == 8) { const uint32_t r = hw::dpp_row_shl1(fill, v); return li == B - 1 ? fill : r; }
-    else { const uint32_t r = hw::dpp_wave_shl1(fill, v); return li == B - 1 ? fill : r; }
+    const uint32_t fw = li == B - 1 ? fill : 0u;
+    if constexpr (B == 16) return hw::dpp_row_shl1_z(v) | fw;
+    else if constexpr (B == 64) return hw::dpp_wave_shl1_z(v) | fw;
+    else if constexpr (B == 8) return (hw::dpp_row_shl1_z(v) & (li == B - 1 ? 0u : ~0u)) | fw;
+    else return (hw::dpp_wave_shl1_z(v) & (li == B - 1 ? 0u : ~0u)) | fw;
 }
 
 template <bool V> struct BoolC { static constexpr bool value = V; };
@@ -829,20 +833,8 @@ constexpr uint32_t NUL32 = 0x80000000u;      // INT_MIN
 
 OCT_DEVICE uint32_t min_i32(uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b ? a : b; }
 
-template <int B> OCT_DEVICE uint32_t shift_up32(uint32_t v, uint32_t li)
-{
-    if constexpr (B == 16) return hw::dpp_row_shr1(INF32, v);
-    else if constexpr (B == 64) return hw::dpp_wave_shr1(INF32, v);
-    else if constexpr (B == 8) { const uint32_t r = hw::dpp_row_shr1(INF32, v); return li == 0 ? INF32 : r; }
-    else { const uint32_t r = hw::dpp_wave_shr1(INF32, v); return li == 0 ? INF32 : r; }
-}
-template <int B> OCT_DEVICE uint32_t shift_down32(uint32_t v, uint32_t li)
-{
-    if constexpr (B == 16) return hw::dpp_row_shl1(INF32, v);
-    else if constexpr (B == 64) return hw::dpp_wave_shl1(INF32, v);
-    else if constexpr (B == 8) { const uint32_t r = hw::dpp_row_shl1(INF32, v); return li == B - 1 ? INF32 : r; }
-    else { const uint32_t r = hw::dpp_wave_shl1(INF32, v); return li == B - 1 ? INF32 : r; }
-}
+template <int B> OCT_DEVICE uint32_t shift_up32(uint32_t v, uint32_t li) { return shift_up<B>(INF32, v, li); }
+template <int B> OCT_DEVICE uint32_t shift_down32(uint32_t v, uint32_t li) { return shift_down<B>(INF32, v, li); }
 
 template <int B, bool TRACE>
 OCT_KERNEL(k_dp32)(DpParams p)

@@ -114,8 +114,14 @@ namespace octphmm { namespace hw {
 
 inline uint32_t dpp_row_shr1(uint32_t fill, uint32_t v)  { return hipsim::xchg_read(v, [](uint32_t l) { return (l & 15) == 0 ? -1 : (int)l - 1; }, fill); }
 inline uint32_t dpp_row_shl1(uint32_t fill, uint32_t v)  { return hipsim::xchg_read(v, [](uint32_t l) { return (l & 15) == 15 ? -1 : (int)l + 1; }, fill); }
+inline uint32_t dpp_row_shr1_z(uint32_t v) { return dpp_row_shr1(0u, v); }
+inline uint32_t dpp_row_shl1_z(uint32_t v) { return dpp_row_shl1(0u, v); }
+inline uint32_t dpp_wave_shr1_z(uint32_t v);
+inline uint32_t dpp_wave_shl1_z(uint32_t v);
 inline uint32_t dpp_wave_shr1(uint32_t fill, uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return l == 0 ? -1 : (int)l - 1; }, fill); }
 inline uint32_t dpp_wave_shl1(uint32_t fill, uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return l == 63 ? -1 : (int)l + 1; }, fill); }
+inline uint32_t dpp_wave_shr1_z(uint32_t v) { return dpp_wave_shr1(0u, v); }
+inline uint32_t dpp_wave_shl1_z(uint32_t v) { return dpp_wave_shl1(0u, v); }
 
 inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
 {
