@@ -175,6 +175,10 @@ int  oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phmm_status* 
 int  oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_phmm_status* status);
 int  oct_phmm_batch_download(oct_phmm_handle* h, oct_phmm_batch* b, double* out, oct_phmm_status* status);
 int  oct_phmm_batch_stats(const oct_phmm_batch* b, oct_phmm_stats* stats);
+/* Test seam: the candidate mapping positions the last run used, pair-major in the order of `out` (pair = haplotype row x read):
+ * counts[pair] = how many, positions[pair * max_mapping_positions + j] = the j-th (ascending) — what map_query_to_target
+ * (utils/kmer_mapper.hpp:120-159) returns when the device mapped, the caller's own CSR otherwise. Entries past counts[pair] are undefined. */
+int  oct_phmm_batch_candidate_positions(oct_phmm_handle* h, oct_phmm_batch* b, uint8_t* counts, uint32_t* positions, oct_phmm_status* status);
 size_t oct_phmm_batch_out_size(const oct_phmm_batch* b); /* number of doubles `out` must hold */
 /* Average device time (ms) of the last run's dominant DP kernel launches measured with HIP events on the
  * handle's stream, and the number of launches; for bench.py's roofline block. */

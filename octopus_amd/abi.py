@@ -224,6 +224,15 @@ class Batch:
         first = (lambda row: row) if self.row_offsets is None else (lambda row: int(self.row_offsets[row]))
         return sum((first(int(ro[g + 1])) - first(int(ro[g]))) * int(ho[g + 1] - ho[g]) for g in range(len(ro) - 1))
 
+    def read_pairs(self):
+        """(haplotype, read) index pairs in the library's pair order: haplotype-major, each with the reads of its region."""
+        ro, ho = self.region_tables()
+        first = (lambda row: row) if self.row_offsets is None else (lambda row: int(self.row_offsets[row]))
+        for g in range(len(ro) - 1):
+            for h in range(int(ho[g]), int(ho[g + 1])):
+                for r in range(first(int(ro[g])), first(int(ro[g + 1]))):
+                    yield h, r
+
     # ---- ctypes views -------------------------------------------------------------------------
     def c_reads(self) -> Reads:
         for name in ("read_bases", "read_quals", "read_offsets", "mapq", "reverse", "read_ref_begin"):

@@ -694,6 +694,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1); pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
         pk.dalloc(&d.rhash, (size_t)n_read_bases + 1);
         b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 64;
+        if (const char* e = getenv("OCT_PHMM_MAP_READS_PER_BLOCK")) { const long n = atol(e); if (n >= 4 && n <= 4096) b->map_reads_per_block = (uint32_t)n; }   // A/B switch
         std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, read chunk of its region)
         for (uint32_t hp = 0; hp < H->n_haps; ++hp) {
             const uint32_t g = hap_region[hp];
@@ -820,9 +821,16 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 OCT_LAUNCH(k_kmer_map_big, (uint32_t)np, 256, lds, s, d, sl.pair0); RT(rt::launch_ok());
             } else if (sl.blk1 > sl.blk0) {
                 const size_t lds = kmer_map_lds_bytes(b->lh_cap);
-                if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map, lds));
-                OCT_LAUNCH(k_kmer_map, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
-                           (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block); RT(rt::launch_ok());
+                const bool sweep = getenv("OCT_PHMM_KMER_MAP_SWEEP") != nullptr;           // A/B switch: the counter-sweeping form of the mapper
+                if (sweep) {
+                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map<false>, lds));
+                    OCT_LAUNCH(k_kmer_map<false>, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
+                               (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block); RT(rt::launch_ok());
+                } else {
+                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map<true>, lds));
+                    OCT_LAUNCH(k_kmer_map<true>, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
+                               (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block); RT(rt::launch_ok());
+                }
             }
         }
         const uint32_t pair_blocks = (uint32_t)((np + 255) / 256);
@@ -970,6 +978,18 @@ extern "C" int oct_phmm_batch_download(oct_phmm_handle* h, oct_phmm_batch* b, do
     const int rc = oct_phmm_batch_wait(h, b, status);
     if (rc != OCT_PHMM_OK) return rc;
     RT(rt::d2h(out, b->d_out, (size_t)b->n_out * sizeof(double), h->stream));
+    RT(rt::stream_sync(h->stream));
+    return ok(status);
+}
+
+extern "C" int oct_phmm_batch_candidate_positions(oct_phmm_handle* h, oct_phmm_batch* b, uint8_t* counts, uint32_t* positions, oct_phmm_status* status)
+{
+    if (!h || !b) return fail(status, OCT_PHMM_EINVAL, "null handle or batch");
+    if (b->n_pairs && (!counts || !positions)) return fail(status, OCT_PHMM_EINVAL, "null output");
+    const int rc = oct_phmm_batch_wait(h, b, status);
+    if (rc != OCT_PHMM_OK) return rc;
+    RT(rt::d2h(counts, b->d.npos, (size_t)b->n_pairs, h->stream));
+    RT(rt::d2h(positions, b->d.pos, (size_t)b->n_pairs * (size_t)b->d.max_pos * sizeof(uint32_t), h->stream));
     RT(rt::stream_sync(h->stream));
     return ok(status);
 }

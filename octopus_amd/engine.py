@@ -60,6 +60,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_wait.argtypes = [pv, pv, pv]
         lib.oct_phmm_batch_download.argtypes = [pv, pv, pv, pv]
         lib.oct_phmm_batch_stats.argtypes = [pv, pv]
+        lib.oct_phmm_batch_candidate_positions.argtypes = [pv, pv, pv, pv, pv]
         lib.oct_phmm_batch_out_size.argtypes = [pv]
         lib.oct_phmm_batch_out_size.restype = C.c_size_t
         lib.oct_phmm_batch_kernel_time.argtypes = [pv, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
@@ -131,6 +132,17 @@ class ResidentBatch:
         if code != abi.OK:
             raise EngineError(code, st, "genotype_likelihoods")
         return out[:n]
+
+    def candidate_positions(self) -> list:
+        """Test seam (oct_phmm_batch_candidate_positions): per (haplotype, read) pair, in the order of Batch.read_pairs(), the list of candidate
+        mapping positions the last run used."""
+        n, S = self.batch.n_read_pairs(), int(self.engine.cfg.max_mapping_positions)
+        cnt, pos = np.zeros(max(n, 1), np.uint8), np.zeros(max(n * S, 1), np.uint32)
+        st = abi.Status()
+        code = self.engine.lib.oct_phmm_batch_candidate_positions(self.engine.handle, self.ptr, _ptr(cnt), _ptr(pos), C.byref(st))
+        if code != abi.OK:
+            raise EngineError(code, st, "candidate_positions")
+        return [pos[e * S: e * S + int(cnt[e])].tolist() for e in range(n)]
 
     def stats(self) -> dict:
         s = abi.Stats()

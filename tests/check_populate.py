@@ -31,6 +31,22 @@ def mapper_positions(batch: abi.Batch, max_positions=10, rng=None, junk=0.0):
     return batch
 
 
+def assert_device_positions(rb, batch, cfg):
+    """map_query_to_target (utils/kmer_mapper.hpp:120-159) for every (haplotype, read) pair: the positions the device mapper
+    handed to the rest of the run (oct_phmm_batch_candidate_positions) equal the oracle's list, same order, same truncation."""
+    got = rb.candidate_positions()
+    S = int(cfg.max_mapping_positions)
+    n = 0
+    for e, (h, r) in enumerate(batch.read_pairs()):
+        hs = bytes(batch.hap_bases[batch.hap_offsets[h]:batch.hap_offsets[h + 1]])
+        rs = bytes(batch.read_bases[batch.read_offsets[r]:batch.read_offsets[r + 1]])
+        want = oracle.map_query_to_target(rs, hs, S)
+        assert got[e] == want, (e, h, r, got[e], want)
+        n += 1
+    assert n == len(got)
+    return n
+
+
 def compare(backend, batch, tol=0.0, **cfg_kw):
     cfg = abi.Config.default(**cfg_kw)
     want, wst, wstats = oracle.populate(cfg, batch, n_threads=2)
@@ -44,6 +60,8 @@ def compare(backend, batch, tol=0.0, **cfg_kw):
     except Exception as e:  # EngineError
         got, code, st = None, e.code, e.status
     stats = rb.stats()
+    if code == abi.OK and batch.pos_offsets is None and batch.n_read_pairs() <= 100000:
+        assert_device_positions(rb, batch, cfg)       # the device mapper's own output, pair by pair
     rb.free()
     eng.close()
     assert code == wst.code, (code, wst.code, wst.message)
@@ -179,6 +197,51 @@ def check_device_kmer_mapper(backend, tol=0.0):
     hl = [dict(seq=bytes(hap), begin=0, gap_open=go, gap_extend=ge, mask_fwd=mf, prior_fwd=pf, mask_rev=mr, prior_rev=pr)]
     out.append(compare(backend, abi.Batch.from_lists(reads, hl, flank=None), tol, max_indel_error=8))
     return out
+
+
+def check_kmer_mapper_positions(backend, seeds=(71, 72, 73, 74, 75, 76)):
+    """The device mapper's positions against the oracle's mapper on haplotypes built to tie: pure tandem repeats and homopolymers (dozens of
+    diagonals with the same vote count: more winners than the tracked form ranks, so it sweeps), two copies of one segment (two winners,
+    ranked without a sweep), reads that straddle a copy boundary (one lane finishes two diagonals), random sequence (one winner), and
+    max_mapping_positions from 1 to 15 (truncation of the ascending list). Returns the number of pairs checked."""
+    n = 0
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        T, R = int(rng.integers(30, 100)), 12
+        Lh = int(rng.integers(2 * T + 40, 420))
+        haps = []
+        base = synth.BASES[rng.integers(0, 4, Lh)]
+        haps.append(base.copy())
+        unit = synth.BASES[rng.integers(0, 4, int(rng.integers(1, 7)))]
+        haps.append(np.resize(unit, Lh).copy())                                   # one tandem repeat end to end
+        two = base.copy(); seg = int(rng.integers(T // 2, Lh // 2)); two[seg:2 * seg] = two[:seg]; haps.append(two)   # a duplicated segment
+        mix = base.copy(); a = int(rng.integers(0, Lh - 60)); mix[a:a + 50] = np.resize(unit, 50); haps.append(mix)
+        hom = base.copy(); hom[20:20 + min(80, Lh - 40)] = hom[20]; haps.append(hom)
+        reads = []
+        for i in range(R):
+            src = haps[i % len(haps)]
+            s0 = int(rng.integers(0, Lh - T + 1))
+            seq = src[s0:s0 + T].copy()
+            for _ in range(int(rng.integers(0, 3))): seq[int(rng.integers(0, T))] = synth.BASES[int(rng.integers(0, 4))]
+            reads.append(dict(seq=bytes(seq), quals=rng.integers(5, 45, T).astype(np.uint8), mapq=50, reverse=bool(i & 1), begin=int(rng.integers(8, Lh - T - 7))))
+        hl = []
+        for hb in haps:
+            go, ge, mf, pf, mr, pr = synth._penalties(hb)
+            hl.append(dict(seq=bytes(hb), begin=0, gap_open=go, gap_extend=ge, mask_fwd=mf, prior_fwd=pf, mask_rev=mr, prior_rev=pr))
+        batch = abi.Batch.from_lists(reads, hl, flank=None)
+        S = int(rng.choice([1, 2, 3, 10, 15]))
+        cfg = abi.Config.default(max_indel_error=8, max_mapping_positions=S)
+        eng = make_engine(backend, max_indel_error=8, max_mapping_positions=S)
+        rb = eng.upload(batch)
+        rb.run()
+        try:
+            rb.wait()
+            n += assert_device_positions(rb, batch, cfg)
+        except Exception as e:      # a ShortHaplotypeError of the later stages does not concern the mapper: its positions are still there
+            if getattr(e, "code", None) != abi.ESHORT_HAPLOTYPE: raise
+        rb.free()
+        eng.close()
+    return n
 
 
 def check_int32_lanes(backend, tol=0.0):

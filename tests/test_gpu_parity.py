@@ -92,6 +92,16 @@ def test_gpu_device_kmer_mapper_matches_reference_mapper():
     cp.check_device_kmer_mapper("gpu", TOL)
 
 
+def test_gpu_device_mapper_positions_equal_the_oracle_mapper_on_tie_rich_haplotypes(monkeypatch):
+    assert cp.check_kmer_mapper_positions("gpu") >= 200
+    monkeypatch.setenv("OCT_PHMM_KMER_MAP_SWEEP", "1")
+    assert cp.check_kmer_mapper_positions("gpu", seeds=(71, 72)) >= 50
+    cp.check_device_kmer_mapper("gpu", TOL)
+    monkeypatch.delenv("OCT_PHMM_KMER_MAP_SWEEP")
+    monkeypatch.setenv("OCT_PHMM_BIG_MAPPER", "1")
+    assert cp.check_kmer_mapper_positions("gpu", seeds=(71, 72)) >= 50
+
+
 def test_gpu_config2_with_device_mapping_matches_oracle():
     """configs[1] again, but with positions == NULL: 6-mer mapping runs on the device (oracle maps on the CPU)."""
     batch = synth.config_batch("1kx64", seed=42, B=16, positions="none")
