@@ -375,6 +375,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
     DpParams p {};
     p.rbases = b->d.rbases; p.rquals = b->d.rquals; p.roff = b->d.roff; p.rrev = b->d.rrev; p.hoff = b->d.hoff;
+    p.rrec = b->d.rrec; p.rrec_stride = b->d.rrec_stride;
     p.tabF = gen ? b->d.tabGenF : b->d.tabFastF; p.tabR = gen ? b->d.tabGenR : b->d.tabFastR;
     p.pair_best = b->d.pair_best;
     p.k_cap = bp_tiles(b->t_cap, (uint32_t)B); p.t_cap = b->t_cap; p.lh_cap = b->lh_cap;
@@ -707,6 +708,11 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         pk.upload(b->h_blk_read0.data(), b->h_blk_read0.size(), (const uint32_t**)&b->d_blk_read0);
     }
     pk.dalloc(&d.racgt, (size_t)R->n_reads);
+    d.rrec = nullptr; d.rrec_stride = 0;
+    if (!b->stream && !h->wide && R->n_reads) {           // the LDS-resident int16 kernels read their read-side operands from per-read record rows
+        d.rrec_stride = dp_rec_n(b->t_cap, (uint32_t)h->band);
+        pk.dalloc(&d.rrec, (size_t)R->n_reads * d.rrec_stride);
+    }
     pk.dalloc(&d.tabFastF, (size_t)n_hap_bases); pk.dalloc(&d.tabFastR, (size_t)n_hap_bases);
     pk.dalloc(&d.tabGenF, (size_t)n_hap_bases);  pk.dalloc(&d.tabGenR, (size_t)n_hap_bases);
     pk.dalloc(&d.pair_best, (size_t)b->n_pairs); pk.dalloc(&d.pair_cls, (size_t)b->n_pairs);
@@ -774,7 +780,10 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     // per-read flags and per-base DP tables (once per batch; HaplotypeLikelihoodModel::reset analogue)
     {
         const uint32_t table_blocks = (n_hap_bases + 255) / 256, flag_blocks = (R->n_reads + 255) / 256;
-        if (table_blocks + flag_blocks) { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks, 256, 0, s, d, n_hap_bases, table_blocks); RT(rt::launch_ok()); }
+        const uint64_t rec_blocks64 = d.rrec ? ((uint64_t)R->n_reads * d.rrec_stride + 255) / 256 : 0;
+        if (table_blocks + flag_blocks + rec_blocks64 >= 0x7fffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "batch too large for one table launch");
+        const uint32_t rec_blocks = (uint32_t)rec_blocks64;
+        if (table_blocks + flag_blocks + rec_blocks) { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok()); }
     }
     RT(rt::stream_sync(s));
     *out = b.release();
@@ -821,16 +830,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 OCT_LAUNCH(k_kmer_map_big, (uint32_t)np, 256, lds, s, d, sl.pair0); RT(rt::launch_ok());
             } else if (sl.blk1 > sl.blk0) {
                 const size_t lds = kmer_map_lds_bytes(b->lh_cap);
-                const bool sweep = getenv("OCT_PHMM_KMER_MAP_SWEEP") != nullptr;           // A/B switch: the counter-sweeping form of the mapper
-                if (sweep) {
-                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map<false>, lds));
-                    OCT_LAUNCH(k_kmer_map<false>, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
-                               (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block); RT(rt::launch_ok());
-                } else {
-                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map<true>, lds));
-                    OCT_LAUNCH(k_kmer_map<true>, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
-                               (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block); RT(rt::launch_ok());
-                }
+                if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map, lds));
+                OCT_LAUNCH(k_kmer_map, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
+                           (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block); RT(rt::launch_ok());
             }
         }
         const uint32_t pair_blocks = (uint32_t)((np + 255) / 256);
@@ -1333,7 +1335,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
         return fail(status, OCT_PHMM_EINVAL, "null argument");
     if (!n) return ok(status);
     const uint32_t B = (uint32_t)h->band;
-    const uint32_t n_truth = truth_offsets[n], n_target = target_offsets[n];
+    const uint32_t n_truth = truth_offsets[n];
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t L = truth_offsets[i + 1] - truth_offsets[i], T = target_offsets[i + 1] - target_offsets[i];
         if (T == 0 || L != T + 2 * B - 1) return fail(status, OCT_PHMM_EINVAL, "truth_len must equal target_len + 2*band - 1");

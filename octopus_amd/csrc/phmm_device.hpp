@@ -36,6 +36,7 @@ struct DevBatch {
     const uint8_t*  rbases;   const uint8_t* rquals;  const uint32_t* roff;
     const uint8_t*  rmapq;    const uint8_t* rrev;    const int64_t*  rbegin;
     uint8_t*        racgt;                            // [n_reads] 1 = only A/C/G/T
+    uint32_t*       rrec; uint32_t rrec_stride;       // [n_reads][rrec_stride] read-side DP records of the fast-cost kernels (k_hap_tables), null when unused
     uint32_t n_rows;          const uint32_t* row_off; // may be null (row == read)
     // haplotypes + the six vectors of HaplotypeLikelihoodModel::reset
     uint32_t n_haps;
@@ -74,6 +75,7 @@ struct DpParams {
     const DevTask* tasks; uint32_t n_tasks;           // n_tasks is a multiple of the group size
     const uint8_t* rbases; const uint8_t* rquals; const uint32_t* roff; const uint8_t* rrev;
     const uint32_t* hoff; const uint2* tabF; const uint2* tabR;
+    const uint32_t* rrec; uint32_t rrec_stride;       // per-read record rows (fast-cost kernels): entry j = read position j - band
     int32_t*  pair_best;                              // score-only kernels: atomicMin target
     uint32_t* bp; TraceEnd* ends;                     // traceback kernels
     uint32_t  k_cap;                                  // 16-iteration backpointer tiles (4 KB each) per task group in the bp scratch

@@ -57,10 +57,26 @@ OCT_DEVICE uint32_t cap_of(uint32_t r, uint32_t h, uint32_t m, uint32_t p)
     return r == m ? p : 255u;
 }
 
-// Once per batch (HaplotypeLikelihoodModel::reset analogue): the per-base DP tables; the workgroups past `table_blocks` set the per-read
-// "pure ACGT" flags in the same launch.
-OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks)
+// Read-side operand of the fast-cost DP kernels, once per read instead of once per task (a read meets every haplotype of its region and
+// ~1.4 candidate positions each): row r, entry j describes read position t = j - band as {v_perm selector of the base's cap byte | 0x0c00,
+// quality << 16}; before the read and after its end {0x0d = "no cap", max_quality_score_ 64} (simd_pair_hmm.hpp:60,260,280). The DP kernel
+// interleaves two rows into its LDS records with two v_perm per entry.
+OCT_DEVICE void read_record_thread(const DevBatch& b, uint64_t g)
 {
+    const uint32_t r = (uint32_t)(g / b.rrec_stride), j = (uint32_t)(g % b.rrec_stride);
+    if (r >= b.n_reads) return;
+    const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro;
+    const int32_t t = (int32_t)j - b.band;
+    const bool in = t >= 0 && (uint32_t)t < T;
+    const uint32_t sel = in ? base_code(b.rbases[ro + t]) : 0x0du, q = in ? (uint32_t)b.rquals[ro + t] : 64u;
+    b.rrec[g] = sel | 0x0c00u | q << 16;
+}
+
+// Once per batch (HaplotypeLikelihoodModel::reset analogue): the per-base DP tables; the workgroups past `table_blocks` set the per-read
+// "pure ACGT" flags, those past `table_blocks + flag_blocks` build the read record rows, in the same launch.
+OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks, uint32_t flag_blocks)
+{
+    if (hw::block_idx() >= table_blocks + flag_blocks) { read_record_thread(b, (uint64_t)(hw::block_idx() - table_blocks - flag_blocks) * hw::block_dim() + hw::thread_idx()); return; }
     if (hw::block_idx() >= table_blocks) { read_flags_thread(b, (hw::block_idx() - table_blocks) * hw::block_dim() + hw::thread_idx()); return; }
     const uint32_t g = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (g >= n_bases) return;
@@ -144,16 +160,8 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint
 // map_query_to_target (:120-159): one wave per (haplotype, read) pair; the workgroup keeps the haplotype's bins in LDS and its
 // four waves stride over a chunk of the region's reads. Votes go to per-wave LDS counters; a 64-lane batch whose votes all fall on
 // one diagonal (the normal case: the read's true offset) is merged into a single add.
-//
-// TRACK = true (the default): the counters are never swept. A counter word is `epoch << 16 | count` (epoch = the wave's read number, so a
-// stale word reads as zero: reset_mapping_counts :115-118 without the clearing pass; ds_max installs the epoch, ds_add_rtn counts), and every
-// lane remembers the largest post-add value it produced and on which diagonal. Counts only grow, so max_hit_count (:145) is the wave maximum
-// of those values, and a diagonal that ends at the maximum got there by exactly one add - the lanes holding the maximum ARE the result
-// (:147-157), ranked by diagonal. A lane that reached the maximum on two diagonals, or more than 16 winners, falls back to sweeping the
-// counters. TRACK = false is the original sweep-everything form (OCT_PHMM_KMER_MAP_SWEEP=1; kept for A/B runs and as a cross-check).
 inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + ((lh_cap + 1) & ~1u) * 2 + kBlockWaves * (lh_cap + 64) * 4; }
 
-template <bool TRACK>
 OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap, uint32_t reads_per_block)
 {
     OCT_DYN_SMEM(smem);
@@ -172,24 +180,9 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
     for (uint32_t d = lane; d < nk + 64; d += 64) counts[d] = 0;
     hw::block_sync();
     const uint32_t max_pos = (uint32_t)b.max_pos;
-    uint32_t epoch = 0;                                                // TRACK: < 2^16 (a wave walks reads_per_block / 4 reads; the host keeps that <= 64)
     for (uint32_t r = r_first + wave; r < r_end; r += kBlockWaves) {
         const uint64_t e = b.hap_pair_off[h] + (r - reg_r0);
         const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;   // compute_kmer_hashes :57-69
-        ++epoch;
-        const uint32_t tag = epoch << 16;
-        uint32_t best_v = 0, best_d = 0, multi = 0;                    // TRACK: this lane's largest post-add count, its diagonal, "reached it twice"
-        auto add_votes = [&](uint32_t d, uint32_t inc) {               // ++mapping_counts[mapping_begin], :132
-            if (TRACK) {
-                hw::atomic_max_lds_u32(&counts[d], tag);               // a word of an earlier read counts as zero
-                const uint32_t nv = (hw::atomic_add_lds_u32(&counts[d], inc) & 0xffffu) + inc;
-                multi = nv == best_v ? 1u : (nv > best_v ? 0u : multi);
-                best_d = nv > best_v ? d : best_d;
-                best_v = nv > best_v ? nv : best_v;
-            } else {
-                hw::atomic_add_lds_u32(&counts[d], inc);
-            }
-        };
         uint32_t hq_next = lane < nq ? b.rhash[ro + lane] : 0;             // software pipeline: next batch's hashes are in flight
         for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
             const uint32_t q = q0 + lane;
@@ -206,70 +199,45 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
                 const uint32_t src = (uint32_t)__builtin_ctzll(voters);
                 const uint32_t d0 = hw::readlane(d, src);
                 if (hw::ballot(vote && d != d0) == 0) {                // every vote on one diagonal: one add
-                    if (lane == src) add_votes(d0, (uint32_t)__builtin_popcountll(voters));
+                    if (lane == src) hw::atomic_add_lds_u32(&counts[d0], (uint32_t)__builtin_popcountll(voters));
                 } else if (vote) {
-                    add_votes(d, 1u);
+                    hw::atomic_add_lds_u32(&counts[d], 1u);            // ++mapping_counts[mapping_begin], :132
                 }
             }
         }
+        hw::wave_lds_fence();
+        // max_hit_count, then the ascending positions that reach it, at most max_pos of them (:145-157). The first 8 chunks of the
+        // counters are read once into registers (and cleared: reset_mapping_counts :115-118) and reused by the output pass.
+        uint32_t cr[8];
+        uint32_t mx = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t d = (uint32_t)q * 64 + lane;
+            cr[q] = d < nk ? counts[d] : 0;
+            if (d < nk) counts[d] = 0;
+            mx = cr[q] > mx ? cr[q] : mx;
+        }
+        for (uint32_t d = 512 + lane; d < nk; d += 64) { const uint32_t c = counts[d]; mx = c > mx ? c : mx; }
+        mx = hw::wave_max_u32(mx);
         uint32_t n_out = 0;
-        if (TRACK) {
-            const uint32_t mx = hw::wave_max_u32(best_v);              // max_hit_count :145 (0 = no vote at all: no positions, :146)
-            const bool win = mx > 0 && best_v == mx;
-            const uint64_t winners = hw::ballot(win);
-            const uint32_t n_win = (uint32_t)__builtin_popcountll(winners);
-            if (hw::ballot(win && multi != 0) == 0 && n_win <= 16) {
-                uint32_t rank = 0;                                     // ascending diagonals (:147-157): rank = winners on a smaller diagonal
-                for (uint64_t m = winners; m != 0; m &= m - 1) rank += hw::readlane(best_d, (uint32_t)__builtin_ctzll(m)) < best_d ? 1u : 0u;
-                if (win && rank < max_pos) b.pos[e * (uint64_t)max_pos + rank] = best_d;
-                n_out = n_win;
-            } else {
-                hw::wave_lds_fence();
-                for (uint32_t d0 = 0; d0 < nk; d0 += 64) {
-                    const uint32_t d = d0 + lane;
-                    const uint32_t w = d < nk ? counts[d] : 0;
-                    const bool is = (w >> 16) == epoch && (w & 0xffffu) == mx;
-                    const uint64_t mask = hw::ballot(is);
-                    const uint32_t rank = n_out + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                    if (is && rank < max_pos) b.pos[e * (uint64_t)max_pos + rank] = d;
-                    n_out += (uint32_t)__builtin_popcountll(mask);
-                }
-                hw::wave_lds_fence();
-            }
-        } else {
-            hw::wave_lds_fence();
-            // max_hit_count, then the ascending positions that reach it, at most max_pos of them (:145-157). The first 8 chunks of the
-            // counters are read once into registers (and cleared: reset_mapping_counts :115-118) and reused by the output pass.
-            uint32_t cr[8];
-            uint32_t mx = 0;
+        auto emit = [&](uint32_t d, uint32_t c) {
+            const bool is = mx > 0 && d < nk && c == mx;
+            const uint64_t mask = hw::ballot(is);
+            const uint32_t rank = n_out + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (is && rank < max_pos) b.pos[e * (uint64_t)max_pos + rank] = d;
+            n_out += (uint32_t)__builtin_popcountll(mask);
+        };
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint32_t d = (uint32_t)q * 64 + lane;
-                cr[q] = d < nk ? counts[d] : 0;
-                if (d < nk) counts[d] = 0;
-                mx = cr[q] > mx ? cr[q] : mx;
-            }
-            for (uint32_t d = 512 + lane; d < nk; d += 64) { const uint32_t c = counts[d]; mx = c > mx ? c : mx; }
-            mx = hw::wave_max_u32(mx);
-            auto emit = [&](uint32_t d, uint32_t c) {
-                const bool is = mx > 0 && d < nk && c == mx;
-                const uint64_t mask = hw::ballot(is);
-                const uint32_t rank = n_out + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                if (is && rank < max_pos) b.pos[e * (uint64_t)max_pos + rank] = d;
-                n_out += (uint32_t)__builtin_popcountll(mask);
-            };
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { if ((uint32_t)q * 64 < nk) emit((uint32_t)q * 64 + lane, cr[q]); }
-            for (uint32_t d0 = 512; d0 < nk; d0 += 64) {
-                const uint32_t d = d0 + lane;
-                const uint32_t c = d < nk ? counts[d] : 0;
-                if (d < nk) counts[d] = 0;
-                emit(d, c);
-            }
-            hw::wave_lds_fence();
+        for (int q = 0; q < 8; ++q) { if ((uint32_t)q * 64 < nk) emit((uint32_t)q * 64 + lane, cr[q]); }
+        for (uint32_t d0 = 512; d0 < nk; d0 += 64) {
+            const uint32_t d = d0 + lane;
+            const uint32_t c = d < nk ? counts[d] : 0;
+            if (d < nk) counts[d] = 0;
+            emit(d, c);
         }
         if (n_out > max_pos) n_out = max_pos;
         if (lane == 0) b.npos[e] = (uint8_t)n_out;
+        hw::wave_lds_fence();
     }
 }
 
@@ -682,6 +650,18 @@ OCT_KERNEL(k_dp)(DpParams p)
             const uint32_t K4 = (Tmax + B + 3) & ~3u;                                 // iterations, run in quads
 
             // ---- stage the read-side records of this row: index j holds read position t = j - B; 4 positions per lane per trip ----
+            if constexpr (!GENERIC) {
+                // fast cost: the two reads' precomputed rows (read_record_thread), interleaved into {selA, selB + 4, qA, qB}
+                const uint4* rowA = (const uint4*)(p.rrec + (size_t)tA.read * p.rrec_stride);
+                const uint4* rowB = (const uint4*)(p.rrec + (size_t)tB.read * p.rrec_stride);
+                for (uint32_t j0 = 4 * li; j0 < K4 + B + 1; j0 += 4 * B) {
+                    const uint4 a = rowA[j0 >> 2], c = rowB[j0 >> 2];
+                    rec_row[j0 + 0] = make_uint2(hw::perm(c.x, a.x, 0x05040100u) | 0x00040000u, hw::perm(c.x, a.x, 0x07060302u));
+                    rec_row[j0 + 1] = make_uint2(hw::perm(c.y, a.y, 0x05040100u) | 0x00040000u, hw::perm(c.y, a.y, 0x07060302u));
+                    rec_row[j0 + 2] = make_uint2(hw::perm(c.z, a.z, 0x05040100u) | 0x00040000u, hw::perm(c.z, a.z, 0x07060302u));
+                    rec_row[j0 + 3] = make_uint2(hw::perm(c.w, a.w, 0x05040100u) | 0x00040000u, hw::perm(c.w, a.w, 0x07060302u));
+                }
+            } else
             for (uint32_t j0 = 4 * li; j0 < K4 + B + 1; j0 += 4 * B) {
                 const int32_t t0 = (int32_t)j0 - B;
                 auto load4 = [&](const uint8_t* base, uint32_t T) -> uint32_t {

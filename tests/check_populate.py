@@ -201,9 +201,8 @@ def check_device_kmer_mapper(backend, tol=0.0):
 
 def check_kmer_mapper_positions(backend, seeds=(71, 72, 73, 74, 75, 76)):
     """The device mapper's positions against the oracle's mapper on haplotypes built to tie: pure tandem repeats and homopolymers (dozens of
-    diagonals with the same vote count: more winners than the tracked form ranks, so it sweeps), two copies of one segment (two winners,
-    ranked without a sweep), reads that straddle a copy boundary (one lane finishes two diagonals), random sequence (one winner), and
-    max_mapping_positions from 1 to 15 (truncation of the ascending list). Returns the number of pairs checked."""
+    diagonals with the same vote count), two copies of one segment (two winners), reads that straddle a copy boundary, random sequence
+    (one winner), and max_mapping_positions from 1 to 15 (truncation of the ascending list). Returns the number of pairs checked."""
     n = 0
     for seed in seeds:
         rng = np.random.default_rng(seed)

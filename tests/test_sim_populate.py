@@ -29,17 +29,9 @@ def test_sim_device_kmer_mapper_matches_reference_mapper():
 
 
 def test_sim_device_mapper_positions_equal_the_oracle_mapper_on_tie_rich_haplotypes(monkeypatch):
-    assert cp.check_kmer_mapper_positions("sim") >= 200                    # tracked form (default): winners ranked from the lanes' own maxima
-    monkeypatch.setenv("OCT_PHMM_KMER_MAP_SWEEP", "1")
-    assert cp.check_kmer_mapper_positions("sim", seeds=(71, 72)) >= 50    # the counter-sweeping form
-    monkeypatch.delenv("OCT_PHMM_KMER_MAP_SWEEP")
+    assert cp.check_kmer_mapper_positions("sim") >= 200
     monkeypatch.setenv("OCT_PHMM_BIG_MAPPER", "1")
     assert cp.check_kmer_mapper_positions("sim", seeds=(71, 72)) >= 50    # the one-workgroup-per-pair mapper of very long haplotypes
-
-
-def test_sim_sweeping_mapper_gives_the_same_matrix(monkeypatch):
-    monkeypatch.setenv("OCT_PHMM_KMER_MAP_SWEEP", "1")
-    cp.check_device_kmer_mapper("sim")
 
 
 def test_sim_populate_int32_lanes():
