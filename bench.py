@@ -29,8 +29,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # 256 CU x 4 SIMD x 2.4 GHz / 4 = 614 G wave-instructions/s is the issue peak the DP kernels run against.
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
 # VALU wave-instructions per DP iteration per wave (8 tasks at B = 16), counted in the ISA of this build
-VALU_PER_ITER = {"score": 31.3, "trace": 53.0}
-PMC_SUMMARY = ROOT / "profiles" / "r01_step14_pmc_summary.json"
+VALU_PER_ITER = {"score": 29.25, "trace": 51.75}
+# Measured issue cost per wave64 instruction on one SIMD, in cycles of the nominal 2.4 GHz clock (profiles/r01_step16_valu_issue_rates.log):
+# v_add_u32 / v_and / v_or / v_mov 2.6 ("fast"), everything packed, VOP3, DPP, perm, min 4.4 ("slow"); shares of fast instructions in the
+# main loops of this build's ISA: score-only 45 of 117, traceback 103 of 207.
+ISSUE_CYCLES = {"score": (45 * 2.6 + 72 * 4.4) / 117, "trace": (103 * 2.6 + 104 * 4.4) / 207}
+PMC_SUMMARY = ROOT / "profiles" / "r01_step17_pmc_summary.json"
 
 
 def algorithmic_bytes_per_task(T: int, B: int) -> int:
@@ -191,6 +195,7 @@ def main():
         valu_instr = (groups(stats["n_dp_score_only"]) * VALU_PER_ITER["score"] + groups(stats["n_dp_traceback"]) * VALU_PER_ITER["trace"]) * (T + B)
         dp_s_per_step = ((tr_ms + sc_ms + kind_ms["score_generic"][0] + kind_ms["trace_generic"][0]) / 1e3) / 3
         traffic = None
+        issue_cycles = valu_instr * (ISSUE_CYCLES["score"] + ISSUE_CYCLES["trace"]) / 2
         valu_src = "loop-body wave-instructions (ISA count of the traceback form; an upper bound for late-start launches) x iterations"
         if PMC_SUMMARY.exists():        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
             pmc = json.loads(PMC_SUMMARY.read_text())
@@ -201,6 +206,7 @@ def main():
             if args.workload == "100kx128" and B == 16 and "SQ_INSTS_VALU" in pm and "SQ_INSTS_VALU" in ps:
                 # the PMC passes ran this very workload: instructions actually issued per launch x launches per step
                 valu_instr = pm["SQ_INSTS_VALU"] * tr_n / 3 + ps["SQ_INSTS_VALU"] * sc_n / 3
+                issue_cycles = pm["SQ_INSTS_VALU"] * tr_n / 3 * ISSUE_CYCLES["trace"] + ps["SQ_INSTS_VALU"] * sc_n / 3 * ISSUE_CYCLES["score"]
                 valu_src = f"SQ_INSTS_VALU per launch ({PMC_SUMMARY.relative_to(ROOT)}) x launches per step"
         out = {
             "metric": "pair-HMM band cell-updates/s", "value": cells / per_step / 1e9, "unit": "GCUPS",
@@ -218,7 +224,7 @@ def main():
                          "traffic": traffic,
                          "traffic_note": f"HBM bytes per launch of k_dp<{B},true,false,true> from {PMC_SUMMARY.relative_to(ROOT)} (FETCH_SIZE x 2 per the gfx950 "
                                          "correction + WRITE_SIZE, separate --pmc passes of this workload, single slice = two launches per step: late-start and full traceback); "
-                                         "~90 % of it is the backpointer tile stream the walk kernel consumes, which SURVEY 8d's per-task figure does not count",
+                                         "~85 % of it is the backpointer tile stream the walk kernel consumes, which SURVEY 8d's per-task figure does not count",
                          "kernel": f"k_dp<{B}, TRACE, fast cost, FASTADD> (traceback DP), single-slice run, HIP events on the library stream",
                          "avg_launch_ms": avg_launch_s * 1e3, "tasks_per_launch": tasks_per_launch,
                          "algorithmic_bytes_per_task": algorithmic_bytes_per_task(T, B),
@@ -226,8 +232,11 @@ def main():
                          "valu": {"achieved_wave_instr_per_s": valu_instr / dp_s_per_step if dp_s_per_step > 0 else 0.0,
                                   "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
                                   "frac": (valu_instr / dp_s_per_step / VALU_PEAK_WAVE_INSTR) if dp_s_per_step > 0 else 0.0,
+                                  "issue_weighted_frac": (issue_cycles / (1024 * 2.4e9) / dp_s_per_step) if dp_s_per_step > 0 else 0.0,
                                   "note": "the DP is integer-VALU issue bound, not HBM bound (SURVEY.md 8d): " + valu_src +
-                                          " / DP kernel time vs 256 CU x 4 SIMD x 2.4 GHz / 4 cycles"}},
+                                          " / DP kernel time vs 256 CU x 4 SIMD x 2.4 GHz / 4 cycles; issue_weighted_frac prices each instruction at its "
+                                          "measured issue cost (profiles/r01_step16_valu_issue_rates.log: 2.6 cycles for plain 32-bit add/and/or/mov, 4.4 for "
+                                          "packed, VOP3, DPP, perm and min) = the share of DP kernel time the instruction stream itself accounts for"}},
         }
         if world == 1 and not args.no_small_batch:
             small = eng.upload(synth.config_batch("1kx64", seed=42, B=B, positions="none"))

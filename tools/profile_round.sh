@@ -1,14 +1,17 @@
-# One gpurun call's worth of profiling for a round: see profiles/ for the summaries this produced.
+# One gpurun call's worth of profiling for a round (see profiles/ for the summaries this produced):
+#   bash tools/profile_round.sh <tag>      -> gpurun_out/<tag>/{bench*.json, kstats/, pmc_*/, pytest_gpu.log}
 set -x
 cd /root/repo; export TMPDIR=/tmp
-O=gpurun_out/p33; mkdir -p $O
-OCT_PHMM_LATE_MIN_PAIRS=99999999999 python bench.py --workload stream --no-cpu-baseline > $O/stream_nolate.json 2> $O/stream_nolate.err
-python bench.py --workload stream --no-cpu-baseline > $O/stream_late.json 2> $O/stream_late.err
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/st_late -o s -- python /root/repo/bench.py --workload stream --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> /root/repo/$O/st_late.err)
-(cd /tmp && OCT_PHMM_LATE_MIN_PAIRS=99999999999 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/st_nolate -o s -- python /root/repo/bench.py --workload stream --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> /root/repo/$O/st_nolate.err)
+O=gpurun_out/${1:-prof}; mkdir -p $O
+timeout 300 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/rc.log
+timeout 150 python bench.py --workload stream --no-cpu-baseline > $O/bench_stream.json 2> $O/bench_stream.err; echo "bench_stream rc=$?" >> $O/rc.log
 export OCT_PHMM_SLICES=1
-for C in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 300 rocprofv3 --pmc $C --output-format csv -d /root/repo/$O/pmc_$C -o p -- python /root/repo/bench.py --no-small-batch --no-cpu-baseline --steps 2 --warmup 1 > /root/repo/$O/pmc_$C.json 2> /root/repo/$O/pmc_$C.err)
-done
+(cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/kstats -o s -- python /root/repo/bench.py --no-small-batch --no-cpu-baseline --steps 3 --warmup 1 > /root/repo/$O/bench_1slice_rocprof.json 2> /root/repo/$O/kstats.err); echo "kstats rc=$?" >> $O/rc.log
 find $O -name "*kernel_trace.csv" -delete
-du -sh $O; cat $O/stream_nolate.json | cut -c1-200; cat $O/stream_late.json | cut -c1-200
+for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" FETCH_SIZE WRITE_SIZE; do
+  D=pmc_$(echo $C | cut -d' ' -f1)
+  (cd /tmp && timeout 200 rocprofv3 --pmc $C --output-format csv -d /root/repo/$O/$D -o p -- python /root/repo/bench.py --no-small-batch --no-cpu-baseline --steps 2 --warmup 1 > /root/repo/$O/$D.json 2> /root/repo/$O/$D.err); echo "$D rc=$?" >> $O/rc.log
+done
+unset OCT_PHMM_SLICES
+timeout 420 python -m pytest tests -x -q -m gpu --durations=5 > $O/pytest_gpu.log 2>&1; echo "pytest_gpu rc=$?" >> $O/rc.log
+du -sh $O; cat $O/rc.log; tail -4 $O/pytest_gpu.log; cut -c1-220 $O/bench.json $O/bench_stream.json
