@@ -144,6 +144,8 @@ typedef struct oct_phmm_stats {
 } oct_phmm_stats;
 
 /* ---- lifecycle -------------------------------------------------------------------------------- */
+/* Number of MI355X (gfx950) devices visible to the process (valid `device_id`s are 0 .. n-1); 0 when there is none. Device-free call. */
+int  oct_phmm_device_count(void);
 int  oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out);
 void oct_phmm_destroy(oct_phmm_handle* h);
 /* HaplotypeLikelihoodModel::pad_requirement() == hmm band size (haplotype_likelihood_model.cpp:55-58). */
@@ -195,19 +197,26 @@ void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b);
 /* ---- region server: many calling threads, one device queue ---------------------------------------- */
 /* Octopus calls populate once per active region from each of its region-task threads (caller.cpp:475, octopus.cpp:867). A
  * region-sized call is bound by its chain of dependent kernels and the runtime serialises submissions per device, so N threads with
- * N handles do not give N times the throughput. A server owns ONE handle and a worker thread: calls that
+ * N handles do not give N times the throughput. A server owns the device's handles and worker threads: calls that
  * arrive while the device is busy are concatenated into one multi-region batch (their regions stay independent: own rows, own
  * haplotypes, own flank state), answered together and scattered back. Results are those of oct_phmm_populate for each call; an
  * error in one region (e.g. OCT_PHMM_ESHORT_HAPLOTYPE) is reported to its caller only. Thread-safe; blocks until the caller's
  * result is in `out`. Calls that bring their own candidate positions are served one by one. */
 typedef struct oct_phmm_server oct_phmm_server;
 int  oct_phmm_server_create(const oct_phmm_config* cfg, uint32_t max_regions_per_batch /* 0 = 256 */, oct_phmm_server** out);
+/* The same server in front of several GPUs of the node (BASELINE configs[3]: independent active regions sharded over the devices, no
+ * collective): two worker threads and handles per device, all draining the one queue, so whichever device is free takes the calls that
+ * have arrived (work sharing rather than a fixed region -> device map; results do not depend on the device). `cfg->device_id` is ignored. */
+int  oct_phmm_server_create_multi(const oct_phmm_config* cfg, const int32_t* device_ids, uint32_t n_devices,
+                                  uint32_t max_regions_per_batch /* 0 = 256 */, oct_phmm_server** out);
 void oct_phmm_server_destroy(oct_phmm_server* s);
 int  oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
                               const oct_phmm_flank_state* flank, const oct_phmm_positions* positions,
                               double* out, oct_phmm_status* status);
 /* calls answered and device batches run so far (calls / batches = achieved batching) */
 int  oct_phmm_server_stats(const oct_phmm_server* s, uint64_t* n_calls, uint64_t* n_batches);
+/* calls answered per device, in the order of `device_ids` */
+int  oct_phmm_server_device_calls(const oct_phmm_server* s, uint64_t* calls_by_device, uint32_t n_devices);
 
 /* ---- genotype read-out on the resident matrix ---------------------------------- */
 /* ConstantMixtureGenotypeLikelihoodModel::evaluate (core/models/genotype/constant_mixture_genotype_likelihood_model.cpp:29-330)

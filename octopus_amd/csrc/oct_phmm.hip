@@ -436,6 +436,14 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
 // ---------------------------------------------------------------------------------------------------------------
 // lifecycle
 // ---------------------------------------------------------------------------------------------------------------
+extern "C" int oct_phmm_device_count(void)
+{
+    int n = 0, ok = 0;
+    if (!rt::device_count(&n) || n <= 0) return 0;
+    for (int d = 0; d < n; ++d) ok += rt::device_is_gfx950(d) ? 1 : 0;
+    return ok == n ? n : 0;            // ordinals are HIP's: a node with anything but gfx950 devices is not a target
+}
+
 extern "C" void oct_phmm_config_default(oct_phmm_config* c)
 {
     if (!c) return;
@@ -1147,13 +1155,15 @@ struct oct_phmm_server {
 #else
     static constexpr int kWorkers = 2;                   // two device queues: while one worker's batch computes, the other gathers and uploads the calls that arrived since
 #endif
-    oct_phmm_handle* hs[kWorkers] = {};
+    std::vector<oct_phmm_handle*> hs;                    // kWorkers handles per device, device-major
     uint32_t max_regions = 256;
     std::mutex mu; std::condition_variable cv_work;
     std::deque<Request*> queue;
     bool stop = false;
-    std::thread workers[kWorkers];
+    std::vector<std::thread> workers;                    // one per handle; all of them drain the one queue, so an idle device takes the next calls
     uint64_t n_calls = 0, n_batches = 0;
+    std::vector<uint64_t> n_calls_by_device;
+    std::vector<int> device_of;                          // worker -> index into the device list
 
     static uint32_t rows_of(const oct_phmm_reads* R) { return R->row_offsets ? R->n_rows : R->n_reads; }
 
@@ -1216,31 +1226,52 @@ struct oct_phmm_server {
             std::vector<Request*> batchable, single;
             for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : batchable).push_back(q);
             if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
-            if (!batchable.empty()) serve_many(h, batchable);
-            for (Request* q : single) serve_one(h, q);
+            {
+#if defined(OCTPHMM_SIM)
+                static std::mutex sim_mu;                // the wave simulator runs one kernel at a time: workers of several "devices" take turns
+                std::lock_guard<std::mutex> sim_lk(sim_mu);
+#endif
+                if (!batchable.empty()) serve_many(h, batchable);
+                for (Request* q : single) serve_one(h, q);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 n_calls += take.size(); n_batches += (batchable.empty() ? 0 : 1) + single.size();
+                n_calls_by_device[(size_t)device_of[(size_t)w]] += take.size();
                 for (Request* q : take) { q->done = true; q->cv.notify_one(); }     // under the lock: the request lives on its caller's stack
             }
         }
     }
 };
 
-extern "C" int oct_phmm_server_create(const oct_phmm_config* cfg, uint32_t max_regions_per_batch, oct_phmm_server** out)
+extern "C" int oct_phmm_server_create_multi(const oct_phmm_config* cfg, const int32_t* device_ids, uint32_t n_devices,
+                                            uint32_t max_regions_per_batch, oct_phmm_server** out)
 {
-    if (!out) return OCT_PHMM_EINVAL;
+    if (!out || !cfg || !device_ids || !n_devices) return OCT_PHMM_EINVAL;
     *out = nullptr;
     oct_phmm_server* s = new (std::nothrow) oct_phmm_server();
     if (!s) return OCT_PHMM_EHIP;
-    for (int w = 0; w < oct_phmm_server::kWorkers; ++w) {
-        const int rc = oct_phmm_create(cfg, &s->hs[w]);
-        if (rc != OCT_PHMM_OK) { for (int k = 0; k < w; ++k) oct_phmm_destroy(s->hs[k]); delete s; return rc; }
+    for (uint32_t dv = 0; dv < n_devices; ++dv) {
+        oct_phmm_config c = *cfg; c.device_id = device_ids[dv];
+        for (int w = 0; w < oct_phmm_server::kWorkers; ++w) {
+            oct_phmm_handle* h = nullptr;
+            const int rc = oct_phmm_create(&c, &h);
+            if (rc != OCT_PHMM_OK) { for (auto* k : s->hs) oct_phmm_destroy(k); delete s; return rc; }
+            s->hs.push_back(h); s->device_of.push_back((int)dv);
+        }
     }
+    s->n_calls_by_device.assign(n_devices, 0);
     if (max_regions_per_batch) s->max_regions = max_regions_per_batch;
-    for (int w = 0; w < oct_phmm_server::kWorkers; ++w) s->workers[w] = std::thread([s, w] { s->run(w); });
+    for (size_t w = 0; w < s->hs.size(); ++w) s->workers.emplace_back([s, w] { s->run((int)w); });
     *out = s;
     return OCT_PHMM_OK;
+}
+
+extern "C" int oct_phmm_server_create(const oct_phmm_config* cfg, uint32_t max_regions_per_batch, oct_phmm_server** out)
+{
+    if (!cfg) return OCT_PHMM_EINVAL;
+    const int32_t dev = cfg->device_id;
+    return oct_phmm_server_create_multi(cfg, &dev, 1, max_regions_per_batch, out);
 }
 
 extern "C" void oct_phmm_server_destroy(oct_phmm_server* s)
@@ -1267,6 +1298,14 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
     }
     if (status) *status = q.st;
     return q.rc;
+}
+
+extern "C" int oct_phmm_server_device_calls(const oct_phmm_server* s, uint64_t* calls_by_device, uint32_t n_devices)
+{
+    if (!s || !calls_by_device) return OCT_PHMM_EINVAL;
+    std::lock_guard<std::mutex> lk(const_cast<oct_phmm_server*>(s)->mu);
+    for (uint32_t i = 0; i < n_devices; ++i) calls_by_device[i] = i < s->n_calls_by_device.size() ? s->n_calls_by_device[i] : 0;
+    return OCT_PHMM_OK;
 }
 
 extern "C" int oct_phmm_server_stats(const oct_phmm_server* s, uint64_t* n_calls, uint64_t* n_batches)

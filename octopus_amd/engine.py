@@ -70,6 +70,8 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_set_timing.argtypes = [pv, C.c_int]
         lib.oct_phmm_server_create.argtypes = [C.POINTER(abi.Config), C.c_uint32, C.POINTER(C.c_void_p)]
         lib.oct_phmm_server_destroy.argtypes = [pv]
+        lib.oct_phmm_server_create_multi.argtypes = [C.POINTER(abi.Config), C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.oct_phmm_server_device_calls.argtypes = [pv, C.POINTER(C.c_uint64), C.c_uint32]
         lib.oct_phmm_server_populate.argtypes = [pv, pv, pv, pv, pv, pv, pv]
         lib.oct_phmm_server_stats.argtypes = [pv, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.oct_phmm_batch_free.argtypes = [pv, pv]
@@ -277,11 +279,18 @@ class Server:
     """oct_phmm_server: one device queue shared by many calling threads; concurrent single-region populate calls are answered by
     multi-region batches. `populate` is thread-safe and blocks until its own result is ready."""
 
-    def __init__(self, cfg: Optional[abi.Config] = None, max_regions_per_batch: int = 0, lib_path: Optional[Path] = None):
+    def __init__(self, cfg: Optional[abi.Config] = None, max_regions_per_batch: int = 0, lib_path: Optional[Path] = None,
+                 devices: Optional[list] = None):
+        """devices: GPU ordinals to serve from (oct_phmm_server_create_multi); None = cfg.device_id only."""
         self.lib = load(lib_path)
         self.cfg = cfg if cfg is not None else abi.Config.default()
         self.ptr = C.c_void_p()
-        code = self.lib.oct_phmm_server_create(C.byref(self.cfg), int(max_regions_per_batch), C.byref(self.ptr))
+        self.n_devices = 1 if devices is None else len(devices)
+        if devices is None:
+            code = self.lib.oct_phmm_server_create(C.byref(self.cfg), int(max_regions_per_batch), C.byref(self.ptr))
+        else:
+            ids = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            code = self.lib.oct_phmm_server_create_multi(C.byref(self.cfg), ids, len(devices), int(max_regions_per_batch), C.byref(self.ptr))
         if code != abi.OK:
             raise EngineError(code, None, "server_create")
 
@@ -300,6 +309,11 @@ class Server:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self.lib.oct_phmm_server_stats(self.ptr, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def device_calls(self) -> list:
+        a = (C.c_uint64 * self.n_devices)()
+        self.lib.oct_phmm_server_device_calls(self.ptr, a, self.n_devices)
+        return [int(x) for x in a]
 
     def close(self):
         if self.ptr:

@@ -32,12 +32,14 @@ def make_requests(rng, n, band=8):
     return reqs
 
 
-def check_server(backend, n_threads=5, per_thread=7, seed=17, band=8):
+def check_server(backend, n_threads=5, per_thread=7, seed=17, band=8, devices=None):
+    """devices: serve through oct_phmm_server_create_multi on these GPU ordinals (the same ordinal may repeat: each entry gets its own
+    workers and handles, which is how a one-GPU box exercises the several-device code path)."""
     rng = np.random.default_rng(seed)
     reqs = [make_requests(rng, per_thread, band) for _ in range(n_threads)]
     cfg = abi.Config.default(max_indel_error=band)
     lib_path = build_sim() if backend == "sim" else None
-    srv = engine.Server(cfg, lib_path=lib_path)
+    srv = engine.Server(cfg, lib_path=lib_path, devices=devices)
     got = [[None] * per_thread for _ in range(n_threads)]
     errors = []
 
@@ -53,7 +55,9 @@ def check_server(backend, n_threads=5, per_thread=7, seed=17, band=8):
     ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
     [t.start() for t in ths]; [t.join() for t in ths]
     calls, batches = srv.stats()
+    by_device = srv.device_calls()
     srv.close()
+    assert sum(by_device) == calls and len(by_device) == (1 if devices is None else len(devices))
     assert not errors, errors
     assert calls == 2 * n_threads * per_thread and 0 < batches <= calls
     n_err = 0

@@ -49,8 +49,7 @@ def test_device_free_entry_points(lib):
 
 
 def test_create_fails_loudly_without_a_device(lib):
-    import torch
-    if torch.cuda.is_available():
+    if lib.oct_phmm_device_count() > 0:
         pytest.skip("a GPU is present")
     h = C.c_void_p()
     cfg = abi.Config.default()

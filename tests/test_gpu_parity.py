@@ -265,6 +265,17 @@ def test_gpu_matrix_equals_the_reference_composed_piece_by_piece():
     check_populate_composed_from_the_reference_pieces("gpu", TOL)
 
 
+def test_gpu_server_over_several_devices_gives_the_same_answers():
+    """oct_phmm_server_create_multi with every visible GPU (a one-GPU box lists its GPU twice: two sets of workers and handles)."""
+    import check_server
+    from octopus_amd import engine
+    n = engine.load().oct_phmm_device_count()
+    assert n >= 1
+    devices = list(range(n)) if n > 1 else [0, 0]
+    calls, batches = check_server.check_server("gpu", n_threads=8, per_thread=10, band=16, seed=29, devices=devices)
+    assert calls == 160
+
+
 def test_gpu_server_batches_concurrent_region_calls():
     import check_server
     calls, batches = check_server.check_server("gpu", n_threads=8, per_thread=12, band=16)

@@ -5,3 +5,9 @@ import check_server
 def test_sim_server_answers_every_caller_as_its_own_populate_would():
     calls, batches = check_server.check_server("sim")
     assert calls == 70
+
+
+def test_sim_server_over_several_devices_gives_the_same_answers():
+    """oct_phmm_server_create_multi: one queue, workers and handles per listed device (the simulator's one device listed twice)."""
+    calls, batches = check_server.check_server("sim", n_threads=4, per_thread=5, seed=23, devices=[0, 0])
+    assert calls == 40
