@@ -2,7 +2,7 @@
 // oct_phmm_populate once per active region (the reference's region tasks, caller.cpp:475 / octopus.cpp:867). Regions are synthetic
 // (R reads x H haplotypes, 150 bp x 300 bp, default-model constants); the point is calls/s and how it scales with threads.
 //   g++ -O2 -std=c++17 tools/region_calls_bench.cpp -Iinclude -Loctopus_amd -loct_phmm -lpthread -o tools/region_calls_bench
-//   LD_LIBRARY_PATH=octopus_amd tools/region_calls_bench [regions=400] [reads=300] [haps=24] [threads...]
+//   LD_LIBRARY_PATH=octopus_amd [OCT_BENCH_DEVICES=0,1,...] tools/region_calls_bench [regions=400] [reads=300] [haps=24] [threads...]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -54,7 +54,11 @@ int main(int argc, char** argv)
     for (int T : threads) {                                     // ---- one region server shared by T calling threads (oct_phmm_server) ----
         oct_phmm_config c; oct_phmm_config_default(&c); c.max_indel_error = 16;
         oct_phmm_server* srv = nullptr;
-        if (oct_phmm_server_create(&c, 0, &srv) != OCT_PHMM_OK) { fprintf(stderr, "no device\n"); return 1; }
+        // OCT_BENCH_DEVICES="0,1,..." (default: every visible MI355X): the server's workers and handles are spread over these devices
+        std::vector<int32_t> devs;
+        if (const char* e = getenv("OCT_BENCH_DEVICES")) { for (const char* p = e; *p; ) { devs.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; } }
+        else for (int d = 0; d < oct_phmm_device_count(); ++d) devs.push_back(d);
+        if (devs.empty() || oct_phmm_server_create_multi(&c, devs.data(), (uint32_t)devs.size(), 0, &srv) != OCT_PHMM_OK) { fprintf(stderr, "no device\n"); return 1; }
         int failures = 0;
         auto work = [&](int t, int count) {
             for (int i = t; i < count; i += T) {
@@ -73,8 +77,8 @@ int main(int argc, char** argv)
             for (auto& x : th) x.join();
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             oct_phmm_server_stats(srv, &c1, &b1);
-            if (pass) printf("{\"mode\": \"server\", \"threads\": %d, \"regions_per_s\": %.1f, \"M_loglik_per_s\": %.2f, \"regions_per_device_batch\": %.2f, \"failures\": %d}\n",
-                             T, n_regions / dt, (double)n_regions * R * H / dt / 1e6, (double)(c1 - c0) / (double)std::max<uint64_t>(1, b1 - b0), failures);
+            if (pass) printf("{\"mode\": \"server\", \"devices\": %d, \"threads\": %d, \"regions_per_s\": %.1f, \"M_loglik_per_s\": %.2f, \"regions_per_device_batch\": %.2f, \"failures\": %d}\n",
+                             (int)devs.size(), T, n_regions / dt, (double)n_regions * R * H / dt / 1e6, (double)(c1 - c0) / (double)std::max<uint64_t>(1, b1 - b0), failures);
         }
         oct_phmm_server_destroy(srv);
     }
