@@ -7,6 +7,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -1163,6 +1164,10 @@ struct oct_phmm_server {
     std::vector<std::thread> workers;                    // one per handle; all of them drain the one queue, so an idle device takes the next calls
     uint64_t n_calls = 0, n_batches = 0;
     std::vector<uint64_t> n_calls_by_device;
+    // OCT_PHMM_SERVER_PROFILE=1: where a worker's time goes (ns, summed over workers), printed by oct_phmm_server_destroy
+    bool profile = getenv("OCT_PHMM_SERVER_PROFILE") != nullptr;
+    std::atomic<uint64_t> ns_idle {0}, ns_concat {0}, ns_upload {0}, ns_run {0}, ns_download {0}, ns_scatter {0}, ns_single {0};
+    static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     std::vector<int> device_of;                          // worker -> index into the device list
 
     static uint32_t rows_of(const oct_phmm_reads* R) { return R->row_offsets ? R->n_rows : R->n_reads; }
@@ -1177,6 +1182,7 @@ struct oct_phmm_server {
         bool templates = false;
         for (Request* q : qs) if (q->R->row_offsets) templates = true;
         size_t n_out = 0;
+        const uint64_t t_begin = profile ? now_ns() : 0;
         for (Request* q : qs) {
             const oct_phmm_reads* R = q->R; const oct_phmm_haplotypes* H = q->H;
             const uint32_t nb = R->n_reads ? R->offsets[R->n_reads] : 0, hn = H->n_haps ? H->offsets[H->n_haps] : 0;
@@ -1202,7 +1208,21 @@ struct oct_phmm_server {
         oct_phmm_regions G {(uint32_t)qs.size(), reg_rows.data(), reg_haps.data(), has_flank.data(), fl.data()};
         std::vector<double> out(n_out + 1);
         oct_phmm_status st;
-        const int rc = oct_phmm_populate(h, &R, &H, &G, nullptr, nullptr, out.data(), &st);
+        int rc;
+        uint64_t t_scatter = 0;
+        if (!profile) {
+            rc = oct_phmm_populate(h, &R, &H, &G, nullptr, nullptr, out.data(), &st);
+        } else {                                           // the same three steps, timed one by one
+            const uint64_t t0 = now_ns(); ns_concat += t0 - t_begin;
+            oct_phmm_batch* bt = nullptr;
+            rc = oct_phmm_batch_upload(h, &R, &H, &G, nullptr, nullptr, &bt, &st);
+            const uint64_t t1 = now_ns(); ns_upload += t1 - t0;
+            if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_run(h, bt, &st);
+            const uint64_t t2 = now_ns(); ns_run += t2 - t1;
+            if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_download(h, bt, out.data(), &st);
+            oct_phmm_batch_free(h, bt);
+            t_scatter = now_ns(); ns_download += t_scatter - t2;
+        }
         if (rc != OCT_PHMM_OK) { for (Request* q : qs) serve_one(h, q); return; }      // one region's error must not reach the others: answer each on its own
         const double* p = out.data();
         for (Request* q : qs) {
@@ -1210,6 +1230,7 @@ struct oct_phmm_server {
             if (n) memcpy(q->out, p, n * sizeof(double));
             p += n; q->rc = OCT_PHMM_OK; memset(&q->st, 0, sizeof(q->st));
         }
+        if (profile) ns_scatter += now_ns() - t_scatter;
     }
 
     void run(int w)
@@ -1218,8 +1239,10 @@ struct oct_phmm_server {
         for (;;) {
             std::vector<Request*> take;
             {
+                const uint64_t t_idle = profile ? now_ns() : 0;
                 std::unique_lock<std::mutex> lk(mu);
                 cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+                if (profile) ns_idle += now_ns() - t_idle;
                 if (queue.empty() && stop) return;
                 while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
             }
@@ -1232,7 +1255,9 @@ struct oct_phmm_server {
                 std::lock_guard<std::mutex> sim_lk(sim_mu);
 #endif
                 if (!batchable.empty()) serve_many(h, batchable);
+                const uint64_t t_single = profile ? now_ns() : 0;
                 for (Request* q : single) serve_one(h, q);
+                if (profile) ns_single += now_ns() - t_single;
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -1281,6 +1306,10 @@ extern "C" void oct_phmm_server_destroy(oct_phmm_server* s)
     s->cv_work.notify_all();
     for (auto& t : s->workers) if (t.joinable()) t.join();
     for (auto* h : s->hs) oct_phmm_destroy(h);
+    if (s->profile)
+        fprintf(stderr, "{\"server_profile_ms\": {\"workers\": %zu, \"calls\": %llu, \"batches\": %llu, \"idle\": %.2f, \"concat\": %.2f, \"upload\": %.2f, \"run\": %.2f, "
+                        "\"download\": %.2f, \"scatter\": %.2f, \"single_calls\": %.2f}}\n", s->hs.size(), (unsigned long long)s->n_calls, (unsigned long long)s->n_batches,
+                s->ns_idle / 1e6, s->ns_concat / 1e6, s->ns_upload / 1e6, s->ns_run / 1e6, s->ns_download / 1e6, s->ns_scatter / 1e6, s->ns_single / 1e6);
     delete s;
 }
 
