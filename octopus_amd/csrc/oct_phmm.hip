@@ -536,7 +536,8 @@ extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
 
 static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
                        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
-                       const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops);
+                       const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
+                       bool one_shot = false);
 
 extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
                                      const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
@@ -547,7 +548,8 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
 
 static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
                        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
-                       const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops)
+                       const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
+                       bool one_shot)
 {
     if (!h || !R || !H || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
     *out = nullptr;
@@ -794,7 +796,10 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         const uint32_t rec_blocks = (uint32_t)rec_blocks64;
         if (table_blocks + flag_blocks + rec_blocks) { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok()); }
     }
-    RT(rt::stream_sync(s));
+    // The copies above read this call's host-side staging (pinned buffer, position vectors): a caller of the split API may upload the next batch
+    // right away, so they must have landed. A one-shot call (populate, align) runs on the same stream at once and does not return before its
+    // results are back, which covers the pinned buffer; it only waits here when it brought pageable position arrays.
+    if (!one_shot || positions) RT(rt::stream_sync(s));
     *out = b.release();
     return ok(status);
 }
@@ -1126,7 +1131,7 @@ extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads
                                  const oct_phmm_positions* positions, double* out, oct_phmm_status* status)
 {
     oct_phmm_batch* b = nullptr;
-    int rc = oct_phmm_batch_upload(h, reads, haps, regions, flank, positions, &b, status);
+    int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, false, 0, true);
     bool early = false;
     if (rc == OCT_PHMM_OK && b->slices.size() > 1 && out) {   // big batch: results stream back slice by slice through a pinned landing zone
         const size_t bytes = (size_t)b->n_out * sizeof(double);
@@ -1356,7 +1361,7 @@ extern "C" int oct_phmm_align(oct_phmm_handle* h, const oct_phmm_reads* reads, c
     if (!out || !out->mapping_position || !out->likelihood || !out->n_cigar_ops || (!out->cigar && out->max_cigar_ops))
         return fail(status, OCT_PHMM_EINVAL, "null output");
     oct_phmm_batch* b = nullptr;
-    int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, true, out->max_cigar_ops);
+    int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, true, out->max_cigar_ops, true);
     struct Guard { oct_phmm_handle* h; oct_phmm_batch*& b; ~Guard() { oct_phmm_batch_free(h, b); } } guard {h, b};
     if (rc != OCT_PHMM_OK) return rc;
     rc = oct_phmm_batch_run(h, b, status);
