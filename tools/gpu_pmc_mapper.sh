@@ -1,8 +1,8 @@
-# PMC pass over the k-mer mapper (counter-sweeping form): where do its issue cycles go?
+# PMC passes with the instruction-mix and wait counters (all kernels of a single-slice run): where do the issue cycles go?
 set -x
 cd /root/repo; export TMPDIR=/tmp
 O=gpurun_out/${1:-pmcmap}; mkdir -p $O
-export OCT_PHMM_SLICES=1 OCT_PHMM_KMER_MAP_SWEEP=1
+export OCT_PHMM_SLICES=1
 (cd /tmp && timeout 200 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /root/repo/$O/pmc_a -o p -- python /root/repo/bench.py --no-small-batch --no-cpu-baseline --steps 1 --warmup 1 > /root/repo/$O/pmc_a.json 2> /root/repo/$O/pmc_a.err); echo "pmc_a rc=$?" >> $O/rc.log
 (cd /tmp && timeout 200 rocprofv3 --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d /root/repo/$O/pmc_b -o p -- python /root/repo/bench.py --no-small-batch --no-cpu-baseline --steps 1 --warmup 1 > /root/repo/$O/pmc_b.json 2> /root/repo/$O/pmc_b.err); echo "pmc_b rc=$?" >> $O/rc.log
 cat $O/rc.log; tail -3 $O/pmc_a.err $O/pmc_b.err; ls -la $O/pmc_a $O/pmc_b
