@@ -57,3 +57,16 @@ def test_create_fails_loudly_without_a_device(lib):
     assert rc in (abi.ENODEVICE, abi.EHIP) and not h.value
     with pytest.raises(Exception):
         engine.Engine(cfg)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/oct_phmm.h compiles as C99 (no C++ in the signatures) and links against the library."""
+    import subprocess
+    engine.build()
+    src = tmp_path / "cabi.c"
+    src.write_text('#include "oct_phmm.h"\n'
+                   'int main(void) { oct_phmm_config c; oct_phmm_config_default(&c); return c.struct_size == sizeof c && oct_phmm_device_count() >= 0 ? 0 : 1; }\n')
+    exe = tmp_path / "cabi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src),
+                    f"-L{ROOT / 'octopus_amd'}", "-loct_phmm", f"-Wl,-rpath,{ROOT / 'octopus_amd'}", "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
