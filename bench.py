@@ -124,18 +124,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # OCT_BENCH_BACKEND=sim: test hook of the CPU suite (tests/test_bench_gloo.py) - the same launch, barrier and reduction logic on two gloo
+    # ranks with the library's wave simulator in place of the GPU; never a measurement
+    sim = os.environ.get("OCT_BENCH_BACKEND") == "sim"
+    dev = "cpu" if sim else "cuda"
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist  # RCCL; only the barrier + max-reduce of the timing contract use it
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if sim:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from octopus_amd import abi, engine, synth
     B = args.band
     T, LH = 150, 300
-    cfg = abi.Config.default(max_indel_error=B, device_id=local_rank)
-    eng = engine.Engine(cfg)                      # fails loudly if liboct_phmm.so / a gfx950 device is missing
+    cfg = abi.Config.default(max_indel_error=B, device_id=0 if sim else local_rank)
+    if sim:
+        sys.path.insert(0, str(ROOT / "tests"))
+        from backends import build_sim
+        eng = engine.Engine(cfg, lib_path=build_sim())
+    else:
+        eng = engine.Engine(cfg)                  # fails loudly if liboct_phmm.so / a gfx950 device is missing
     if args.workload == "stream":                 # configs[3]: a stream of independent active regions, region i -> rank i mod N, one flat batch per rank
         batch = synth.batch_from_regions(synth.region_stream(seed=42 + rank, n_regions=args.regions, B=B, positions="none"))
     else:
@@ -146,7 +158,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if not sim:
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         rb.run(); rb.wait()
@@ -161,10 +174,10 @@ def main():
     n_tasks = stats["n_dp_score_only"] + stats["n_dp_traceback"]
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([float(cells), float(pairs)], dtype=torch.float64, device="cuda")
+        c = torch.tensor([float(cells), float(pairs)], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         cells, pairs = float(c[0].item()), float(c[1].item())
 
@@ -211,7 +224,7 @@ def main():
         out = {
             "metric": "pair-HMM band cell-updates/s", "value": cells / per_step / 1e9, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic" if not sim else "synthetic, SIMULATOR BACKEND (test hook, not a measurement)",
             "config": {"workload": (f"{args.workload}: Illumina-like 150 bp reads x 300 bp haplotypes per region, band {B}, "
                                     f"int16 lanes, flank 40/40, device k-mer mapping, one region per GPU") if args.workload != "stream" else
                                    (f"stream: {args.regions} synthetic active regions per GPU per step (R ~ lognormal(300, 0.8) in [20, 5000], H ~ min(200, geometric(24)), "

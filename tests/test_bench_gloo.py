@@ -1,0 +1,45 @@
+"""bench.py's N > 1 launch path on CPU: the driver's own command line (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`)
+with the library's wave simulator in place of the GPU and gloo in place of RCCL (OCT_BENCH_BACKEND=sim). Checks what the contract asks of
+the line: ONE JSON line from rank 0, whole-job aggregates over both ranks, the steps / warmup it was given, weak scaling."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run(n):
+    from backends import build_sim
+    build_sim()
+    env = dict(os.environ, OCT_BENCH_BACKEND="sim")
+    args = ["bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1", "--workload", "tiny", "--band", "8", "--no-cpu-baseline", "--no-small-batch"]
+    if n == 1:
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + args
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_over_two_ranks_aggregates_the_whole_job():
+    one, two = _run(1), _run(2)
+    for b, n in ((one, 1), (two, 2)):
+        assert b["n_gpus"] == n and b["steps"] == 2 and b["warmup"] == 1 and b["scaling"] == "weak" and b["higher_is_better"] is True
+        assert b["unit"] == "GCUPS" and b["value"] > 0 and b["ms_per_step"] > 0 and b["vs_baseline"] is None
+        assert set(b["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+        assert "SIMULATOR" in b["data"]
+    # every rank brings a region of the same shape (seed 42 + rank): the job's pairs double, the per-rank stats stay one region's
+    assert two["config"]["pairs_per_step"] == 2 * one["config"]["pairs_per_step"]
+    assert two["stats"]["n_pairs"] == one["stats"]["n_pairs"]
+    assert abs(two["value"] * two["ms_per_step"] / (one["value"] * one["ms_per_step"]) - 2.0) < 0.2     # cells per step: twice one region's, up to the seeds
