@@ -821,6 +821,9 @@ OCT_KERNEL(k_dp)(DpParams p)
                 for (; k < k_sw; k += 4) quad(k, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
                 if (k_sw) { I1 |= 0x00010001u; D1 |= 0x00030003u; I2 |= 0x00010001u; D2 |= 0x00030003u; y1 = hw::pk_min_u(M1, I1); }
             }
+            if (Tmin >= (uint32_t)B) {                                                                   // no read of the wave ends inside the rolling initialisation: no end cells to capture yet
+                for (; k < (uint32_t)B; k += 4) quad(k, BoolC<true>{}, BoolC<false>{}, BoolC<true>{});
+            }
             for (; k < (uint32_t)B; k += 4) quad(k, BoolC<true>{}, BoolC<true>{}, BoolC<true>{});         // rolling initialisation lasts B iterations
             for (; k < kB; k += 4) quad(k, BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
             for (; k < K4; k += 4) quad(k, BoolC<false>{}, BoolC<true>{}, BoolC<true>{});
