@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py — one "step" = one pass of the hot path (HaplotypeLikelihoodArray::populate on the GPU: candidate
-classification + scalar fast path, banded pair-HMM DP with and without traceback, flank walk, mapping-quality
-epilogue) over one synthetic batch that is already resident in HBM.
+"""bench.py — one "step" = one pass of the hot path (HaplotypeLikelihoodArray::populate on the GPU: candidate mapping,
+classification + scalar fast path, banded pair-HMM DP with and without traceback, flank walk, mapping-quality epilogue) over
+one synthetic batch that is already resident in HBM.
 
-Workload at N=1: BASELINE.json configs[2] — 100k Illumina-like 150 bp reads x 128 300 bp haplotypes, band 16,
-int16 lanes, flank state 40/40 (the largest single-GPU configuration; configs[1], the 1k x 64 batch, is a parity
-test and is additionally timed as `small_batch_ms`). N>1: one process per GPU, each with its own region of the same
-shape (weak scaling, no collective: regions are independent), value = sum over ranks / max-over-ranks time.
+Workload at N=1: BASELINE.json configs[2] — 100k Illumina-like 150 bp reads x 128 300 bp haplotypes, band 16, int16 lanes,
+flank state 40/40 (the largest single-GPU short-read configuration). N>1: one process per GPU, each with its own region of the
+same shape (weak scaling, no collective: regions are independent), value = sum over ranks / max-over-ranks time.
+`--workload stream` is BASELINE configs[3]: ONE fixed stream of --regions synthetic active regions, region i on rank i mod N
+(strong scaling, no collective).
 
+After the timed region rank 0 (i) verifies the matrix the timed loop produced against the reference's own populate on a 5 % sample
+of its rows, (ii) re-runs the batch single-slice with HIP events for the roofline block, (iii) at N=1 adds the PCIe-inclusive
+populate, the configs[3] stream, the configs[4] long-read batch, the 1k x 64 latency case and the CPU baseline.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -25,21 +29,87 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# Packed-int16 / min / perm / DPP wave64 instructions issue at 4 cycles per SIMD on gfx950 (tools/valu_ubench.hip, measured):
-# 256 CU x 4 SIMD x 2.4 GHz / 4 = 614 G wave-instructions/s is the issue peak the DP kernels run against.
-VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4
-# VALU wave-instructions per DP iteration per wave (8 tasks at B = 16), counted in the ISA of this build
+# VALU issue peak per MI355X_MICROARCH.md (SIMD-32: a wave64 VALU instruction issues in 2 cycles): 256 CU x 4 SIMD x 2.4 GHz / 2
+VALU_PEAK_2CYCLE = 256 * 4 * 2.4e9 / 2
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+# Measured issue cost per wave64 instruction on one SIMD in cycles of the nominal 2.4 GHz clock (profiles/r01_step16_valu_issue_rates.log):
+# v_add_u32 / v_and / v_or / v_mov 2.6 ("cheap"), everything packed, VOP3, DPP, perm, min 4.4 ("dear").
+CHEAP_CYCLES, DEAR_CYCLES = 2.6, 4.4
+# Fallback instruction budget (main-loop ISA count of the shipped build, VALU wave-instructions per DP iteration per wave = 8 tasks at
+# B = 16, and the share of cheap ones) for when no committed counter summary matches the kernels being timed.
 VALU_PER_ITER = {"score": 29.25, "trace": 51.75}
-# Measured issue cost per wave64 instruction on one SIMD, in cycles of the nominal 2.4 GHz clock (profiles/r01_step16_valu_issue_rates.log):
-# v_add_u32 / v_and / v_or / v_mov 2.6 ("fast"), everything packed, VOP3, DPP, perm, min 4.4 ("slow"); shares of fast instructions in the
-# main loops of this build's ISA: score-only 45 of 117, traceback 103 of 207.
-ISSUE_CYCLES = {"score": (45 * 2.6 + 72 * 4.4) / 117, "trace": (103 * 2.6 + 104 * 4.4) / 207}
-PMC_SUMMARY = ROOT / "profiles" / "r01_step17_pmc_summary.json"
+CHEAP_SHARE = {"score": 45 / 117, "trace": 103 / 207}
+
+
+def issue_cycles_per_instr(kind: str) -> float:
+    return CHEAP_SHARE[kind] * CHEAP_CYCLES + (1 - CHEAP_SHARE[kind]) * DEAR_CYCLES
 
 
 def algorithmic_bytes_per_task(T: int, B: int) -> int:
     """2T (bases + quals) + 5 (T + 2B - 1) (haplotype window, gap open/extend, SNV mask/prior) + 8 + 8."""
     return 2 * T + 5 * (T + 2 * B - 1) + 16
+
+
+def latest_pmc_summary():
+    """The newest committed counter summary (tools/summarize_pmc.py) and whether it was collected on the kernels of this tree."""
+    from octopus_amd import engine
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_summary.json")):
+        try:
+            d = json.loads(f.read_text())
+        except ValueError:
+            continue
+        if "_meta" in d:
+            best = (f, d)
+    if best is None:
+        return None, None, False
+    f, d = best
+    return f, d, d["_meta"].get("kernel_source_sha") == engine.kernel_source_sha()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# checker + CPU baseline: the only places that touch oracle/ (never inside a timed GPU region)
+# ------------------------------------------------------------------------------------------------------------------
+def verify_against_reference(got: np.ndarray, regions, B: int, frac: float = 0.05, seed: int = 1):
+    """Compare the matrix the timed loop left on the device with the reference's OWN HaplotypeLikelihoodArray::populate
+    (oracle/_ref/libref_array*.so; the oracle restatement where that build is absent) on a sample of rows: for a one-region batch
+    a random `frac` of its reads against all haplotypes, for a multi-region batch every 1/frac-th region in full. A (read, haplotype)
+    result does not depend on the other reads of its call, so the sub-call reproduces the sampled rows exactly."""
+    import oracle
+    from octopus_amd import abi, synth
+    cfg = abi.Config.default(max_indel_error=B)
+    cores = oracle.host_cores()
+    use_ref = oracle.have_ref_array()
+    isa = "avx2" if use_ref and oracle.have_ref_array("avx2") else "sse2"
+
+    def reference(batch):
+        if use_ref:
+            code, want, _, _, _ = oracle.ref_array_populate(cfg, batch, n_threads=cores, isa=isa)
+            assert code == 0
+            return want
+        return oracle.populate(cfg, batch, n_threads=cores)[0]
+
+    rng = np.random.default_rng(seed)
+    rows, worst = 0, 0.0
+    if len(regions) == 1:
+        g = regions[0]
+        R, H = g["reads"].shape[0], len(g["haps"])
+        idx = np.sort(rng.choice(R, size=max(1, int(np.ceil(R * frac))), replace=False))
+        want = reference(synth.batch_from_regions([synth.subset_reads(g, idx)])).reshape(H, len(idx))
+        mine = got.reshape(H, R)[:, idx]
+        worst = float(np.max(np.abs(mine - want)))
+        rows = len(idx)
+    else:
+        step = max(1, int(round(1 / frac)))
+        first = int(rng.integers(0, min(step, len(regions))))
+        off = np.concatenate([[0], np.cumsum([g["reads"].shape[0] * len(g["haps"]) for g in regions])])
+        for i in range(first, len(regions), step):
+            want = reference(synth.batch_from_regions([regions[i]]))
+            worst = max(worst, float(np.max(np.abs(got[off[i]:off[i + 1]] - want), initial=0.0)))
+            rows += regions[i]["reads"].shape[0]
+    return {"verified_rows": rows, "verified_max_abs_diff": worst,
+            "verified_against": (f"the reference's own HaplotypeLikelihoodArray::populate ({isa.upper()} kernels, {cores} host threads)" if use_ref
+                                 else "CPU oracle restatement (no reference build on this box)")}
 
 
 def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
@@ -109,6 +179,16 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------------
+def timed_resident(rb, steps: int, warmup: int = 1):
+    for _ in range(warmup):
+        rb.run(); rb.wait()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rb.run(); rb.wait()
+    return (time.perf_counter() - t0) / steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,9 +196,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="100kx128")
     ap.add_argument("--band", type=int, default=16)
-    ap.add_argument("--regions", type=int, default=2000, help="--workload stream: active regions per rank per step (BASELINE configs[3] stand-in)")
+    ap.add_argument("--regions", type=int, default=2000, help="--workload stream: regions of the ONE stream that is sharded over the ranks (BASELINE configs[3] stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the 1k x 64 latency leg (for rocprof runs: keeps every k_dp launch full-size)")
+    ap.add_argument("--stream-cap", type=int, nargs=2, default=None, metavar=("READS", "HAPS"), help="test hook: cap every stream region's size (simulator runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip verification, PCIe-inclusive, stream and long-read legs (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,13 +227,17 @@ def main():
     if sim:
         sys.path.insert(0, str(ROOT / "tests"))
         from backends import build_sim
-        eng = engine.Engine(cfg, lib_path=build_sim())
+        lib_path = build_sim()
+        eng = engine.Engine(cfg, lib_path=lib_path)
     else:
+        lib_path = None
         eng = engine.Engine(cfg)                  # fails loudly if liboct_phmm.so / a gfx950 device is missing
-    if args.workload == "stream":                 # configs[3]: a stream of independent active regions, region i -> rank i mod N, one flat batch per rank
-        batch = synth.batch_from_regions(synth.region_stream(seed=42 + rank, n_regions=args.regions, B=B, positions="none"))
-    else:
-        batch = synth.config_batch(args.workload, seed=42 + rank, B=B, positions="none")   # candidate positions come from the device k-mer mapper
+    stream = args.workload == "stream"
+    if stream:        # configs[3]: ONE stream of independent active regions, region i -> rank i mod N, one flat batch per rank per step
+        regions = synth.region_stream_shard(seed=42, n_regions=args.regions, rank=rank, world=world, B=B, positions="none", cap=args.stream_cap)
+    else:             # candidate positions come from the device k-mer mapper
+        regions = [synth.config_region(args.workload, seed=42 + rank, B=B, positions="none")]
+    batch = synth.batch_from_regions(regions)
     rb = eng.upload(batch)                        # inputs resident in HBM before the timed region
 
     def sync_all():
@@ -172,17 +258,23 @@ def main():
     stats = rb.stats()
     cells, pairs = stats["band_cells"], stats["n_pairs"]
     n_tasks = stats["n_dp_score_only"] + stats["n_dp_traceback"]
+    n_regions_all = len(regions)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([float(cells), float(pairs)], dtype=torch.float64, device=dev)
+        c = torch.tensor([float(cells), float(pairs), float(n_regions_all)], dtype=torch.float64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        cells, pairs = float(c[0].item()), float(c[1].item())
+        cells, pairs, n_regions_all = float(c[0].item()), float(c[1].item()), int(c[2].item())
 
     if rank == 0:
         per_step = elapsed / args.steps
+        extras = not args.no_extras
+        verified = {}
+        if extras:
+            # the matrix the timed loop produced (rank 0's), against the reference's own populate on >= 5 % of its rows
+            verified = verify_against_reference(rb.download(), regions, B)
         # Roofline leg (outside the timed region): the pipeline above overlaps launches of different slices, so per-launch
         # durations are taken from a single-slice run of the same batch, where every launch has the device to itself.
         # Dominant kernel = k_dp<B, TRACE=true, fast cost, FASTADD> (the traceback DP); HIP events on the library's stream.
@@ -197,60 +289,96 @@ def main():
             for k, (ms, n) in rb1.kernel_time_by_kind().items():
                 kind_ms[k][0] += ms; kind_ms[k][1] += n
         rb1.free()
+        eng.set_timing(False)
         tr_ms, tr_n = kind_ms["trace_fast"]
         sc_ms, sc_n = kind_ms["score_fast"]
         avg_launch_s = (tr_ms / 1e3) / max(tr_n, 1)
         tasks_per_launch = stats["n_dp_traceback"] * 3 / max(tr_n, 1)
         alg_bytes = algorithmic_bytes_per_task(T, B) * tasks_per_launch
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # VALU view (what actually binds): wave-instructions the DP launches issued per second vs the 4-cycle issue peak
+        # VALU view (what actually binds): wave-instructions the DP launches issued per second
         groups = lambda n: n / (2 * (64 // B))
-        valu_instr = (groups(stats["n_dp_score_only"]) * VALU_PER_ITER["score"] + groups(stats["n_dp_traceback"]) * VALU_PER_ITER["trace"]) * (T + B)
+        instr = {"score": groups(stats["n_dp_score_only"]) * VALU_PER_ITER["score"] * (T + B),
+                 "trace": groups(stats["n_dp_traceback"]) * VALU_PER_ITER["trace"] * (T + B)}
+        valu_src = "loop-body wave-instructions (ISA count of the traceback form; an upper bound for late-start launches) x iterations"
         dp_s_per_step = ((tr_ms + sc_ms + kind_ms["score_generic"][0] + kind_ms["trace_generic"][0]) / 1e3) / 3
         traffic = None
-        issue_cycles = valu_instr * (ISSUE_CYCLES["score"] + ISSUE_CYCLES["trace"]) / 2
-        valu_src = "loop-body wave-instructions (ISA count of the traceback form; an upper bound for late-start launches) x iterations"
-        if PMC_SUMMARY.exists():        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-            pmc = json.loads(PMC_SUMMARY.read_text())
+        pmc_file, pmc, pmc_current = latest_pmc_summary()
+        if pmc is not None and args.workload == "100kx128" and B == 16:
             pm = pmc.get(f"octphmm::k_dp<{B}, true, false, true>", {})
+            ps = pmc.get(f"octphmm::k_dp<{B}, false, false, true>", {})
             if "hbm_read_bytes_corrected" in pm and "hbm_write_bytes" in pm:
                 traffic = pm["hbm_read_bytes_corrected"] + pm["hbm_write_bytes"]
-            ps = pmc.get(f"octphmm::k_dp<{B}, false, false, true>", {})
-            if args.workload == "100kx128" and B == 16 and "SQ_INSTS_VALU" in pm and "SQ_INSTS_VALU" in ps:
-                # the PMC passes ran this very workload: instructions actually issued per launch x launches per step
-                valu_instr = pm["SQ_INSTS_VALU"] * tr_n / 3 + ps["SQ_INSTS_VALU"] * sc_n / 3
-                issue_cycles = pm["SQ_INSTS_VALU"] * tr_n / 3 * ISSUE_CYCLES["trace"] + ps["SQ_INSTS_VALU"] * sc_n / 3 * ISSUE_CYCLES["score"]
-                valu_src = f"SQ_INSTS_VALU per launch ({PMC_SUMMARY.relative_to(ROOT)}) x launches per step"
+            if "SQ_INSTS_VALU" in pm and "SQ_INSTS_VALU" in ps:
+                # the counter passes ran this very workload: instructions actually issued per launch x launches per step
+                instr = {"trace": pm["SQ_INSTS_VALU"] * tr_n / 3, "score": ps["SQ_INSTS_VALU"] * sc_n / 3}
+                valu_src = f"SQ_INSTS_VALU per launch ({pmc_file.relative_to(ROOT)}) x launches per step"
+        valu_instr = instr["score"] + instr["trace"]
+        issue_cycles = instr["score"] * issue_cycles_per_instr("score") + instr["trace"] * issue_cycles_per_instr("trace")
+        instr_rate = valu_instr / dp_s_per_step if dp_s_per_step > 0 else 0.0
         out = {
             "metric": "pair-HMM band cell-updates/s", "value": cells / per_step / 1e9, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic" if not sim else "synthetic, SIMULATOR BACKEND (test hook, not a measurement)",
+            "higher_is_better": True, "scaling": "strong" if stream else "weak", "vs_baseline": None, "dtype": "int16",
+            "data": "synthetic" if not sim else "synthetic, SIMULATOR BACKEND (test hook, not a measurement)",
             "config": {"workload": (f"{args.workload}: Illumina-like 150 bp reads x 300 bp haplotypes per region, band {B}, "
-                                    f"int16 lanes, flank 40/40, device k-mer mapping, one region per GPU") if args.workload != "stream" else
-                                   (f"stream: {args.regions} synthetic active regions per GPU per step (R ~ lognormal(300, 0.8) in [20, 5000], H ~ min(200, geometric(24)), "
-                                    f"Lh 300-500, T 150), band {B}, int16 lanes, flank 40/40, device k-mer mapping"), "band": B, "read_len": T, "hap_len": LH,
+                                    f"int16 lanes, flank 40/40, device k-mer mapping, one region per GPU") if not stream else
+                                   (f"stream: ONE stream of {args.regions} synthetic active regions per step (R ~ lognormal(300, 0.8) in [20, 5000], H ~ min(200, geometric(24)), "
+                                    f"Lh 300-500, T 150), region i on GPU i mod {world}, band {B}, int16 lanes, flank 40/40, device k-mer mapping"), "band": B, "read_len": T, "hap_len": LH,
                        "pairs_per_step": pairs, "dp_tasks_per_step": n_tasks, "parallelism": f"regions sharded over {world} GPU(s), no collective"},
             "loglik_per_s": pairs / per_step,
-            **({"regions_per_s": args.regions * world / per_step} if args.workload == "stream" else {}),
+            **({"regions_per_s": n_regions_all / per_step} if stream else {}),
             "stats": stats,
+            **verified,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "traffic_note": f"HBM bytes per launch of k_dp<{B},true,false,true> from {PMC_SUMMARY.relative_to(ROOT)} (FETCH_SIZE x 2 per the gfx950 "
-                                         "correction + WRITE_SIZE, separate --pmc passes of this workload, single slice = two launches per step: late-start and full traceback); "
-                                         "~85 % of it is the backpointer tile stream the walk kernel consumes, which SURVEY 8d's per-task figure does not count",
+                         "traffic": traffic, "traffic_ratio": (traffic / alg_bytes) if traffic and alg_bytes else None,
+                         "traffic_note": (f"HBM bytes per launch of k_dp<{B},true,false,true> from {pmc_file.relative_to(ROOT)} (FETCH_SIZE x 2 per the gfx950 "
+                                          "correction + WRITE_SIZE, separate --pmc passes of this workload, single slice); traffic_ratio = counter bytes / algorithmic "
+                                          "bytes of the same launch") if traffic else "no committed counter summary for this workload",
+                         "pmc_summary_matches_these_kernels": bool(pmc_current) if pmc is not None else None,
                          "kernel": f"k_dp<{B}, TRACE, fast cost, FASTADD> (traceback DP), single-slice run, HIP events on the library stream",
                          "avg_launch_ms": avg_launch_s * 1e3, "tasks_per_launch": tasks_per_launch,
                          "algorithmic_bytes_per_task": algorithmic_bytes_per_task(T, B),
                          "score_only_kernel_avg_launch_ms": (sc_ms / max(sc_n, 1)),
-                         "valu": {"achieved_wave_instr_per_s": valu_instr / dp_s_per_step if dp_s_per_step > 0 else 0.0,
-                                  "peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
-                                  "frac": (valu_instr / dp_s_per_step / VALU_PEAK_WAVE_INSTR) if dp_s_per_step > 0 else 0.0,
-                                  "issue_weighted_frac": (issue_cycles / (1024 * 2.4e9) / dp_s_per_step) if dp_s_per_step > 0 else 0.0,
-                                  "note": "the DP is integer-VALU issue bound, not HBM bound (SURVEY.md 8d): " + valu_src +
-                                          " / DP kernel time vs 256 CU x 4 SIMD x 2.4 GHz / 4 cycles; issue_weighted_frac prices each instruction at its "
-                                          "measured issue cost (profiles/r01_step16_valu_issue_rates.log: 2.6 cycles for plain 32-bit add/and/or/mov, 4.4 for "
-                                          "packed, VOP3, DPP, perm and min) = the share of DP kernel time the instruction stream itself accounts for"}},
+                         "valu": {"achieved_wave_instr_per_s": instr_rate,
+                                  "peak_wave_instr_per_s": VALU_PEAK_2CYCLE, "frac": instr_rate / VALU_PEAK_2CYCLE,
+                                  "issue_weighted_frac": (issue_cycles / SIMD_CYCLES_PER_S / dp_s_per_step) if dp_s_per_step > 0 else 0.0,
+                                  "note": "the DP is integer-VALU issue bound, not HBM bound (SURVEY.md 8d). frac = " + valu_src + " / DP kernel time vs the "
+                                          "2-cycle issue peak of MI355X_MICROARCH.md (256 CU x 4 SIMD x 2.4 GHz / 2): this instruction mix (packed int16, "
+                                          "min, perm, DPP = 4.4 measured cycles, plain 32-bit add/and/or/mov 2.6, profiles/r01_step16_valu_issue_rates.log) cannot "
+                                          "exceed ~0.55 of it; issue_weighted_frac prices every instruction at its measured cost = the share of DP kernel time "
+                                          "the instruction stream itself accounts for (the rest: staging latency, reductions, tile flushes, tails)"}},
         }
+        if world == 1 and extras and not sim:
+            # PCIe-inclusive: one oct_phmm_populate of the same batch from host buffers (H2D, table build, run, results streamed back)
+            outbuf = np.empty(batch.out_size())
+            eng.populate(batch, out=outbuf)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                eng.populate(batch, out=outbuf)
+            e2e = (time.perf_counter() - t1) / 3
+            out["e2e_ms_from_host"] = e2e * 1e3
+            out["e2e_gcups_pcie_inclusive"] = stats["band_cells"] / e2e / 1e9
+            if not stream:
+                # configs[3]: the 2,000-region stream in one flat batch (resident), verified like the main batch
+                sregs = synth.region_stream_shard(seed=42, n_regions=args.regions, B=B, positions="none")
+                sb = eng.upload(synth.batch_from_regions(sregs))
+                dt = timed_resident(sb, 5)
+                ss = sb.stats()
+                sv = verify_against_reference(sb.download(), sregs, B, frac=0.05)
+                sb.free()
+                out["stream"] = {"ms": dt * 1e3, "regions": len(sregs), "regions_per_s": len(sregs) / dt, "gcups": ss["band_cells"] / dt / 1e9,
+                                 "loglik_per_s": ss["n_pairs"] / dt, "verified_rows": sv["verified_rows"], "verified_max_abs_diff": sv["verified_max_abs_diff"]}
+                # configs[4]: 64 x 10 kb reads, 8 x 20 kb haplotypes, band 256, int32 lanes (streaming DP kernels, traceback in HBM)
+                lcfg = abi.Config.default(max_indel_error=256, use_int_scores=1, device_id=local_rank)
+                leng = engine.Engine(lcfg)
+                lbat = synth.config_batch("long64x8", seed=42, B=256, positions="none")
+                lb = leng.upload(lbat)
+                dt = timed_resident(lb, 3)
+                ls = lb.stats()
+                lb.free(); leng.close()
+                out["long_read"] = {"ms": dt * 1e3, "gcups": ls["band_cells"] / dt / 1e9, "dtype": "int32", "band": 256,
+                                    "workload": "long64x8: 64 x 10 kb reads x 8 x 20 kb haplotypes (BASELINE configs[4])", "dp_tasks": ls["n_dp_score_only"] + ls["n_dp_traceback"]}
         if world == 1 and not args.no_small_batch:
             small = eng.upload(synth.config_batch("1kx64", seed=42, B=B, positions="none"))
             for _ in range(3):
@@ -262,6 +390,10 @@ def main():
             small.free()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, seed=42)
+            if out["cpu_baseline"]["unit"] == out["unit"] and out["cpu_baseline"]["value"] > 0:
+                out["vs_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+                out["vs_baseline_note"] = (f"GPU value / cpu_baseline.value measured in this run on {out['cpu_baseline']['cores']} host threads (the cgroup's quota, not a "
+                                           "socket); BASELINE.md publishes no number for this metric")
         print(json.dumps(out))
     rb.free()
     eng.close()

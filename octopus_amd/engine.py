@@ -38,6 +38,17 @@ def build(force: bool = False) -> Path:
     return LIB_PATH
 
 
+def kernel_source_sha() -> str:
+    """sha256 over the sources liboct_phmm.so is built from: stamps profile summaries (tools/summarize_pmc.py) so that bench.py can tell
+    whether committed counter values belong to the kernels it is timing (the GPU box has no .git to ask)."""
+    import hashlib
+    m = hashlib.sha256()
+    for f in sorted((PKG_DIR / "csrc").iterdir()) + [PKG_DIR.parent / "include" / "oct_phmm.h"]:
+        if f.is_file():
+            m.update(f.name.encode()); m.update(f.read_bytes())
+    return m.hexdigest()[:16]
+
+
 _LIBS = {}
 
 

@@ -22,16 +22,13 @@ HOMOPOLYMER_OPEN = np.array([45, 45, 43, 43, 41, 38, 35, 32, 29, 25, 21, 20, 19,
 def _penalties(seq: np.ndarray):
     """Default-model penalty vectors for one haplotype sequence."""
     L = len(seq)
-    go = np.full(L, 45, np.int8)
     ge = np.full(L, 3, np.int8)
-    # homopolymer runs -> table penalty over the run
+    # homopolymer runs of three or more bases -> table penalty over the run
     change = np.flatnonzero(np.diff(seq) != 0) + 1
     starts = np.concatenate([[0], change])
     ends = np.concatenate([change, [L]])
-    for s, e in zip(starts, ends):
-        n = e - s
-        if n >= 3:
-            go[s:e] = HOMOPOLYMER_OPEN[min(n, len(HOMOPOLYMER_OPEN) - 1)]
+    n = ends - starts
+    go = np.repeat(np.where(n >= 3, HOMOPOLYMER_OPEN[np.minimum(n, len(HOMOPOLYMER_OPEN) - 1)], np.int8(45)).astype(np.int8), n)
     mask_f = np.roll(seq, 1)    # repeat_based_snv_error_model.cpp:174-178: masks are the haplotype rotated by one base
     mask_r = np.roll(seq, -1)
     pr = np.full(L, 125, np.int8)
@@ -87,11 +84,8 @@ def make_reads(rng: np.random.Generator, haps, maps, R: int, T: int, B: int, min
         quals = rng.integers(q_values[0], q_values[1] + 1, size=(R, T)).astype(np.uint8)
     decay = np.concatenate([np.zeros(T - min(30, T)), np.linspace(0, 20, min(30, T))]).astype(np.int64)
     quals = np.clip(quals.astype(np.int64) - decay[None, :], 2, 64).astype(np.uint8)
-    reads = np.empty((R, T), dtype=np.uint8)
-    for r in range(R):
-        h = haps[src[r]]
-        s = int(min(maps[src[r]][start[r]], Lh - T))
-        reads[r] = h[s:s + T]
+    first = np.minimum(np.stack(maps)[src, start], Lh - T)
+    reads = np.stack(haps)[src[:, None], first[:, None] + np.arange(T)[None, :]]
     err = rng.random((R, T)) < np.power(10.0, -quals.astype(np.float64) / 10.0)
     sub = BASES[rng.integers(0, 4, (R, T))]
     reads = np.where(err, sub, reads)
@@ -167,23 +161,40 @@ def batch_from_regions(regions: List[dict]) -> abi.Batch:
     return b
 
 
-def config_batch(name: str, seed: int = 42, B: int = 16, positions: str = "true") -> abi.Batch:
-    """BASELINE.json configs: '1k x 64' (configs[0]/[1]), '100k x 128' (configs[2]), 'stress' (every read >= 2 differences)."""
+def config_region(name: str, seed: int = 42, B: int = 16, positions: str = "true") -> dict:
+    """The one region of a BASELINE.json config as a region dict (config_batch flattens it): '1k x 64' (configs[0]/[1]),
+    '100k x 128' (configs[2]), 'stress' (every read >= 2 differences), 'long64x8' (configs[4])."""
     rng = np.random.default_rng(seed)
     if name == "1kx64":
-        return batch_from_regions([make_region(rng, 1000, 64, B=B, positions=positions)])
+        return make_region(rng, 1000, 64, B=B, positions=positions)
     if name == "100kx128":
-        return batch_from_regions([make_region(rng, 100_000, 128, B=B, positions=positions)])
+        return make_region(rng, 100_000, 128, B=B, positions=positions)
     if name == "100kx128-nofast":
-        return batch_from_regions([make_region(rng, 100_000, 128, B=B, min_diffs=2, positions=positions)])
+        return make_region(rng, 100_000, 128, B=B, min_diffs=2, positions=positions)
     if name == "10kx64":
-        return batch_from_regions([make_region(rng, 10_000, 64, B=B, positions=positions)])
+        return make_region(rng, 10_000, 64, B=B, positions=positions)
     if name == "long64x8":      # BASELINE.json configs[4]: 10 kb reads x 20 kb haplotypes, band 256 (int32 lanes), PacBio-like Q 8-15, indel-rich
-        return batch_from_regions([make_region(rng, 64, 8, T=10_000, Lh=20_000, B=256, flank=(400, 400), positions=positions,
-                                               q_values=(8, 15), indels_per_read=40)])
+        return make_region(rng, 64, 8, T=10_000, Lh=20_000, B=256, flank=(400, 400), positions=positions,
+                           q_values=(8, 15), indels_per_read=40)
     if name == "tiny":
-        return batch_from_regions([make_region(rng, 40, 6, B=B, positions=positions)])
+        return make_region(rng, 40, 6, B=B, positions=positions)
     raise KeyError(name)
+
+
+def config_batch(name: str, seed: int = 42, B: int = 16, positions: str = "true") -> abi.Batch:
+    return batch_from_regions([config_region(name, seed, B, positions)])
+
+
+def subset_reads(region: dict, idx) -> dict:
+    """The same region (haplotypes, flank state) with only the reads `idx`: every (read, haplotype) result is independent of the
+    other reads of the call, so the rows of the sub-region equal the corresponding rows of the full one."""
+    idx = np.asarray(idx)
+    sub = dict(region)
+    for k in ("reads", "quals", "begin", "reverse", "mapq"):
+        sub[k] = region[k][idx]
+    if region["pos"] is not None:
+        sub["pos"] = region["pos"][:, idx]
+    return sub
 
 
 def region_stream(seed: int, n_regions: int, B: int = 16, positions: str = "true") -> List[dict]:
@@ -197,3 +208,20 @@ def region_stream(seed: int, n_regions: int, B: int = 16, positions: str = "true
         Lh = 300 + int(rng.integers(0, 201))
         out.append(make_region(rng, R, max(H, 1), Lh=Lh, B=B, positions=positions))
     return out
+
+
+def stream_region(seed: int, i: int, B: int = 16, positions: str = "true", cap=None) -> dict:
+    """Region i of the fixed active-region stream `seed`: same shape distribution as region_stream, but every region has its own
+    generator state, so any rank can produce exactly its share of ONE stream without generating the rest."""
+    rng = np.random.default_rng([seed, i])
+    R = int(np.clip(rng.lognormal(np.log(300), 0.8), 20, 5000))
+    H = int(min(200, rng.geometric(1 / 24.0)))
+    Lh = 300 + int(rng.integers(0, 201))
+    if cap is not None:          # (max reads, max haplotypes): toy sizes for the simulator-backed tests
+        R, H = min(R, cap[0]), min(H, cap[1])
+    return make_region(rng, R, max(H, 1), Lh=Lh, B=B, positions=positions)
+
+
+def region_stream_shard(seed: int, n_regions: int, rank: int = 0, world: int = 1, B: int = 16, positions: str = "true", cap=None) -> List[dict]:
+    """BASELINE.json configs[3]: the regions i = rank (mod world) of a stream of n_regions regions (round-robin over the GPUs, no exchange)."""
+    return [stream_region(seed, i, B=B, positions=positions, cap=cap) for i in range(rank, n_regions, world)]

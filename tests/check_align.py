@@ -11,9 +11,9 @@ from check_populate import mapper_positions
 TOL = 1e-9
 
 
-def compare_align(backend, batch, max_cigar_ops=64, **cfg_kw):
+def compare_align(backend, batch, max_cigar_ops=64, n_threads=2, **cfg_kw):
     cfg = abi.Config.default(**cfg_kw)
-    want, wst = oracle.align_batch(cfg, batch, max_cigar_ops, n_threads=2)
+    want, wst = oracle.align_batch(cfg, batch, max_cigar_ops, n_threads=n_threads)
     eng = make_engine(backend, **cfg_kw)
     got, st = eng.align(batch, max_cigar_ops, raise_on_error=False)
     eng.close()

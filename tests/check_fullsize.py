@@ -1,0 +1,96 @@
+"""The BASELINE.json configs that carry the headline numbers, compared with the REFERENCE's own code at full size.
+
+Checker = the reference's own HaplotypeLikelihoodArray::populate (haplotype_likelihood_array.cpp + model + pair_hmm.hpp + its SIMD
+kernels, built in place into oracle/_ref/libref_array*.so, all host threads through its own thread pool). No restatement of ours
+sits between the two sides, and the product runs with its defaults (slice pipeline, late traceback start): exactly what bench.py times.
+
+Each check also accepts ready-made regions so that the same code runs on the wave simulator at toy size in the CPU suite.
+"""
+import time
+
+import numpy as np
+
+import oracle
+from backends import make_engine
+from octopus_amd import abi, synth
+
+TOL = 1e-9
+
+
+def _ref_isa():
+    return "avx2" if oracle.have_ref_array("avx2") else "sse2"
+
+
+def _ref_populate(cfg, batch, threads):
+    code, want, _, _, _ = oracle.ref_array_populate(cfg, batch, n_threads=threads, isa=_ref_isa())
+    assert code == 0
+    return want
+
+
+def check_bench_batch(backend, name="100kx128", B=16, seed=42, region=None):
+    """configs[2]: the batch bench.py's default run times — same generator call, device k-mer mapping, default slices."""
+    g = region if region is not None else synth.config_region(name, seed=seed, B=B, positions="none")
+    batch = synth.batch_from_regions([g])
+    cfg = abi.Config.default(max_indel_error=B)
+    eng = make_engine(backend, max_indel_error=B)
+    rb = eng.upload(batch)
+    rb.run(); got = rb.download().copy()
+    stats = rb.stats()
+    rb.free(); eng.close()
+    t0 = time.perf_counter()
+    want = _ref_populate(cfg, batch, oracle.host_cores())
+    dt = time.perf_counter() - t0
+    assert got.shape == want.shape
+    bad = np.flatnonzero(~(np.abs(got - want) <= TOL))
+    assert bad.size == 0, (bad[:10], got[bad[:10]], want[bad[:10]])
+    return dict(stats=stats, n=got.size, reference_s=dt, reference_gcups=stats["band_cells"] / dt / 1e9)
+
+
+def check_region_stream(backend, n_regions=2000, B=16, seed=42, regions=None):
+    """configs[3] stand-in, as `bench.py --workload stream` runs it (one flat multi-region batch per step); the reference answers
+    region by region, one populate() call each, as Octopus itself would."""
+    if regions is None:
+        regions = synth.region_stream(seed=seed, n_regions=n_regions, B=B, positions="none")
+    flat = synth.batch_from_regions(regions)
+    cfg = abi.Config.default(max_indel_error=B)
+    eng = make_engine(backend, max_indel_error=B)
+    rb = eng.upload(flat)
+    rb.run(); got = rb.download().copy()
+    stats = rb.stats()
+    rb.free(); eng.close()
+    threads = oracle.host_cores()
+    at, worst = 0, 0.0
+    for i, g in enumerate(regions):
+        one = synth.batch_from_regions([g])
+        want = _ref_populate(cfg, one, threads)
+        mine = got[at:at + want.size]
+        d = float(np.max(np.abs(mine - want), initial=0.0))
+        assert d <= TOL, (i, d)
+        worst = max(worst, d)
+        at += want.size
+    assert at == got.size
+    return dict(stats=stats, n=got.size, regions=len(regions), max_abs_diff=worst)
+
+
+def check_long_reads(backend, region=None, B=256, max_cigar_ops=4096):
+    """configs[4]: 64 x 10 kb reads against 8 x 20 kb haplotypes, band 256, int32 lanes — populate against the reference's own populate,
+    align (position, CIGAR, likelihood of every pair) against the oracle's align path driving the reference's SIMD kernels (that path is
+    pinned to the reference's HaplotypeLikelihoodModel::align in tests/test_oracle_l3.py)."""
+    import check_align as ca
+    g = region if region is not None else synth.config_region("long64x8", seed=42, B=B, positions="none")
+    batch = synth.batch_from_regions([g])
+    kw = dict(max_indel_error=B, use_int_scores=1)
+    cfg = abi.Config.default(**kw)
+    eng = make_engine(backend, **kw)
+    rb = eng.upload(batch)
+    rb.run(); got = rb.download().copy()
+    stats = rb.stats()
+    rb.free(); eng.close()
+    want = _ref_populate(cfg, batch, oracle.host_cores())
+    assert got.shape == want.shape and np.max(np.abs(got - want), initial=0.0) <= TOL
+    oracle.set_l1_backend("native" if oracle.have_ref() else "oracle")
+    try:
+        res = ca.compare_align(backend, batch, max_cigar_ops=max_cigar_ops, n_threads=oracle.host_cores(), **kw)
+    finally:
+        oracle.set_l1_backend("oracle")
+    return dict(stats=stats, n=got.size, n_alignments=len(res["cigar_strings"]))

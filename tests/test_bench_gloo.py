@@ -15,11 +15,11 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run(n):
+def _run(n, workload=("--workload", "tiny")):
     from backends import build_sim
     build_sim()
     env = dict(os.environ, OCT_BENCH_BACKEND="sim")
-    args = ["bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1", "--workload", "tiny", "--band", "8", "--no-cpu-baseline", "--no-small-batch"]
+    args = ["bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1", *workload, "--band", "8", "--no-cpu-baseline", "--no-small-batch"]
     if n == 1:
         cmd = [sys.executable] + args
     else:
@@ -39,7 +39,19 @@ def test_bench_line_over_two_ranks_aggregates_the_whole_job():
         assert b["unit"] == "GCUPS" and b["value"] > 0 and b["ms_per_step"] > 0 and b["vs_baseline"] is None
         assert set(b["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
         assert "SIMULATOR" in b["data"]
+        assert b["verified_rows"] >= 1 and b["verified_max_abs_diff"] <= 1e-9       # the line carries its own check against the reference
     # every rank brings a region of the same shape (seed 42 + rank): the job's pairs double, the per-rank stats stay one region's
     assert two["config"]["pairs_per_step"] == 2 * one["config"]["pairs_per_step"]
     assert two["stats"]["n_pairs"] == one["stats"]["n_pairs"]
     assert abs(two["value"] * two["ms_per_step"] / (one["value"] * one["ms_per_step"]) - 2.0) < 0.2     # cells per step: twice one region's, up to the seeds
+
+
+def test_bench_stream_mode_shards_one_fixed_stream_over_the_ranks():
+    """--workload stream: ONE stream of regions, region i on rank i mod N (strong scaling): the job's work does not depend on N."""
+    wl = ("--workload", "stream", "--regions", "6", "--stream-cap", "12", "3")
+    one, two = _run(1, wl), _run(2, wl)
+    for b in (one, two):
+        assert b["scaling"] == "strong" and b["regions_per_s"] > 0 and b["verified_rows"] >= 1 and b["verified_max_abs_diff"] <= 1e-9
+    assert two["config"]["pairs_per_step"] == one["config"]["pairs_per_step"]
+    assert two["stats"]["n_pairs"] < one["stats"]["n_pairs"]                     # rank 0 of two holds regions 0, 2, 4 only
+    assert abs(two["value"] * two["ms_per_step"] / (one["value"] * one["ms_per_step"]) - 1.0) < 1e-6
