@@ -393,7 +393,11 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         const size_t fit = std::max<size_t>(1, h->bp_budget / std::max<size_t>(1, b->slices.size()) / per_group);
         chunk_groups = (uint32_t)std::min<size_t>(n_groups, fit);
         if (chunk_groups < n_groups) chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / p.groups_per_block * p.groups_per_block);   // several launches: whole workgroups each
-        if (!ensure_bp(h, slice, (size_t)std::min(chunk_groups, n_groups) * per_group)) return fail(status, OCT_PHMM_EHIP, "traceback scratch allocation");
+        // the device may not have the budget free (other handles, other processes): fall back to smaller chunks of whole workgroups
+        while (!ensure_bp(h, slice, (size_t)std::min(chunk_groups, n_groups) * per_group)) {
+            if (chunk_groups <= p.groups_per_block || b->align_mode) return fail(status, OCT_PHMM_EHIP, "traceback scratch allocation");
+            chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / 2 / p.groups_per_block * p.groups_per_block);
+        }
     }
     for (uint32_t g0 = 0; g0 < n_groups; g0 += chunk_groups) {
         const uint32_t ng = std::min(chunk_groups, n_groups - g0);
@@ -486,6 +490,10 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     if (h->cfg.mapping_quality_cap_trigger >= 0 && h->cfg.mapping_quality_cap_trigger >= h->cfg.mapping_quality_cap)
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
     h->timing = getenv("OCT_PHMM_TIMING") != nullptr;
+    {   // never plan for more than 60 % of what the device has free now (two server handles per device, other processes)
+        size_t free_b = 0, total_b = 0;
+        if (rt::mem_info(&free_b, &total_b) && free_b) h->bp_budget = std::min<size_t>(h->bp_budget, free_b / 10 * 6);
+    }
     if (const char* e = getenv("OCT_PHMM_BP_BUDGET_GB")) { const long gb = atol(e); if (gb > 0) h->bp_budget = (size_t)gb << 30; }
     if (const char* e = getenv("OCT_PHMM_BP_BUDGET_KB")) { const long kb = atol(e); if (kb > 0) h->bp_budget = (size_t)kb << 10; }   // test hook: forces chunked traceback launches on small batches
     if (!rt::stream_create(&h->stream)) return OCT_PHMM_EHIP;
@@ -626,16 +634,16 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         // path along its diagonal plus one gap opening, every not-yet-initialised ("infinite") cell by infinity_ plus the deletion chain's
         // growth (the 0x7FF tolerance the reference itself relies on, simd_pair_hmm.hpp:55). If neither can, a 32-bit add of two packed
         // halves never carries between them and k_dp uses v_add_u32 (FASTADD); otherwise it keeps v_pk_add_u16. Results are identical.
-        std::mutex mx; uint64_t sum_q_max = 0; uint32_t gomax = 0, gemax = 0;
+        std::mutex mx; uint64_t sum_q_max = 0; uint32_t gomax = 0, gemax = 0, t_min = 0xffffffffu;
         host_parallel(R->n_reads, (size_t)50000, [&](size_t r0, size_t r1) {
-            uint64_t best = 0;
+            uint64_t best = 0; uint32_t shortest = 0xffffffffu;
             for (size_t r = r0; r < r1; ++r) {
                 uint32_t sq = 0;                               // reads are < 32,768 bases of quality <= 127
                 const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
                 for (uint32_t i = 0; i < n; ++i) sq += q[i];
-                best = std::max<uint64_t>(best, sq);
+                best = std::max<uint64_t>(best, sq); shortest = std::min(shortest, n);
             }
-            std::lock_guard<std::mutex> lk(mx); sum_q_max = std::max(sum_q_max, best);
+            std::lock_guard<std::mutex> lk(mx); sum_q_max = std::max(sum_q_max, best); t_min = std::min(t_min, shortest);
         });
         host_parallel(n_hap_bases, (size_t)4 << 20, [&](size_t lo, size_t hi) {
             uint32_t a = 0, e = 0;
@@ -643,8 +651,12 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             std::lock_guard<std::mutex> lk(mx); gomax = std::max(gomax, a); gemax = std::max(gemax, e);
         });
         const uint64_t B64 = (uint64_t)h->band, nuc = (uint64_t)std::max(0, h->cfg.nuc_prior);
-        const uint64_t finite = 4 * (sum_q_max + 2 * 64 * B64 + gomax + gemax + nuc) + 1024;
-        const uint64_t garbage = 4 * (2 * B64 * gemax + 64 + gomax + gemax + nuc) + 64;
+        // A read shorter than its wave's longest keeps iterating (padding quality 64) after its end cells were captured: its rows past the end
+        // grow by at most one insertion step (gap extend + nuc_prior) per iteration. An uninitialised lane runs its insertion chain
+        // (gap extend + nuc_prior per step) and its deletion chain for up to 2 B steps before the rolling initialiser reaches it.
+        const uint64_t tail = R->n_reads ? (uint64_t)(b->t_cap - std::min(b->t_cap, t_min)) * (gemax + nuc) : 0;
+        const uint64_t finite = 4 * (sum_q_max + 2 * 64 * B64 + gomax + gemax + nuc + tail) + 1024;
+        const uint64_t garbage = 4 * (2 * B64 * (gemax + nuc) + 64 + gomax + gemax + nuc) + 64;
         b->fast_adds = finite < 0xF800u && garbage < 0x7FFu && h->cfg.nuc_prior >= 0 && !getenv("OCT_PHMM_EXACT_ADDS");
     }
     for (uint32_t r = 0; r < R->n_reads; ++r) if (R->offsets[r + 1] == R->offsets[r]) return fail(status, OCT_PHMM_EINVAL, "empty read");
@@ -827,17 +839,19 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
 
     // phase 1 of a slice: candidate mapping, classification + scalar fast path, task counts -> slot offsets (everything up to the one
     // host read-back that sizes the DP launches)
+    int hash_slice = -1;                                  // the slice whose table launch also hashed the reads
     auto phase1 = [&](int i) -> int {
         oct_phmm_batch::Slice& sl = b->slices[i];
         rt::Stream s = h->slice_stream(i);
         const uint64_t np = sl.pair1 - sl.pair0;
-        if (!np) { sl.totals = make_uint4(0, 0, 0, 0); return OCT_PHMM_OK; }
+        if (!np) { sl.totals = make_uint4(0, 0, 0, 0); sl.totals_late = make_uint4(0, 0, 0, 0); return OCT_PHMM_OK; }
         if (b->device_map) {                              // HaplotypeLikelihoodArray::populate maps per haplotype (array.cpp:118-158)
-            // slice 0's launch also hashes every read of the batch once (array.cpp:118-131); the other slices' mappers wait for it
-            const uint32_t n_rb = b->h_roff[b->n_reads], hash_blocks = i == 0 ? (n_rb + 255) / 256 : 0;
+            // the first slice that has pairs also hashes every read of the batch once (array.cpp:118-131); the later slices' mappers wait for it
+            const bool hashes_here = hash_slice < 0;
+            const uint32_t n_rb = b->h_roff[b->n_reads], hash_blocks = hashes_here ? (n_rb + 255) / 256 : 0;
             OCT_LAUNCH(k_kmer_tables, sl.hap1 - sl.hap0 + hash_blocks, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d, sl.hap0, sl.hap1 - sl.hap0, n_rb); RT(rt::launch_ok());
-            if (i == 0 && S > 1) RT(rt::event_record(b->ev_hashes, s));
-            if (i > 0) RT(rt::stream_wait_event(s, b->ev_hashes));
+            if (hashes_here) { hash_slice = i; if (S > 1) RT(rt::event_record(b->ev_hashes, s)); }
+            else RT(rt::stream_wait_event(s, b->ev_hashes));
             if (b->map_big) {
                 const size_t lds = (size_t)b->lh_cap * 4 + 64;
                 if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_big, lds));
@@ -1259,9 +1273,17 @@ struct oct_phmm_server {
                 static std::mutex sim_mu;                // the wave simulator runs one kernel at a time: workers of several "devices" take turns
                 std::lock_guard<std::mutex> sim_lk(sim_mu);
 #endif
-                if (!batchable.empty()) serve_many(h, batchable);
+                if (!batchable.empty()) {
+                    bool served = false;
+                    try { serve_many(h, batchable); served = true; } catch (const std::exception&) {}      // e.g. bad_alloc while concatenating
+                    if (!served) for (Request* q : batchable) {
+                        try { serve_one(h, q); } catch (const std::exception&) { q->rc = fail(&q->st, OCT_PHMM_EHIP, "host allocation"); }
+                    }
+                }
                 const uint64_t t_single = profile ? now_ns() : 0;
-                for (Request* q : single) serve_one(h, q);
+                for (Request* q : single) {
+                    try { serve_one(h, q); } catch (const std::exception&) { q->rc = fail(&q->st, OCT_PHMM_EHIP, "host allocation"); }
+                }
                 if (profile) ns_single += now_ns() - t_single;
             }
             {
@@ -1322,6 +1344,19 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
                                         const oct_phmm_flank_state* flank, const oct_phmm_positions* positions, double* out, oct_phmm_status* status)
 {
     if (!s || !reads || !haps) return fail(status, OCT_PHMM_EINVAL, "null argument");
+    // the workers concatenate queued calls before the library proper validates them: a malformed call is answered here, not in a worker thread
+    if ((reads->n_reads && (!reads->bases || !reads->qualities || !reads->offsets || !reads->mapping_quality || !reads->reverse_strand || !reads->ref_begin))
+        || (haps->n_haps && (!haps->bases || !haps->offsets || !haps->ref_begin || !haps->gap_open || !haps->gap_extend || !haps->snv_mask_fwd
+                             || !haps->snv_prior_fwd || !haps->snv_mask_rev || !haps->snv_prior_rev)))
+        return fail(status, OCT_PHMM_EINVAL, "null array");
+    if ((reads->n_reads && !monotone(reads->offsets, reads->n_reads)) || (haps->n_haps && !monotone(haps->offsets, haps->n_haps)))
+        return fail(status, OCT_PHMM_EINVAL, "offsets not monotone");
+    {
+        const uint32_t rows = reads->row_offsets ? reads->n_rows : reads->n_reads;
+        if (reads->row_offsets && (!monotone(reads->row_offsets, rows) || reads->row_offsets[0] != 0 || reads->row_offsets[rows] != reads->n_reads))
+            return fail(status, OCT_PHMM_EINVAL, "row_offsets must partition the reads");
+        if (!out && (size_t)rows * haps->n_haps) return fail(status, OCT_PHMM_EINVAL, "null output");
+    }
     oct_phmm_server::Request q; q.R = reads; q.H = haps; q.flank = flank; q.pos = positions; q.out = out; memset(&q.st, 0, sizeof(q.st));
     {
         std::unique_lock<std::mutex> lk(s->mu);

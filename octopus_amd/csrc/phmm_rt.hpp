@@ -31,6 +31,7 @@ inline void stream_destroy(Stream s) { (void)hipStreamDestroy(s); }
 inline bool stream_sync(Stream s) { OCT_RT_CHECK(hipStreamSynchronize(s)); return true; }
 inline bool dev_malloc(void** p, size_t n) { OCT_RT_CHECK(hipMalloc(p, n ? n : 16)); return true; }
 inline void dev_free(void* p) { if (p) (void)hipFree(p); }
+inline bool mem_info(size_t* free_b, size_t* total_b) { OCT_RT_CHECK(hipMemGetInfo(free_b, total_b)); return true; }
 inline bool host_pinned_malloc(void** p, size_t n) { OCT_RT_CHECK(hipHostMalloc(p, n ? n : 16, hipHostMallocDefault)); return true; }
 inline void host_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
 inline bool h2d(void* d, const void* h, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); return true; }

@@ -115,17 +115,21 @@ public:
     explicit HaplotypeLikelihoodModel(Config config, PenaltyModel penalties = {})
     : config_ {config}, penalties_ {penalties ? std::move(penalties) : PenaltyModel {[] (const Haplotype& h) { return flat_penalties(h); }}}
     {
-        oct_phmm_config c; oct_phmm_config_default(&c);
-        c.max_indel_error = static_cast<int>(config.max_indel_error); c.use_int_scores = config.use_int_scores;
-        c.use_mapping_quality = config.use_mapping_quality; c.mapping_quality_cap = config.mapping_quality_cap;
-        c.mapping_quality_cap_trigger = config.mapping_quality_cap_trigger; c.use_flank_state = config.use_flank_state;
-        c.device_id = config.device_id;
-        oct_phmm_handle* h = nullptr;
-        const int rc = oct_phmm_create(&c, &h);
-        if (rc == OCT_PHMM_EBAND) throw TooLargeBandSizeError {static_cast<int>(config.max_indel_error)};
-        if (rc != OCT_PHMM_OK) throw DeviceError {std::string {"oct_phmm_create: "} + oct_phmm_strerror(rc)};
-        handle_.reset(h, [] (oct_phmm_handle* p) { oct_phmm_destroy(p); });
+        band_ = 0;
+        for (int b = 8; b <= 256 && !band_; b *= 2) if (static_cast<int>(config.max_indel_error) <= b) band_ = b;     // simd_pair_hmm_wrapper.hpp:219-241
+        if (!band_) throw TooLargeBandSizeError {static_cast<int>(config.max_indel_error)};
     }
+    // One oct_phmm_handle per model OBJECT: the handle owns streams, staging buffers and scratch and must not be shared between threads
+    // (include/oct_phmm.h), while the reference copies its model into every worker task (haplotype_likelihood_array.cpp:172) and into every
+    // array. A copy therefore starts without a handle and creates its own on first use.
+    HaplotypeLikelihoodModel(const HaplotypeLikelihoodModel& other) : config_ {other.config_}, penalties_ {other.penalties_}, band_ {other.band_} {}
+    HaplotypeLikelihoodModel& operator=(const HaplotypeLikelihoodModel& other)
+    {
+        if (this != &other) { config_ = other.config_; penalties_ = other.penalties_; band_ = other.band_; handle_.reset(); }
+        return *this;
+    }
+    HaplotypeLikelihoodModel(HaplotypeLikelihoodModel&&) = default;
+    HaplotypeLikelihoodModel& operator=(HaplotypeLikelihoodModel&&) = default;
     struct Alignment { std::size_t mapping_position; std::string cigar; double likelihood; };   // ref: haplotype_likelihood_model.hpp:57-62 (CigarString as text)
     class HMMOverflow : public std::runtime_error { public: HMMOverflow() : std::runtime_error {"Pair HMM alignment overflowed"} {} };   // ref: pair_hmm.hpp:47-64
 
@@ -149,7 +153,7 @@ public:
             std::vector<std::uint32_t> mpos(reads.size() + 1), n_ops(reads.size() + 1), ops(reads.size() * cap + 1); std::vector<double> lik(reads.size() + 1);
             oct_phmm_alignments out {cap, mpos.data(), lik.data(), n_ops.data(), ops.data()};
             oct_phmm_status st;
-            const int rc = oct_phmm_align(handle_.get(), &R, &H, nullptr, flank_state ? &fs : nullptr, nullptr, &out, &st);
+            const int rc = oct_phmm_align(handle(), &R, &H, nullptr, flank_state ? &fs : nullptr, nullptr, &out, &st);
             if (rc == OCT_PHMM_EINVAL && st.required_extension > cap) { cap = st.required_extension; continue; }   // CIGARs longer than guessed: once more with room
             if (rc == OCT_PHMM_ESHORT_HAPLOTYPE) throw ShortHaplotypeError {st.hap_index, st.required_extension};
             if (rc == OCT_PHMM_EOVERFLOW) throw HMMOverflow {};
@@ -168,14 +172,32 @@ public:
     }
 
     const Config& config() const noexcept { return config_; }
-    unsigned pad_requirement() const noexcept { return static_cast<unsigned>(oct_phmm_band_size(handle_.get())); }   // ref: model.cpp:55-58
+    unsigned pad_requirement() const noexcept { return static_cast<unsigned>(band_); }   // ref: model.cpp:55-58 (== oct_phmm_band_size)
     bool can_use_flank_state() const noexcept { return config_.use_flank_state; }
     PenaltyVectors penalties(const Haplotype& h) const { return penalties_(h); }
-    oct_phmm_handle* handle() const noexcept { return handle_.get(); }
+    // this object's own device handle, created on first use; shared_ptr so that a device-resident matrix can keep it alive
+    const std::shared_ptr<oct_phmm_handle>& shared_handle() const
+    {
+        if (!handle_) {
+            oct_phmm_config c; oct_phmm_config_default(&c);
+            c.max_indel_error = static_cast<int>(config_.max_indel_error); c.use_int_scores = config_.use_int_scores;
+            c.use_mapping_quality = config_.use_mapping_quality; c.mapping_quality_cap = config_.mapping_quality_cap;
+            c.mapping_quality_cap_trigger = config_.mapping_quality_cap_trigger; c.use_flank_state = config_.use_flank_state;
+            c.device_id = config_.device_id;
+            oct_phmm_handle* h = nullptr;
+            const int rc = oct_phmm_create(&c, &h);
+            if (rc == OCT_PHMM_EBAND) throw TooLargeBandSizeError {static_cast<int>(config_.max_indel_error)};
+            if (rc != OCT_PHMM_OK) throw DeviceError {std::string {"oct_phmm_create: "} + oct_phmm_strerror(rc)};
+            handle_.reset(h, [] (oct_phmm_handle* p) { oct_phmm_destroy(p); });
+        }
+        return handle_;
+    }
+    oct_phmm_handle* handle() const { return shared_handle().get(); }
 private:
     Config config_;
     PenaltyModel penalties_;
-    std::shared_ptr<oct_phmm_handle> handle_;
+    int band_ = 0;
+    mutable std::shared_ptr<oct_phmm_handle> handle_;
 };
 
 class HaplotypeLikelihoodArray
@@ -185,9 +207,19 @@ public:
     using LogProbability = double;
     using LikelihoodVector = std::vector<LogProbability>;
 
+    using SampleLikelihoodMap = std::unordered_map<Haplotype, LikelihoodVector, HaplotypeHash>;   // ref: hpp:46 (by value here)
+
     HaplotypeLikelihoodArray() = default;
     HaplotypeLikelihoodArray(HaplotypeLikelihoodModel model, std::vector<SampleName> samples)
     : likelihood_model_ {std::move(model)}, samples_ {std::move(samples)} {}
+    // A copy gets the host-side matrix and its own model (own device handle); the device-resident matrix stays with the original, whose
+    // handle it lives on - two arrays on two threads never touch one handle.
+    HaplotypeLikelihoodArray(const HaplotypeLikelihoodArray& o)
+    : likelihood_model_ {o.likelihood_model_}, likelihoods_ {o.likelihoods_}, haplotype_indices_ {o.haplotype_indices_}, sample_indices_ {o.sample_indices_},
+      samples_ {o.samples_}, haplotypes_ {o.haplotypes_}, primed_sample_ {o.primed_sample_}, primed_ {o.primed_}, sample_row_begin_ {o.sample_row_begin_} {}
+    HaplotypeLikelihoodArray& operator=(const HaplotypeLikelihoodArray& o) { if (this != &o) { HaplotypeLikelihoodArray tmp {o}; *this = std::move(tmp); } return *this; }
+    HaplotypeLikelihoodArray(HaplotypeLikelihoodArray&&) = default;
+    HaplotypeLikelihoodArray& operator=(HaplotypeLikelihoodArray&&) = default;
 
     // ref: haplotype_likelihood_array.cpp:51-103
     void populate(const ReadMap& reads, const std::vector<Haplotype>& haplotypes, const FlankState* flank_state = nullptr)
@@ -225,12 +257,19 @@ public:
     const LikelihoodVector& operator[](std::size_t haplotype_index) const noexcept { return likelihoods_[haplotype_index][primed_sample_]; }
     std::vector<SampleName> samples() const { return samples_; }
     const std::vector<Haplotype>& haplotypes() const noexcept { return haplotypes_; }
+    SampleLikelihoodMap extract_sample(const SampleName& sample) const                        // ref: cpp:248-257
+    {
+        const auto sample_index = sample_indices_.at(sample);
+        SampleLikelihoodMap result {haplotype_indices_.size()};
+        for (const auto& p : haplotype_indices_) result.emplace(p.first, likelihoods_[p.second][sample_index]);
+        return result;
+    }
     bool contains(const Haplotype& haplotype) const noexcept { return haplotype_indices_.count(haplotype) == 1; }
     bool is_empty() const noexcept { return likelihoods_.empty(); }
-    void clear() noexcept { likelihoods_.clear(); haplotype_indices_.clear(); sample_indices_.clear(); haplotypes_.clear(); resident_.reset(); unprime(); }
+    void clear() noexcept { likelihoods_.clear(); haplotype_indices_.clear(); sample_indices_.clear(); haplotypes_.clear(); resident_.reset(); resident_handle_.reset(); unprime(); }
     // the device-resident matrix of the last populate (null after reset()/merge_samples(), whose row layout it no longer matches)
     oct_phmm_batch* resident_batch() const noexcept { return resident_.get(); }
-    oct_phmm_handle* handle() const noexcept { return likelihood_model_.handle(); }
+    oct_phmm_handle* handle() const { return resident_handle_ ? resident_handle_.get() : likelihood_model_.handle(); }   // the handle the resident matrix lives on
     std::pair<std::uint32_t, std::uint32_t> primed_rows() const { return {sample_row_begin_.at(primed_sample_), sample_row_begin_.at(primed_sample_ + 1)}; }
     bool is_primed() const noexcept { return primed_; }
     void prime(const SampleName& sample) const { primed_sample_ = sample_indices_.at(sample); primed_ = true; }
@@ -297,10 +336,11 @@ private:
         // models can read it out there (ConstantMixtureGenotypeLikelihoodModel below)
         resident_.reset(); sample_row_begin_.assign(1, 0);
         for (std::size_t n : rows_per_sample) sample_row_begin_.push_back(sample_row_begin_.back() + static_cast<std::uint32_t>(n));
-        oct_phmm_handle* hd = likelihood_model_.handle();
+        const std::shared_ptr<oct_phmm_handle> keep = likelihood_model_.shared_handle();   // the batch holds its handle alive
+        oct_phmm_handle* hd = keep.get();
         oct_phmm_batch* batch = nullptr;
         int rc = oct_phmm_batch_upload(hd, &R, &H, nullptr, flank_state ? &fs : nullptr, nullptr, &batch, &st);
-        if (batch) resident_.reset(batch, [hd] (oct_phmm_batch* b) { oct_phmm_batch_free(hd, b); });
+        if (batch) { resident_.reset(batch, [keep] (oct_phmm_batch* b) { oct_phmm_batch_free(keep.get(), b); }); resident_handle_ = keep; }
         if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_run(hd, batch, &st);
         if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_download(hd, batch, out.data(), &st);
         if (rc != OCT_PHMM_OK) resident_.reset();
@@ -324,6 +364,7 @@ private:
     mutable std::size_t primed_sample_ = 0;
     mutable bool primed_ = false;
     std::shared_ptr<oct_phmm_batch> resident_;
+    std::shared_ptr<oct_phmm_handle> resident_handle_;
     std::vector<std::uint32_t> sample_row_begin_ {0};
 };
 

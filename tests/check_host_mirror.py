@@ -116,6 +116,7 @@ def check(backend, tol=0.0):
         assert any(ln.startswith("primed %d contains 1" % split) for ln in lines)
         assert any(ln == "merged %d" % (len(rows) - 1) for ln in lines)
         assert any(ln == "reset 1 0" for ln in lines)
+        assert "extract 1 copy 1 1" in lines                  # extract_sample; a copied array owns its handle, has no device matrix, populates alone
     # error mapping: ShortHaplotypeError and TooLargeBandSizeError surface as the reference's exception types
     g, rows, split = scenario(9, 16, False, None, short=True)
     rows = list(range(15)); split = 7

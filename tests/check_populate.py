@@ -443,3 +443,27 @@ def check_streamed_upload_and_growing_calls(backend, tol=0.0):
         assert st.code == abi.OK and np.max(np.abs(got - want), initial=0.0) <= tol, (R, H)
     eng.close()
 
+
+
+def check_leading_haplotypes_without_reads(backend, tol=0.0):
+    """A batch whose first region has haplotypes but no reads, run in several slices: the leading slice holds no pairs, and the read
+    hashes every later slice's mapper needs must still be computed (by the first slice that has pairs)."""
+    import os
+    rng = np.random.default_rng(404)
+    g0 = synth.make_region(rng, 1, 3, T=40, Lh=130, B=8, flank=(10, 10), positions="none")
+    for k in ("reads", "quals", "begin", "reverse", "mapq"):
+        g0[k] = g0[k][:0]
+    g1 = synth.make_region(rng, 20, 4, T=50, Lh=150, B=8, flank=(20, 20), positions="none")
+    g2 = synth.make_region(rng, 15, 3, T=45, Lh=140, B=8, flank=None, positions="none")
+    batch = synth.batch_from_regions([g0, g1, g2])
+    old = os.environ.get("OCT_PHMM_SLICES")
+    try:
+        for n in ("3", "8"):
+            os.environ["OCT_PHMM_SLICES"] = n
+            stats = compare(backend, batch, tol, max_indel_error=8)
+            assert stats["n_pairs"] == 20 * 4 + 15 * 3
+    finally:
+        if old is None:
+            os.environ.pop("OCT_PHMM_SLICES", None)
+        else:
+            os.environ["OCT_PHMM_SLICES"] = old

@@ -73,3 +73,28 @@ def check_server(backend, n_threads=5, per_thread=7, seed=17, band=8, devices=No
                 assert (hi, ri, ext) == (wst.hap_index, wst.read_index, wst.required_extension)
     assert n_err > 0
     return calls, batches
+
+
+def check_server_rejects_malformed_calls(backend):
+    """A call with a NULL array (or no output buffer) gets OCT_PHMM_EINVAL back from oct_phmm_server_populate itself and never reaches a
+    worker thread; the server keeps answering the well-formed calls around it."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    good = make_requests(rng, 2, 8)[0]
+    cfg = abi.Config.default(max_indel_error=8)
+    srv = engine.Server(cfg, lib_path=build_sim() if backend == "sim" else None)
+    want, _ = srv.populate(good)
+    out = np.zeros(good.out_size())
+    fl = good.c_flank()
+    for field, owner in (("qualities", 0), ("offsets", 0), ("gap_open", 1), ("snv_mask_rev", 1), (None, None)):
+        r, h = good.c_reads(), good.c_haps()
+        if field is not None:
+            setattr((r, h)[owner], field, None)
+        st = abi.Status()
+        code = srv.lib.oct_phmm_server_populate(srv.ptr, C.cast(C.byref(r), C.c_void_p), C.cast(C.byref(h), C.c_void_p),
+                                                None if fl is None else C.cast(C.byref(fl), C.c_void_p), None,
+                                                out.ctypes.data_as(C.c_void_p) if field is not None else None, C.byref(st))
+        assert code == abi.EINVAL and st.code == abi.EINVAL, (field, code)
+    again, _ = srv.populate(good)
+    assert np.array_equal(again, want)
+    srv.close()

@@ -56,6 +56,17 @@ int main()
         }
         const auto merged = arr.merge_samples(names);
         std::printf("merged %zu\n", merged[0].size());
+        {   // extract_sample (ref hpp:85) and copy semantics: a copy has its own handle and no device matrix, and can populate on its own
+            const auto ex = arr.extract_sample(names.back());
+            bool same = ex.size() == haps.size();
+            for (std::size_t h = 0; h < haps.size() && same; ++h) same = ex.at(haps[h]) == arr(names.back(), haps[h]);
+            HaplotypeLikelihoodArray copy {arr};
+            const bool distinct = copy.handle() != arr.handle() && copy.resident_batch() == nullptr && arr.resident_batch() != nullptr;
+            bool equal = true;
+            if (templates) copy.populate(tm, haps, has_flank ? &fs : nullptr); else copy.populate(rm, haps, has_flank ? &fs : nullptr);
+            for (std::size_t h = 0; h < haps.size(); ++h) for (const auto& n : names) equal = equal && copy(n, haps[h]) == arr(n, haps[h]);
+            std::printf("extract %d copy %d %d\n", same ? 1 : 0, distinct ? 1 : 0, equal ? 1 : 0);
+        }
         if (haps.size() > 1) {
             arr.reset({haps.back()}); std::printf("reset %zu %d\n", arr.haplotypes().size(), arr.contains(haps.front()) ? 1 : 0);
             arr.prime(names.front());                           // no device matrix any more: the mirror says so instead of computing on the host

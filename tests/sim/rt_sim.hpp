@@ -19,6 +19,7 @@ inline void stream_destroy(Stream) {}
 inline bool stream_sync(Stream) { return true; }
 inline bool dev_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); if (*p) memset(*p, 0xCD, n ? n : 16); return *p != nullptr; }
 inline void dev_free(void* p) { free(p); }
+inline bool mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)288 << 30; return true; }
 inline bool host_pinned_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); return *p != nullptr; }
 inline void host_pinned_free(void* p) { free(p); }
 inline bool h2d(void* d, const void* h, size_t n, Stream) { if (n) memcpy(d, h, n); return true; }

@@ -280,3 +280,12 @@ def test_gpu_server_batches_concurrent_region_calls():
     import check_server
     calls, batches = check_server.check_server("gpu", n_threads=8, per_thread=12, band=16)
     assert calls == 192 and batches < calls            # some calls were answered together
+
+
+def test_gpu_server_answers_a_malformed_call_with_einval():
+    import check_server
+    check_server.check_server_rejects_malformed_calls("gpu")
+
+
+def test_gpu_leading_slice_without_pairs_still_hashes_the_reads():
+    cp.check_leading_haplotypes_without_reads("gpu", TOL)

@@ -92,3 +92,7 @@ def test_sim_matrix_equals_the_reference_array_populate():
 def test_sim_streamed_upload_and_growing_calls():
     cp.check_streamed_upload_and_growing_calls("sim")
 
+
+
+def test_sim_leading_slice_without_pairs_still_hashes_the_reads():
+    cp.check_leading_haplotypes_without_reads("sim")

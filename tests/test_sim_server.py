@@ -20,3 +20,7 @@ def test_sim_server_rejects_a_device_that_does_not_exist():
     with pytest.raises(engine.EngineError) as e:
         engine.Server(abi.Config.default(max_indel_error=8), lib_path=build_sim(), devices=[0, 7])     # the simulator has one device
     assert e.value.code == abi.ENODEVICE
+
+
+def test_sim_server_answers_a_malformed_call_with_einval_instead_of_crashing_a_worker():
+    check_server.check_server_rejects_malformed_calls("sim")

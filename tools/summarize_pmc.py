@@ -10,12 +10,19 @@ import argparse
 import collections
 import csv
 import json
+import subprocess
+import sys
 from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+from octopus_amd import engine   # noqa: E402  (kernel_source_sha only)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("passes", nargs="+")
 ap.add_argument("--out", required=True)
 ap.add_argument("--min-grid", type=int, default=1_000_000)
+ap.add_argument("--sha", default=None, help="kernel_source_sha recorded on the GPU box beside the passes (default: this tree's)")
 a = ap.parse_args()
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
@@ -54,11 +61,18 @@ for k, c in agg.items():
     if "SQ_INSTS_VALU" in d and "SQ_ACTIVE_INST_VALU" in d:
         d["valu_quad_cycles_per_inst"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_INSTS_VALU"]
     out[k] = d
+# stamp: which kernels these counters belong to. bench.py compares kernel_source_sha with the tree it runs in (the GPU box has no .git)
+# and flags a summary collected on other kernels; the git hash is for humans (run this script at the commit that was profiled).
+git = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "-C", str(ROOT), "status", "--porcelain", "--", "octopus_amd/csrc", "include"], capture_output=True, text=True).stdout.strip())
+out["_meta"] = {"kernel_source_sha": a.sha or engine.kernel_source_sha(), "git": git + ("+dirty" if dirty else ""), "passes": [str(p) for p in a.passes]}
 Path(a.out + ".json").write_text(json.dumps(out, indent=1) + "\n")
 cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
         "SQ_WAIT_INST_ANY", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"]
 with open(a.out + ".md", "w") as f:
     f.write("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols) + "\n")
     for k, d in sorted(out.items()):
+        if k == "_meta":
+            continue
         f.write(f"| {k} | " + " | ".join(f"{d.get(c, float('nan')):.4g}" for c in cols) + " |\n")
-print(json.dumps({k: {n: d[n] for n in d if n.startswith("hbm") or n.startswith("valu") or n == "GRBM_GUI_ACTIVE"} for k, d in out.items()}, indent=1))
+print(json.dumps({k: {n: d[n] for n in d if n.startswith("hbm") or n.startswith("valu") or n == "GRBM_GUI_ACTIVE"} for k, d in out.items() if k != "_meta"}, indent=1))
