@@ -25,9 +25,10 @@ ISA = {"sse2": 0, "avx2": 1, "avx512": 2, "native": -1}
 
 
 def build(quiet: bool = True) -> None:
-    """make liboracle.so (always) and _ref/libref_phmm.so (only where /root/reference is present)."""
-    subprocess.run(["make", "-C", str(_DIR), "-j4", "all"], check=True,
-                   stdout=subprocess.DEVNULL if quiet else None)
+    """make liboracle.so (always), _ref/libref_phmm.so + libref_array*.so and the INTEGRATION-patched class against whichever builds of
+    the C ABI exist (only where /root/reference is present)."""
+    for target in ("all", "patched"):
+        subprocess.run(["make", "-C", str(_DIR), "-j4", target], check=True, stdout=subprocess.DEVNULL if quiet else None)
 
 
 def lib() -> C.CDLL:
@@ -66,9 +67,18 @@ def have_ref_array(isa: str = "sse2") -> bool:
     return (_DIR / "_ref" / name).exists() and (isa == "sse2" or ref_isa_supported("avx2"))
 
 
+_ARRAY_LIBS = {"sse2": "libref_array.so", "avx2": "libref_array_avx2.so",
+               # the reference's class with INTEGRATION.md's patch applied (oracle/apply_integration_patch.py), on the simulator / GPU build of the C ABI
+               "patched_sim": "libref_array_patched_sim.so", "patched_gpu": "libref_array_patched_gpu.so"}
+
+
+def have_patched_array(backend: str) -> bool:
+    return (_DIR / "_ref" / _ARRAY_LIBS["patched_" + backend]).exists()
+
+
 def _ref_array_lib(isa: str = "sse2") -> C.CDLL:
     if isa not in _REF_ARRAYS:
-        lib_ = C.CDLL(str(_DIR / "_ref" / ("libref_array.so" if isa == "sse2" else "libref_array_avx2.so")))
+        lib_ = C.CDLL(str(_DIR / "_ref" / _ARRAY_LIBS[isa]))
         lib_.ref_array_time_populate.restype = C.c_double
         _REF_ARRAYS[isa] = lib_
     return _REF_ARRAYS[isa]
@@ -124,6 +134,19 @@ def ref_array_populate(cfg: abi.Config, batch: abi.Batch, sample_rows=None, n_th
     err_hap, ext = C.c_uint32(0), C.c_uint32(0)
     code = _ref_array_lib(isa).ref_array_populate(C.byref(a), _p(out), _p(mg) if merged else None, C.byref(err_hap), C.byref(ext))
     return code, out[:n_haps * n_rows], (mg[:n_haps * n_rows] if merged else None), err_hap.value, ext.value
+
+
+def ref_array_exercise(cfg: abi.Config, batch: abi.Batch, sample_rows, keep, n_threads: int = 1, lib: str = "sse2"):
+    """populate() + every read-back method of HaplotypeLikelihoodArray (oracle/ref_array_bridge.cpp: ref_array_exercise) on the unpatched
+    reference class (lib "sse2"/"avx2") or on the class with INTEGRATION.md's patch applied (lib "patched_sim"/"patched_gpu").
+    Returns (code, sections [6, H, rows], flags [5], err_hap, required_extension)."""
+    a, (keep_alive, rows, n_haps, n_rows) = _ref_array_args(cfg, batch, sample_rows, n_threads)
+    sec = np.full(6 * max(n_haps * n_rows, 1), np.nan)
+    flags = np.zeros(5, np.uint32)
+    kp = np.ascontiguousarray(keep, dtype=np.uint32)
+    err_hap, ext = C.c_uint32(0), C.c_uint32(0)
+    code = _ref_array_lib(lib).ref_array_exercise(C.byref(a), _p(kp), len(kp), _p(sec), _p(flags), C.byref(err_hap), C.byref(ext))
+    return code, sec[:6 * n_haps * n_rows].reshape(6, n_haps, n_rows), flags, err_hap.value, ext.value
 
 
 def ref_isa_supported(isa: str) -> bool:

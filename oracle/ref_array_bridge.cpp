@@ -178,3 +178,123 @@ extern "C" double ref_array_time_populate(const ref_array_args* a, int reps)
     return seconds;
 }
 
+
+
+// Every read-back method of the class after one populate(), for tests/test_integration_patch.py (the same bridge is compiled against the
+// unpatched reference class and against the class with INTEGRATION.md's patch applied, oracle/apply_integration_patch.py):
+//   sec[0] operator()(sample, Haplotype)            sec[1] extract_sample(sample).at(haplotype)
+//   sec[2] prime(sample) + operator[](Haplotype)    sec[3] merge_samples(all) + operator[](IndexedHaplotype)
+//   sec[4] merge_samples({first, last sample}) + operator[](Haplotype)   (rows of those two samples only, row-major per haplotype)
+//   sec[5] after reset(kept haplotypes): operator()(sample, IndexedHaplotype) of the kept rows, [n_keep][n_rows]
+// each of sec[0..3] is [n_haps][n_rows]; flags[0] = num_likelihoods() when primed with sample 0, flags[1] = haplotypes().size() after reset,
+// flags[2] = contains(dropped haplotype) after reset, flags[3] = contains(kept haplotype), flags[4] = is_empty() after clear().
+// returns 0 ok, 1 ShortHaplotypeError (as ref_array_populate), 2.. shape mismatch
+extern "C" int ref_array_exercise(const ref_array_args* a, const uint32_t* keep, uint32_t n_keep, double* sec, uint32_t* flags, uint32_t* err_hap, uint32_t* ext)
+{
+    std::vector<Vectors> vecs(a->n_haps);
+    MappableBlock<Haplotype> haps(a->n_haps);
+    for (uint32_t h = 0; h < a->n_haps; ++h) {
+        const uint32_t o = a->hap_off[h], n = a->hap_off[h + 1] - o;
+        auto& v = vecs[h];
+        v.go.assign(a->gap_open + o, a->gap_open + o + n); v.ge.assign(a->gap_extend + o, a->gap_extend + o + n);
+        v.mask_f.assign(a->mask_f + o, a->mask_f + o + n); v.mask_r.assign(a->mask_r + o, a->mask_r + o + n);
+        v.prior_f.assign(a->prior_f + o, a->prior_f + o + n); v.prior_r.assign(a->prior_r + o, a->prior_r + o + n);
+        haps[h].sequence_.assign(a->hap_bases + o, a->hap_bases + o + n); haps[h].begin_ = a->hap_begin[h]; haps[h].payload_ = &v;
+    }
+    auto make_read = [&](uint32_t r) {
+        AlignedRead x; const uint32_t o = a->read_off[r], n = a->read_off[r + 1] - o;
+        x.sequence_.assign(a->read_bases + o, a->read_bases + o + n); x.base_qualities_.assign(a->quals + o, a->quals + o + n);
+        x.mapping_quality_ = a->mapq[r]; x.reverse_ = a->reverse[r] != 0; x.begin_ = a->read_begin[r];
+        return x;
+    };
+    std::vector<SampleName> samples;
+    for (uint32_t s = 0; s < a->n_samples; ++s) { char nm[16]; std::snprintf(nm, sizeof nm, "s%04u", s); samples.emplace_back(nm); }
+    HaplotypeLikelihoodModel::Config cfg;
+    cfg.use_mapping_quality = a->use_mapping_quality != 0; cfg.mapping_quality_cap = static_cast<std::uint8_t>(a->mapping_quality_cap);
+    if (a->mapping_quality_cap_trigger >= 0) cfg.mapping_quality_cap_trigger = static_cast<std::uint8_t>(a->mapping_quality_cap_trigger);
+    cfg.use_flank_state = a->use_flank_state != 0; cfg.max_indel_error = static_cast<unsigned>(a->max_indel_error); cfg.use_int_scores = a->use_int_scores != 0;
+    HaplotypeLikelihoodModel model {std::make_unique<GivenSnvModel>(), std::make_unique<GivenIndelModel>(), cfg};
+    const bool can_flank = model.can_use_flank_state();
+    HaplotypeLikelihoodArray arr {std::move(model), a->n_haps, samples};
+    boost::optional<HaplotypeLikelihoodArray::FlankState> fs;
+    if (a->has_flank && can_flank) fs = HaplotypeLikelihoodArray::FlankState {a->lhs_flank, a->rhs_flank};
+    std::unique_ptr<ThreadPool> pool;
+    HaplotypeLikelihoodArray::OptionalThreadPool workers;
+    if (a->n_threads > 2) { pool = std::make_unique<ThreadPool>(static_cast<std::size_t>(a->n_threads)); workers = *pool; }
+    try {
+        if (!a->row_off) {
+            ReadMap reads;
+            for (uint32_t s = 0; s < a->n_samples; ++s) { auto& dst = reads[samples[s]]; for (uint32_t r = a->sample_row_off[s]; r < a->sample_row_off[s + 1]; ++r) dst.push_back(make_read(r)); }
+            arr.populate(reads, haps, fs, workers);
+        } else {
+            TemplateMap reads;
+            for (uint32_t s = 0; s < a->n_samples; ++s) {
+                auto& dst = reads[samples[s]];
+                for (uint32_t row = a->sample_row_off[s]; row < a->sample_row_off[s + 1]; ++row) {
+                    AlignedTemplate t;
+                    for (uint32_t r = a->row_off[row]; r < a->row_off[row + 1]; ++r) t.push_back(make_read(r));
+                    dst.push_back(std::move(t));
+                }
+            }
+            arr.populate(reads, haps, fs, workers);
+        }
+    } catch (const HaplotypeLikelihoodModel::ShortHaplotypeError& e) {
+        *ext = static_cast<uint32_t>(e.required_extension()); *err_hap = ~0u;
+        for (uint32_t h = 0; h < a->n_haps; ++h) if (&e.haplotype() == &haps[h] || e.haplotype() == haps[h]) { *err_hap = h; break; }
+        return 1;
+    }
+    const std::size_t H = a->n_haps, NR = a->n_rows, plane = H * NR;
+    auto rows_of = [&](uint32_t s) { return a->sample_row_off[s + 1] - a->sample_row_off[s]; };
+    for (uint32_t s = 0; s < a->n_samples; ++s) {
+        const auto ex = arr.extract_sample(samples[s]);
+        arr.prime(samples[s]);
+        if (!arr.is_primed() || arr.num_likelihoods() != rows_of(s) || arr.num_likelihoods(samples[s]) != rows_of(s)) return 2;
+        for (uint32_t h = 0; h < H; ++h) {
+            const auto& v0 = arr(samples[s], haps[h]);
+            const auto& v1 = ex.at(haps[h]).get();
+            const auto& v2 = arr[haps[h]];
+            if (v0.size() != rows_of(s) || v1.size() != rows_of(s) || v2.size() != rows_of(s)) return 3;
+            for (std::size_t i = 0; i < v0.size(); ++i) {
+                const std::size_t at = h * NR + a->sample_row_off[s] + i;
+                sec[at] = v0[i]; sec[plane + at] = v1[i]; sec[2 * plane + at] = v2[i];
+            }
+        }
+        arr.unprime();
+        if (arr.is_primed()) return 4;
+    }
+    arr.prime(samples[0]); flags[0] = static_cast<uint32_t>(arr.num_likelihoods()); arr.unprime();
+    {
+        const auto m = arr.merge_samples();
+        for (uint32_t h = 0; h < H; ++h) {
+            const auto& v = m[IndexedHaplotype<> {h}];
+            if (v.size() != NR) return 5;
+            for (std::size_t i = 0; i < NR; ++i) sec[3 * plane + h * NR + i] = v[i];
+        }
+        const std::vector<SampleName> two {samples.front(), samples.back()};
+        const auto m2 = arr.merge_samples(two, SampleName {"both"});
+        const std::size_t n2 = rows_of(0) + rows_of(a->n_samples - 1);
+        for (uint32_t h = 0; h < H; ++h) {
+            const auto& v = m2[haps[h]];
+            if (v.size() != n2) return 6;
+            for (std::size_t i = 0; i < n2; ++i) sec[4 * plane + h * NR + i] = v[i];
+        }
+    }
+    MappableBlock<Haplotype> kept;
+    for (uint32_t k = 0; k < n_keep; ++k) kept.push_back(haps[keep[k]]);
+    arr.reset(kept);
+    flags[1] = static_cast<uint32_t>(arr.haplotypes().size());
+    uint32_t dropped = ~0u;
+    for (uint32_t h = 0; h < H && dropped == ~0u; ++h) { bool in = false; for (uint32_t k = 0; k < n_keep; ++k) in = in || keep[k] == h; if (!in) dropped = h; }
+    flags[2] = dropped != ~0u && arr.contains(haps[dropped]) ? 1 : 0;     // the reference leaves dropped haplotypes in its index map (cpp:331-355); whatever it says, the patched class must say the same
+    flags[3] = n_keep && arr.contains(haps[keep[0]]) ? 1 : 0;
+    for (uint32_t k = 0; k < n_keep; ++k)
+        for (uint32_t s = 0; s < a->n_samples; ++s) {
+            const auto& v = arr(samples[s], IndexedHaplotype<> {k});
+            const auto& w = arr(samples[s], haps[keep[k]]);
+            if (v.size() != rows_of(s) || &v != &w) return 7;
+            for (std::size_t i = 0; i < v.size(); ++i) sec[5 * plane + k * NR + a->sample_row_off[s] + i] = v[i];
+        }
+    arr.clear();
+    flags[4] = arr.is_empty() ? 1 : 0;
+    return 0;
+}

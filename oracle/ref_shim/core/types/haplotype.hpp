@@ -23,6 +23,8 @@ namespace debug { template <typename S> void print_variant_alleles(S&, const Hap
 inline std::size_t sequence_size(const Haplotype& h) noexcept { return h.sequence_.size(); }
 inline bool contains(const Haplotype&, const AlignedRead&) noexcept { return true; }                       // concepts/mappable.hpp
 inline std::int64_t begin_distance(const Haplotype& h, const AlignedRead& r) noexcept { return r.begin_ - h.begin_; }
+inline std::int64_t mapped_begin(const Haplotype& h) noexcept { return h.begin_; }                        // concepts/mappable.hpp:181
+inline std::int64_t mapped_begin(const AlignedRead& r) noexcept { return r.begin_; }
 } // namespace octopus
 namespace std {
 template <> struct hash<reference_wrapper<const octopus::Haplotype>>

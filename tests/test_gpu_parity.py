@@ -289,3 +289,11 @@ def test_gpu_server_answers_a_malformed_call_with_einval():
 
 def test_gpu_leading_slice_without_pairs_still_hashes_the_reads():
     cp.check_leading_haplotypes_without_reads("gpu", TOL)
+
+
+def test_gpu_patched_reference_class_equals_the_unpatched_one():
+    """INTEGRATION.md's patch compiled into the reference's own class, linked against liboct_phmm.so (prebuilt oracle/_ref/libref_array_patched_gpu.so)."""
+    if not (oracle.have_ref_array() and oracle.have_patched_array("gpu")):
+        pytest.skip("oracle/_ref patched build absent")
+    import check_integration_patch as ci
+    assert ci.check("gpu", TOL) > 2000
