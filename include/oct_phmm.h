@@ -65,6 +65,7 @@ typedef struct oct_phmm_config {
 void oct_phmm_config_default(oct_phmm_config* cfg);
 
 typedef struct oct_phmm_handle oct_phmm_handle;
+struct oct_phmm_error_model;          /* per-haplotype penalty vectors, below */
 
 /* ---- batch description ---------------------------------------------------------------------- */
 
@@ -91,7 +92,8 @@ typedef struct oct_phmm_haplotypes {
     const char*     bases;            /* Haplotype::sequence() */
     const uint32_t* offsets;          /* [n_haps+1] */
     const int64_t*  ref_begin;        /* [n_haps] mapped_region(haplotype).begin() */
-    const int8_t*   gap_open;         /* haplotype_gap_open_penalities_,  each in [0,127] */
+    const int8_t*   gap_open;         /* haplotype_gap_open_penalities_,  each in [0,127]. All six vector pointers NULL = generate them
+                                         from the handle's error model (oct_phmm_set_error_model) */
     const int8_t*   gap_extend;       /* haplotype_gap_extend_penalities_, each in [0,127] */
     const char*     snv_mask_fwd;     /* haplotype_snv_forward_mask_ */
     const int8_t*   snv_prior_fwd;    /* haplotype_snv_forward_priors_, each in [0,127] */
@@ -213,6 +215,9 @@ void oct_phmm_server_destroy(oct_phmm_server* s);
 int  oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
                               const oct_phmm_flank_state* flank, const oct_phmm_positions* positions,
                               double* out, oct_phmm_status* status);
+/* oct_phmm_set_error_model for every handle of the server: callers may then leave their six penalty-vector pointers NULL. Call it before the
+ * region threads start calling (a worker that is mid-batch keeps the model it started with). */
+int  oct_phmm_server_set_error_model(oct_phmm_server* s, const struct oct_phmm_error_model* model);
 /* calls answered and device batches run so far (calls / batches = achieved batching) */
 int  oct_phmm_server_stats(const oct_phmm_server* s, uint64_t* n_calls, uint64_t* n_batches);
 /* calls answered per device, in the order of `device_ids` */
@@ -239,6 +244,47 @@ typedef struct oct_phmm_genotype_sets {
 /* out: gt_offsets[n_sets] doubles. The batch must have been run; blocks until the result is on the host. */
 int  oct_phmm_batch_genotype_likelihoods(oct_phmm_handle* h, oct_phmm_batch* b, const oct_phmm_genotype_sets* sets,
                                          double* out, oct_phmm_status* status);
+
+/* ---- per-haplotype penalty vectors ------------------------------------------------ */
+/* The six vectors HaplotypeLikelihoodModel::reset (haplotype_likelihood_model.cpp:60-78) obtains from its two error models, computed by the
+ * library: gap open / extend from RepeatBasedIndelErrorModel::do_set_penalties (core/models/error/repeat_based_indel_error_model.cpp:67-83)
+ * with BasicRepeatBasedIndelErrorModel's table look-ups (basic_repeat_based_indel_error_model.cpp:44-103) over
+ * tandem::extract_exact_tandem_repeats(sequence, 1, 5) (lib/tandem/tandem.hpp:497-514); SNV masks and prior caps from
+ * BasicRepeatBasedSNVErrorModel::do_evaluate (repeat_based_snv_error_model.cpp:144-179). Bit-identical to those classes.
+ *
+ * A model is its tables, ALREADY EXPANDED the way the reference's constructors expand them (copy the first min(size, N) entries,
+ * fill the rest with the last one: basic_repeat_based_indel_error_model.cpp:15-34, repeat_based_snv_error_model.cpp:20-34);
+ * oct_phmm_error_model_expand does exactly that for one table. The reference's built-in parameter sets live in
+ * error_model_factory.cpp:220-517; oct_phmm_error_model_default fills in its default_model_config (PCR-free, HiSeq-2500). */
+#define OCT_PHMM_INDEL_TABLE 50
+#define OCT_PHMM_SNV_TABLE   51
+typedef struct oct_phmm_error_model {
+    int8_t  at_homopolymer_open[OCT_PHMM_INDEL_TABLE], cg_homopolymer_open[OCT_PHMM_INDEL_TABLE];
+    int8_t  dinucleotide_open[OCT_PHMM_INDEL_TABLE], trinucleotide_open[OCT_PHMM_INDEL_TABLE];
+    int8_t  homopolymer_extend[OCT_PHMM_INDEL_TABLE], dinucleotide_extend[OCT_PHMM_INDEL_TABLE], trinucleotide_extend[OCT_PHMM_INDEL_TABLE];
+    int8_t  snv_caps[3][OCT_PHMM_SNV_TABLE];   /* homopolymer, dinucleotide, trinucleotide penalty caps */
+    int32_t use_snv_model;                     /* 0: no SNV model (PacBio sequencers, error_model_factory.cpp:480-483): masks = the haplotype itself, priors = 100 (model.cpp:69-73) */
+} oct_phmm_error_model;
+void oct_phmm_error_model_default(oct_phmm_error_model* model);
+/* dst[0 .. capacity) = src[0 .. min(n, capacity)) then the last source entry repeated; n >= 1 */
+void oct_phmm_error_model_expand(int8_t* dst, uint32_t capacity, const int8_t* src, uint32_t n);
+/* The vectors of n_haps haplotypes (concatenated like oct_phmm_haplotypes, same offsets) into caller-allocated arrays of offsets[n_haps]
+ * entries each. substitution_mask (may be NULL): 1 where the haplotype's own CIGAR against the reference holds a substitution - those
+ * bases keep the maximum prior (repeat_based_snv_error_model.cpp:168-172). Host entry: haplotypes are spread over host threads; no
+ * device needed. */
+int  oct_phmm_penalty_vectors(const oct_phmm_error_model* model, uint32_t n_haps, const char* bases, const uint32_t* offsets,
+                              const uint8_t* substitution_mask,
+                              int8_t* gap_open, int8_t* gap_extend, char* snv_mask_fwd, int8_t* snv_prior_fwd, char* snv_mask_rev, int8_t* snv_prior_rev,
+                              oct_phmm_status* status);
+/* Give the handle an error model (NULL: take it away). From then on oct_phmm_populate / _batch_upload / _align / _server_populate accept an
+ * oct_phmm_haplotypes whose SIX vector pointers are all NULL and generate the vectors inside the call (HaplotypeLikelihoodModel::reset
+ * for every haplotype): on host threads for region-sized calls, on the device (one haplotype per lane) from a few thousand haplotypes. */
+int  oct_phmm_set_error_model(oct_phmm_handle* h, const oct_phmm_error_model* model);
+/* Haplotype substitution masks for the in-call generation (see oct_phmm_penalty_vectors): borrowed for the NEXT upload on this handle only; NULL = none. */
+int  oct_phmm_set_substitution_mask(oct_phmm_handle* h, const uint8_t* substitution_mask);
+/* Test seam: the vectors the last upload of this batch generated (device or host path), concatenated like the haplotypes. */
+int  oct_phmm_batch_penalty_vectors(oct_phmm_handle* h, oct_phmm_batch* b, int8_t* gap_open, int8_t* gap_extend, char* snv_mask_fwd,
+                                    int8_t* snv_prior_fwd, char* snv_mask_rev, int8_t* snv_prior_rev, oct_phmm_status* status);
 
 /* ---- realignment: best alignment per (read, haplotype) pair ---------------------- */
 /* HaplotypeLikelihoodModel::align (haplotype_likelihood_model.cpp:322-431; compute_optimal_alignment :335-395,

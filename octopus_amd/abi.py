@@ -242,10 +242,20 @@ class Batch:
         return Reads(self.n_reads, _ptr(self.read_bases), _ptr(self.read_quals), _ptr(self.read_offsets),
                      _ptr(self.mapq), _ptr(self.reverse), _ptr(self.read_ref_begin), self.n_rows, _ptr(self.row_offsets))
 
+    def without_penalty_vectors(self) -> "Batch":
+        """The same batch with its six per-haplotype vectors left to the library (all six pointers NULL: oct_phmm_set_error_model)."""
+        import copy
+        b = copy.copy(self)
+        b._keep = []
+        for name in ("gap_open", "gap_extend", "snv_mask_fwd", "snv_prior_fwd", "snv_mask_rev", "snv_prior_rev"):
+            setattr(b, name, None)
+        return b
+
     def c_haps(self) -> Haplotypes:
         for name in ("hap_bases", "hap_offsets", "hap_ref_begin", "gap_open", "gap_extend", "snv_mask_fwd",
                      "snv_prior_fwd", "snv_mask_rev", "snv_prior_rev"):
-            setattr(self, name, np.ascontiguousarray(getattr(self, name)))
+            if getattr(self, name) is not None:
+                setattr(self, name, np.ascontiguousarray(getattr(self, name)))
         return Haplotypes(self.n_haps, _ptr(self.hap_bases), _ptr(self.hap_offsets), _ptr(self.hap_ref_begin),
                           _ptr(self.gap_open), _ptr(self.gap_extend), _ptr(self.snv_mask_fwd), _ptr(self.snv_prior_fwd),
                           _ptr(self.snv_mask_rev), _ptr(self.snv_prior_rev))
@@ -328,3 +338,26 @@ def alignments_result(arrays: dict, n_pairs: int, max_cigar_ops: int) -> dict:
     strings = ["".join(f"{int(v) >> 4}{CIGAR_OPS.get(int(v) & 15, '?')}" for v in cig[e, :min(int(n[e]), max_cigar_ops)]) for e in range(n_pairs)]
     return dict(mapping_position=arrays["mapping_position"][:n_pairs].copy(), likelihood=arrays["likelihood"][:n_pairs].copy(),
                 n_cigar_ops=n.copy(), cigar=cig.copy(), cigar_strings=strings)
+
+
+class ErrorModel(C.Structure):
+    """oct_phmm_error_model (include/oct_phmm.h): the error models' tables as the reference's constructors expand them."""
+    _fields_ = [(n, C.c_int8 * 50) for n in ("at_homopolymer_open", "cg_homopolymer_open", "dinucleotide_open", "trinucleotide_open",
+                                            "homopolymer_extend", "dinucleotide_extend", "trinucleotide_extend")] + \
+               [("snv_caps", (C.c_int8 * 51) * 3), ("use_snv_model", C.c_int32)]
+
+    @staticmethod
+    def make(at_open, cg_open, di_open, tri_open, snv_caps, homo_ext=(3, 3, 3, 3, 3, 3, 4, 5, 6, 6, 8, 8, 7, 6, 5, 4, 3),
+             di_ext=(3, 3, 5, 4, 3, 2), tri_ext=(3, 3, 5, 4, 3, 2)):
+        m = ErrorModel()
+        def fill(dst, src, n):                      # copy(): first min(size, N) entries, the rest = the last one
+            for i in range(n):
+                dst[i] = src[i] if i < len(src) else src[-1]
+        for name, src in (("at_homopolymer_open", at_open), ("cg_homopolymer_open", cg_open), ("dinucleotide_open", di_open),
+                          ("trinucleotide_open", tri_open), ("homopolymer_extend", homo_ext), ("dinucleotide_extend", di_ext),
+                          ("trinucleotide_extend", tri_ext)):
+            fill(getattr(m, name), src, 50)
+        for p in range(3):
+            fill(m.snv_caps[p], snv_caps[p], 51)
+        m.use_snv_model = 1
+        return m

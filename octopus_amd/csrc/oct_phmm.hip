@@ -22,6 +22,7 @@
 #include "phmm_rt.hpp"
 #include "phmm_kernels.hpp"
 #include "phmm_readout.hpp"
+#include "phmm_error_model.hpp"
 
 using namespace octphmm;
 
@@ -90,6 +91,9 @@ struct oct_phmm_handle {
     // traceback scratch budget: large, so that all traceback tasks of a batch run in ONE DP launch and ONE walk launch (the walk
     // is a latency-bound pointer chase that needs every task in flight to hide it); MI355X has 288 GB. OCT_PHMM_BP_BUDGET_GB overrides.
     size_t bp_budget = (size_t)96 << 30;
+    // error model for in-call penalty vectors (oct_phmm_set_error_model); sub_mask is borrowed for the next upload only
+    bool has_model = false; oct_phmm_error_model model {}; const uint8_t* sub_mask = nullptr;
+    oct_phmm_error_model* d_model = nullptr;             // device copy, made on first use
 };
 
 struct oct_phmm_batch {
@@ -128,6 +132,7 @@ struct oct_phmm_batch {
     bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
     uint32_t* d_blk_hap = nullptr; uint32_t* d_blk_read0 = nullptr; uint32_t n_map_blocks = 0;
     uint32_t map_reads_per_block = 64;   // reads one k_kmer_map workgroup walks with the haplotype's bins staged once; fewer for small batches (latency)
+    std::vector<int8_t> gen_go, gen_ge, gen_pf, gen_pr; std::vector<char> gen_mf, gen_mr;   // penalty vectors generated on the host for this batch
     double dp_ms = 0; uint32_t dp_launches = 0;
     std::vector<std::pair<rt::Event, rt::Event>> timers;       // one (start, stop) pair per DP launch
     std::vector<int> timer_kind;
@@ -439,6 +444,123 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
+// per-haplotype penalty vectors (phmm_error_model.hpp): host threads, or one device lane per haplotype
+// ---------------------------------------------------------------------------------------------------------------
+struct PenaltyOut { int8_t* go; int8_t* ge; uint8_t* mf; int8_t* pf; uint8_t* mr; int8_t* pr; };
+
+OCT_KERNEL(k_penalty_vectors)(const oct_phmm_error_model* model, const uint8_t* hbases, const uint32_t* hoff, uint32_t hap0, uint32_t hap1,
+                              const uint8_t* sub_mask, uint32_t* workspace, size_t words_per_hap, PenaltyOut out, uint32_t* overflow)
+{
+    const uint32_t h = hap0 + hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (h >= hap1) return;
+    const uint32_t o = hoff[h], n = hoff[h + 1] - o;
+    uint32_t* w = workspace + (size_t)(h - hap0) * words_per_hap;
+    const int rc = em::penalty_vectors(*model, hbases + o, n, sub_mask ? sub_mask + o : nullptr, w, 1, out.go + o, out.ge + o, out.mf + o, out.pf + o, out.mr + o, out.pr + o);
+    if (rc != em::kOk) overflow[h] = 1;
+}
+
+namespace {
+
+// one haplotype on the calling thread; the workspace grows until the run lists fit (pathological repeat structure only)
+void host_penalty_vectors_one(const oct_phmm_error_model& m, const uint8_t* s, uint32_t n, const uint8_t* sub, std::vector<uint32_t>& w, PenaltyOut out, size_t o)
+{
+    for (uint32_t grow = 1; ; grow *= 4) {
+        const size_t need = em::workspace_words(n, grow);
+        if (w.size() < need) w.resize(need);
+        if (em::penalty_vectors(m, s, n, sub, w.data(), grow, out.go + o, out.ge + o, out.mf + o, out.pf + o, out.mr + o, out.pr + o) == em::kOk) return;
+    }
+}
+
+void host_penalty_vectors(const oct_phmm_error_model& m, uint32_t n_haps, const uint8_t* bases, const uint32_t* off, const uint8_t* sub, PenaltyOut out)
+{
+    unsigned T = std::thread::hardware_concurrency(); T = T ? std::min(T, 16u) : 1;
+    const uint32_t n_bases = n_haps ? off[n_haps] : 0;
+    if (n_bases < 2000 || n_haps < 4) T = 1;                           // a thread start costs more than a few short haplotypes
+    T = std::min<unsigned>(T, std::max<uint32_t>(1, n_haps / 2));
+    std::atomic<uint32_t> next {0};
+    auto work = [&] {
+        std::vector<uint32_t> w;
+        for (uint32_t h = next.fetch_add(1); h < n_haps; h = next.fetch_add(1))
+            host_penalty_vectors_one(m, bases + off[h], off[h + 1] - off[h], sub ? sub + off[h] : nullptr, w, out, off[h]);
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+
+bool model_is_valid(const oct_phmm_error_model* m)
+{
+    const int8_t* p = (const int8_t*)m; bool ok = true;
+    for (size_t i = 0; i < offsetof(oct_phmm_error_model, use_snv_model); ++i) ok = ok && p[i] >= 0;
+    return ok;
+}
+
+} // namespace
+
+extern "C" void oct_phmm_error_model_expand(int8_t* dst, uint32_t capacity, const int8_t* src, uint32_t n)
+{
+    if (!dst || !src || !n) return;
+    for (uint32_t i = 0; i < capacity; ++i) dst[i] = src[i < n ? i : n - 1];
+}
+
+extern "C" void oct_phmm_error_model_default(oct_phmm_error_model* m)
+{
+    if (!m) return;
+    // default_model_config = {PCR-free, HiSeq-2500} (error_model_factory.hpp:26-28): indel open tables error_model_factory.cpp:231-238, extension
+    // tables = BasicRepeatBasedIndelErrorModel::Parameters' defaults (basic_repeat_based_indel_error_model.hpp:26-28), SNV caps :488-495
+    static const int8_t at[] = {45,45,43,43,41,38,35,32,29,25,21,20,19,18,17,17,16,16,15,14,14,13,12,12,11,10,9,9,8,7,7,7,6,6,6,6,6,6,6,6,6,6,6,6,6,6,6,6,6,5};
+    static const int8_t cg[] = {45,45,45,41,39,34,30,24,21,18,15,13,12,10,8,7,7,6,6,6,6,6,6,5,5,5,5,5,5,5,5,5,5,5,5,5,5,5,5,5,3};
+    static const int8_t di[] = {45,45,42,40,35,29,26,24,22,21,20,19,18,18,17,17,16,16,15,15,15,14,13,13,12,12,11,11,10,10,9,9,9,7,7,7,6,6,5,4,4,4,4,4,4,4,4,4,3};
+    static const int8_t tri[] = {45,45,40,36,30,28,26,25,23,22,22,22,21,21,20,20,20,18,17,16,14,14,14,14,12,11,11,11,10,10,10,7,7,7,4,4,4,4,4,4,4,3};
+    static const int8_t he[] = {3,3,3,3,3,3,4,5,6,6,8,8,7,6,5,4,3};
+    static const int8_t de[] = {3,3,5,4,3,2};
+    static const int8_t s1[] = {125,125,60,55,50,30,20,15,12,12,10,10,10,10,8,7,6,6,6,6,6,6,5,5,5,5,5,5,5,5,5,5,5,4,4,4,3,3,3,3,2,2,2,2,2,1,1,1,1,1,1};
+    static const int8_t s2[] = {125,125,60,60,52,52,38,38,22,22,17,17,15,15,13,13,10,10,10,10,8,8,7,6,6,6,6,6,6,5,5,5,5,4,4,4,3,3,3,3,2,2,2,2,2,1,1,1,1,1,1};
+    static const int8_t s3[] = {125,125,125,55,55,55,40,40,40,25,25,25,19,19,19,11,11,11,9,9,9,7,7,6,6,6,6,6,6,5,5,5,5,4,4,4,3,3,3,3,2,2,2,2,2,1,1,1,1,1,1};
+    memset(m, 0, sizeof(*m));
+#define OCT_EXPAND(field, cap, src) oct_phmm_error_model_expand(m->field, cap, src, (uint32_t)sizeof(src))
+    OCT_EXPAND(at_homopolymer_open, OCT_PHMM_INDEL_TABLE, at); OCT_EXPAND(cg_homopolymer_open, OCT_PHMM_INDEL_TABLE, cg);
+    OCT_EXPAND(dinucleotide_open, OCT_PHMM_INDEL_TABLE, di); OCT_EXPAND(trinucleotide_open, OCT_PHMM_INDEL_TABLE, tri);
+    OCT_EXPAND(homopolymer_extend, OCT_PHMM_INDEL_TABLE, he); OCT_EXPAND(dinucleotide_extend, OCT_PHMM_INDEL_TABLE, de); OCT_EXPAND(trinucleotide_extend, OCT_PHMM_INDEL_TABLE, de);
+    OCT_EXPAND(snv_caps[0], OCT_PHMM_SNV_TABLE, s1); OCT_EXPAND(snv_caps[1], OCT_PHMM_SNV_TABLE, s2); OCT_EXPAND(snv_caps[2], OCT_PHMM_SNV_TABLE, s3);
+#undef OCT_EXPAND
+    m->use_snv_model = 1;
+}
+
+extern "C" int oct_phmm_penalty_vectors(const oct_phmm_error_model* model, uint32_t n_haps, const char* bases, const uint32_t* offsets,
+                                        const uint8_t* substitution_mask, int8_t* gap_open, int8_t* gap_extend, char* snv_mask_fwd,
+                                        int8_t* snv_prior_fwd, char* snv_mask_rev, int8_t* snv_prior_rev, oct_phmm_status* status)
+{
+    if (!model || (n_haps && (!bases || !offsets || !gap_open || !gap_extend || !snv_mask_fwd || !snv_prior_fwd || !snv_mask_rev || !snv_prior_rev)))
+        return fail(status, OCT_PHMM_EINVAL, "null argument");
+    if (n_haps && !monotone(offsets, n_haps)) return fail(status, OCT_PHMM_EINVAL, "offsets not monotone");
+    if (!model_is_valid(model)) return fail(status, OCT_PHMM_EINVAL, "negative penalty in the error model's tables");
+    try {
+        host_penalty_vectors(*model, n_haps, (const uint8_t*)bases, offsets, substitution_mask,
+                             PenaltyOut {gap_open, gap_extend, (uint8_t*)snv_mask_fwd, snv_prior_fwd, (uint8_t*)snv_mask_rev, snv_prior_rev});
+    } catch (const std::exception&) { return fail(status, OCT_PHMM_EHIP, "host allocation"); }
+    return ok(status);
+}
+
+extern "C" int oct_phmm_set_error_model(oct_phmm_handle* h, const oct_phmm_error_model* model)
+{
+    if (!h) return OCT_PHMM_EINVAL;
+    if (model && !model_is_valid(model)) return OCT_PHMM_EINVAL;
+    h->has_model = model != nullptr;
+    if (model) h->model = *model;
+    if (h->d_model) { rt::set_device(h->cfg.device_id); rt::stream_sync(h->stream); h->pool.release(h->d_model); h->d_model = nullptr; }
+    return OCT_PHMM_OK;
+}
+
+extern "C" int oct_phmm_set_substitution_mask(oct_phmm_handle* h, const uint8_t* substitution_mask)
+{
+    if (!h) return OCT_PHMM_EINVAL;
+    h->sub_mask = substitution_mask;
+    return OCT_PHMM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // lifecycle
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int oct_phmm_device_count(void)
@@ -554,19 +676,39 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     return upload_impl(h, R, H, regions, flank, positions, out, status, false, 0);
 }
 
-static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
+static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
                        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                        const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
                        bool one_shot)
 {
-    if (!h || !R || !H || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
+    if (!h || !R || !H_in || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
     *out = nullptr;
+    oct_phmm_haplotypes Hv = *H_in;
+    const oct_phmm_haplotypes* H = &Hv;
+    const uint8_t* sub_mask = h->sub_mask; h->sub_mask = nullptr;          // borrowed for this upload only
+    const int n_vec = (H->gap_open ? 1 : 0) + (H->gap_extend ? 1 : 0) + (H->snv_mask_fwd ? 1 : 0) + (H->snv_prior_fwd ? 1 : 0) + (H->snv_mask_rev ? 1 : 0) + (H->snv_prior_rev ? 1 : 0);
+    const bool generate = H->n_haps && n_vec == 0;                           // HaplotypeLikelihoodModel::reset inside the call (oct_phmm_set_error_model)
+    if (generate && !h->has_model) return fail(status, OCT_PHMM_EINVAL, "penalty vectors are NULL and the handle has no error model");
     if ((R->n_reads && (!R->bases || !R->qualities || !R->offsets || !R->mapping_quality || !R->reverse_strand || !R->ref_begin))
-        || (H->n_haps && (!H->bases || !H->offsets || !H->ref_begin || !H->gap_open || !H->gap_extend || !H->snv_mask_fwd
-                          || !H->snv_prior_fwd || !H->snv_mask_rev || !H->snv_prior_rev)))
+        || (H->n_haps && (!H->bases || !H->offsets || !H->ref_begin || (!generate && n_vec != 6))))
         return fail(status, OCT_PHMM_EINVAL, "null array");
     if (!R->offsets || !H->offsets || !monotone(R->offsets, R->n_reads) || !monotone(H->offsets, H->n_haps))
         return fail(status, OCT_PHMM_EINVAL, "offsets not monotone");
+    // Where the vectors are made: region-sized calls on host threads (a lone GPU lane is far slower than a host core, and the call is
+    // latency-bound), big batches on the device, one haplotype per lane (tens of thousands of lanes beat sixteen cores). OCT_PHMM_PENALTIES=host|device overrides.
+    bool gen_device = generate && H->n_haps >= 2048;
+    if (const char* e = getenv("OCT_PHMM_PENALTIES")) gen_device = generate && e[0] == 'd';
+    std::vector<int8_t> gen_go, gen_ge, gen_pf, gen_pr; std::vector<char> gen_mf, gen_mr;
+    if (generate && !gen_device) {
+        const size_t nb = H->offsets[H->n_haps];
+        try {
+            gen_go.resize(nb + 1); gen_ge.resize(nb + 1); gen_pf.resize(nb + 1); gen_pr.resize(nb + 1); gen_mf.resize(nb + 1); gen_mr.resize(nb + 1);
+            host_penalty_vectors(h->model, H->n_haps, (const uint8_t*)H->bases, H->offsets, sub_mask,
+                                 PenaltyOut {gen_go.data(), gen_ge.data(), (uint8_t*)gen_mf.data(), gen_pf.data(), (uint8_t*)gen_mr.data(), gen_pr.data()});
+        } catch (const std::exception&) { return fail(status, OCT_PHMM_EHIP, "host allocation"); }
+        Hv.gap_open = gen_go.data(); Hv.gap_extend = gen_ge.data(); Hv.snv_mask_fwd = gen_mf.data(); Hv.snv_prior_fwd = gen_pf.data();
+        Hv.snv_mask_rev = gen_mr.data(); Hv.snv_prior_rev = gen_pr.data();
+    }
     const uint32_t n_rows = R->row_offsets ? R->n_rows : R->n_reads;
     if (R->row_offsets && (!monotone(R->row_offsets, n_rows) || R->row_offsets[0] != 0 || R->row_offsets[n_rows] != R->n_reads))
         return fail(status, OCT_PHMM_EINVAL, "row_offsets must partition the reads");
@@ -579,7 +721,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             qor.fetch_or(v);
         });
         if (qor.load() & 0x80u) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
-        host_parallel(n_hap_bases, (size_t)4 << 20, [&](size_t lo, size_t hi) {
+        if (!gen_device) host_parallel(n_hap_bases, (size_t)4 << 20, [&](size_t lo, size_t hi) {       // (device-made vectors come out of validated tables)
             uint32_t v = 0;
             for (size_t i = lo; i < hi; ++i)
                 v |= (uint32_t)(uint8_t)H->gap_open[i] | (uint8_t)H->gap_extend[i] | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
@@ -645,6 +787,13 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             }
             std::lock_guard<std::mutex> lk(mx); sum_q_max = std::max(sum_q_max, best); t_min = std::min(t_min, shortest);
         });
+        if (gen_device) {                                   // the vectors do not exist yet: bound them by the model's tables
+            const oct_phmm_error_model& m = h->model;
+            for (int i = 0; i < OCT_PHMM_INDEL_TABLE; ++i) {
+                gomax = std::max<uint32_t>(gomax, std::max(std::max(m.at_homopolymer_open[i], m.cg_homopolymer_open[i]), std::max(m.dinucleotide_open[i], m.trinucleotide_open[i])));
+                gemax = std::max<uint32_t>(gemax, std::max(m.homopolymer_extend[i], std::max(m.dinucleotide_extend[i], m.trinucleotide_extend[i])));
+            }
+        } else
         host_parallel(n_hap_bases, (size_t)4 << 20, [&](size_t lo, size_t hi) {
             uint32_t a = 0, e = 0;
             for (size_t i = lo; i < hi; ++i) { a = std::max<uint32_t>(a, (uint32_t)H->gap_open[i]); e = std::max<uint32_t>(e, (uint32_t)H->gap_extend[i]); }
@@ -699,12 +848,20 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     pk.upload((const uint8_t*)H->bases, n_hap_bases, &d.hbases);
     pk.upload(H->offsets, (size_t)H->n_haps + 1, &d.hoff);
     pk.upload(H->ref_begin, H->n_haps, &d.hbegin);
+    const uint8_t* d_sub_mask = nullptr;
+    if (gen_device) {                                       // written by k_penalty_vectors below
+        pk.dalloc((int8_t**)&d.go, (size_t)n_hap_bases + 16); pk.dalloc((int8_t**)&d.ge, (size_t)n_hap_bases + 16);
+        pk.dalloc((uint8_t**)&d.maskF, (size_t)n_hap_bases + 16); pk.dalloc((int8_t**)&d.priorF, (size_t)n_hap_bases + 16);
+        pk.dalloc((uint8_t**)&d.maskR, (size_t)n_hap_bases + 16); pk.dalloc((int8_t**)&d.priorR, (size_t)n_hap_bases + 16);
+        if (sub_mask) pk.upload(sub_mask, n_hap_bases, &d_sub_mask);
+    } else {
     pk.upload(H->gap_open, n_hap_bases, &d.go);
     pk.upload(H->gap_extend, n_hap_bases, &d.ge);
     pk.upload((const uint8_t*)H->snv_mask_fwd, n_hap_bases, &d.maskF);
     pk.upload(H->snv_prior_fwd, n_hap_bases, &d.priorF);
     pk.upload((const uint8_t*)H->snv_mask_rev, n_hap_bases, &d.maskR);
     pk.upload(H->snv_prior_rev, n_hap_bases, &d.priorR);
+    }
     pk.upload(hap_region.data(), hap_region.size(), &d.hap_region);
     pk.upload(hap_out_off.data(), hap_out_off.size(), &d.hap_out_off);
     pk.upload(hap_pair_off.data(), hap_pair_off.size(), &d.hap_pair_off);
@@ -799,6 +956,38 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     if (positions) {
         RT(rt::h2d(d.pos, h_pos.data(), (size_t)b->n_pairs * S * sizeof(uint32_t), s));
         RT(rt::h2d(d.npos, h_npos.data(), (size_t)b->n_pairs, s));
+    }
+    if (gen_device) {
+        // HaplotypeLikelihoodModel::reset for every haplotype on the device: one lane per haplotype, its workspace in HBM, in chunks that keep
+        // the workspace below 2 GB; a haplotype whose run lists outgrow the fixed workspace (pathological repeats) is redone on the host
+        if (!h->d_model) {
+            void* p = nullptr; RT(h->pool.alloc(&p, sizeof(oct_phmm_error_model))); h->d_model = (oct_phmm_error_model*)p;
+            RT(rt::h2d(h->d_model, &h->model, sizeof(oct_phmm_error_model), s)); RT(rt::stream_sync(s));
+        }
+        const size_t words = em::workspace_words(b->lh_cap, 1);
+        const uint32_t chunk = (uint32_t)std::max<size_t>(256, std::min<size_t>(H->n_haps, (((size_t)2 << 30) / (words * 4)) / 256 * 256));
+        void* ws = nullptr; RT(h->pool.alloc(&ws, (size_t)chunk * words * 4));
+        void* ovf = nullptr; RT(h->pool.alloc(&ovf, ((size_t)H->n_haps + 1) * 4));
+        RT(rt::dev_memset(ovf, 0, ((size_t)H->n_haps + 1) * 4, s));
+        const PenaltyOut po {(int8_t*)d.go, (int8_t*)d.ge, (uint8_t*)d.maskF, (int8_t*)d.priorF, (uint8_t*)d.maskR, (int8_t*)d.priorR};
+        for (uint32_t h0 = 0; h0 < H->n_haps; h0 += chunk) {
+            const uint32_t h1 = std::min<uint32_t>(H->n_haps, h0 + chunk);
+            OCT_LAUNCH(k_penalty_vectors, (h1 - h0 + 63) / 64, 64, 0, s, (const oct_phmm_error_model*)h->d_model, d.hbases, d.hoff, h0, h1, d_sub_mask,
+                       (uint32_t*)ws, words, po, (uint32_t*)ovf);
+            RT(rt::launch_ok());
+        }
+        std::vector<uint32_t> flags(H->n_haps);
+        RT(rt::d2h(flags.data(), ovf, (size_t)H->n_haps * 4, s)); RT(rt::stream_sync(s));
+        h->pool.release(ws); h->pool.release(ovf);
+        std::vector<uint32_t> w;
+        for (uint32_t hp = 0; hp < H->n_haps; ++hp) if (flags[hp]) {
+            const uint32_t o = H->offsets[hp], n = H->offsets[hp + 1] - o;
+            std::vector<int8_t> go(n), ge(n), pf(n), pr(n); std::vector<uint8_t> mf(n), mr(n);
+            host_penalty_vectors_one(h->model, (const uint8_t*)H->bases + o, n, sub_mask ? sub_mask + o : nullptr, w, PenaltyOut {go.data(), ge.data(), mf.data(), pf.data(), mr.data(), pr.data()}, 0);
+            RT(rt::h2d((void*)(d.go + o), go.data(), n, s)); RT(rt::h2d((void*)(d.ge + o), ge.data(), n, s)); RT(rt::h2d((void*)(d.maskF + o), mf.data(), n, s));
+            RT(rt::h2d((void*)(d.priorF + o), pf.data(), n, s)); RT(rt::h2d((void*)(d.maskR + o), mr.data(), n, s)); RT(rt::h2d((void*)(d.priorR + o), pr.data(), n, s));
+            RT(rt::stream_sync(s));
+        }
     }
     // per-read flags and per-base DP tables (once per batch; HaplotypeLikelihoodModel::reset analogue)
     {
@@ -1024,6 +1213,20 @@ extern "C" int oct_phmm_batch_candidate_positions(oct_phmm_handle* h, oct_phmm_b
     return ok(status);
 }
 
+extern "C" int oct_phmm_batch_penalty_vectors(oct_phmm_handle* h, oct_phmm_batch* b, int8_t* gap_open, int8_t* gap_extend, char* snv_mask_fwd,
+                                              int8_t* snv_prior_fwd, char* snv_mask_rev, int8_t* snv_prior_rev, oct_phmm_status* status)
+{
+    if (!h || !b || b->owner != h) return fail(status, OCT_PHMM_EINVAL, "bad handle/batch");
+    const size_t n = b->n_hap_bases;
+    if (n && (!gap_open || !gap_extend || !snv_mask_fwd || !snv_prior_fwd || !snv_mask_rev || !snv_prior_rev)) return fail(status, OCT_PHMM_EINVAL, "null output");
+    RT(rt::set_device(h->cfg.device_id));
+    RT(rt::d2h(gap_open, b->d.go, n, h->stream)); RT(rt::d2h(gap_extend, b->d.ge, n, h->stream));
+    RT(rt::d2h(snv_mask_fwd, b->d.maskF, n, h->stream)); RT(rt::d2h(snv_prior_fwd, b->d.priorF, n, h->stream));
+    RT(rt::d2h(snv_mask_rev, b->d.maskR, n, h->stream)); RT(rt::d2h(snv_prior_rev, b->d.priorR, n, h->stream));
+    RT(rt::stream_sync(h->stream));
+    return ok(status);
+}
+
 extern "C" int oct_phmm_batch_stats(const oct_phmm_batch* b, oct_phmm_stats* st)
 {
     if (!b || !st) return OCT_PHMM_EINVAL;
@@ -1183,6 +1386,7 @@ struct oct_phmm_server {
     std::vector<std::thread> workers;                    // one per handle; all of them drain the one queue, so an idle device takes the next calls
     uint64_t n_calls = 0, n_batches = 0;
     std::vector<uint64_t> n_calls_by_device;
+    std::atomic<bool> has_model {false};                 // oct_phmm_server_set_error_model: calls may leave their penalty vectors NULL
     // OCT_PHMM_SERVER_PROFILE=1: where a worker's time goes (ns, summed over workers), printed by oct_phmm_server_destroy
     bool profile = getenv("OCT_PHMM_SERVER_PROFILE") != nullptr;
     std::atomic<uint64_t> ns_idle {0}, ns_concat {0}, ns_upload {0}, ns_run {0}, ns_download {0}, ns_scatter {0}, ns_single {0};
@@ -1214,16 +1418,20 @@ struct oct_phmm_server {
             hb.append(H->bases, hn);
             for (uint32_t k = 0; k < H->n_haps; ++k) hoff.push_back(hoff.back() + (H->offsets[k + 1] - H->offsets[k]));
             hbeg.insert(hbeg.end(), H->ref_begin, H->ref_begin + H->n_haps);
-            go.insert(go.end(), H->gap_open, H->gap_open + hn); ge.insert(ge.end(), H->gap_extend, H->gap_extend + hn);
-            mf.append(H->snv_mask_fwd, hn); mr.append(H->snv_mask_rev, hn);
-            pf.insert(pf.end(), H->snv_prior_fwd, H->snv_prior_fwd + hn); pr.insert(pr.end(), H->snv_prior_rev, H->snv_prior_rev + hn);
+            if (H->gap_open) {                             // (a device batch holds either calls with vectors or calls without, run())
+                go.insert(go.end(), H->gap_open, H->gap_open + hn); ge.insert(ge.end(), H->gap_extend, H->gap_extend + hn);
+                mf.append(H->snv_mask_fwd, hn); mr.append(H->snv_mask_rev, hn);
+                pf.insert(pf.end(), H->snv_prior_fwd, H->snv_prior_fwd + hn); pr.insert(pr.end(), H->snv_prior_rev, H->snv_prior_rev + hn);
+            }
             reg_rows.push_back(reg_rows.back() + rows_of(R)); reg_haps.push_back(reg_haps.back() + H->n_haps);
             has_flank.push_back(q->flank ? 1 : 0); fl.push_back(q->flank ? *q->flank : oct_phmm_flank_state {0, 0});
             n_out += (size_t)rows_of(R) * H->n_haps;
         }
         const uint32_t n_reads = (uint32_t)mq.size(), n_rows = reg_rows.back();
         oct_phmm_reads R {n_reads, rb.data(), rq.data(), roff.data(), mq.data(), rv.data(), rbeg.data(), templates ? n_rows : 0, templates ? row_off.data() : nullptr};
-        oct_phmm_haplotypes H {(uint32_t)hbeg.size(), hb.data(), hoff.data(), hbeg.data(), go.data(), ge.data(), mf.data(), pf.data(), mr.data(), pr.data()};
+        const bool given = qs.front()->H->gap_open != nullptr;
+        oct_phmm_haplotypes H {(uint32_t)hbeg.size(), hb.data(), hoff.data(), hbeg.data(), given ? go.data() : nullptr, given ? ge.data() : nullptr,
+                               given ? mf.data() : nullptr, given ? pf.data() : nullptr, given ? mr.data() : nullptr, given ? pr.data() : nullptr};
         oct_phmm_regions G {(uint32_t)qs.size(), reg_rows.data(), reg_haps.data(), has_flank.data(), fl.data()};
         std::vector<double> out(n_out + 1);
         oct_phmm_status st;
@@ -1267,16 +1475,20 @@ struct oct_phmm_server {
             }
             std::vector<Request*> batchable, single;
             for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : batchable).push_back(q);
+            std::vector<Request*> batchable_gen;          // calls that leave their penalty vectors to the library batch among themselves
+            for (auto it = batchable.begin(); it != batchable.end();) { if (!(*it)->H->gap_open) { batchable_gen.push_back(*it); it = batchable.erase(it); } else ++it; }
             if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
+            if (batchable_gen.size() == 1) { single.push_back(batchable_gen[0]); batchable_gen.clear(); }
             {
 #if defined(OCTPHMM_SIM)
                 static std::mutex sim_mu;                // the wave simulator runs one kernel at a time: workers of several "devices" take turns
                 std::lock_guard<std::mutex> sim_lk(sim_mu);
 #endif
-                if (!batchable.empty()) {
+                for (std::vector<Request*>* group : {&batchable, &batchable_gen}) {
+                    if (group->empty()) continue;
                     bool served = false;
-                    try { serve_many(h, batchable); served = true; } catch (const std::exception&) {}      // e.g. bad_alloc while concatenating
-                    if (!served) for (Request* q : batchable) {
+                    try { serve_many(h, *group); served = true; } catch (const std::exception&) {}      // e.g. bad_alloc while concatenating
+                    if (!served) for (Request* q : *group) {
                         try { serve_one(h, q); } catch (const std::exception&) { q->rc = fail(&q->st, OCT_PHMM_EHIP, "host allocation"); }
                     }
                 }
@@ -1288,7 +1500,7 @@ struct oct_phmm_server {
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                n_calls += take.size(); n_batches += (batchable.empty() ? 0 : 1) + single.size();
+                n_calls += take.size(); n_batches += (batchable.empty() ? 0 : 1) + (batchable_gen.empty() ? 0 : 1) + single.size();
                 n_calls_by_device[(size_t)device_of[(size_t)w]] += take.size();
                 for (Request* q : take) { q->done = true; q->cv.notify_one(); }     // under the lock: the request lives on its caller's stack
             }
@@ -1346,9 +1558,13 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
     if (!s || !reads || !haps) return fail(status, OCT_PHMM_EINVAL, "null argument");
     // the workers concatenate queued calls before the library proper validates them: a malformed call is answered here, not in a worker thread
     if ((reads->n_reads && (!reads->bases || !reads->qualities || !reads->offsets || !reads->mapping_quality || !reads->reverse_strand || !reads->ref_begin))
-        || (haps->n_haps && (!haps->bases || !haps->offsets || !haps->ref_begin || !haps->gap_open || !haps->gap_extend || !haps->snv_mask_fwd
-                             || !haps->snv_prior_fwd || !haps->snv_mask_rev || !haps->snv_prior_rev)))
+        || (haps->n_haps && (!haps->bases || !haps->offsets || !haps->ref_begin)))
         return fail(status, OCT_PHMM_EINVAL, "null array");
+    {
+        const int n_vec = (haps->gap_open ? 1 : 0) + (haps->gap_extend ? 1 : 0) + (haps->snv_mask_fwd ? 1 : 0) + (haps->snv_prior_fwd ? 1 : 0)
+                        + (haps->snv_mask_rev ? 1 : 0) + (haps->snv_prior_rev ? 1 : 0);
+        if (haps->n_haps && n_vec != 6 && !(n_vec == 0 && s->has_model.load())) return fail(status, OCT_PHMM_EINVAL, "null array");
+    }
     if ((reads->n_reads && !monotone(reads->offsets, reads->n_reads)) || (haps->n_haps && !monotone(haps->offsets, haps->n_haps)))
         return fail(status, OCT_PHMM_EINVAL, "offsets not monotone");
     {
@@ -1367,6 +1583,15 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
     }
     if (status) *status = q.st;
     return q.rc;
+}
+
+extern "C" int oct_phmm_server_set_error_model(oct_phmm_server* s, const oct_phmm_error_model* model)
+{
+    if (!s) return OCT_PHMM_EINVAL;
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (auto* h : s->hs) { const int rc = oct_phmm_set_error_model(h, model); if (rc != OCT_PHMM_OK) return rc; }
+    s->has_model = model != nullptr;
+    return OCT_PHMM_OK;
 }
 
 extern "C" int oct_phmm_server_device_calls(const oct_phmm_server* s, uint64_t* calls_by_device, uint32_t n_devices)

@@ -86,6 +86,12 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_server_populate.argtypes = [pv, pv, pv, pv, pv, pv, pv]
         lib.oct_phmm_server_stats.argtypes = [pv, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.oct_phmm_batch_free.argtypes = [pv, pv]
+        lib.oct_phmm_error_model_default.argtypes = [C.POINTER(abi.ErrorModel)]
+        lib.oct_phmm_penalty_vectors.argtypes = [C.POINTER(abi.ErrorModel), C.c_uint32] + [pv] * 10
+        lib.oct_phmm_set_error_model.argtypes = [pv, C.POINTER(abi.ErrorModel)]
+        lib.oct_phmm_set_substitution_mask.argtypes = [pv, pv]
+        lib.oct_phmm_batch_penalty_vectors.argtypes = [pv] * 9
+        lib.oct_phmm_server_set_error_model.argtypes = [pv, C.POINTER(abi.ErrorModel)]
         _LIBS[key] = lib
     return _LIBS[key]
 
@@ -100,6 +106,27 @@ def _arr(a, dtype):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_error_model(lib_path: Optional[Path] = None) -> abi.ErrorModel:
+    """oct_phmm_error_model_default: the reference's default_model_config (PCR-free, HiSeq-2500)."""
+    m = abi.ErrorModel()
+    load(lib_path).oct_phmm_error_model_default(C.byref(m))
+    return m
+
+
+def penalty_vectors(model: abi.ErrorModel, hap_bases: np.ndarray, hap_offsets: np.ndarray, substitution_mask=None, lib_path: Optional[Path] = None):
+    """oct_phmm_penalty_vectors (host entry, no device): (gap_open, gap_extend, mask_fwd, prior_fwd, mask_rev, prior_rev), concatenated like the haplotypes."""
+    lib = load(lib_path)
+    bases = np.ascontiguousarray(hap_bases, dtype=np.uint8); off = np.ascontiguousarray(hap_offsets, dtype=np.uint32)
+    n = int(off[-1]) if len(off) else 0
+    go, ge, pf, pr = (np.zeros(max(n, 1), np.int8) for _ in range(4)); mf, mr = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+    sub = None if substitution_mask is None else np.ascontiguousarray(substitution_mask, dtype=np.uint8)
+    st = abi.Status()
+    code = lib.oct_phmm_penalty_vectors(C.byref(model), len(off) - 1, _ptr(bases), _ptr(off), _ptr(sub), _ptr(go), _ptr(ge), _ptr(mf), _ptr(pf), _ptr(mr), _ptr(pr), C.byref(st))
+    if code != abi.OK:
+        raise EngineError(code, st, "penalty_vectors")
+    return go[:n], ge[:n], mf[:n], pf[:n], mr[:n], pr[:n]
 
 
 class ResidentBatch:
@@ -156,6 +183,16 @@ class ResidentBatch:
         if code != abi.OK:
             raise EngineError(code, st, "candidate_positions")
         return [pos[e * S: e * S + int(cnt[e])].tolist() for e in range(n)]
+
+    def penalty_vectors(self):
+        """Test seam (oct_phmm_batch_penalty_vectors): the six per-haplotype vectors this batch runs with (given by the caller or generated at upload)."""
+        n = int(self.batch.hap_offsets[-1])
+        go, ge, pf, pr = (np.zeros(max(n, 1), np.int8) for _ in range(4)); mf, mr = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+        st = abi.Status()
+        code = self.engine.lib.oct_phmm_batch_penalty_vectors(self.engine.handle, self.ptr, _ptr(go), _ptr(ge), _ptr(mf), _ptr(pf), _ptr(mr), _ptr(pr), C.byref(st))
+        if code != abi.OK:
+            raise EngineError(code, st, "batch_penalty_vectors")
+        return go[:n], ge[:n], mf[:n], pf[:n], mr[:n], pr[:n]
 
     def stats(self) -> dict:
         s = abi.Stats()
@@ -233,6 +270,16 @@ class Engine:
         if code != abi.OK and raise_on_error:
             raise EngineError(code, st, "align")
         return abi.alignments_result(arrays, n, max_cigar_ops), st
+
+    def set_error_model(self, model: Optional[abi.ErrorModel]):
+        """oct_phmm_set_error_model: batches whose six penalty vectors are None (Batch.without_penalty_vectors) get them generated at upload."""
+        code = self.lib.oct_phmm_set_error_model(self.handle, None if model is None else C.byref(model))
+        if code != abi.OK:
+            raise EngineError(code, None, "set_error_model")
+
+    def set_substitution_mask(self, mask: Optional[np.ndarray]):
+        self._sub_mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)      # borrowed until the next upload
+        self.lib.oct_phmm_set_substitution_mask(self.handle, _ptr(self._sub_mask))
 
     def set_timing(self, enabled: bool = True):
         """Bracket the DP launches with HIP events (ResidentBatch.kernel_time*); off by default."""
@@ -315,6 +362,11 @@ class Server:
         if code != abi.OK and raise_on_error:
             raise EngineError(code, st, "server_populate")
         return out[:batch.out_size()], st
+
+    def set_error_model(self, model: Optional[abi.ErrorModel]):
+        code = self.lib.oct_phmm_server_set_error_model(self.ptr, None if model is None else C.byref(model))
+        if code != abi.OK:
+            raise EngineError(code, None, "server_set_error_model")
 
     def stats(self):
         a, b = C.c_uint64(0), C.c_uint64(0)

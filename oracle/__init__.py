@@ -279,27 +279,7 @@ def genotype_likelihoods(lik, hap_out_off, genotypes, rows=None):
     return out[:len(g)]
 
 
-class ErrorModel(C.Structure):
-    """oct_phmm_error_model (oracle/error_model_oracle.h): the model tables as the reference's constructors expand them."""
-    _fields_ = [(n, C.c_int8 * 50) for n in ("at_homopolymer_open", "cg_homopolymer_open", "dinucleotide_open", "trinucleotide_open",
-                                            "homopolymer_extend", "dinucleotide_extend", "trinucleotide_extend")] + \
-               [("snv_caps", (C.c_int8 * 51) * 3), ("use_snv_model", C.c_int32)]
-
-    @staticmethod
-    def make(at_open, cg_open, di_open, tri_open, snv_caps, homo_ext=(3, 3, 3, 3, 3, 3, 4, 5, 6, 6, 8, 8, 7, 6, 5, 4, 3),
-             di_ext=(3, 3, 5, 4, 3, 2), tri_ext=(3, 3, 5, 4, 3, 2)):
-        m = ErrorModel()
-        def fill(dst, src, n):                      # copy(): first min(size, N) entries, the rest = the last one
-            for i in range(n):
-                dst[i] = src[i] if i < len(src) else src[-1]
-        for name, src in (("at_homopolymer_open", at_open), ("cg_homopolymer_open", cg_open), ("dinucleotide_open", di_open),
-                          ("trinucleotide_open", tri_open), ("homopolymer_extend", homo_ext), ("dinucleotide_extend", di_ext),
-                          ("trinucleotide_extend", tri_ext)):
-            fill(getattr(m, name), src, 50)
-        for p in range(3):
-            fill(m.snv_caps[p], snv_caps[p], 51)
-        m.use_snv_model = 1
-        return m
+ErrorModel = abi.ErrorModel      # oct_phmm_error_model is part of the C ABI (include/oct_phmm.h)
 
 
 def tandem_repeats(seq, min_period=1, max_period=5, backend="oracle"):

@@ -6,21 +6,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* What HaplotypeLikelihoodModel::reset (haplotype_likelihood_model.cpp:60-78) asks of its error models, as data:
- * BasicRepeatBasedIndelErrorModel's seven tables and BasicRepeatBasedSNVErrorModel's three cap tables, ALREADY EXPANDED as
- * their constructors do (copy the first min(size, N) entries, fill the rest with the last one:
- * basic_repeat_based_indel_error_model.cpp:15-34, repeat_based_snv_error_model.cpp:20-34), e.g. from
- * error_model_factory.cpp:220-517. */
-#define OCT_PHMM_INDEL_TABLE 50
-#define OCT_PHMM_SNV_TABLE   51
-typedef struct oct_phmm_error_model {
-    int8_t  at_homopolymer_open[OCT_PHMM_INDEL_TABLE], cg_homopolymer_open[OCT_PHMM_INDEL_TABLE];
-    int8_t  dinucleotide_open[OCT_PHMM_INDEL_TABLE], trinucleotide_open[OCT_PHMM_INDEL_TABLE];
-    int8_t  homopolymer_extend[OCT_PHMM_INDEL_TABLE], dinucleotide_extend[OCT_PHMM_INDEL_TABLE], trinucleotide_extend[OCT_PHMM_INDEL_TABLE];
-    int8_t  snv_caps[3][OCT_PHMM_SNV_TABLE];   /* homopolymer, dinucleotide, trinucleotide penalty caps */
-    int32_t use_snv_model;                     /* 0: masks = the haplotype itself, priors = 100 (model.cpp:69-73) */
-} oct_phmm_error_model;
-
+/* oct_phmm_error_model (the tables, already expanded) is declared by the C ABI header. */
 
 /* tandem::extract_exact_tandem_repeats(str, min_period, max_period): (pos, length, period) triples in the library's output order.
  * Returns the number of repeats (written while they fit). */

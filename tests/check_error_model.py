@@ -1,0 +1,92 @@
+"""The product's per-haplotype penalty vectors (octopus_amd/csrc/phmm_error_model.hpp behind oct_phmm_penalty_vectors, and
+generated inside populate when the caller leaves the six vectors NULL) against the REFERENCE's own error-model classes
+(BasicRepeatBasedIndelErrorModel / BasicRepeatBasedSNVErrorModel over its tandem library, compiled in place: oracle/_ref) and the oracle."""
+import os
+
+import numpy as np
+
+import oracle
+from backends import build_sim, make_engine
+from octopus_amd import abi, engine, synth
+from test_oracle_error_models import model as default_tables, random_sequence, ref_penalty_vectors
+
+NAMES = ("gap_open", "gap_extend", "mask_fwd", "prior_fwd", "mask_rev", "prior_rev")
+
+
+def corpus(seed, n_strings, with_sub=True):
+    """Random haplotypes with planted repeats of periods 1-6 (the corpus of tests/test_oracle_error_models.py), some with non-ACGT bases,
+    some with substitution masks; concatenated like a batch's haplotypes."""
+    rng = np.random.default_rng(seed)
+    seqs, subs = [], []
+    for it in range(n_strings):
+        seq = random_sequence(rng, int(rng.integers(2, 420)), b"ACGT" if it % 6 else b"ACGTN")
+        sub = np.zeros(len(seq), np.uint8)
+        if with_sub and it % 3 == 0:
+            for _ in range(int(rng.integers(0, 4))):
+                a = int(rng.integers(0, len(seq))); sub[a:a + int(rng.integers(1, 6))] = 1
+        seqs.append(seq); subs.append(sub)
+    bases = np.frombuffer(b"".join(seqs), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint32)
+    return seqs, subs, bases, off
+
+
+def check_host_entry(lib_path=None, n_strings=2400, reference=True):
+    """oct_phmm_penalty_vectors (device-free) on the 2,400-string corpus: all six vectors equal the reference's classes', string by string."""
+    m = engine.default_error_model(lib_path)
+    assert bytes(m) == bytes(default_tables())                  # oct_phmm_error_model_default = the factory's default tables, expanded
+    seqs, subs, bases, off = corpus(77, n_strings)
+    got = engine.penalty_vectors(m, bases, off, np.concatenate(subs), lib_path=lib_path)
+    n_diff = 0
+    for i, (seq, sub) in enumerate(zip(seqs, subs)):
+        want = ref_penalty_vectors(seq, sub) if reference else oracle.penalty_vectors(m, seq, sub)
+        for name, g, w in zip(NAMES, got, want):
+            assert np.array_equal(g[off[i]:off[i + 1]], w), (name, i, seq, np.flatnonzero(g[off[i]:off[i + 1]] != w)[:5])
+        n_diff += 1
+    # degenerate inputs: no haplotypes, one base, no SNV model
+    assert all(len(v) == 0 for v in engine.penalty_vectors(m, np.zeros(0, np.uint8), np.zeros(1, np.uint32), lib_path=lib_path))
+    m2 = engine.default_error_model(lib_path); m2.use_snv_model = 0
+    s = np.frombuffer(b"ACGTTTTTTTTGA", np.uint8)
+    go, ge, mf, pf, mr, pr = engine.penalty_vectors(m2, s, np.asarray([0, len(s)], np.uint32), lib_path=lib_path)
+    assert np.array_equal(mf, s) and np.array_equal(mr, s) and set(pf.tolist()) == {100} and set(pr.tolist()) == {100}      # model.cpp:68-73
+    return n_diff
+
+
+def check_populate_generates_the_vectors(backend, tol=0.0, where=("host", "device")):
+    """A batch uploaded WITHOUT its six vectors (all pointers NULL) after oct_phmm_set_error_model: the vectors the library generated equal
+    the reference's (oct_phmm_batch_penalty_vectors), and the matrix equals the one computed from given vectors - on both generation paths."""
+    rng = np.random.default_rng(31)
+    m = engine.default_error_model(build_sim() if backend == "sim" else None)
+    old = os.environ.get("OCT_PHMM_PENALTIES")
+    n = 0
+    try:
+        for path in where:
+            os.environ["OCT_PHMM_PENALTIES"] = path
+            for B, R, H, T, Lh in ((8, 14, 5, 50, 160), (16, 10, 4, 60, 200)):
+                g = synth.make_region(rng, R, H, T=T, Lh=Lh, B=B, flank=(20, 20), positions="none")
+                for h in g["haps"][1:3]:                      # plant repeats so that the vectors are not flat
+                    a = int(rng.integers(30, Lh - 60)); h[a:a + 14] = ord("A"); h[a + 20:a + 36] = np.frombuffer(b"CG" * 8, np.uint8)
+                batch = synth.batch_from_regions([g])
+                want_vec = [np.concatenate(v) for v in zip(*[ref_penalty_vectors(bytes(h)) for h in g["haps"]])]
+                given = synth.batch_from_regions([g])
+                given.gap_open, given.gap_extend, given.snv_mask_fwd, given.snv_prior_fwd, given.snv_mask_rev, given.snv_prior_rev = want_vec
+                eng = make_engine(backend, max_indel_error=B)
+                want, _ = eng.populate(given)
+                eng.set_error_model(m)
+                rb = eng.upload(batch.without_penalty_vectors())
+                for name, gvec, wvec in zip(NAMES, rb.penalty_vectors(), want_vec):
+                    assert np.array_equal(gvec, wvec), (path, name)
+                rb.run(); got = rb.download().copy(); rb.free()
+                assert np.max(np.abs(got - want), initial=0.0) <= tol
+                one_shot, _ = eng.populate(batch.without_penalty_vectors())
+                assert np.array_equal(one_shot, got)
+                eng.set_error_model(None)                      # without a model NULL vectors are an error, not a crash
+                _, st = eng.populate(batch.without_penalty_vectors(), raise_on_error=False)
+                assert st.code == abi.EINVAL
+                eng.close()
+                n += got.size
+    finally:
+        if old is None:
+            os.environ.pop("OCT_PHMM_PENALTIES", None)
+        else:
+            os.environ["OCT_PHMM_PENALTIES"] = old
+    return n

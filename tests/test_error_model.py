@@ -1,0 +1,20 @@
+"""CPU suite: the product's penalty-vector generator (device-free host entry of the C ABI, and the in-call generation on the simulator)."""
+import pytest
+
+import check_error_model as ce
+import oracle
+from backends import build_sim
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="reference build absent")
+def test_product_penalty_vectors_equal_the_reference_error_models_on_the_corpus():
+    assert ce.check_host_entry(build_sim()) == 2400
+
+
+def test_product_penalty_vectors_equal_the_oracle_restatement():
+    assert ce.check_host_entry(build_sim(), n_strings=300, reference=False) == 300
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="reference build absent")
+def test_sim_populate_generates_the_vectors_on_host_threads_and_on_the_device():
+    assert ce.check_populate_generates_the_vectors("sim") > 0
