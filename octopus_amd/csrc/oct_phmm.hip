@@ -129,6 +129,7 @@ struct oct_phmm_batch {
     double* early_out = nullptr;  // oct_phmm_populate: copy every slice's rows to the caller as soon as its epilogue is done
     bool stream = false;          // streaming DP path (k_dp_wide): band 128/256, or band 64 with reads/haplotypes too long for LDS
     bool map_big = false;         // haplotypes too long for the LDS-resident k-mer mapper
+    int  map_lanes = 0;           // > 0: k_kmer_map_lanes with this many lanes (= reads) per workgroup
     bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
     uint32_t* d_blk_hap = nullptr; uint32_t* d_blk_read0 = nullptr; uint32_t n_map_blocks = 0;
     uint32_t map_reads_per_block = 64;   // reads one k_kmer_map workgroup walks with the haplotype's bins staged once; fewer for small batches (latency)
@@ -870,12 +871,19 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     pk.upload(reg_lhs.data(), reg_lhs.size(), &d.reg_lhs);
     pk.upload(reg_rhs.data(), reg_rhs.size(), &d.reg_rhs);
     pk.dalloc(&d.pos, (size_t)b->n_pairs * S + 1); pk.dalloc(&d.npos, (size_t)b->n_pairs + 1);
-    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr;
+    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr;
     if (!positions) {
         pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1); pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
         pk.dalloc(&d.rhash, (size_t)n_read_bases + 1);
         b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 64;
         if (const char* e = getenv("OCT_PHMM_MAP_READS_PER_BLOCK")) { const long n = atol(e); if (n >= 4 && n <= 4096) b->map_reads_per_block = (uint32_t)n; }   // A/B switch
+        // lane-per-pair mapper: byte counters need every read's k-mer count to stay below 256, and bins + LANES counter rows must fit LDS
+        if (!b->map_big && b->t_cap <= 255 + kKmer - 1 && !getenv("OCT_PHMM_WAVE_MAPPER")) {
+            const int lanes = b->n_pairs < 500000 ? 64 : 256;                 // region-sized calls: more, smaller workgroups (latency)
+            if (kmer_map_lanes_lds_bytes(b->lh_cap, (uint32_t)lanes) <= rt::kMaxLdsBytes) b->map_lanes = lanes;
+            else if (kmer_map_lanes_lds_bytes(b->lh_cap, 64) <= rt::kMaxLdsBytes) b->map_lanes = 64;
+        }
+        if (b->map_lanes) { b->map_reads_per_block = (uint32_t)b->map_lanes; pk.dalloc(&d.bin32, (size_t)H->n_haps * kKmerBins + 1); }
         std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, read chunk of its region)
         for (uint32_t hp = 0; hp < H->n_haps; ++hp) {
             const uint32_t g = hap_region[hp];
@@ -1045,6 +1053,16 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 const size_t lds = (size_t)b->lh_cap * 4 + 64;
                 if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_big, lds));
                 OCT_LAUNCH(k_kmer_map_big, (uint32_t)np, 256, lds, s, d, sl.pair0); RT(rt::launch_ok());
+            } else if (sl.blk1 > sl.blk0 && b->map_lanes) {
+                const size_t lds = kmer_map_lanes_lds_bytes(b->lh_cap, (uint32_t)b->map_lanes);
+                if (b->map_lanes == 256) {
+                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_lanes<256>, lds));
+                    OCT_LAUNCH(k_kmer_map_lanes<256>, sl.blk1 - sl.blk0, 256, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0, (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap);
+                } else {
+                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_lanes<64>, lds));
+                    OCT_LAUNCH(k_kmer_map_lanes<64>, sl.blk1 - sl.blk0, 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0, (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap);
+                }
+                RT(rt::launch_ok());
             } else if (sl.blk1 > sl.blk0) {
                 const size_t lds = kmer_map_lds_bytes(b->lh_cap);
                 if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map, lds));

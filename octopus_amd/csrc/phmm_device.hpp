@@ -53,6 +53,7 @@ struct DevBatch {
     // candidate mapping positions per pair: pos[e * max_pos + j], j < npos[e] (host-provided or written by k_kmer_map)
     uint32_t* pos; uint8_t* npos;
     // 6-mer tables per haplotype (k_kmer_tables): bin_start[h * 4097 + hash], bin_idx[hoff[h] + slot]
+    uint32_t* bin32;                                  // bin32[h * 4096 + hash] = start | occupancy << 16 (k_kmer_map_lanes); null when unused
     uint16_t* bin_start; uint16_t* bin_idx; uint16_t* rhash;   // rhash[roff[r] + q]: 6-mer hash of read r at q (written by the trailing workgroups of k_kmer_tables)
     // per pair
     uint64_t  n_pairs;

@@ -145,7 +145,12 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint
     }
     if (tid < 256) {
         uint32_t run = tid ? part[tid - 1] : 0;
-        for (uint32_t i = 0; i < per; ++i) { const uint32_t c = hist[tid * per + i]; hist[tid * per + i] = run; b.bin_start[(size_t)h * (kKmerBins + 1) + tid * per + i] = (uint16_t)run; run += c; }
+        for (uint32_t i = 0; i < per; ++i) {
+            const uint32_t c = hist[tid * per + i]; hist[tid * per + i] = run;
+            b.bin_start[(size_t)h * (kKmerBins + 1) + tid * per + i] = (uint16_t)run;
+            if (b.bin32) b.bin32[(size_t)h * kKmerBins + tid * per + i] = run | c << 16;      // start and occupancy in one word, for k_kmer_map_lanes
+            run += c;
+        }
         if (tid == 255) b.bin_start[(size_t)h * (kKmerBins + 1) + kKmerBins] = (uint16_t)run;
     }
     hw::block_sync();
@@ -239,6 +244,88 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
         if (lane == 0) b.npos[e] = (uint8_t)n_out;
         hw::wave_lds_fence();
     }
+}
+
+// The same mapping with ONE LANE per (haplotype, read) pair: a workgroup of LANES lanes takes LANES reads of one haplotype. The haplotype's
+// bins (start | occupancy << 16, one LDS read per k-mer) and bin entries sit in LDS once; every lane owns a row of BYTE counters (a
+// diagonal is voted at most once per read k-mer, so its count is at most T - 5 <= 255: the host checks the batch's longest read), needs
+// no atomics, no ballots and no scalar control flow, keeps the run of consecutive votes for one diagonal in registers (a read that
+// matches its haplotype votes one diagonal ~T times: one counter update), and tracks the maximum and how many diagonals hold it as it
+// goes, so the usual case - one winning diagonal - ends without a sweep over the counters.
+// (k_kmer_map above issues ~670 instructions per pair around wave-wide ballots and LDS atomics and waits half of its time; this form
+// issues a few dozen. Same votes, same output: tests/check_populate.py::assert_device_positions.)
+inline uint32_t kmer_lanes_stride(uint32_t lh_cap) { return ((lh_cap + 3) & ~3u) + 4; }      // bytes per lane; the odd dword count staggers the lanes' banks
+inline uint32_t kmer_map_lanes_lds_bytes(uint32_t lh_cap, uint32_t lanes) { return kKmerBins * 4 + ((lh_cap + 1) & ~1u) * 2 + lanes * kmer_lanes_stride(lh_cap); }
+
+template <int LANES>
+OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap)
+{
+    OCT_DYN_SMEM(smem);
+    uint32_t* bins = (uint32_t*)smem;                                  // [4096] start | occupancy << 16
+    uint16_t* idx = (uint16_t*)(bins + kKmerBins);                     // [lh_cap rounded to even] haplotype positions, bin by bin
+    const uint32_t stride = kmer_lanes_stride(lh_cap);
+    uint8_t* counters = (uint8_t*)(idx + ((lh_cap + 1) & ~1u));        // [LANES][stride]
+    const uint32_t tid = hw::thread_idx();
+    const uint32_t h = blk_hap[hw::block_idx()], r = blk_read0[hw::block_idx()] + tid;
+    const uint32_t g = b.hap_region[h];
+    const uint32_t reg_r0 = b.reg_read0[g], reg_r1 = b.reg_read0[g + 1];
+    const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;
+    for (uint32_t i = tid; i < kKmerBins; i += LANES) bins[i] = b.bin32[(size_t)h * kKmerBins + i];
+    for (uint32_t i = tid; i < nk; i += LANES) idx[i] = b.bin_idx[ho + i];
+    uint8_t* cnt = counters + tid * stride;
+    for (uint32_t d = 0; d < stride; d += 4) *(uint32_t*)(cnt + d) = 0;
+    hw::block_sync();
+    if (r >= reg_r1) return;
+    const uint64_t e = b.hap_pair_off[h] + (r - reg_r0);
+    const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;      // compute_kmer_hashes :57-69
+    const uint32_t max_pos = (uint32_t)b.max_pos;
+    uint32_t mx = 0, n_best = 0, d_best = 0;                            // max_hit_count, the number of diagonals that hold it, one of them
+    uint32_t d_run = 0, run = 0;                                        // consecutive votes for one diagonal, not yet in its counter
+    auto flush = [&]() {
+        if (!run) return;
+        const uint32_t c = (uint32_t)cnt[d_run] + run;
+        cnt[d_run] = (uint8_t)c;
+        if (c > mx) { mx = c; n_best = 1; d_best = d_run; }
+        else if (c == mx) ++n_best;
+    };
+    auto vote = [&](uint32_t ti, uint32_t q) {
+        if (ti < q) return;                                             // :130
+        const uint32_t d = ti - q;                                      // mapping_begin :131
+        if (run && d == d_run) { ++run; return; }
+        flush();
+        d_run = d; run = 1;
+    };
+    // Eight k-mers per trip: one 16-byte load of the read's hashes (the next trip's is in flight), eight independent bin reads, eight
+    // independent first-entry reads, then the votes in order; a bin with more than one entry (a k-mer that repeats in the haplotype)
+    // walks its remaining entries in a loop that is almost never entered.
+    const uint8_t* rh = (const uint8_t*)(b.rhash + ro);
+    uint4 hnext = make_uint4(0, 0, 0, 0);
+    if (nq) __builtin_memcpy(&hnext, rh, 16);
+    for (uint32_t q0 = 0; q0 < nq; q0 += 8) {
+        const uint4 hv = hnext;
+        if (q0 + 8 < nq) __builtin_memcpy(&hnext, rh + 2 * (q0 + 8), 16);
+        const uint32_t hw4[4] = {hv.x, hv.y, hv.z, hv.w};
+        uint32_t ent[8], ti0[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ent[k] = bins[(hw4[k >> 1] >> (16 * (k & 1))) & 0xfffu];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ti0[k] = idx[ent[k] & 0xffffu];     // in bounds even for an empty bin (its start is at most nk)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t q = q0 + (uint32_t)k, n = q < nq ? ent[k] >> 16 : 0u;
+            if (n) vote(ti0[k], q);
+            for (uint32_t j = 1; j < n; ++j) vote(idx[(ent[k] & 0xffffu) + j], q);
+        }
+    }
+    flush();
+    // the ascending positions that reach the maximum, at most max_pos of them (:145-157)
+    uint32_t n_out = 0;
+    if (mx > 0 && n_best == 1) {
+        if (max_pos) { b.pos[e * (uint64_t)max_pos] = d_best; n_out = 1; }
+    } else if (mx > 0) {
+        for (uint32_t d = 0; d < nk && n_out < max_pos; ++d) if (cnt[d] == mx) b.pos[e * (uint64_t)max_pos + n_out++] = d;
+    }
+    b.npos[e] = (uint8_t)n_out;
 }
 
 // Long haplotypes (bins + per-wave counters no longer fit LDS beside each other): one workgroup per (haplotype, read) pair, the

@@ -1,11 +1,20 @@
-# Lean measurement call: smoke, a parity subset, bench (default), single-slice kernel stats, stream bench.
+# A/B of environment switches on the GPU box: bash tools/gpu_ab.sh <tag> "VAR=1" "VAR2=x" ... (first run = no switch)
 set -x
 cd /root/repo; export TMPDIR=/tmp
-O=gpurun_out/${1:-ab}; mkdir -p $O
-timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/rc.log
-timeout 240 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "${2:-golden or random_windows_fast or config2 or slices or random_scenarios or populate_basic or late}" > $O/pytest_subset.log 2>&1; echo "pytest_subset rc=$?" >> $O/rc.log
-timeout 200 python bench.py --no-cpu-baseline > $O/bench_default.json 2> $O/bench_default.err; echo "bench_default rc=$?" >> $O/rc.log
-(cd /tmp && OCT_PHMM_SLICES=1 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/kstats -o s -- python /root/repo/bench.py --no-small-batch --no-cpu-baseline --steps 3 --warmup 1 > /root/repo/$O/bench_1slice_rocprof.json 2> /root/repo/$O/kstats.err); echo "kstats rc=$?" >> $O/rc.log
+O=gpurun_out/$1; mkdir -p $O; shift
+P="--no-small-batch --no-cpu-baseline --no-extras"
+timeout 300 python bench.py $P > $O/bench_default.json 2> $O/bench_default.err
+for V in "$@"; do
+  N=$(echo $V | tr -c 'A-Za-z0-9_=\n' '_')
+  env $V timeout 300 python bench.py $P > $O/bench_$N.json 2> $O/bench_$N.err
+  env $V timeout 300 python bench.py $P --workload stream > $O/bench_stream_$N.json 2> $O/bench_stream_$N.err
+done
+timeout 300 python bench.py $P --workload stream > $O/bench_stream_default.json 2> $O/bench_stream_default.err
+export OCT_PHMM_SLICES=1
+(cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/kstats -o s -- python /root/repo/bench.py $P --steps 3 --warmup 1 > /root/repo/$O/bench_1slice_rocprof.json 2> /root/repo/$O/kstats.err)
 find $O -name "*kernel_trace.csv" -delete
-timeout 150 python bench.py --workload stream --no-cpu-baseline > $O/bench_stream.json 2> $O/bench_stream.err; echo "bench_stream rc=$?" >> $O/rc.log
-cat $O/rc.log; tail -3 $O/pytest_subset.log; cut -c1-200 $O/bench_default.json $O/bench_stream.json; head -6 $O/kstats/s_kernel_stats.csv | cut -c1-150
+unset OCT_PHMM_SLICES
+for f in $O/bench*.json; do echo $f; python -c "
+import json,sys
+b=json.load(open('$f')); print({k:b[k] for k in ('value','ms_per_step','loglik_per_s')}, b['roofline']['avg_launch_ms'], b['roofline']['score_only_kernel_avg_launch_ms'])"; done
+head -8 $O/kstats/s_kernel_stats.csv | cut -c1-150
