@@ -684,6 +684,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
 {
     if (!h || !R || !H_in || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
     *out = nullptr;
+    rt::Range range_("oct_phmm upload");
     oct_phmm_haplotypes Hv = *H_in;
     const oct_phmm_haplotypes* H = &Hv;
     const uint8_t* sub_mask = h->sub_mask; h->sub_mask = nullptr;          // borrowed for this upload only
@@ -871,19 +872,21 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     pk.upload(reg_lhs.data(), reg_lhs.size(), &d.reg_lhs);
     pk.upload(reg_rhs.data(), reg_rhs.size(), &d.reg_rhs);
     pk.dalloc(&d.pos, (size_t)b->n_pairs * S + 1); pk.dalloc(&d.npos, (size_t)b->n_pairs + 1);
-    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr;
+    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr; d.hhash = nullptr; d.map_count_only = 0; d.map_stats = 0;
     if (!positions) {
         pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1); pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
-        pk.dalloc(&d.rhash, (size_t)n_read_bases + 1);
-        b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 64;
+        pk.dalloc(&d.rhash, (size_t)n_read_bases + 1); pk.dalloc(&d.hhash, (size_t)n_hap_bases + 1);
+        d.map_count_only = getenv("OCT_PHMM_MAP_COUNT_ONLY") != nullptr; d.map_stats = getenv("OCT_PHMM_MAP_STATS") != nullptr;
+        b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 256;      // the haplotype's tables are staged once per workgroup: big batches amortise them over more reads
+        pk.dalloc(&d.bin32, (size_t)H->n_haps * kKmerBins + 4);
         if (const char* e = getenv("OCT_PHMM_MAP_READS_PER_BLOCK")) { const long n = atol(e); if (n >= 4 && n <= 4096) b->map_reads_per_block = (uint32_t)n; }   // A/B switch
         // lane-per-pair mapper: byte counters need every read's k-mer count to stay below 256, and bins + LANES counter rows must fit LDS
-        if (!b->map_big && b->t_cap <= 255 + kKmer - 1 && !getenv("OCT_PHMM_WAVE_MAPPER")) {
+        if (!b->map_big && b->t_cap <= 255 + kKmer - 1 && getenv("OCT_PHMM_LANE_MAPPER")) {     // A/B switch: measured 3.8x SLOWER than the wave mapper
             const int lanes = b->n_pairs < 500000 ? 64 : 256;                 // region-sized calls: more, smaller workgroups (latency)
             if (kmer_map_lanes_lds_bytes(b->lh_cap, (uint32_t)lanes) <= rt::kMaxLdsBytes) b->map_lanes = lanes;
             else if (kmer_map_lanes_lds_bytes(b->lh_cap, 64) <= rt::kMaxLdsBytes) b->map_lanes = 64;
         }
-        if (b->map_lanes) { b->map_reads_per_block = (uint32_t)b->map_lanes; pk.dalloc(&d.bin32, (size_t)H->n_haps * kKmerBins + 1); }
+        if (b->map_lanes) b->map_reads_per_block = (uint32_t)b->map_lanes;
         std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, read chunk of its region)
         for (uint32_t hp = 0; hp < H->n_haps; ++hp) {
             const uint32_t g = hap_region[hp];
@@ -1019,6 +1022,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
 extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phmm_status* status)
 {
     if (!h || !b || b->owner != h) return fail(status, OCT_PHMM_EINVAL, "bad handle/batch");
+    rt::Range range_("oct_phmm run");
     RT(rt::set_device(h->cfg.device_id));
     rt::Stream s0 = h->stream;
     DevBatch& d = b->d;
@@ -1038,6 +1042,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     // host read-back that sizes the DP launches)
     int hash_slice = -1;                                  // the slice whose table launch also hashed the reads
     auto phase1 = [&](int i) -> int {
+        rt::Range range_p1("slice phase 1: map, classify, scan");
         oct_phmm_batch::Slice& sl = b->slices[i];
         rt::Stream s = h->slice_stream(i);
         const uint64_t np = sl.pair1 - sl.pair0;
@@ -1098,6 +1103,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     };
     // phase 2: task emission, the DP kernels (+ traceback walk), epilogue for the slice's rows
     auto phase2 = [&](int i) -> int {
+        rt::Range range_p2("slice phase 2: emit, DP, walk, epilogue");
         oct_phmm_batch::Slice& sl = b->slices[i];
         rt::Stream s = h->slice_stream(i);
         const uint64_t np = sl.pair1 - sl.pair0;
@@ -1186,6 +1192,11 @@ extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_ph
     RT(rt::stream_sync(h->stream));
     for (int k = 0; k < 6; ++k) { b->h_stats[k] = 0; for (uint32_t sl = 0; sl < kStatSlots; ++sl) b->h_stats[k] += b->h_stat_stripes[(size_t)sl * 8 + k]; }
     b->h_err_key = ~b->h_stat_stripes[(size_t)kStatSlots * 8];
+    if (getenv("OCT_PHMM_MAP_STATS")) {
+        unsigned long long dec = 0, cnt = 0;
+        for (uint32_t sl = 0; sl < kStatSlots; ++sl) { dec += b->h_stat_stripes[(size_t)sl * 8 + 6]; cnt += b->h_stat_stripes[(size_t)sl * 8 + 7]; }
+        fprintf(stderr, "{\"mapper_pairs_decided_by_shortcut\": %llu, \"mapper_pairs_counted\": %llu}\n", dec, cnt);
+    }
     b->dp_ms = 0; b->dp_launches = 0;
     for (int k = 0; k < kNumKinds; ++k) { b->kind_ms[k] = 0; b->kind_launches[k] = 0; }
     for (size_t i = 0; i < b->timers.size(); ++i) {
@@ -1212,6 +1223,7 @@ extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_ph
 extern "C" int oct_phmm_batch_download(oct_phmm_handle* h, oct_phmm_batch* b, double* out, oct_phmm_status* status)
 {
     if (!out && b && b->n_out) return fail(status, OCT_PHMM_EINVAL, "null output");
+    rt::Range range_("oct_phmm download");
     const int rc = oct_phmm_batch_wait(h, b, status);
     if (rc != OCT_PHMM_OK) return rc;
     RT(rt::d2h(out, b->d_out, (size_t)b->n_out * sizeof(double), h->stream));

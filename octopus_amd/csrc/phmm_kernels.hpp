@@ -128,7 +128,11 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint
     const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;
     for (uint32_t i = tid; i < kKmerBins; i += nt) hist[i] = 0;
     hw::block_sync();
-    for (uint32_t p = tid; p < nk; p += nt) hw::atomic_add_lds_u32(&hist[kmer_hash6(b.hbases + ho + p)], 1u);
+    for (uint32_t p = tid; p < nk; p += nt) {
+        const uint32_t hsh = kmer_hash6(b.hbases + ho + p);
+        hw::atomic_add_lds_u32(&hist[hsh], 1u);
+        b.hhash[ho + p] = (uint16_t)hsh;                              // the haplotype's own hash sequence (k_kmer_map's exact-count shortcut)
+    }
     hw::block_sync();
     // exclusive scan of the 4096 counters: 16 per thread (256 threads)
     const uint32_t per = kKmerBins / 256;
@@ -165,29 +169,160 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint
 // map_query_to_target (:120-159): one wave per (haplotype, read) pair; the workgroup keeps the haplotype's bins in LDS and its
 // four waves stride over a chunk of the region's reads. Votes go to per-wave LDS counters; a 64-lane batch whose votes all fall on
 // one diagonal (the normal case: the read's true offset) is merged into a single add.
-inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + ((lh_cap + 1) & ~1u) * 2 + kBlockWaves * (lh_cap + 64) * 4; }
+inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + 2 * ((lh_cap + 1) & ~1u) * 2 + kKmerBins + kBlockWaves * (lh_cap + 64) * 4; }
 
 OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap, uint32_t reads_per_block)
 {
     OCT_DYN_SMEM(smem);
     uint16_t* bins = (uint16_t*)smem;                                  // [4097]
     uint16_t* idx = bins + kKmerBins + 2;                              // [lh_cap rounded to even]
-    uint32_t* counts_all = (uint32_t*)(idx + ((lh_cap + 1) & ~1u));    // [waves][lh_cap + 64]
-    const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
+    uint16_t* hh = idx + ((lh_cap + 1) & ~1u);                         // [lh_cap rounded to even] the haplotype's hash at every position
+    uint8_t* occ = (uint8_t*)(hh + ((lh_cap + 1) & ~1u));              // [4096] bin occupancy, capped at 255 (only 0 / 1 / more matter)
+    uint32_t* counts_all = (uint32_t*)(occ + kKmerBins);               // [waves][lh_cap + 64]
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63;
+    const uint32_t wave = hw::readfirstlane(tid >> 6);                 // wave-uniform BY CONSTRUCTION, and the compiler must know it: read index, read offsets and
+                                                                       // k-mer count then live in SGPRs (scalar loads, scalar branches) instead of per-lane copies
     const uint32_t h = blk_hap[hw::block_idx()], r_first = blk_read0[hw::block_idx()];
     const uint32_t g = b.hap_region[h];
     const uint32_t reg_r0 = b.reg_read0[g], reg_r1 = b.reg_read0[g + 1];
     const uint32_t r_end = r_first + reads_per_block < reg_r1 ? r_first + reads_per_block : reg_r1;
     const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;   // table.second
-    for (uint32_t i = tid; i <= kKmerBins; i += kBlockWaves * 64) bins[i] = b.bin_start[(size_t)h * (kKmerBins + 1) + i];
-    for (uint32_t i = tid; i < nk; i += kBlockWaves * 64) idx[i] = b.bin_idx[ho + i];
+    {   // bins and their occupancies out of the start | count << 16 table, four bins per 16-byte load (staging is per workgroup: it must stay small
+        // beside the ~100 instructions a decided read costs)
+        const uint4* src = (const uint4*)(b.bin32 + (size_t)h * kKmerBins);
+        for (uint32_t i = tid; i < kKmerBins / 4; i += kBlockWaves * 64) {
+            const uint4 v = src[i];
+            const uint32_t c0 = v.x >> 16, c1 = v.y >> 16, c2 = v.z >> 16, c3 = v.w >> 16;
+            *(uint2*)(bins + 4 * i) = make_uint2((v.x & 0xffffu) | v.y << 16, (v.z & 0xffffu) | v.w << 16);
+            *(uint32_t*)(occ + 4 * i) = (c0 < 255 ? c0 : 255u) | (c1 < 255 ? c1 : 255u) << 8 | (c2 < 255 ? c2 : 255u) << 16 | (c3 < 255 ? c3 : 255u) << 24;
+        }
+        if (tid == 0) bins[kKmerBins] = (uint16_t)nk;
+    }
+    for (uint32_t i = tid; i < nk; i += kBlockWaves * 64) { idx[i] = b.bin_idx[ho + i]; hh[i] = b.hhash[ho + i]; }
     uint32_t* counts = counts_all + wave * (lh_cap + 64);
     for (uint32_t d = lane; d < nk + 64; d += 64) counts[d] = 0;
     hw::block_sync();
     const uint32_t max_pos = (uint32_t)b.max_pos;
+    const uint64_t e_first = b.hap_pair_off[h];
+    // The per-read work is a chain of dependent round trips (read offsets -> hashes -> bins -> bin entries); a wave walks its reads one
+    // after the other, so the two global legs are software-pipelined across reads: while read i is processed, the hashes of read i + 1
+    // and the offsets of read i + 2 are in flight.
+    auto load_offsets = [&](uint32_t rr, uint32_t& ro_, uint32_t& nq_) {
+        ro_ = 0; nq_ = 0;
+        if (rr < r_end) { ro_ = b.roff[rr]; const uint32_t T_ = b.roff[rr + 1] - ro_; nq_ = T_ >= kKmer ? T_ - kKmer + 1 : 0; }   // compute_kmer_hashes :57-69
+    };
+    auto load_hashes = [&](uint32_t ro_, uint32_t nq_, uint32_t (&hv)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t q = (uint32_t)k * 64 + lane; hv[k] = ((uint32_t)k * 64 < nq_ && q < nq_) ? (uint32_t)b.rhash[ro_ + q] : 0u; }
+    };
+    uint32_t ro = 0, nq = 0, ro_n = 0, nq_n = 0, hq4[4], hq4_n[4];
+    load_offsets(r_first + wave, ro, nq);
+    load_offsets(r_first + wave + kBlockWaves, ro_n, nq_n);
+    load_hashes(ro, nq, hq4);
     for (uint32_t r = r_first + wave; r < r_end; r += kBlockWaves) {
-        const uint64_t e = b.hap_pair_off[h] + (r - reg_r0);
-        const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;   // compute_kmer_hashes :57-69
+        const uint64_t e = e_first + (r - reg_r0);
+        load_hashes(ro_n, nq_n, hq4_n);                                        // read i + 1 (its offsets arrived during read i - 1)
+        uint32_t ro_nn, nq_nn;
+        load_offsets(r + 2 * kBlockWaves, ro_nn, nq_nn);                       // read i + 2
+        bool decided = false;
+        // Exact shortcut for the usual case, a read whose k-mers agree on ONE diagonal: the most frequent first-bin-entry diagonal d is a
+        // candidate; its true count is a plain comparison of the two hash sequences along d (no counters); any other diagonal collects at
+        // most one vote from each read k-mer that has a bin entry off d. If count(d) exceeds the number of such k-mers, d alone holds
+        // max_hit_count and the answer is {d}. Anything else (near-even indel splits, repeats) takes the counting path below.
+        if (nq > 0 && nq <= 256 && !b.map_count_only) {
+            uint32_t n4[4]; uint64_t has4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                n4[k] = 0; has4[k] = 0;
+                if ((uint32_t)k * 64 < nq) {                                     // wave-uniform: a 150-base read fills three of the four rounds
+                    n4[k] = (uint32_t)k * 64 + lane < nq ? (uint32_t)occ[hq4[k]] : 0u;
+                    has4[k] = hw::ballot(n4[k] != 0);
+                }
+            }
+            // Exact votes of up to two diagonals = positions where the two hash sequences agree along them; `others` = read k-mers that have a bin
+            // entry on neither, i.e. an upper bound for the votes of ANY other diagonal. If the better of the two beats that bound, the answer is
+            // that diagonal - or both, ascending, when they tie (a read split evenly by an indel).
+            uint32_t w0 = 0xffffffffu, w1 = 0xffffffffu;                     // the winning diagonal(s)
+            auto decide = [&](uint32_t dA, uint32_t dB) -> bool {           // dB may be "none" (0xffffffff)
+                uint32_t cntA = 0, cntB = 0, others = 0;
+                const bool two = dB != 0xffffffffu && dB != dA;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if ((uint32_t)k * 64 < nq) {
+                    const uint32_t q = (uint32_t)k * 64 + lane, xa = q + dA, xb = q + dB;
+                    const bool onA = q < nq && xa < nk && (uint32_t)hh[xa < nk ? xa : 0] == hq4[k];
+                    cntA += (uint32_t)__builtin_popcountll(hw::ballot(onA));
+                    uint32_t mine = onA ? 1u : 0u;
+                    if (two) {
+                        const bool onB = q < nq && xb < nk && (uint32_t)hh[xb < nk ? xb : 0] == hq4[k];
+                        cntB += (uint32_t)__builtin_popcountll(hw::ballot(onB));
+                        mine += onB ? 1u : 0u;
+                    }
+                    others += (uint32_t)__builtin_popcountll(hw::ballot(n4[k] > mine));
+                }
+                const uint32_t best = cntA > cntB ? cntA : cntB;
+                if (best == 0 || best <= others) return false;
+                if (cntA == cntB) { w0 = dA < dB ? dA : dB; w1 = dA < dB ? dB : dA; }       // only possible when `two`
+                else { w0 = cntA > cntB ? dA : dB; w1 = 0xffffffffu; }
+                return true;
+            };
+            // first attempt: the diagonals named by the first and by the last read k-mer that occur in the haplotype (first entry of their bins)
+            uint32_t tried1 = 0xffffffffu, tried2 = 0xffffffffu;
+            {
+                int kf = -1, kl = -1;
+#pragma unroll
+                for (int k = 3; k >= 0; --k) if (has4[k]) kf = k;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (has4[k]) kl = k;
+                if (kf >= 0) {
+                    const uint32_t Lf = (uint32_t)__builtin_ctzll(has4[kf]), Ll = 63u - (uint32_t)__builtin_clzll(has4[kl]);
+                    const uint32_t hf = hw::readlane(kf == 0 ? hq4[0] : kf == 1 ? hq4[1] : kf == 2 ? hq4[2] : hq4[3], Lf);
+                    const uint32_t hl = hw::readlane(kl == 0 ? hq4[0] : kl == 1 ? hq4[1] : kl == 2 ? hq4[2] : hq4[3], Ll);
+                    const uint32_t qf = (uint32_t)kf * 64 + Lf, ql = (uint32_t)kl * 64 + Ll;
+                    const uint32_t tf = idx[bins[hf]], tl = idx[bins[hl]];
+                    if (tf >= qf) tried1 = tf - qf;
+                    if (tl >= ql) tried2 = tl - ql;
+                    if (tried1 == 0xffffffffu) { tried1 = tried2; tried2 = 0xffffffffu; }
+                    if (tried1 != 0xffffffffu) decided = decide(tried1, tried2);
+                }
+            }
+            // second attempt: the two most frequent first-entry diagonals over all read k-mers
+            if (!decided) {
+                uint32_t cand4[4]; uint64_t rem4[4]; uint32_t remaining = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cand4[k] = 0xffffffffu; rem4[k] = 0;
+                    if ((uint32_t)k * 64 < nq) {
+                        const uint32_t q = (uint32_t)k * 64 + lane;
+                        const uint32_t t0 = idx[bins[hq4[k]] < nk ? bins[hq4[k]] : 0];
+                        cand4[k] = (n4[k] && t0 >= q) ? t0 - q : 0xffffffffu;
+                        rem4[k] = hw::ballot(cand4[k] != 0xffffffffu);
+                        remaining += (uint32_t)__builtin_popcountll(rem4[k]);
+                    }
+                }
+                uint32_t c1 = 0, d1 = 0xffffffffu, c2 = 0, d2 = 0xffffffffu;
+                for (int it = 0; it < 8 && remaining > c1; ++it) {
+                    uint32_t d = 0;
+                    if (rem4[0]) d = hw::readlane(cand4[0], (uint32_t)__builtin_ctzll(rem4[0]));
+                    else if (rem4[1]) d = hw::readlane(cand4[1], (uint32_t)__builtin_ctzll(rem4[1]));
+                    else if (rem4[2]) d = hw::readlane(cand4[2], (uint32_t)__builtin_ctzll(rem4[2]));
+                    else d = hw::readlane(cand4[3], (uint32_t)__builtin_ctzll(rem4[3]));
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if ((uint32_t)k * 64 < nq) { const uint64_t same = hw::ballot(cand4[k] == d) & rem4[k]; rem4[k] &= ~same; c += (uint32_t)__builtin_popcountll(same); }
+                    remaining -= c;
+                    if (c > c1) { c2 = c1; d2 = d1; c1 = c; d1 = d; } else if (c > c2) { c2 = c; d2 = d; }
+                }
+                if (c1 > 0 && remaining <= c1 && !(d1 == tried1 && d2 == tried2) && !(d1 == tried2 && d2 == tried1)) decided = decide(d1, d2);
+            }
+            if (decided && lane == 0) {
+                uint32_t n_w = 0;
+                if (max_pos >= 1) { b.pos[e * (uint64_t)max_pos] = w0; n_w = 1; }
+                if (w1 != 0xffffffffu && max_pos >= 2) { b.pos[e * (uint64_t)max_pos + 1] = w1; n_w = 2; }
+                b.npos[e] = (uint8_t)n_w;
+            }
+        }
+        if (b.map_stats && lane == 0) hw::atomic_add_u64(b.stats + (size_t)(hw::block_idx() % kStatSlots) * 8 + (decided ? 6 : 7), 1ull);   // OCT_PHMM_MAP_STATS: pairs decided by the shortcut / counted
+        if (!decided) {
         uint32_t hq_next = lane < nq ? b.rhash[ro + lane] : 0;             // software pipeline: next batch's hashes are in flight
         for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
             const uint32_t q = q0 + lane;
@@ -243,6 +378,10 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
         if (n_out > max_pos) n_out = max_pos;
         if (lane == 0) b.npos[e] = (uint8_t)n_out;
         hw::wave_lds_fence();
+        }
+        ro = ro_n; nq = nq_n; ro_n = ro_nn; nq_n = nq_nn;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hq4[k] = hq4_n[k];
     }
 }
 
@@ -254,7 +393,7 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
 // goes, so the usual case - one winning diagonal - ends without a sweep over the counters.
 // (k_kmer_map above issues ~670 instructions per pair around wave-wide ballots and LDS atomics and waits half of its time; this form
 // issues a few dozen. Same votes, same output: tests/check_populate.py::assert_device_positions.)
-inline uint32_t kmer_lanes_stride(uint32_t lh_cap) { return ((lh_cap + 3) & ~3u) + 4; }      // bytes per lane; the odd dword count staggers the lanes' banks
+OCT_HD uint32_t kmer_lanes_stride(uint32_t lh_cap) { return ((lh_cap + 3) & ~3u) + 4; }      // bytes per lane; the odd dword count staggers the lanes' banks
 inline uint32_t kmer_map_lanes_lds_bytes(uint32_t lh_cap, uint32_t lanes) { return kKmerBins * 4 + ((lh_cap + 1) & ~1u) * 2 + lanes * kmer_lanes_stride(lh_cap); }
 
 template <int LANES>
@@ -688,7 +827,7 @@ OCT_KERNEL(k_dp)(DpParams p)
 {
     constexpr uint32_t ROWS = 64 / B, G = 2 * ROWS;
     OCT_DYN_SMEM(smem);
-    const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = hw::readfirstlane(tid >> 6);   // uniform, and known to be: group index and tile addresses live in SGPRs
     const uint32_t row = lane / B, li = lane % B;
     const uint32_t lh_n = (p.lh_cap + 8 + 1) & ~1u, rec_n = dp_rec_n(p.t_cap, B);
     uint2* tabF = (uint2*)smem;                      // [lh_n] forward-strand table of the current haplotype
@@ -795,11 +934,12 @@ OCT_KERNEL(k_dp)(DpParams p)
             uint32_t GOn = hw::perm(nB.y, nA.y, 0x05040100u), GEn = hw::perm(nB.y, nA.y, 0x07060302u);
 
             // returns the packed match cost; fsrc = a word that is non-zero per half exactly where the walk would charge a flank penalty
-            auto cost = [&](const uint2 r2, const uint2 a, const uint2 b, uint32_t& fsrc) -> uint32_t {
+            auto cost = [&](const uint2 r2, const uint2 a2, const uint2 b2, uint32_t& fsrc) -> uint32_t {
+                const uint32_t a = a2.x, b = b2.x;                                          // cost words of the two packed tasks
                 if constexpr (GENERIC) {
                     // update_match_state with the reference's equality tests on raw bytes (:121-132)
-                    const uint32_t hh = hw::perm(b.x, a.x, 0x0c040c00u), mm = hw::perm(b.x, a.x, 0x0c050c01u);
-                    const uint32_t pp = hw::pk_shl2(hw::perm(b.x, a.x, 0x0c060c02u)), nn = hw::perm(b.x, a.x, 0x0c070c03u);
+                    const uint32_t hh = hw::perm(b, a, 0x0c040c00u), mm = hw::perm(b, a, 0x0c050c01u);
+                    const uint32_t pp = hw::pk_shl2(hw::perm(b, a, 0x0c060c02u)), nn = hw::perm(b, a, 0x0c070c03u);
                     const uint32_t ne = hw::pk_min_u(r2.x ^ hh, 0x00010001u), nf = hw::pk_min_u(r2.x ^ mm, 0x00010001u);
                     const uint32_t inner = hw::pk_mad(nf, hw::pk_sub(r2.y, pp), pp);        // target == mask ? prior : quality
                     uint32_t c = hw::pk_mul(ne, hw::pk_min_i(r2.y, inner));                 // 0 where target == truth
@@ -807,7 +947,7 @@ OCT_KERNEL(k_dp)(DpParams p)
                     fsrc = ne;                                                              // target != truth (also charges 2 on 'N', even at quality 0)
                     return hw::pk_min_i(c, nq);
                 } else {
-                    const uint32_t cp = hw::perm(b.x, a.x, r2.x);                           // {capA, capB} for this read base
+                    const uint32_t cp = hw::perm(b, a, r2.x);                               // {capA, capB} for this read base
                     const uint32_t c = hw::pk_min_u(cp, r2.y);                              // min(quality, cap), unshifted
                     fsrc = c;                                                               // the flank penalty of this column is exactly c
                     return c;
@@ -856,7 +996,7 @@ OCT_KERNEL(k_dp)(DpParams p)
                     uint32_t bpe = 0;
                     if constexpr (TR) {                                                     // update_traceback :147-163
                         const uint32_t tm = M1 & 0x00030003u, ti = I1 & 0x00030003u, td = D1 & 0x00030003u;
-                        M1 ^= tm; I1 = (I1 & ~0x00030003u) | 0x00010001u; D1 |= 0x00030003u;
+                        M1 ^= tm; I1 |= 0x00010001u; D1 |= 0x00030003u;   // I inherits label 0 or 1 only (its predecessors are M and I, all addends are multiples of 4): setting bit 0 relabels it
                         bpe = hw_lshl_or(td, 4, hw_lshl_or(ti, 2, tm | flag_of(fe, 15)));   // + "this match cell costs something" flag
                     }
                     // ---- odd diagonal s = 2k+1: lane li is cell (t, x+1) ----
@@ -870,7 +1010,7 @@ OCT_KERNEL(k_dp)(DpParams p)
                     I2 = shift_down<B>(INFB, ish, li);                                      // :318-319
                     if constexpr (TR) {
                         const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
-                        M2 ^= tm; I2 = (I2 & ~0x00030003u) | 0x00010001u; D2 |= 0x00030003u;
+                        M2 ^= tm; I2 |= 0x00010001u; D2 |= 0x00030003u;
                         const uint32_t bpo = hw_lshl_or(td, 4, hw_lshl_or(ti, 2, tm));
                         tile[(k & 15) * kTileStride + lane] = hw_lshl_or(bpo, 6, bpe | flag_of(fo, 14));
                     }

@@ -8,6 +8,8 @@
 #if defined(OCTPHMM_SIM)
 #include "rt_sim.hpp"
 #else
+#include <dlfcn.h>
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 
 namespace octphmm { namespace rt {
@@ -50,6 +52,30 @@ template <class K> inline bool allow_lds(K kernel, size_t bytes)
     return true;
 }
 constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+// roctx ranges around the host-side phases (upload, run, per-slice phases, download) for rocprofv3 --marker-trace timelines. The tracer library
+// is looked up at run time and only when OCT_PHMM_ROCTX is set: the product has no link-time dependency on it and pays one branch otherwise.
+struct Range {
+    typedef int (*PushFn)(const char*); typedef int (*PopFn)();
+    static PushFn& push_fn() { static PushFn f = nullptr; return f; }
+    static PopFn& pop_fn() { static PopFn f = nullptr; return f; }
+    static bool enabled()
+    {
+        static const bool on = [] {
+            if (!getenv("OCT_PHMM_ROCTX")) return false;
+            void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) lib = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) return false;
+            push_fn() = (PushFn)dlsym(lib, "roctxRangePushA"); pop_fn() = (PopFn)dlsym(lib, "roctxRangePop");
+            return push_fn() && pop_fn();
+        }();
+        return on;
+    }
+    bool live;
+    explicit Range(const char* name) : live(enabled()) { if (live) push_fn()(name); }
+    ~Range() { if (live) pop_fn()(); }
+    Range(const Range&) = delete; Range& operator=(const Range&) = delete;
+};
 
 }} // namespace octphmm::rt
 

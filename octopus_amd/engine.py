@@ -53,7 +53,8 @@ _LIBS = {}
 
 
 def load(path: Optional[Path] = None) -> C.CDLL:
-    p = Path(path) if path is not None else LIB_PATH
+    import os
+    p = Path(path) if path is not None else Path(os.environ.get("OCT_PHMM_LIB", LIB_PATH))      # OCT_PHMM_LIB: A/B of two builds in one GPU session (tools/)
     if not p.exists():
         raise FileNotFoundError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
