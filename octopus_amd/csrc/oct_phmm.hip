@@ -1070,9 +1070,17 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 RT(rt::launch_ok());
             } else if (sl.blk1 > sl.blk0) {
                 const size_t lds = kmer_map_lds_bytes(b->lh_cap);
-                if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map, lds));
-                OCT_LAUNCH(k_kmer_map, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
-                           (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block); RT(rt::launch_ok());
+                const uint32_t nq_cap = b->t_cap >= kKmer ? b->t_cap - kKmer + 1 : 0;
+                if (nq_cap <= 192) {                          // reads up to 197 bases: three 64-lane rounds hold a read's k-mers
+                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map<3>, lds));
+                    OCT_LAUNCH(k_kmer_map<3>, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
+                               (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block);
+                } else {
+                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map<4>, lds));
+                    OCT_LAUNCH(k_kmer_map<4>, sl.blk1 - sl.blk0, kBlockWaves * 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0,
+                               (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap, b->map_reads_per_block);
+                }
+                RT(rt::launch_ok());
             }
         }
         const uint32_t pair_blocks = (uint32_t)((np + 255) / 256);

@@ -74,6 +74,30 @@ OCT_DEVICE uint32_t wave_max_u32(uint32_t v)
     v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave max
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// wave-wide unsigned min: lanes without a DPP source read 0xffffffff
+OCT_DEVICE uint32_t wave_min_u32(uint32_t v)
+{
+    auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false));
+    v = mn(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// wave-wide sum, result in every lane: the same DPP ladder (row prefix sums, then row broadcasts); six VALU instructions and one v_readlane,
+// no scalar-unit work - the k-mer mapper is bound by the CU's single scalar ALU, so its reductions stay on the vector side
+OCT_DEVICE uint32_t wave_sum_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8  -> lane 15 of each row holds the row sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 OCT_DEVICE uint32_t atomic_add_lds_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 OCT_DEVICE uint32_t atomic_max_lds_u32(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 OCT_DEVICE void block_sync() { __syncthreads(); }

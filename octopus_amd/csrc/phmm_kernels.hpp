@@ -171,6 +171,7 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint
 // one diagonal (the normal case: the read's true offset) is merged into a single add.
 inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + 2 * ((lh_cap + 1) & ~1u) * 2 + kKmerBins + kBlockWaves * (lh_cap + 64) * 4; }
 
+template <int ROUNDS>      // 64-lane rounds that hold the k-mers of the batch's longest read (3 for 150-base reads, at most 4 for the shortcut)
 OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap, uint32_t reads_per_block)
 {
     OCT_DYN_SMEM(smem);
@@ -211,11 +212,11 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
         ro_ = 0; nq_ = 0;
         if (rr < r_end) { ro_ = b.roff[rr]; const uint32_t T_ = b.roff[rr + 1] - ro_; nq_ = T_ >= kKmer ? T_ - kKmer + 1 : 0; }   // compute_kmer_hashes :57-69
     };
-    auto load_hashes = [&](uint32_t ro_, uint32_t nq_, uint32_t (&hv)[4]) {
+    auto load_hashes = [&](uint32_t ro_, uint32_t nq_, uint32_t (&hv)[ROUNDS]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const uint32_t q = (uint32_t)k * 64 + lane; hv[k] = ((uint32_t)k * 64 < nq_ && q < nq_) ? (uint32_t)b.rhash[ro_ + q] : 0u; }
+        for (int k = 0; k < ROUNDS; ++k) { const uint32_t q = (uint32_t)k * 64 + lane; hv[k] = q < nq_ ? (uint32_t)b.rhash[ro_ + q] : 0u; }
     };
-    uint32_t ro = 0, nq = 0, ro_n = 0, nq_n = 0, hq4[4], hq4_n[4];
+    uint32_t ro = 0, nq = 0, ro_n = 0, nq_n = 0, hq4[ROUNDS], hq4_n[ROUNDS];
     load_offsets(r_first + wave, ro, nq);
     load_offsets(r_first + wave + kBlockWaves, ro_n, nq_n);
     load_hashes(ro, nq, hq4);
@@ -229,36 +230,38 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
         // candidate; its true count is a plain comparison of the two hash sequences along d (no counters); any other diagonal collects at
         // most one vote from each read k-mer that has a bin entry off d. If count(d) exceeds the number of such k-mers, d alone holds
         // max_hit_count and the answer is {d}. Anything else (near-even indel splits, repeats) takes the counting path below.
-        if (nq > 0 && nq <= 256 && !b.map_count_only) {
-            uint32_t n4[4]; uint64_t has4[4];
+        if (nq > 0 && nq <= 64 * ROUNDS && nq <= 255 && !b.map_count_only) {     // (vote counts travel in bytes)
+            // The CU's one scalar ALU is what this kernel runs out of (ballots, popcounts, scalar selects: ~2 scalar per vector instruction
+            // in the first version), so everything below stays per lane and is reduced over the wave with DPP ladders on the vector side.
+            uint32_t n4[ROUNDS];
+            uint32_t key_lo = 0xffffffffu, key_hi = 0;                       // first / last read k-mer that occurs in the haplotype: q << 12 | hash
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                n4[k] = 0; has4[k] = 0;
-                if ((uint32_t)k * 64 < nq) {                                     // wave-uniform: a 150-base read fills three of the four rounds
-                    n4[k] = (uint32_t)k * 64 + lane < nq ? (uint32_t)occ[hq4[k]] : 0u;
-                    has4[k] = hw::ballot(n4[k] != 0);
-                }
+            for (int k = 0; k < ROUNDS; ++k) {
+                const uint32_t q = (uint32_t)k * 64 + lane;
+                const uint32_t o = (uint32_t)occ[hq4[k]];
+                n4[k] = q < nq ? o : 0u;
+                const uint32_t key = q << 12 | hq4[k];
+                key_lo = n4[k] && key < key_lo ? key : key_lo;
+                key_hi = n4[k] && key > key_hi ? key : key_hi;
             }
+            uint32_t w0 = 0xffffffffu, w1 = 0xffffffffu;                     // the winning diagonal(s)
             // Exact votes of up to two diagonals = positions where the two hash sequences agree along them; `others` = read k-mers that have a bin
             // entry on neither, i.e. an upper bound for the votes of ANY other diagonal. If the better of the two beats that bound, the answer is
             // that diagonal - or both, ascending, when they tie (a read split evenly by an indel).
-            uint32_t w0 = 0xffffffffu, w1 = 0xffffffffu;                     // the winning diagonal(s)
             auto decide = [&](uint32_t dA, uint32_t dB) -> bool {           // dB may be "none" (0xffffffff)
-                uint32_t cntA = 0, cntB = 0, others = 0;
+                // per lane {votes on dA, votes on dB, k-mers with an entry on neither} in three bytes (a lane holds at most four k-mers)
+                uint32_t acc = 0;
                 const bool two = dB != 0xffffffffu && dB != dA;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if ((uint32_t)k * 64 < nq) {
+                for (int k = 0; k < ROUNDS; ++k) {
                     const uint32_t q = (uint32_t)k * 64 + lane, xa = q + dA, xb = q + dB;
-                    const bool onA = q < nq && xa < nk && (uint32_t)hh[xa < nk ? xa : 0] == hq4[k];
-                    cntA += (uint32_t)__builtin_popcountll(hw::ballot(onA));
-                    uint32_t mine = onA ? 1u : 0u;
-                    if (two) {
-                        const bool onB = q < nq && xb < nk && (uint32_t)hh[xb < nk ? xb : 0] == hq4[k];
-                        cntB += (uint32_t)__builtin_popcountll(hw::ballot(onB));
-                        mine += onB ? 1u : 0u;
-                    }
-                    others += (uint32_t)__builtin_popcountll(hw::ballot(n4[k] > mine));
+                    const uint32_t onA = (q < nq && xa < nk && (uint32_t)hh[xa < nk ? xa : 0] == hq4[k]) ? 1u : 0u;
+                    uint32_t onB = 0;
+                    if (two) onB = (q < nq && xb < nk && (uint32_t)hh[xb < nk ? xb : 0] == hq4[k]) ? 1u : 0u;
+                    acc += onA | onB << 8 | (n4[k] > onA + onB ? 1u << 16 : 0u);
                 }
+                const uint32_t tot = hw::wave_sum_u32(acc);
+                const uint32_t cntA = tot & 0xffu, cntB = (tot >> 8) & 0xffu, others = tot >> 16;
                 const uint32_t best = cntA > cntB ? cntA : cntB;
                 if (best == 0 || best <= others) return false;
                 if (cntA == cntB) { w0 = dA < dB ? dA : dB; w1 = dA < dB ? dB : dA; }       // only possible when `two`
@@ -268,47 +271,35 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
             // first attempt: the diagonals named by the first and by the last read k-mer that occur in the haplotype (first entry of their bins)
             uint32_t tried1 = 0xffffffffu, tried2 = 0xffffffffu;
             {
-                int kf = -1, kl = -1;
-#pragma unroll
-                for (int k = 3; k >= 0; --k) if (has4[k]) kf = k;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (has4[k]) kl = k;
-                if (kf >= 0) {
-                    const uint32_t Lf = (uint32_t)__builtin_ctzll(has4[kf]), Ll = 63u - (uint32_t)__builtin_clzll(has4[kl]);
-                    const uint32_t hf = hw::readlane(kf == 0 ? hq4[0] : kf == 1 ? hq4[1] : kf == 2 ? hq4[2] : hq4[3], Lf);
-                    const uint32_t hl = hw::readlane(kl == 0 ? hq4[0] : kl == 1 ? hq4[1] : kl == 2 ? hq4[2] : hq4[3], Ll);
-                    const uint32_t qf = (uint32_t)kf * 64 + Lf, ql = (uint32_t)kl * 64 + Ll;
-                    const uint32_t tf = idx[bins[hf]], tl = idx[bins[hl]];
+                const uint32_t kf = hw::wave_min_u32(key_lo), kl = hw::wave_max_u32(key_hi);
+                if (kf != 0xffffffffu) {
+                    const uint32_t qf = kf >> 12, ql = kl >> 12;
+                    const uint32_t tf = idx[bins[kf & 0xfffu]], tl = idx[bins[kl & 0xfffu]];
                     if (tf >= qf) tried1 = tf - qf;
                     if (tl >= ql) tried2 = tl - ql;
                     if (tried1 == 0xffffffffu) { tried1 = tried2; tried2 = 0xffffffffu; }
                     if (tried1 != 0xffffffffu) decided = decide(tried1, tried2);
                 }
             }
-            // second attempt: the two most frequent first-entry diagonals over all read k-mers
+            // second attempt (a few percent of the pairs): the two most frequent first-entry diagonals over all read k-mers
             if (!decided) {
-                uint32_t cand4[4]; uint64_t rem4[4]; uint32_t remaining = 0;
+                uint32_t cand4[ROUNDS]; uint64_t rem4[ROUNDS]; uint32_t remaining = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cand4[k] = 0xffffffffu; rem4[k] = 0;
-                    if ((uint32_t)k * 64 < nq) {
-                        const uint32_t q = (uint32_t)k * 64 + lane;
-                        const uint32_t t0 = idx[bins[hq4[k]] < nk ? bins[hq4[k]] : 0];
-                        cand4[k] = (n4[k] && t0 >= q) ? t0 - q : 0xffffffffu;
-                        rem4[k] = hw::ballot(cand4[k] != 0xffffffffu);
-                        remaining += (uint32_t)__builtin_popcountll(rem4[k]);
-                    }
+                for (int k = 0; k < ROUNDS; ++k) {
+                    const uint32_t q = (uint32_t)k * 64 + lane;
+                    const uint32_t t0 = idx[bins[hq4[k]] < nk ? bins[hq4[k]] : 0];
+                    cand4[k] = (n4[k] && t0 >= q) ? t0 - q : 0xffffffffu;
+                    rem4[k] = hw::ballot(cand4[k] != 0xffffffffu);
+                    remaining += (uint32_t)__builtin_popcountll(rem4[k]);
                 }
                 uint32_t c1 = 0, d1 = 0xffffffffu, c2 = 0, d2 = 0xffffffffu;
                 for (int it = 0; it < 8 && remaining > c1; ++it) {
-                    uint32_t d = 0;
-                    if (rem4[0]) d = hw::readlane(cand4[0], (uint32_t)__builtin_ctzll(rem4[0]));
-                    else if (rem4[1]) d = hw::readlane(cand4[1], (uint32_t)__builtin_ctzll(rem4[1]));
-                    else if (rem4[2]) d = hw::readlane(cand4[2], (uint32_t)__builtin_ctzll(rem4[2]));
-                    else d = hw::readlane(cand4[3], (uint32_t)__builtin_ctzll(rem4[3]));
+                    uint32_t d = 0; bool got = false;
+#pragma unroll
+                    for (int k = 0; k < ROUNDS; ++k) if (!got && rem4[k]) { d = hw::readlane(cand4[k], (uint32_t)__builtin_ctzll(rem4[k])); got = true; }
                     uint32_t c = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if ((uint32_t)k * 64 < nq) { const uint64_t same = hw::ballot(cand4[k] == d) & rem4[k]; rem4[k] &= ~same; c += (uint32_t)__builtin_popcountll(same); }
+                    for (int k = 0; k < ROUNDS; ++k) { const uint64_t same = hw::ballot(cand4[k] == d) & rem4[k]; rem4[k] &= ~same; c += (uint32_t)__builtin_popcountll(same); }
                     remaining -= c;
                     if (c > c1) { c2 = c1; d2 = d1; c1 = c; d1 = d; } else if (c > c2) { c2 = c; d2 = d; }
                 }
@@ -381,7 +372,7 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
         }
         ro = ro_n; nq = nq_n; ro_n = ro_nn; nq_n = nq_nn;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) hq4[k] = hq4_n[k];
+        for (int k = 0; k < ROUNDS; ++k) hq4[k] = hq4_n[k];
     }
 }
 

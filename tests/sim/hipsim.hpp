@@ -183,6 +183,16 @@ inline uint32_t wave_max_u32(uint32_t v)
     for (int m = 1; m < 64; m <<= 1) { const uint32_t o = shfl_xor(v, m); v = o > v ? o : v; }
     return v;
 }
+inline uint32_t wave_min_u32(uint32_t v)
+{
+    for (int m = 1; m < 64; m <<= 1) { const uint32_t o = shfl_xor(v, m); v = o < v ? o : v; }
+    return v;
+}
+inline uint32_t wave_sum_u32(uint32_t v)
+{
+    for (int m = 1; m < 64; m <<= 1) v += shfl_xor(v, m);
+    return v;
+}
 inline uint32_t atomic_max_lds_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_add_lds_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline void block_sync() { hipsim::block_sync_impl(); }
