@@ -169,7 +169,8 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint
 // map_query_to_target (:120-159): one wave per (haplotype, read) pair; the workgroup keeps the haplotype's bins in LDS and its
 // four waves stride over a chunk of the region's reads. Votes go to per-wave LDS counters; a 64-lane batch whose votes all fall on
 // one diagonal (the normal case: the read's true offset) is merged into a single add.
-inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + 2 * ((lh_cap + 1) & ~1u) * 2 + kKmerBins + kBlockWaves * (lh_cap + 64) * 4; }
+constexpr uint32_t kMapPad = 256;          // sentinel entries behind the haplotype's hash sequence: q + d never needs a bounds test (q <= 255, d < nk)
+inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + (2 * ((lh_cap + 1) & ~1u) + kMapPad) * 2 + kKmerBins + 4 + kBlockWaves * (lh_cap + 64) * 4; }
 
 template <int ROUNDS>      // 64-lane rounds that hold the k-mers of the batch's longest read (3 for 150-base reads, at most 4 for the shortcut)
 OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap, uint32_t reads_per_block)
@@ -178,8 +179,9 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
     uint16_t* bins = (uint16_t*)smem;                                  // [4097]
     uint16_t* idx = bins + kKmerBins + 2;                              // [lh_cap rounded to even]
     uint16_t* hh = idx + ((lh_cap + 1) & ~1u);                         // [lh_cap rounded to even] the haplotype's hash at every position
-    uint8_t* occ = (uint8_t*)(hh + ((lh_cap + 1) & ~1u));              // [4096] bin occupancy, capped at 255 (only 0 / 1 / more matter)
-    uint32_t* counts_all = (uint32_t*)(occ + kKmerBins);               // [waves][lh_cap + 64]
+    uint8_t* occ = (uint8_t*)(hh + ((lh_cap + 1) & ~1u) + kMapPad);    // [4096 + 1] bin occupancy, capped at 255 (only 0 / 1 / more matter); entry 4096 = 0 is
+                                                                       // the "hash" of lanes beyond a read's last k-mer
+    uint32_t* counts_all = (uint32_t*)(occ + kKmerBins + 4);           // [waves][lh_cap + 64]
     const uint32_t tid = hw::thread_idx(), lane = tid & 63;
     const uint32_t wave = hw::readfirstlane(tid >> 6);                 // wave-uniform BY CONSTRUCTION, and the compiler must know it: read index, read offsets and
                                                                        // k-mer count then live in SGPRs (scalar loads, scalar branches) instead of per-lane copies
@@ -197,9 +199,10 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
             *(uint2*)(bins + 4 * i) = make_uint2((v.x & 0xffffu) | v.y << 16, (v.z & 0xffffu) | v.w << 16);
             *(uint32_t*)(occ + 4 * i) = (c0 < 255 ? c0 : 255u) | (c1 < 255 ? c1 : 255u) << 8 | (c2 < 255 ? c2 : 255u) << 16 | (c3 < 255 ? c3 : 255u) << 24;
         }
-        if (tid == 0) bins[kKmerBins] = (uint16_t)nk;
+        if (tid == 0) { bins[kKmerBins] = (uint16_t)nk; *(uint32_t*)(occ + kKmerBins) = 0; }
     }
     for (uint32_t i = tid; i < nk; i += kBlockWaves * 64) { idx[i] = b.bin_idx[ho + i]; hh[i] = b.hhash[ho + i]; }
+    for (uint32_t i = nk + tid; i < ((lh_cap + 1) & ~1u) + kMapPad; i += kBlockWaves * 64) hh[i] = 0xffffu;   // no read hash equals it
     uint32_t* counts = counts_all + wave * (lh_cap + 64);
     for (uint32_t d = lane; d < nk + 64; d += 64) counts[d] = 0;
     hw::block_sync();
@@ -214,7 +217,7 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
     };
     auto load_hashes = [&](uint32_t ro_, uint32_t nq_, uint32_t (&hv)[ROUNDS]) {
 #pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) { const uint32_t q = (uint32_t)k * 64 + lane; hv[k] = q < nq_ ? (uint32_t)b.rhash[ro_ + q] : 0u; }
+        for (int k = 0; k < ROUNDS; ++k) { const uint32_t q = (uint32_t)k * 64 + lane; hv[k] = q < nq_ ? (uint32_t)b.rhash[ro_ + q] : kKmerBins; }   // 4096 = "no k-mer": occupancy 0, matches nothing
     };
     uint32_t ro = 0, nq = 0, ro_n = 0, nq_n = 0, hq4[ROUNDS], hq4_n[ROUNDS];
     load_offsets(r_first + wave, ro, nq);
@@ -237,12 +240,11 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
             uint32_t key_lo = 0xffffffffu, key_hi = 0;                       // first / last read k-mer that occurs in the haplotype: q << 12 | hash
 #pragma unroll
             for (int k = 0; k < ROUNDS; ++k) {
-                const uint32_t q = (uint32_t)k * 64 + lane;
-                const uint32_t o = (uint32_t)occ[hq4[k]];
-                n4[k] = q < nq ? o : 0u;
-                const uint32_t key = q << 12 | hq4[k];
-                key_lo = n4[k] && key < key_lo ? key : key_lo;
-                key_hi = n4[k] && key > key_hi ? key : key_hi;
+                n4[k] = (uint32_t)occ[hq4[k]];
+                const uint32_t key = ((uint32_t)k * 64 + lane) << 13 | hq4[k];
+                const uint32_t lo = n4[k] ? key : 0xffffffffu, hi = n4[k] ? key : 0u;
+                key_lo = lo < key_lo ? lo : key_lo;
+                key_hi = hi > key_hi ? hi : key_hi;
             }
             uint32_t w0 = 0xffffffffu, w1 = 0xffffffffu;                     // the winning diagonal(s)
             // Exact votes of up to two diagonals = positions where the two hash sequences agree along them; `others` = read k-mers that have a bin
@@ -253,11 +255,12 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
                 uint32_t acc = 0;
                 const bool two = dB != 0xffffffffu && dB != dA;
 #pragma unroll
-                for (int k = 0; k < ROUNDS; ++k) {
-                    const uint32_t q = (uint32_t)k * 64 + lane, xa = q + dA, xb = q + dB;
-                    const uint32_t onA = (q < nq && xa < nk && (uint32_t)hh[xa < nk ? xa : 0] == hq4[k]) ? 1u : 0u;
+                for (int k = 0; k < ROUNDS; ++k) {                           // no predicates: lanes beyond the read hold the non-hash 4096, positions
+                    const uint32_t q = (uint32_t)k * 64 + lane;             // beyond the haplotype's last k-mer hold the sentinel 0xffff
+                    const uint32_t ha = hh[q + dA];
+                    const uint32_t onA = ha == hq4[k] ? 1u : 0u;
                     uint32_t onB = 0;
-                    if (two) onB = (q < nq && xb < nk && (uint32_t)hh[xb < nk ? xb : 0] == hq4[k]) ? 1u : 0u;
+                    if (two) { const uint32_t hb = hh[q + dB]; onB = hb == hq4[k] ? 1u : 0u; }
                     acc += onA | onB << 8 | (n4[k] > onA + onB ? 1u << 16 : 0u);
                 }
                 const uint32_t tot = hw::wave_sum_u32(acc);
@@ -273,7 +276,7 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
             {
                 const uint32_t kf = hw::wave_min_u32(key_lo), kl = hw::wave_max_u32(key_hi);
                 if (kf != 0xffffffffu) {
-                    const uint32_t qf = kf >> 12, ql = kl >> 12;
+                    const uint32_t qf = kf >> 13, ql = kl >> 13;
                     const uint32_t tf = idx[bins[kf & 0xfffu]], tl = idx[bins[kl & 0xfffu]];
                     if (tf >= qf) tried1 = tf - qf;
                     if (tl >= ql) tried2 = tl - ql;
