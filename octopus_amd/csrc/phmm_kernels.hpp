@@ -1554,7 +1554,7 @@ OCT_KERNEL(k_walk)(WalkParams w)
     int32_t sidx = end.sidx, i = sidx / 2 - T, y = T, x = sidx - T;
     int32_t flank = 0, msz = 0; uint32_t nev = 0, state = 0;
     // walker flags in ONE register word (separate bools ended up in scratch memory: the compiler merged their stores through a pointer select)
-    constexpr uint32_t kOk = 1u, kFin = 2u, kStarted = 4u;
+    constexpr uint32_t kOk = 1u, kFin = 2u;
     uint32_t fl = (active && sidx >= 0) ? kOk : kFin;
     if (fl & kOk) { const int64_t f0 = (int64_t)sidx * B + i; if (f0 < 0 || f0 >= n_flat) fl = kFin; }   // :186-190
 
@@ -1574,10 +1574,11 @@ OCT_KERNEL(k_walk)(WalkParams w)
     // one alignment column from backpointer word `wv` of cell (sidx, i). Written with selects instead of a three-way branch (the
     // unrolled sweep below instantiates it 32 times per tile; the branchy form overflowed the instruction cache); only the rare
     // in-flank event push is a branch.
+    // nothing is left to charge once a walk without left flank has passed the right one (early_stop: the traceback cannot fail when no lane wraps)
+    const int32_t stop_below_x = (w.early_stop && lhs == 0) ? rhs_begin : INT32_MIN;
     auto step = [&](uint32_t wv) {
         const uint32_t par = (uint32_t)sidx & 1u;
         const uint32_t bits = (wv >> (hshift + 6 * par)) & 63u, mism = (wv >> (hshift + 15 - par)) & 1u;
-        if (!(fl & kStarted)) { state = bits & 3u; sidx -= 2; fl |= kStarted; return; }          // :191-192
         const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;                 // :200
         const bool isM = state == 0, isI = state == 1, isD = !isM && !isI;
         i += isI ? (sidx & 1) : 0;                                                              // insert :205-209
@@ -1593,9 +1594,7 @@ OCT_KERNEL(k_walk)(WalkParams w)
             push_event(isM ? 0u : (ext ? 2u : 1u), isI ? xi : x, isM ? y : 0);
         }
         state = new_state;
-        if (y <= 0) fl |= kFin;                                                                 // :194
-        // nothing left to charge: no left flank in this window and the walk is past the right one (the traceback cannot fail when no lane wraps)
-        if (w.early_stop && lhs == 0 && x < rhs_begin) fl |= kFin;
+        fl |= (y <= 0 || x < stop_below_x) ? kFin : 0u;                                         // :194 / early stop
     };
     auto slow_word = [&](int64_t flat) -> uint32_t {                                            // any cell by flat index = diagonal * B + lane
         const int32_t s = (int32_t)(flat / B), li = (int32_t)(flat % B);
@@ -1605,13 +1604,21 @@ OCT_KERNEL(k_walk)(WalkParams w)
         return w.bp[(size_t)group * w.k_cap * C * 1024 + line * 16 + (k & 15)];
     };
 
-    uint32_t kmax = (fl & kOk) ? (uint32_t)(sidx >> 1) : 0;
+    // The walk's first move only reads the end cell's own label (:191-192). It is taken here, with one word fetched straight from the tiles, so that the
+    // sweep below has ONE kind of step and no "started yet?" branch in it.
+    if (fl & kOk) {
+        const int64_t f0 = (int64_t)sidx * B + i;
+        const uint32_t wv = slow_word(f0);
+        state = (wv >> (hshift + 6 * ((uint32_t)sidx & 1u))) & 3u;
+        sidx -= 2;
+    }
+    uint32_t kmax = ((fl & kOk) && sidx >= 0) ? (uint32_t)(sidx >> 1) : 0;
     for (int m = 1; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(kmax, m); kmax = o > kmax ? o : kmax; }
     kmax = hw::readfirstlane(kmax);
     for (int32_t kt = (int32_t)(kmax >> 4); kt >= 0; --kt) {
         if (hw::ballot(!(fl & kFin)) == 0) break;                                              // every walk of the wave is over (early stops)
         uint32_t c[16];
-        int32_t line_i = -1;
+        int32_t line_i = INT32_MIN;                                                             // no band lane: a walker outside the band takes the rare path below
         auto load_line = [&]() {
             const size_t line = C == 1 ? (size_t)kt * 64 + row * B + (uint32_t)i : ((size_t)kt * C + (uint32_t)i % C) * 64 + (uint32_t)i / C;
             const uint4* l = bpg + line * 4;
@@ -1626,15 +1633,17 @@ OCT_KERNEL(k_walk)(WalkParams w)
             const int32_t k = kt * 16 + kk;                                                     // the loop body stays small enough for the instruction cache
 #pragma unroll
             for (int rep = 0; rep < 2; ++rep) {                                                 // an insertion/deletion can add a second step at the same k
-                if (!(fl & kFin) && (sidx >> 1) == k && sidx >= 0) {
-                    if (i < 0) fl = (fl & ~kOk) | kFin;                                         // :195-199
-                    else if (i >= B) {                                                          // the reference indexes its array flat: lane overflow reads the next diagonal
-                        const int64_t f = (int64_t)sidx * B + i;
-                        if (f >= n_flat) fl = (fl & ~kOk) | kFin; else step(slow_word(f));
-                    } else {
-                        if (i != line_i) load_line();
-                        step(c[kk]);
+                if (!(fl & kFin) && (sidx >> 1) == k) {                                         // (a negative sidx never equals k >= 0)
+                    uint32_t wv = c[kk];
+                    bool go = true;
+                    if (i != line_i) {                                                          // rare: the walk changed its band lane (an indel), or left the band
+                        if (i < 0) { fl = (fl & ~kOk) | kFin; go = false; }                     // :195-199
+                        else if (i >= B) {                                                      // the reference indexes its array flat: lane overflow reads the next diagonal
+                            const int64_t f = (int64_t)sidx * B + i;
+                            if (f >= n_flat) { fl = (fl & ~kOk) | kFin; go = false; } else wv = slow_word(f);
+                        } else { load_line(); wv = c[kk]; }
                     }
+                    if (go) step(wv);
                 }
             }
         }
