@@ -38,7 +38,7 @@ CHEAP_CYCLES, DEAR_CYCLES = 2.6, 4.4
 # Fallback instruction budget (main-loop ISA count of the shipped build, VALU wave-instructions per DP iteration per wave = 8 tasks at
 # B = 16, and the share of cheap ones) for when no committed counter summary matches the kernels being timed.
 VALU_PER_ITER = {"score": 29.25, "trace": 51.75}
-CHEAP_SHARE = {"score": 45 / 117, "trace": 103 / 207}
+CHEAP_SHARE = {"score": 45 / 117, "trace": 111 / 207}     # round 2: the two I-state relabels per iteration are v_or_b32 (cheap) instead of v_and_or_b32 (dear)
 
 
 def issue_cycles_per_instr(kind: str) -> float:

@@ -141,6 +141,29 @@ struct oct_phmm_batch {
     oct_phmm_handle* owner = nullptr;
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Every environment switch of the library, in one place (documented for callers in INTEGRATION.md section 7). None is needed in
+// production. They are read when a handle is created or a batch is uploaded - never by a kernel - and fall in three groups:
+//   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS
+//   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
+//                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB
+//   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
+//                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER
+// ---------------------------------------------------------------------------------------------------------------
+namespace tune {
+inline bool flag(const char* name) { return getenv(name) != nullptr; }
+inline bool number(const char* name, long long* v) { const char* e = getenv(name); if (!e) return false; *v = atoll(e); return true; }
+inline bool timing()          { return flag("OCT_PHMM_TIMING"); }             // HIP events around every DP launch (bench.py's roofline leg)
+inline bool server_profile()  { return flag("OCT_PHMM_SERVER_PROFILE"); }     // region server: where the workers' time goes, printed at destroy
+inline bool map_stats()       { return flag("OCT_PHMM_MAP_STATS"); }          // k-mer mapper: pairs decided by the shortcut / counted, printed per run
+inline bool exact_adds()      { return flag("OCT_PHMM_EXACT_ADDS"); }         // keep v_pk_add_u16 even where the host bound allows v_add_u32
+inline bool pageable_h2d()    { return flag("OCT_PHMM_PAGEABLE_H2D"); }       // big batches: copy from the caller's arrays instead of the pinned staging halves
+inline bool map_count_only()  { return flag("OCT_PHMM_MAP_COUNT_ONLY"); }     // k-mer mapper without the exact shortcut
+inline bool lane_mapper()     { return flag("OCT_PHMM_LANE_MAPPER"); }        // the (slower) lane-per-pair mapper
+inline bool big_mapper()      { return flag("OCT_PHMM_BIG_MAPPER"); }         // test hook: the long-haplotype mapper on short haplotypes
+inline int  penalties_where() { const char* e = getenv("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
+}
+
 namespace {
 
 int fail(oct_phmm_status* st, int code, const char* msg)
@@ -191,7 +214,7 @@ struct Packer {
 // OCT_PHMM_STAGE_MAX_KB: test hook (small batches through the streaming path).
 static size_t stage_max()
 {
-    if (const char* e = getenv("OCT_PHMM_STAGE_MAX_KB")) { const long kb = atol(e); if (kb >= 2) return (size_t)kb << 10; }
+    long long kb; if (tune::number("OCT_PHMM_STAGE_MAX_KB", &kb) && kb >= 2) return (size_t)kb << 10;
     return (size_t)64 << 20;
 }
 
@@ -220,7 +243,7 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
         }
         return rt::h2d(base, h->stage, in_bytes, s);
     }
-    if (getenv("OCT_PHMM_PAGEABLE_H2D")) {                 // A/B switch: straight from the caller's (pageable) arrays
+    if (tune::pageable_h2d()) {                 // A/B switch: straight from the caller's (pageable) arrays
         for (auto& it : items) {
             if (!it.src) break;
             if (!rt::dev_memset((char*)base + it.off + it.bytes, 0, 16, s)) return false;
@@ -612,13 +635,13 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     h->cfg = *cfg; h->band = band; h->wide = cfg->use_int_scores != 0; h->lanes_c = band > 64 ? band / 64 : 1;
     if (h->cfg.mapping_quality_cap_trigger >= 0 && h->cfg.mapping_quality_cap_trigger >= h->cfg.mapping_quality_cap)
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
-    h->timing = getenv("OCT_PHMM_TIMING") != nullptr;
+    h->timing = tune::timing();
     {   // never plan for more than 60 % of what the device has free now (two server handles per device, other processes)
         size_t free_b = 0, total_b = 0;
         if (rt::mem_info(&free_b, &total_b) && free_b) h->bp_budget = std::min<size_t>(h->bp_budget, free_b / 10 * 6);
     }
-    if (const char* e = getenv("OCT_PHMM_BP_BUDGET_GB")) { const long gb = atol(e); if (gb > 0) h->bp_budget = (size_t)gb << 30; }
-    if (const char* e = getenv("OCT_PHMM_BP_BUDGET_KB")) { const long kb = atol(e); if (kb > 0) h->bp_budget = (size_t)kb << 10; }   // test hook: forces chunked traceback launches on small batches
+    { long long v; if (tune::number("OCT_PHMM_BP_BUDGET_GB", &v) && v > 0) h->bp_budget = (size_t)v << 30;
+      if (tune::number("OCT_PHMM_BP_BUDGET_KB", &v) && v > 0) h->bp_budget = (size_t)v << 10; }   // KB: test hook, forces chunked traceback launches on small batches
     if (!rt::stream_create(&h->stream)) return OCT_PHMM_EHIP;
     for (auto& es : h->extra_streams) if (!rt::stream_create(&es)) return OCT_PHMM_EHIP;
     if (!rt::event_create(&h->ev_ready)) return OCT_PHMM_EHIP;
@@ -699,7 +722,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     // Where the vectors are made: region-sized calls on host threads (a lone GPU lane is far slower than a host core, and the call is
     // latency-bound), big batches on the device, one haplotype per lane (tens of thousands of lanes beat sixteen cores). OCT_PHMM_PENALTIES=host|device overrides.
     bool gen_device = generate && H->n_haps >= 2048;
-    if (const char* e = getenv("OCT_PHMM_PENALTIES")) gen_device = generate && e[0] == 'd';
+    if (tune::penalties_where()) gen_device = generate && tune::penalties_where() == 2;
     std::vector<int8_t> gen_go, gen_ge, gen_pf, gen_pr; std::vector<char> gen_mf, gen_mr;
     if (generate && !gen_device) {
         const size_t nb = H->offsets[H->n_haps];
@@ -808,7 +831,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         const uint64_t tail = R->n_reads ? (uint64_t)(b->t_cap - std::min(b->t_cap, t_min)) * (gemax + nuc) : 0;
         const uint64_t finite = 4 * (sum_q_max + 2 * 64 * B64 + gomax + gemax + nuc + tail) + 1024;
         const uint64_t garbage = 4 * (2 * B64 * (gemax + nuc) + 64 + gomax + gemax + nuc) + 64;
-        b->fast_adds = finite < 0xF800u && garbage < 0x7FFu && h->cfg.nuc_prior >= 0 && !getenv("OCT_PHMM_EXACT_ADDS");
+        b->fast_adds = finite < 0xF800u && garbage < 0x7FFu && h->cfg.nuc_prior >= 0 && !tune::exact_adds();
     }
     for (uint32_t r = 0; r < R->n_reads; ++r) if (R->offsets[r + 1] == R->offsets[r]) return fail(status, OCT_PHMM_EINVAL, "empty read");
     std::vector<uint32_t> h_pos; std::vector<uint8_t> h_npos;
@@ -824,7 +847,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         }
     } else {
         b->device_map = true;
-        b->map_big = kmer_map_lds_bytes(b->lh_cap) > rt::kMaxLdsBytes || getenv("OCT_PHMM_BIG_MAPPER") != nullptr;   // env: test hook
+        b->map_big = kmer_map_lds_bytes(b->lh_cap) > rt::kMaxLdsBytes || tune::big_mapper();
         if (b->lh_cap >= 65536 || (size_t)b->lh_cap * 4 + 64 > rt::kMaxLdsBytes)
             return fail(status, OCT_PHMM_EUNSUPPORTED, "haplotype too long for the k-mer mapper (>= 40k bases)");
     }
@@ -876,12 +899,12 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     if (!positions) {
         pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1); pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
         pk.dalloc(&d.rhash, (size_t)n_read_bases + 1); pk.dalloc(&d.hhash, (size_t)n_hap_bases + 1);
-        d.map_count_only = getenv("OCT_PHMM_MAP_COUNT_ONLY") != nullptr; d.map_stats = getenv("OCT_PHMM_MAP_STATS") != nullptr;
+        d.map_count_only = tune::map_count_only(); d.map_stats = tune::map_stats();
         b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 256;      // the haplotype's tables are staged once per workgroup: big batches amortise them over more reads
         pk.dalloc(&d.bin32, (size_t)H->n_haps * kKmerBins + 4);
-        if (const char* e = getenv("OCT_PHMM_MAP_READS_PER_BLOCK")) { const long n = atol(e); if (n >= 4 && n <= 4096) b->map_reads_per_block = (uint32_t)n; }   // A/B switch
+        { long long n; if (tune::number("OCT_PHMM_MAP_READS_PER_BLOCK", &n) && n >= 4 && n <= 4096) b->map_reads_per_block = (uint32_t)n; }
         // lane-per-pair mapper: byte counters need every read's k-mer count to stay below 256, and bins + LANES counter rows must fit LDS
-        if (!b->map_big && b->t_cap <= 255 + kKmer - 1 && getenv("OCT_PHMM_LANE_MAPPER")) {     // A/B switch: measured 3.8x SLOWER than the wave mapper
+        if (!b->map_big && b->t_cap <= 255 + kKmer - 1 && tune::lane_mapper()) {     // A/B switch: measured 3.8x SLOWER than the wave mapper
             const int lanes = b->n_pairs < 500000 ? 64 : 256;                 // region-sized calls: more, smaller workgroups (latency)
             if (kmer_map_lanes_lds_bytes(b->lh_cap, (uint32_t)lanes) <= rt::kMaxLdsBytes) b->map_lanes = lanes;
             else if (kmer_map_lanes_lds_bytes(b->lh_cap, 64) <= rt::kMaxLdsBytes) b->map_lanes = 64;
@@ -913,7 +936,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     // late traceback start (k_dp): packed int16 kernels only, no lane can wrap (a failed traceback is then impossible,
     // so a walk may stop once it has left the right flank), populate only, and only where the three extra scan launches do not show
     uint64_t late_min_pairs = 100000;
-    if (const char* e = getenv("OCT_PHMM_LATE_MIN_PAIRS")) late_min_pairs = (uint64_t)atoll(e);   // test hook (0 = always, a huge value = never)
+    { long long v; if (tune::number("OCT_PHMM_LATE_MIN_PAIRS", &v)) late_min_pairs = (uint64_t)v; }   // test hook (0 = always, a huge value = never)
     b->late_ok = b->fast_adds && !align_mode && !b->stream && !h->wide && b->n_pairs >= late_min_pairs;
     if (b->late_ok) {
         pk.dalloc(&b->d_pair_cnt_late, (size_t)b->n_pairs + oct_phmm_handle::kMaxSlices + 1); pk.dalloc(&b->d_hap_base_late, (size_t)H->n_haps + 1);
@@ -922,7 +945,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         // Slices of whole haplotypes, each on its own stream: while slice i is in its VALU-bound DP kernels, slice i+1 runs its
         // latency-bound mapper/classifier and slice i-1 its latency-bound walk. Small batches stay in one slice.
         int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / 1000000));
-        if (const char* e = getenv("OCT_PHMM_SLICES")) n_slices = std::max(1, std::min(oct_phmm_handle::kMaxSlices, atoi(e)));
+        { long long v; if (tune::number("OCT_PHMM_SLICES", &v)) n_slices = std::max(1, std::min(oct_phmm_handle::kMaxSlices, (int)v)); }
         n_slices = (int)std::min<uint32_t>((uint32_t)n_slices, std::max<uint32_t>(1, H->n_haps));
         pk.dalloc(&b->d_totals, (size_t)n_slices);
         if (b->late_ok) pk.dalloc(&b->d_totals_late, (size_t)n_slices);
@@ -1200,7 +1223,7 @@ extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_ph
     RT(rt::stream_sync(h->stream));
     for (int k = 0; k < 6; ++k) { b->h_stats[k] = 0; for (uint32_t sl = 0; sl < kStatSlots; ++sl) b->h_stats[k] += b->h_stat_stripes[(size_t)sl * 8 + k]; }
     b->h_err_key = ~b->h_stat_stripes[(size_t)kStatSlots * 8];
-    if (getenv("OCT_PHMM_MAP_STATS")) {
+    if (tune::map_stats()) {
         unsigned long long dec = 0, cnt = 0;
         for (uint32_t sl = 0; sl < kStatSlots; ++sl) { dec += b->h_stat_stripes[(size_t)sl * 8 + 6]; cnt += b->h_stat_stripes[(size_t)sl * 8 + 7]; }
         fprintf(stderr, "{\"mapper_pairs_decided_by_shortcut\": %llu, \"mapper_pairs_counted\": %llu}\n", dec, cnt);
@@ -1426,7 +1449,7 @@ struct oct_phmm_server {
     std::vector<uint64_t> n_calls_by_device;
     std::atomic<bool> has_model {false};                 // oct_phmm_server_set_error_model: calls may leave their penalty vectors NULL
     // OCT_PHMM_SERVER_PROFILE=1: where a worker's time goes (ns, summed over workers), printed by oct_phmm_server_destroy
-    bool profile = getenv("OCT_PHMM_SERVER_PROFILE") != nullptr;
+    bool profile = tune::server_profile();
     std::atomic<uint64_t> ns_idle {0}, ns_concat {0}, ns_upload {0}, ns_run {0}, ns_download {0}, ns_scatter {0}, ns_single {0};
     static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     std::vector<int> device_of;                          // worker -> index into the device list
