@@ -211,7 +211,7 @@ def main():
     sim = os.environ.get("OCT_BENCH_BACKEND") == "sim"
     dev = "cpu" if sim else "cuda"
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("OCT_BENCH_FORCE_DIST"):       # FORCE_DIST: exercise the RCCL init / barrier / reductions on a one-GPU box (world_size 1)
         import torch
         import torch.distributed as dist  # RCCL; only the barrier + max-reduce of the timing contract use it
         if sim:

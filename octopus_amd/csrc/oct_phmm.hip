@@ -236,11 +236,19 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
             if (!rt::host_pinned_malloc(&h->stage, want)) return false;
             h->stage_bytes = want;
         }
-        for (auto& it : items) {
-            if (!it.src) break;
-            if (it.bytes) memcpy((char*)h->stage + it.off, it.src, it.bytes);
-            memset((char*)h->stage + it.off + it.bytes, 0, aligned(it.bytes) - it.bytes);
-        }
+        // the image of the input arrays in the pinned buffer, copied by a few host threads once it is worth their start-up (one thread moves
+        // ~10 GB/s: the 30 MB of a 100k x 128 batch took 3 ms of the call on one thread)
+        size_t n_in = 0; while (n_in < items.size() && items[n_in].src) ++n_in;
+        host_parallel(in_bytes, (size_t)2 << 20, [&](size_t lo, size_t hi) {
+            for (size_t i = 0; i < n_in; ++i) {
+                const Item& it = items[i];
+                const size_t slot_end = it.off + aligned(it.bytes), a = std::max(lo, it.off), z = std::min(hi, slot_end);
+                if (a >= z) continue;
+                const size_t data_end = it.off + it.bytes;
+                if (a < data_end) memcpy((char*)h->stage + a, (const char*)it.src + (a - it.off), std::min(z, data_end) - a);
+                if (z > data_end) { const size_t p0 = std::max(a, data_end); memset((char*)h->stage + p0, 0, z - p0); }
+            }
+        });
         return rt::h2d(base, h->stage, in_bytes, s);
     }
     if (tune::pageable_h2d()) {                 // A/B switch: straight from the caller's (pageable) arrays
@@ -1195,7 +1203,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         const oct_phmm_batch::Slice& sl = b->slices[i];
         if (!b->early_out || sl.out1 <= sl.out0) return OCT_PHMM_OK;
         RT(rt::event_sync(sl.done));
-        memcpy(b->early_out + sl.out0, (const double*)h->out_stage + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double));
+        const char* src = (const char*)((const double*)h->out_stage + sl.out0); char* dst = (char*)(b->early_out + sl.out0);
+        host_parallel((size_t)(sl.out1 - sl.out0) * sizeof(double), (size_t)2 << 20, [&](size_t lo, size_t hi) { memcpy(dst + lo, src + lo, hi - lo); });
         return OCT_PHMM_OK;
     };
     // software pipeline over slices: phase 1 of slice i+1 is enqueued before the host waits for slice i's task counts

@@ -39,13 +39,12 @@ def build(force: bool = False) -> Path:
 
 
 def kernel_source_sha() -> str:
-    """sha256 over the sources liboct_phmm.so is built from: stamps profile summaries (tools/summarize_pmc.py) so that bench.py can tell
+    """sha256 over the kernel sources of liboct_phmm.so (octopus_amd/csrc/*.hpp): stamps profile summaries (tools/summarize_pmc.py) so that bench.py can tell
     whether committed counter values belong to the kernels it is timing (the GPU box has no .git to ask)."""
     import hashlib
     m = hashlib.sha256()
-    for f in sorted((PKG_DIR / "csrc").iterdir()) + [PKG_DIR.parent / "include" / "oct_phmm.h"]:
-        if f.is_file():
-            m.update(f.name.encode()); m.update(f.read_bytes())
+    for f in sorted((PKG_DIR / "csrc").glob("*.hpp")):          # the device code: kernels, intrinsics layer, device data model (not the host API file)
+        m.update(f.name.encode()); m.update(f.read_bytes())
     return m.hexdigest()[:16]
 
 
