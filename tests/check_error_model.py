@@ -90,3 +90,61 @@ def check_populate_generates_the_vectors(backend, tol=0.0, where=("host", "devic
         else:
             os.environ["OCT_PHMM_PENALTIES"] = old
     return n
+
+
+def check_align_and_server_generate_the_vectors(backend, tol=0.0):
+    """oct_phmm_align and the region server with NULL penalty vectors + a model: same alignments / matrices as with the vectors given."""
+    import threading
+    from check_server import make_requests
+    lib_path = build_sim() if backend == "sim" else None
+    m = engine.default_error_model(lib_path)
+    rng = np.random.default_rng(91)
+
+    def with_model_vectors(batch):
+        given = synth.batch_from_regions([])  if False else batch
+        vec = engine.penalty_vectors(m, batch.hap_bases, batch.hap_offsets, lib_path=lib_path)
+        import copy
+        g = copy.copy(batch); g._keep = []
+        g.gap_open, g.gap_extend, g.snv_mask_fwd, g.snv_prior_fwd, g.snv_mask_rev, g.snv_prior_rev = vec
+        return g
+
+    # align
+    b = synth.batch_from_regions([synth.make_region(rng, 25, 4, T=60, Lh=180, B=8, flank=(20, 20), positions="none", indels_per_read=1)])
+    eng = make_engine(backend, max_indel_error=8)
+    want, wst = eng.align(with_model_vectors(b), 64)
+    eng.set_error_model(m)
+    got, gst = eng.align(b.without_penalty_vectors(), 64)
+    eng.close()
+    assert wst.code == gst.code == abi.OK
+    assert got["cigar_strings"] == want["cigar_strings"] and np.array_equal(got["mapping_position"], want["mapping_position"])
+    assert np.max(np.abs(got["likelihood"] - want["likelihood"]), initial=0.0) <= tol
+    # region server: callers with and without vectors at the same time
+    reqs = [r for r in make_requests(rng, 10, 8) if r.pos_offsets is None]
+    cfg = abi.Config.default(max_indel_error=8)
+    ref_eng = make_engine(backend, max_indel_error=8)
+    want = [ref_eng.populate(with_model_vectors(r), raise_on_error=False) for r in reqs]
+    want = [(o.copy(), st.code) for o, st in want]
+    ref_eng.close()
+    srv = engine.Server(cfg, lib_path=lib_path)
+    srv.set_error_model(m)
+    got = [None] * len(reqs)
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(t, len(reqs), 3):
+                r = reqs[i].without_penalty_vectors() if i % 2 == 0 else with_model_vectors(reqs[i])
+                o, st = srv.populate(r, raise_on_error=False)
+                got[i] = (o.copy(), st.code)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    srv.close()
+    assert not errors, errors
+    for (go, gc), (wo, wc) in zip(got, want):
+        assert gc == wc
+        if gc == abi.OK:
+            assert np.max(np.abs(go - wo), initial=0.0) <= tol
+    return len(reqs)

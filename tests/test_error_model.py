@@ -18,3 +18,7 @@ def test_product_penalty_vectors_equal_the_oracle_restatement():
 @pytest.mark.skipif(not oracle.have_ref(), reason="reference build absent")
 def test_sim_populate_generates_the_vectors_on_host_threads_and_on_the_device():
     assert ce.check_populate_generates_the_vectors("sim") > 0
+
+
+def test_sim_align_and_server_generate_the_vectors():
+    assert ce.check_align_and_server_generate_the_vectors("sim") >= 5

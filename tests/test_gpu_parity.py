@@ -332,3 +332,8 @@ def test_gpu_device_penalty_vectors_on_the_corpus_and_on_many_haplotypes():
     rb.free(); eng.close()
     for name, g, w in zip(ce.NAMES, got, want):
         assert np.array_equal(g, w), name
+
+
+def test_gpu_align_and_server_generate_the_penalty_vectors():
+    import check_error_model as ce
+    assert ce.check_align_and_server_generate_the_vectors("gpu", TOL) >= 5
