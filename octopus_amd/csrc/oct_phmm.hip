@@ -161,7 +161,9 @@ inline bool pageable_h2d()    { return flag("OCT_PHMM_PAGEABLE_H2D"); }       //
 inline bool map_count_only()  { return flag("OCT_PHMM_MAP_COUNT_ONLY"); }     // k-mer mapper without the exact shortcut
 inline bool lane_mapper()     { return flag("OCT_PHMM_LANE_MAPPER"); }        // the (slower) lane-per-pair mapper
 inline bool big_mapper()      { return flag("OCT_PHMM_BIG_MAPPER"); }         // test hook: the long-haplotype mapper on short haplotypes
-inline int  penalties_where() { const char* e = getenv("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
+inline int  penalties_where() { const char* e = getenv("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' || e[0] == 'l' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
+inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
+inline bool penalties_lane_kernel() { const char* e = getenv("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
 }
 
 namespace {
@@ -479,6 +481,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
 // per-haplotype penalty vectors (phmm_error_model.hpp): host threads, or one device lane per haplotype
 // ---------------------------------------------------------------------------------------------------------------
 struct PenaltyOut { int8_t* go; int8_t* ge; uint8_t* mf; int8_t* pf; uint8_t* mr; int8_t* pr; };
+constexpr size_t kPenaltyLdsBytes = 64 * 1024;     // LDS a wave of k_penalty_vectors_wave may take: the 160 KB of a CU then hold two haplotypes
 
 OCT_KERNEL(k_penalty_vectors)(const oct_phmm_error_model* model, const uint8_t* hbases, const uint32_t* hoff, uint32_t hap0, uint32_t hap1,
                               const uint8_t* sub_mask, uint32_t* workspace, size_t words_per_hap, PenaltyOut out, uint32_t* overflow)
@@ -489,6 +492,28 @@ OCT_KERNEL(k_penalty_vectors)(const oct_phmm_error_model* model, const uint8_t* 
     uint32_t* w = workspace + (size_t)(h - hap0) * words_per_hap;
     const int rc = em::penalty_vectors(*model, hbases + o, n, sub_mask ? sub_mask + o : nullptr, w, 1, out.go + o, out.ge + o, out.mf + o, out.pf + o, out.mr + o, out.pr + o);
     if (rc != em::kOk) overflow[h] = 1;
+}
+
+// One wave per haplotype, everything but the six output vectors in LDS: the haplotype's bases and the flat workspace of
+// phmm_error_model.hpp at its tight sizing. The wave's lanes share the parallel phases; lane 0 runs the sequential ones at LDS latency.
+OCT_KERNEL(k_penalty_vectors_wave)(const oct_phmm_error_model* model, const uint8_t* hbases, const uint32_t* hoff, uint32_t n_haps,
+                                   const uint8_t* sub_mask, uint32_t lds_words, PenaltyOut out, uint32_t* overflow, unsigned long long* prof)
+{
+    OCT_DYN_SMEM(lds_raw);
+    uint32_t* w = (uint32_t*)lds_raw;
+    const uint32_t h = hw::block_idx();
+    if (h >= n_haps) return;
+    em::Wave x;
+    x.prof = prof;
+    x.tick(0);
+    const uint32_t o = hoff[h], n = hoff[h + 1] - o;
+    const size_t need = em::workspace_words(n, 0);
+    uint8_t* s = (uint8_t*)(w + need);
+    if (need + (n + 3) / 4 > lds_words) { if (x.lane() == 0) overflow[h] = 1; return; }
+    for (uint32_t i = x.lane(); i < n; i += 64) s[i] = hbases[o + i];
+    x.sync();
+    const int rc = em::penalty_vectors(x, *model, s, n, sub_mask ? sub_mask + o : nullptr, w, 0, out.go + o, out.ge + o, out.mf + o, out.pf + o, out.mr + o, out.pr + o);
+    if (rc != em::kOk && x.lane() == 0) overflow[h] = 1;
 }
 
 namespace {
@@ -727,9 +752,10 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         return fail(status, OCT_PHMM_EINVAL, "null array");
     if (!R->offsets || !H->offsets || !monotone(R->offsets, R->n_reads) || !monotone(H->offsets, H->n_haps))
         return fail(status, OCT_PHMM_EINVAL, "offsets not monotone");
-    // Where the vectors are made: region-sized calls on host threads (a lone GPU lane is far slower than a host core, and the call is
-    // latency-bound), big batches on the device, one haplotype per lane (tens of thousands of lanes beat sixteen cores). OCT_PHMM_PENALTIES=host|device overrides.
-    bool gen_device = generate && H->n_haps >= 2048;
+    // Where the vectors are made: region-sized calls on host threads (one haplotype takes a host core 30 us and a wave 0.5 ms, and the call is
+    // latency-bound), batches on the device, one haplotype per wave (five waves per CU beat sixteen cores from a few hundred haplotypes on).
+    // OCT_PHMM_PENALTIES=host|device|lanes overrides.
+    bool gen_device = generate && H->n_haps >= 512;
     if (tune::penalties_where()) gen_device = generate && tune::penalties_where() == 2;
     std::vector<int8_t> gen_go, gen_ge, gen_pf, gen_pr; std::vector<char> gen_mf, gen_mr;
     if (generate && !gen_device) {
@@ -1000,27 +1026,52 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         RT(rt::h2d(d.npos, h_npos.data(), (size_t)b->n_pairs, s));
     }
     if (gen_device) {
-        // HaplotypeLikelihoodModel::reset for every haplotype on the device: one lane per haplotype, its workspace in HBM, in chunks that keep
-        // the workspace below 2 GB; a haplotype whose run lists outgrow the fixed workspace (pathological repeats) is redone on the host
+        // HaplotypeLikelihoodModel::reset for every haplotype on the device; a haplotype whose run lists outgrow the fixed workspace
+        // (pathological repeats) is redone on the host
         if (!h->d_model) {
             void* p = nullptr; RT(h->pool.alloc(&p, sizeof(oct_phmm_error_model))); h->d_model = (oct_phmm_error_model*)p;
             RT(rt::h2d(h->d_model, &h->model, sizeof(oct_phmm_error_model), s)); RT(rt::stream_sync(s));
         }
-        const size_t words = em::workspace_words(b->lh_cap, 1);
-        const uint32_t chunk = (uint32_t)std::max<size_t>(256, std::min<size_t>(H->n_haps, (((size_t)2 << 30) / (words * 4)) / 256 * 256));
-        void* ws = nullptr; RT(h->pool.alloc(&ws, (size_t)chunk * words * 4));
         void* ovf = nullptr; RT(h->pool.alloc(&ovf, ((size_t)H->n_haps + 1) * 4));
         RT(rt::dev_memset(ovf, 0, ((size_t)H->n_haps + 1) * 4, s));
         const PenaltyOut po {(int8_t*)d.go, (int8_t*)d.ge, (uint8_t*)d.maskF, (int8_t*)d.priorF, (uint8_t*)d.maskR, (int8_t*)d.priorR};
-        for (uint32_t h0 = 0; h0 < H->n_haps; h0 += chunk) {
-            const uint32_t h1 = std::min<uint32_t>(H->n_haps, h0 + chunk);
-            OCT_LAUNCH(k_penalty_vectors, (h1 - h0 + 63) / 64, 64, 0, s, (const oct_phmm_error_model*)h->d_model, d.hbases, d.hoff, h0, h1, d_sub_mask,
-                       (uint32_t*)ws, words, po, (uint32_t*)ovf);
+        const size_t lds_words = em::workspace_words(b->lh_cap, 0) + (b->lh_cap + 3) / 4;
+        if (lds_words * 4 <= kPenaltyLdsBytes && !tune::penalties_lane_kernel()) {
+            void* prof = nullptr;
+            if (tune::penalties_report()) { RT(h->pool.alloc(&prof, 16 * 8)); RT(rt::dev_memset(prof, 0, 16 * 8, s)); }
+            // one wave per haplotype, workspace in LDS (at least two waves per CU)
+            OCT_LAUNCH(k_penalty_vectors_wave, H->n_haps, 64, lds_words * 4, s, (const oct_phmm_error_model*)h->d_model, d.hbases, d.hoff, H->n_haps, d_sub_mask,
+                       (uint32_t)lds_words, po, (uint32_t*)ovf, (unsigned long long*)prof);
             RT(rt::launch_ok());
+            if (prof) {
+                unsigned long long t[16];
+                RT(rt::d2h(t, prof, sizeof t, s)); RT(rt::stream_sync(s));
+                h->pool.release(prof);
+                fprintf(stderr, "oct_phmm: k_penalty_vectors_wave lane-0 clocks per haplotype by phase:");
+                for (int k = 1; k <= 12; ++k) fprintf(stderr, " %d:%llu", k, t[k] / std::max<uint32_t>(1, H->n_haps));
+                fprintf(stderr, "\n");
+            }
+        } else {
+            // long haplotypes: one lane per haplotype, its workspace in HBM, in chunks that keep the workspace below 2 GB
+            const size_t words = em::workspace_words(b->lh_cap, 1);
+            const uint32_t chunk = (uint32_t)std::max<size_t>(256, std::min<size_t>(H->n_haps, (((size_t)2 << 30) / (words * 4)) / 256 * 256));
+            void* ws = nullptr; RT(h->pool.alloc(&ws, (size_t)chunk * words * 4));
+            for (uint32_t h0 = 0; h0 < H->n_haps; h0 += chunk) {
+                const uint32_t h1 = std::min<uint32_t>(H->n_haps, h0 + chunk);
+                OCT_LAUNCH(k_penalty_vectors, (h1 - h0 + 63) / 64, 64, 0, s, (const oct_phmm_error_model*)h->d_model, d.hbases, d.hoff, h0, h1, d_sub_mask,
+                           (uint32_t*)ws, words, po, (uint32_t*)ovf);
+                RT(rt::launch_ok());
+            }
+            RT(rt::stream_sync(s));
+            h->pool.release(ws);
         }
         std::vector<uint32_t> flags(H->n_haps);
         RT(rt::d2h(flags.data(), ovf, (size_t)H->n_haps * 4, s)); RT(rt::stream_sync(s));
-        h->pool.release(ws); h->pool.release(ovf);
+        h->pool.release(ovf);
+        if (tune::penalties_report()) {
+            size_t redo = 0; for (uint32_t f : flags) redo += f;
+            fprintf(stderr, "oct_phmm: penalty vectors of %u haplotypes on the device (LDS words %zu), %zu redone on the host\n", H->n_haps, lds_words, redo);
+        }
         std::vector<uint32_t> w;
         for (uint32_t hp = 0; hp < H->n_haps; ++hp) if (flags[hp]) {
             const uint32_t o = H->offsets[hp], n = H->offsets[hp + 1] - o;

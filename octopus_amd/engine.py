@@ -28,7 +28,7 @@ class EngineError(RuntimeError):
 
 def build(force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 the kernels + host API into octopus_amd/liboct_phmm.so (in-tree)."""
-    srcs = [PKG_DIR / "csrc" / n for n in ("oct_phmm.hip", "phmm_kernels.hpp", "phmm_readout.hpp", "phmm_device.hpp", "phmm_hw.hpp", "phmm_rt.hpp")]
+    srcs = [PKG_DIR / "csrc" / "oct_phmm.hip"] + sorted((PKG_DIR / "csrc").glob("*.hpp"))      # every header the one translation unit includes
     srcs.append(PKG_DIR.parent / "include" / "oct_phmm.h")
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return LIB_PATH

@@ -92,6 +92,42 @@ def check_populate_generates_the_vectors(backend, tol=0.0, where=("host", "devic
     return n
 
 
+def check_device_kernels_on_the_corpus(backend, n_strings=600, where=("device", "lanes"), seed=78):
+    """The two device kernels (one wave per haplotype with its workspace in LDS; one lane per haplotype with its workspace in HBM) on corpus
+    haplotypes with substitution masks: the vectors a NULL-vector upload leaves on the device equal the device-free host entry's, which
+    check_host_entry pins to the reference's classes."""
+    lib_path = build_sim() if backend == "sim" else None
+    m = engine.default_error_model(lib_path)
+    seqs, subs, bases, off = corpus(seed, n_strings)
+    sub = np.concatenate(subs)
+    want = engine.penalty_vectors(m, bases, off, sub, lib_path=lib_path)
+    rng = np.random.default_rng(seed)
+    read = rng.choice(np.frombuffer(b"ACGT", np.uint8), 30)
+    batch = abi.Batch(read_bases=read, read_quals=np.full(30, 30, np.uint8), read_offsets=np.asarray([0, 30], np.uint32), mapq=np.asarray([60], np.uint8),
+                      reverse=np.zeros(1, np.uint8), read_ref_begin=np.zeros(1, np.int64), row_offsets=None, hap_bases=bases.copy(), hap_offsets=off,
+                      hap_ref_begin=np.zeros(len(seqs), np.int64), gap_open=None, gap_extend=None, snv_mask_fwd=None, snv_prior_fwd=None,
+                      snv_mask_rev=None, snv_prior_rev=None)
+    old = os.environ.get("OCT_PHMM_PENALTIES")
+    try:
+        for path in where:
+            os.environ["OCT_PHMM_PENALTIES"] = path
+            eng = make_engine(backend, max_indel_error=8)
+            eng.set_error_model(m)
+            eng.set_substitution_mask(sub)
+            rb = eng.upload(batch)
+            got = rb.penalty_vectors()
+            rb.free(); eng.close()
+            for name, g, w in zip(NAMES, got, want):
+                bad = np.flatnonzero(g != w)
+                assert bad.size == 0, (path, name, int(np.searchsorted(off, bad[0], "right") - 1), bad[:5])
+    finally:
+        if old is None:
+            os.environ.pop("OCT_PHMM_PENALTIES", None)
+        else:
+            os.environ["OCT_PHMM_PENALTIES"] = old
+    return len(seqs)
+
+
 def check_align_and_server_generate_the_vectors(backend, tol=0.0):
     """oct_phmm_align and the region server with NULL penalty vectors + a model: same alignments / matrices as with the vectors given."""
     import threading

@@ -22,3 +22,7 @@ def test_sim_populate_generates_the_vectors_on_host_threads_and_on_the_device():
 
 def test_sim_align_and_server_generate_the_vectors():
     assert ce.check_align_and_server_generate_the_vectors("sim") >= 5
+
+
+def test_sim_both_device_kernels_equal_the_host_entry_on_corpus_strings():
+    assert ce.check_device_kernels_on_the_corpus("sim", 150) == 150

@@ -308,30 +308,10 @@ def test_gpu_populate_generates_the_penalty_vectors_on_host_threads_and_on_the_d
 
 
 def test_gpu_device_penalty_vectors_on_the_corpus_and_on_many_haplotypes():
-    """k_penalty_vectors (one haplotype per lane) on the 2,400-string corpus of the error-model tests, and on a 3,000-haplotype batch where the
-    device path is the default."""
-    if not oracle.have_ref():
-        pytest.skip("reference build absent")
-    import os
+    """k_penalty_vectors_wave (one haplotype per wave, workspace in LDS) and k_penalty_vectors (one haplotype per lane, workspace in HBM) on the
+    2,400-string corpus of the error-model tests with substitution masks."""
     import check_error_model as ce
-    from octopus_amd import engine
-    m = engine.default_error_model()
-    seqs, subs, bases, off = ce.corpus(78, 2400, with_sub=True)
-    want = engine.penalty_vectors(m, bases, off, np.concatenate(subs))              # host entry, itself pinned to the reference classes on the CPU suite
-    # one read so that the batch is valid; haplotypes = the corpus strings
-    n = len(seqs)
-    batch = abi.Batch(read_bases=np.frombuffer(b"ACGTACGTAC", np.uint8), read_quals=np.full(10, 30, np.uint8), read_offsets=np.asarray([0, 10], np.uint32),
-                      mapq=np.asarray([60], np.uint8), reverse=np.asarray([0], np.uint8), read_ref_begin=np.asarray([0], np.int64), row_offsets=None,
-                      hap_bases=bases, hap_offsets=off, hap_ref_begin=np.zeros(n, np.int64), gap_open=None, gap_extend=None, snv_mask_fwd=None,
-                      snv_prior_fwd=None, snv_mask_rev=None, snv_prior_rev=None)
-    eng = make_engine("gpu", max_indel_error=8)
-    eng.set_error_model(m)
-    eng.set_substitution_mask(np.concatenate(subs))
-    rb = eng.upload(batch)                                                          # 2,400 haplotypes >= 2,048: device path by default
-    got = rb.penalty_vectors()
-    rb.free(); eng.close()
-    for name, g, w in zip(ce.NAMES, got, want):
-        assert np.array_equal(g, w), name
+    assert ce.check_device_kernels_on_the_corpus("gpu", 2400) == 2400
 
 
 def test_gpu_align_and_server_generate_the_penalty_vectors():

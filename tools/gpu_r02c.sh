@@ -1,3 +1,8 @@
-cd /root/repo
-timeout 600 python -m pytest tests -x -q -m gpu -k "mapper or config2 or slices or basic or fuzz or random_scenarios or 100k or server_batches" > gpurun_out/r02c_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r02c_pytest.log
-bash tools/gpu_ab.sh r02c OCT_PHMM_WAVE_MAPPER=1
+#!/bin/bash
+# round 2, wave-per-haplotype penalty kernel: corpus parity on both device kernels, then the three-way timing
+set -x
+cd /root/repo; export TMPDIR=/tmp
+O=gpurun_out/r02c; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "penalty" > $O/pytest.log 2>&1; echo "pytest rc=$?" > $O/rc.log
+OCT_PHMM_PENALTIES_REPORT=1 timeout 300 python tools/penalty_bench.py > $O/penalty_bench.json 2> $O/penalty_bench.err; echo "penalty rc=$?" >> $O/rc.log
+cat $O/rc.log; tail -8 $O/pytest.log; cat $O/penalty_bench.json; tail -5 $O/penalty_bench.err

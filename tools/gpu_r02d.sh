@@ -1,3 +1,7 @@
-cd /root/repo
-timeout 600 python -m pytest tests -x -q -m gpu -k "mapper or config2 or slices or basic or fuzz or random_scenarios or 100k or server_batches or stream" > gpurun_out/r02d_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r02d_pytest.log
-bash tools/gpu_ab.sh r02d OCT_PHMM_MAP_COUNT_ONLY=1
+#!/bin/bash
+set -x
+cd /root/repo; export TMPDIR=/tmp
+O=gpurun_out/r02d; mkdir -p $O
+REGIONS=2000 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o pen -- python tools/penalty_bench.py > $O/penalty_bench.json 2> $O/err.log
+find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -12 {}' 
+cat $O/penalty_bench.json

@@ -1,3 +1,5 @@
-cd /root/repo
-timeout 900 python -m pytest tests -x -q -m gpu > gpurun_out/r02e_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r02e_pytest.log
-bash tools/gpu_ab.sh r02e OCT_PHMM_LIB=/root/repo/octopus_amd/variants/perm_tables.so
+#!/bin/bash
+cd /root/repo; export TMPDIR=/tmp
+O=gpurun_out/r02e; mkdir -p $O
+OCT_PHMM_PENALTIES_REPORT=1 timeout 300 python tools/penalty_bench.py > $O/penalty_bench.json 2> $O/err.log
+cat $O/penalty_bench.json; grep -v "^$" $O/err.log | sort | uniq -c | tail -12

@@ -1,7 +1,7 @@
-cd /root/repo
-timeout 600 python -m pytest tests -x -q -m gpu -k "mapper or config2 or slices or basic or fuzz or random_scenarios or 100k or server_batches or stream or ragged" > gpurun_out/r02f_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r02f_pytest.log
-bash tools/gpu_ab.sh r02f OCT_PHMM_LIB=/root/repo/octopus_amd/variants/perm_tables.so
-export OCT_PHMM_SLICES=1 OCT_PHMM_LIB=/root/repo/octopus_amd/variants/perm_tables.so
-(cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r02f/kstats_variant -o s -- python /root/repo/bench.py --no-small-batch --no-cpu-baseline --no-extras --steps 3 --warmup 1 > /dev/null 2>&1)
-find gpurun_out/r02f -name "*kernel_trace.csv" -delete
-head -5 gpurun_out/r02f/kstats_variant/s_kernel_stats.csv | cut -c1-150
+#!/bin/bash
+# round 2, step 4: all GPU tests on the wave penalty kernel build, then the three-way penalty timing
+cd /root/repo; export TMPDIR=/tmp
+O=gpurun_out/r02f; mkdir -p $O
+timeout 1200 python -m pytest tests -x -q -m gpu --durations=5 > $O/pytest_gpu.log 2>&1; echo "pytest_gpu rc=$?" > $O/rc.log
+OCT_PHMM_PENALTIES_REPORT=1 timeout 300 python tools/penalty_bench.py > $O/penalty_bench.json 2> $O/penalty_bench.err; echo "penalty rc=$?" >> $O/rc.log
+cat $O/rc.log; tail -12 $O/pytest_gpu.log; cat $O/penalty_bench.json; sort $O/penalty_bench.err | uniq -c | tail -4

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the per-haplotype penalty vectors are best made: host threads vs one GPU lane per haplotype.
+"""Where the per-haplotype penalty vectors are best made: host threads vs one wave per haplotype (LDS) vs one GPU lane per haplotype.
 (a) oct_phmm_penalty_vectors on the host, per haplotype; (b) the 2,000-region stream's ~48 k haplotypes: upload with given vectors vs
 vectors generated at upload on the host threads / on the device; (c) a region-sized call (300 reads x 24 haplotypes) from host buffers
 with given vs generated vectors."""
@@ -42,7 +42,7 @@ def time_upload(b, reps=3):
 
 
 res["stream_upload_ms"] = {"given_vectors": time_upload(flat)}
-for where in ("host", "device"):
+for where in ("host", "device", "lanes"):
     os.environ["OCT_PHMM_PENALTIES"] = where
     res["stream_upload_ms"]["generated_on_" + where] = time_upload(nov)
     rb = eng.upload(nov)
