@@ -143,6 +143,12 @@ typedef struct oct_phmm_stats {
     uint64_t n_dp_score_only;         /* simd align, score only */
     uint64_t n_dp_traceback;          /* simd align + traceback + flank score */
     uint64_t band_cells;              /* sum over DP tasks of 2*B*(T+B) */
+    /* of the above, what the library did not run because the pair's candidates (fast-path minimum, task classes, positions, band windows
+     * byte for byte) equal those of another pair of the same read, whose result it shares: the reference computes these again */
+    uint64_t n_dp_score_only_shared;  /* score-only DP tasks */
+    uint64_t n_dp_traceback_shared;   /* traceback DP tasks */
+    uint64_t band_cells_shared;       /* their band cells */
+    uint64_t n_pairs_shared;          /* pairs that share another pair's result */
 } oct_phmm_stats;
 
 /* ---- lifecycle -------------------------------------------------------------------------------- */

@@ -107,6 +107,10 @@ class Stats(C.Structure):
         ("n_dp_score_only", C.c_uint64),
         ("n_dp_traceback", C.c_uint64),
         ("band_cells", C.c_uint64),
+        ("n_dp_score_only_shared", C.c_uint64),
+        ("n_dp_traceback_shared", C.c_uint64),
+        ("band_cells_shared", C.c_uint64),
+        ("n_pairs_shared", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -94,6 +94,8 @@ struct oct_phmm_handle {
     // error model for in-call penalty vectors (oct_phmm_set_error_model); sub_mask is borrowed for the next upload only
     bool has_model = false; oct_phmm_error_model model {}; const uint8_t* sub_mask = nullptr;
     oct_phmm_error_model* d_model = nullptr;             // device copy, made on first use
+    // canonical-window pass of an upload (exact de-duplication of pairs): scratch and the two power tables, kept and grown on demand
+    void* dedup_scratch = nullptr; size_t dedup_scratch_bytes = 0; uint64_t* d_pw = nullptr; uint64_t* d_pwinv = nullptr; size_t pw_n = 0;
 };
 
 struct oct_phmm_batch {
@@ -111,6 +113,7 @@ struct oct_phmm_batch {
         uint4* cnt_late = nullptr; uint4* tile_sums_late = nullptr; uint4* d_totals_late = nullptr; uint4 totals_late {};   // right-flank-only traceback tasks (x fast, y generic)
         DevTask* d_tasks = nullptr; size_t tasks_cap = 0; TraceEnd* d_ends = nullptr; size_t ends_cap = 0;
         unsigned long long* d_keys = nullptr; size_t keys_cap = 0;   // align mode: per traceback task
+        uint32_t seg0 = 0, n_segs = 0, n_seg_tiles = 0;              // k_dedup_match: this slice's (region, haplotype range) segments and their 64-read tiles
         rt::Event done {};
     };
     std::vector<Slice> slices;
@@ -118,7 +121,8 @@ struct oct_phmm_batch {
     bool late_ok = false; uint4* d_pair_cnt_late = nullptr; uint4* d_hap_base_late = nullptr; uint4* d_totals_late = nullptr;
     double* d_out = nullptr;
     uint32_t n_tasks[kNumKinds] = {0, 0, 0, 0};
-    unsigned long long h_stats[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long h_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool dedup = false; std::vector<DedupSeg> h_segs; DedupSeg* d_segs = nullptr;   // exact de-duplication of pairs (phmm_kernels.hpp)
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
@@ -146,7 +150,7 @@ struct oct_phmm_batch {
 // production. They are read when a handle is created or a batch is uploaded - never by a kernel - and fall in three groups:
 //   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS
 //   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
-//                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB
+//                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER
 // ---------------------------------------------------------------------------------------------------------------
@@ -162,6 +166,7 @@ inline bool map_count_only()  { return flag("OCT_PHMM_MAP_COUNT_ONLY"); }     //
 inline bool lane_mapper()     { return flag("OCT_PHMM_LANE_MAPPER"); }        // the (slower) lane-per-pair mapper
 inline bool big_mapper()      { return flag("OCT_PHMM_BIG_MAPPER"); }         // test hook: the long-haplotype mapper on short haplotypes
 inline int  penalties_where() { const char* e = getenv("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' || e[0] == 'l' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
+inline int  dedup()           { const char* e = getenv("OCT_PHMM_DEDUP"); return !e ? -1 : atoi(e); }                                  // -1 by shape, 0 never, 1 wherever it is possible
 inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
 inline bool penalties_lane_kernel() { const char* e = getenv("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
 }
@@ -965,7 +970,14 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     pk.dalloc(&d.tabGenF, (size_t)n_hap_bases);  pk.dalloc(&d.tabGenR, (size_t)n_hap_bases);
     pk.dalloc(&d.pair_best, (size_t)b->n_pairs); pk.dalloc(&d.pair_cls, (size_t)b->n_pairs);
     pk.dalloc(&d.pair_extra, (size_t)b->n_pairs); pk.dalloc(&d.pair_cnt, (size_t)b->n_pairs + oct_phmm_handle::kMaxSlices + 1);
-    pk.dalloc(&d.stats, (size_t)kStatSlots * 8 + 8);
+    // Exact de-duplication of pairs (phmm_kernels.hpp): populate on the LDS-resident int16 path, where some region has several haplotypes and
+    // the batch is big enough for the matcher's walk over a region's haplotypes (one after the other, ~1.5 us each) not to show: a 1k x 64
+    // call went from 0.48 to 0.71 ms with it, the 100k x 128 batch from 32.4 to 30.9 ms, the 2,000-region stream from 49.6 to 44.5 ms.
+    d.canon = nullptr; d.pair_rep = nullptr; d.pair_hash = nullptr; d.window_len = b->t_cap + 2 * (uint32_t)h->band - 1;
+    b->dedup = !align_mode && !b->stream && !h->wide && H->n_haps > G && b->lh_cap <= 8192 && b->n_pairs >= 500000 && tune::dedup() != 0;
+    if (tune::dedup() > 0) b->dedup = !align_mode && !b->stream && !h->wide && H->n_haps > G;
+    if (b->dedup) { pk.dalloc(&d.canon, (size_t)n_hap_bases + 1); pk.dalloc(&d.pair_rep, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_hash, (size_t)b->n_pairs + 1); }
+    pk.dalloc(&d.stats, (size_t)kStatSlots * kStatStride + 8);
     pk.dalloc(&b->d_hap_base, (size_t)H->n_haps + 1);
     // late traceback start (k_dp): packed int16 kernels only, no lane can wrap (a failed traceback is then impossible,
     // so a walk may stop once it has left the right flank), populate only, and only where the three extra scan launches do not show
@@ -978,7 +990,8 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     {
         // Slices of whole haplotypes, each on its own stream: while slice i is in its VALU-bound DP kernels, slice i+1 runs its
         // latency-bound mapper/classifier and slice i-1 its latency-bound walk. Small batches stay in one slice.
-        int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / 1000000));
+        // (a pair only shares the result of a pair of its own slice: fewer, larger slices when de-duplicating)
+        int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / (b->dedup ? 3000000 : 1000000)));
         { long long v; if (tune::number("OCT_PHMM_SLICES", &v)) n_slices = std::max(1, std::min(oct_phmm_handle::kMaxSlices, (int)v)); }
         n_slices = (int)std::min<uint32_t>((uint32_t)n_slices, std::max<uint32_t>(1, H->n_haps));
         pk.dalloc(&b->d_totals, (size_t)n_slices);
@@ -997,11 +1010,23 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             RT(h->get_event(&sl.done));
             sl.blk0 = (uint32_t)(std::lower_bound(b->h_blk_hap.begin(), b->h_blk_hap.end(), sl.hap0) - b->h_blk_hap.begin());
             sl.blk1 = (uint32_t)(std::lower_bound(b->h_blk_hap.begin(), b->h_blk_hap.end(), sl.hap1) - b->h_blk_hap.begin());
+            if (b->dedup) {                                       // the slice's haplotypes region by region, the region's reads in tiles of 64
+                sl.seg0 = (uint32_t)b->h_segs.size();
+                for (uint32_t hp = sl.hap0; hp < sl.hap1;) {
+                    const uint32_t g = hap_region[hp];
+                    uint32_t e = hp; while (e < sl.hap1 && hap_region[e] == g) ++e;
+                    const uint32_t nreads = first_read(g_row[g + 1]) - reg_read0[g];
+                    if (e - hp >= 2 && nreads) { b->h_segs.push_back(DedupSeg {g, hp, e, reg_read0[g], nreads, sl.n_seg_tiles}); sl.n_seg_tiles += (nreads + 63) / 64; }
+                    hp = e;
+                }
+                sl.n_segs = (uint32_t)b->h_segs.size() - sl.seg0;
+            }
             b->slices.push_back(sl);
             pk.dalloc(&b->slices.back().tile_sums, (size_t)sl.n_tiles + 1);
             if (b->late_ok) pk.dalloc(&b->slices.back().tile_sums_late, (size_t)sl.n_tiles + 1);
         }
     }
+    if (b->dedup && !b->h_segs.empty()) pk.upload(b->h_segs.data(), b->h_segs.size(), (const DedupSeg**)&b->d_segs);
     pk.dalloc(&b->d_out, (size_t)b->n_out);
     d.align_mode = align_mode ? 1 : 0; d.pair_key = nullptr;
     if (align_mode) {
@@ -1015,7 +1040,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     pk.upload(ones.data(), (size_t)H->n_haps, (const uint32_t**)&d.hclean);
     RT(h->get_event(&b->ev_fork)); RT(h->get_event(&b->ev_join)); RT(h->get_event(&b->ev_hashes));
     RT(pk.commit(h, bp, s));
-    d.err_key = d.stats + (size_t)kStatSlots * 8;
+    d.err_key = d.stats + (size_t)kStatSlots * kStatStride;
     for (size_t i = 0; i < b->slices.size(); ++i) {
         b->slices[i].cnt = d.pair_cnt + b->slices[i].pair0 + i;      // each slice owns pair1 - pair0 + 1 scan entries
         b->slices[i].d_totals = b->d_totals + i;
@@ -1090,6 +1115,43 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         const uint32_t rec_blocks = (uint32_t)rec_blocks64;
         if (table_blocks + flag_blocks + rec_blocks) { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok()); }
     }
+    if (b->dedup) {
+        // canonical band windows: polynomial prefix sums per haplotype, a hash table from window key to the first window with that key,
+        // then every window is compared byte by byte with the table's (phmm_kernels.hpp)
+        if (h->pw_n < (size_t)b->lh_cap + 2) {                       // powers of the hash base and of its inverse mod 2^64, up to the longest haplotype seen
+            const uint64_t base = 0x9e3779b97f4a7c15ull;              // odd: invertible
+            uint64_t inv = base; for (int it = 0; it < 6; ++it) inv *= 2 - base * inv;   // Newton: inv * base == 1 (mod 2^64)
+            size_t n = 1024; while (n < (size_t)b->lh_cap + 2) n <<= 1;
+            std::vector<uint64_t> pw(n), pwinv(n);
+            pw[0] = 1; pwinv[0] = 1;
+            for (size_t i = 1; i < n; ++i) { pw[i] = pw[i - 1] * base; pwinv[i] = pwinv[i - 1] * inv; }
+            RT(rt::stream_sync(s));                                  // earlier uploads on this stream may still read the old tables
+            h->pool.release(h->d_pw); h->pool.release(h->d_pwinv); h->d_pw = h->d_pwinv = nullptr; h->pw_n = 0;
+            void* p1 = nullptr; void* p2 = nullptr; RT(h->pool.alloc(&p1, n * 8)); RT(h->pool.alloc(&p2, n * 8));
+            h->d_pw = (uint64_t*)p1; h->d_pwinv = (uint64_t*)p2;
+            RT(rt::h2d(h->d_pw, pw.data(), n * 8, s)); RT(rt::h2d(h->d_pwinv, pwinv.data(), n * 8, s)); RT(rt::stream_sync(s));
+            h->pw_n = n;
+        }
+        uint32_t tbits = 10; while (((size_t)1 << tbits) < (size_t)n_hap_bases * 2) ++tbits;
+        const size_t tsize = (size_t)1 << tbits;
+        const size_t n_prefix = ((size_t)n_hap_bases + H->n_haps + 2) & ~(size_t)1, n_wkey = ((size_t)n_hap_bases + 2) & ~(size_t)1;
+        const size_t need = (n_prefix + n_wkey + tsize) * 8 + tsize * 4;
+        if (h->dedup_scratch_bytes < need) {
+            RT(rt::stream_sync(s));
+            h->pool.release(h->dedup_scratch); h->dedup_scratch = nullptr; h->dedup_scratch_bytes = 0;
+            RT(h->pool.alloc(&h->dedup_scratch, need + need / 4)); h->dedup_scratch_bytes = need + need / 4;
+        }
+        uint64_t* d_prefix = (uint64_t*)h->dedup_scratch; unsigned long long* d_wkey = (unsigned long long*)(d_prefix + n_prefix);
+        unsigned long long* d_tkeys = d_wkey + n_wkey; uint32_t* d_tvals = (uint32_t*)(d_tkeys + tsize);
+        RT(rt::dev_memset(d_tkeys, 0, tsize * 8, s)); RT(rt::dev_memset(d_tvals, 0xff, tsize * 4, s));
+        OCT_LAUNCH(k_window_prefix, (H->n_haps + 63) / 64, 64, 0, s, d, (const uint64_t*)h->d_pw, d_prefix); RT(rt::launch_ok());
+        if (n_hap_bases) {
+            OCT_LAUNCH(k_window_insert, (n_hap_bases + 255) / 256, 256, 0, s, d, (const uint64_t*)h->d_pwinv, (const uint64_t*)d_prefix, n_hap_bases,
+                       d_wkey, d_tkeys, d_tvals, (uint32_t)(tsize - 1)); RT(rt::launch_ok());
+            OCT_LAUNCH(k_window_resolve, (n_hap_bases + 255) / 256, 256, 0, s, d, n_hap_bases, (const unsigned long long*)d_wkey,
+                       (const unsigned long long*)d_tkeys, (const uint32_t*)d_tvals, (uint32_t)(tsize - 1)); RT(rt::launch_ok());
+        }
+    }
     // The copies above read this call's host-side staging (pinned buffer, position vectors): a caller of the split API may upload the next batch
     // right away, so they must have landed. A one-shot call (populate, align) runs on the same stream at once and does not return before its
     // results are back, which covers the pinned buffer; it only waits here when it brought pageable position arrays.
@@ -1112,8 +1174,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     b->timers.clear(); b->timer_kind.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
     const uint32_t G = b->stream ? (h->band < 64 ? 64u / (uint32_t)h->band : 1u) : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
     const int S = (int)b->slices.size();
-    RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * 8 + 1) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key behind them
+    RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 1) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key behind them
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
+    if (b->dedup) RT(rt::dev_memset(d.pair_rep, 0xff, (size_t)b->n_pairs * sizeof(uint32_t), s0));      // kNoPair: every pair is computed itself until k_dedup_verify says otherwise
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
     if (S > 1) {
         RT(rt::event_record(h->ev_ready, s0));
@@ -1167,6 +1230,10 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         }
         const uint32_t pair_blocks = (uint32_t)((np + 255) / 256);
         OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late); RT(rt::launch_ok());
+        if (b->dedup && sl.n_seg_tiles) {                     // pairs whose candidates equal an earlier pair's of the same read drop their tasks
+            OCT_LAUNCH(k_dedup_match, sl.n_seg_tiles, 64, (size_t)kDedupReps * 64 * 2 * sizeof(uint32_t), s, d, (const DedupSeg*)b->d_segs + sl.seg0, sl.n_segs); RT(rt::launch_ok());
+            OCT_LAUNCH(k_dedup_verify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late); RT(rt::launch_ok());
+        }
         const uint64_t n_scan = np + 1;
         if (sl.n_tiles == 1) {
             OCT_LAUNCH(k_scan_tiles, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 2); RT(rt::launch_ok());
@@ -1270,8 +1337,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     if (rc != OCT_PHMM_OK) return rc;
     for (int i = std::max(0, S - 2); i < S; ++i) { rc = deliver(i); if (rc != OCT_PHMM_OK) return rc; }
     for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(s0, b->slices[i].done));
-    b->h_stat_stripes.assign((size_t)kStatSlots * 8 + 1, 0);  // counters + the inverted error key, one copy
-    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, ((size_t)kStatSlots * 8 + 1) * sizeof(unsigned long long), s0));
+    b->h_stat_stripes.assign((size_t)kStatSlots * kStatStride + 1, 0);  // counters + the inverted error key, one copy
+    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, ((size_t)kStatSlots * kStatStride + 1) * sizeof(unsigned long long), s0));
     b->ran = true;
     return ok(status);
 }
@@ -1281,11 +1348,11 @@ extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_ph
     if (!h || !b || b->owner != h || !b->ran) return fail(status, OCT_PHMM_EINVAL, "batch was not run");
     RT(rt::set_device(h->cfg.device_id));
     RT(rt::stream_sync(h->stream));
-    for (int k = 0; k < 6; ++k) { b->h_stats[k] = 0; for (uint32_t sl = 0; sl < kStatSlots; ++sl) b->h_stats[k] += b->h_stat_stripes[(size_t)sl * 8 + k]; }
-    b->h_err_key = ~b->h_stat_stripes[(size_t)kStatSlots * 8];
+    for (int k = 0; k < 12; ++k) { b->h_stats[k] = 0; for (uint32_t sl = 0; sl < kStatSlots; ++sl) b->h_stats[k] += b->h_stat_stripes[(size_t)sl * kStatStride + k]; }
+    b->h_err_key = ~b->h_stat_stripes[(size_t)kStatSlots * kStatStride];
     if (tune::map_stats()) {
         unsigned long long dec = 0, cnt = 0;
-        for (uint32_t sl = 0; sl < kStatSlots; ++sl) { dec += b->h_stat_stripes[(size_t)sl * 8 + 6]; cnt += b->h_stat_stripes[(size_t)sl * 8 + 7]; }
+        for (uint32_t sl = 0; sl < kStatSlots; ++sl) { dec += b->h_stat_stripes[(size_t)sl * kStatStride + 6]; cnt += b->h_stat_stripes[(size_t)sl * kStatStride + 7]; }
         fprintf(stderr, "{\"mapper_pairs_decided_by_shortcut\": %llu, \"mapper_pairs_counted\": %llu}\n", dec, cnt);
     }
     b->dp_ms = 0; b->dp_launches = 0;
@@ -1353,6 +1420,7 @@ extern "C" int oct_phmm_batch_stats(const oct_phmm_batch* b, oct_phmm_stats* st)
     if (!b || !st) return OCT_PHMM_EINVAL;
     st->n_candidates = b->h_stats[0]; st->n_fast_path = b->h_stats[1]; st->n_dp_score_only = b->h_stats[2];
     st->n_dp_traceback = b->h_stats[3]; st->band_cells = b->h_stats[4]; st->n_pairs = b->h_stats[5];
+    st->n_dp_score_only_shared = b->h_stats[8]; st->n_dp_traceback_shared = b->h_stats[9]; st->band_cells_shared = b->h_stats[10]; st->n_pairs_shared = b->h_stats[11];
     return OCT_PHMM_OK;
 }
 

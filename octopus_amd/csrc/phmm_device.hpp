@@ -11,7 +11,10 @@ constexpr int32_t  kNoScore    = 0x7fffffff;   // "lowest()" in the integer pena
 constexpr uint32_t kPadTask    = 0xffffffffu;  // DevTask::pair of a padding task
 constexpr int      kBlockWaves = 4;            // waves per DP workgroup
 constexpr int      kGroupsPerWave = 4;         // task groups each wave works through per workgroup
-constexpr uint32_t kStatSlots  = 256;          // statistics counters are striped over this many 64-byte lines
+constexpr uint32_t kStatSlots  = 256;          // statistics counters are striped over this many lines
+constexpr uint32_t kStatStride = 16;           // counters per stripe (128 bytes)
+constexpr uint32_t kNoPair     = 0xffffffffu;  // DevBatch::pair_rep of a pair that is computed itself
+constexpr uint32_t kDedupReps  = 48;           // distinct pairs a read remembers per haplotype segment (k_dedup_match)
 
 // Task kinds = DP kernel variants. "fast" = reads are pure ACGT and the haplotype holds only ACGT (and no
 // '0' in its masks), so the match cost is one byte-permute out of a per-position cap table; "generic" = any
@@ -70,9 +73,17 @@ struct DevBatch {
     // under key = penalty << 32 | order << 8 | naive, order = 0 for the read's original position (it wins ties, model.cpp:365), 1 + j for
     // mapped position j (the first maximum wins, :355)
     int align_mode; unsigned long long* pair_key;
-    // counters, kStatSlots stripes of 8: [0] candidates [1] fast path [2] score-only DP [3] traceback DP [4] band cells [5] pairs
+    // exact de-duplication of pairs (k_window_*, k_dedup_match, k_dedup_verify), null when off: canon[hoff[h] + off] = the first band window of the region
+    // with the bytes of haplotype h's window at off (bases and the six vectors); pair_rep[e] = the pair whose result pair e shares, or kNoPair
+    uint32_t* canon; uint32_t* pair_rep; uint32_t* pair_hash; uint32_t window_len;            // pair_hash: k_classify's hash of what decides a pair (0 = no DP task)
+    // counters, kStatSlots stripes of kStatStride: [0] candidates [1] fast path [2] score-only DP [3] traceback DP [4] band cells [5] pairs
+    // [6] [7] mapper diagnostics (OCT_PHMM_MAP_STATS) [8] score-only / [9] traceback DP tasks not run because their pair shares another pair's result [10] their band cells [11] such pairs
     unsigned long long* stats;
     unsigned long long* err_key;                      // min over failing pairs of (hap << 32 | read); ~0 = none
+};
+
+struct DedupSeg {     // the haplotypes [hap_lo, hap_hi) of one region inside one slice, and the reads of that region in tiles of 64
+    uint32_t region, hap_lo, hap_hi, read0, n_reads, tile0;
 };
 
 struct DpParams {

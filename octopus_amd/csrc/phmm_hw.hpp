@@ -107,6 +107,8 @@ OCT_DEVICE uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, 
 OCT_DEVICE unsigned long long atomic_max_u64(unsigned long long* p, unsigned long long v) { return atomicMax(p, v); }
 OCT_DEVICE unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 OCT_DEVICE uint32_t atomic_and_u32(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
+OCT_DEVICE uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+OCT_DEVICE unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long expected, unsigned long long v) { return atomicCAS(p, expected, v); }
 OCT_DEVICE uint32_t thread_idx() { return threadIdx.x; }
 OCT_DEVICE uint32_t block_idx() { return blockIdx.x; }
 OCT_DEVICE uint32_t block_dim() { return blockDim.x; }

@@ -315,7 +315,7 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
                 b.npos[e] = (uint8_t)n_w;
             }
         }
-        if (b.map_stats && lane == 0) hw::atomic_add_u64(b.stats + (size_t)(hw::block_idx() % kStatSlots) * 8 + (decided ? 6 : 7), 1ull);   // OCT_PHMM_MAP_STATS: pairs decided by the shortcut / counted
+        if (b.map_stats && lane == 0) hw::atomic_add_u64(b.stats + (size_t)(hw::block_idx() % kStatSlots) * kStatStride + (decided ? 6 : 7), 1ull);   // OCT_PHMM_MAP_STATS: pairs decided by the shortcut / counted
         if (!decided) {
         uint32_t hq_next = lane < nq ? b.rhash[ro + lane] : 0;             // software pipeline: next batch's hashes are in flight
         for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
@@ -567,6 +567,32 @@ OCT_DEVICE uint64_t wave_sum(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+OCT_DEVICE uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+
+// Exact de-duplication of pairs (section below k_classify). What decides a pair's result beyond the read: fast-path minimum, task classes,
+// haplotype length, and per DP task its position and the canonical window it starts in. k_classify leaves a 32-bit hash of these per pair
+// (0 = no DP task); `pair_views_same` compares two pairs of one read field by field.
+OCT_DEVICE uint64_t pair_hash_task(uint64_t acc, uint32_t p, uint32_t canon) { return mix64(acc ^ ((uint64_t)p << 32 | canon)); }
+OCT_DEVICE uint32_t pair_hash_final(uint64_t acc, uint32_t cls, int32_t best, uint32_t Lh)
+{
+    const uint32_t k = (uint32_t)mix64(acc ^ mix64((uint64_t)cls << 32 | (uint32_t)best) ^ Lh);
+    return k ? k : 1u;
+}
+struct PairView { uint32_t cls; int32_t best; uint32_t Lh; uint64_t e; uint32_t ho; };
+OCT_DEVICE uint32_t pair_slot_pos(const DevBatch& b, const PairView& v, uint32_t slot) { return slot < (uint32_t)b.max_pos ? b.pos[v.e * (uint64_t)b.max_pos + slot] : b.pair_extra[v.e]; }
+OCT_DEVICE bool pair_views_same(const DevBatch& b, const PairView& v, const PairView& w)
+{
+    if (v.cls != w.cls || v.best != w.best || v.Lh != w.Lh) return false;
+    for (uint32_t slot = 0; slot <= (uint32_t)b.max_pos; ++slot) {
+        if (!((v.cls >> (2 * slot)) & 3u)) continue;
+        const uint32_t p = pair_slot_pos(b, v, slot), q = pair_slot_pos(b, w, slot);
+        if (p != q) return false;
+        const uint32_t off = p > (uint32_t)b.band ? p - (uint32_t)b.band : 0;
+        if (b.canon[v.ho + off] != b.canon[w.ho + off]) return false;
+    }
+    return true;
+}
+
 // Pass 1: one thread per (read, haplotype) pair. Runs the candidate-position logic and the scalar fast path, leaves the
 // best fast-path penalty in pair_best, classifies every remaining candidate as score-only or traceback DP.
 // A batch is processed in slices of whole haplotypes (pairs [pair0, pair1)); `cnt` is the slice's own scan array (pair1 - pair0 + 1 entries).
@@ -589,6 +615,7 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
         int32_t best = kNoScore; uint32_t cls = 0, n_score = 0, n_trace = 0, n_late = 0, extra = 0;
         bool orig_mapped = false, any = false;
         unsigned long long key = ~0ull;
+        uint64_t dedup_acc = 0;                                                                     // k_dedup_match: hash over the DP tasks, in slot order
         auto visit = [&](uint32_t slot, uint32_t p) {
             ++st_cand;
             if (b.align_mode) {                                                                     // hmm::align, pair_hmm.hpp:861-872
@@ -606,6 +633,7 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
             if ((uint64_t)off + T + 2 * B - 1 > Lh) return;                                         // :736-738 -> lowest()
             const bool adjusted = (uint64_t)p < (uint64_t)lhs + B || (uint64_t)p + T + B > (uint64_t)Lh - (uint64_t)rhs;   // :123-137
             st_cells += 2ull * B * (T + B);
+            if (b.canon) dedup_acc = pair_hash_task(dedup_acc, p, b.canon[ho + off]);
             // class 3 = traceback needed for the right flank only (the window starts at or after the left flank's end): late traceback start
             if (adjusted && cnt_late && (uint64_t)lhs + B <= (uint64_t)p) { cls |= 3u << (2 * slot); ++n_late; ++st_trace; }
             else if (adjusted) { cls |= 2u << (2 * slot); ++n_trace; ++st_trace; } else { cls |= 1u << (2 * slot); ++n_score; ++st_score; }
@@ -625,6 +653,7 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
             else { extra = (uint32_t)fin; visit((uint32_t)b.max_pos, extra); }
         }
         b.pair_best[e] = best; b.pair_cls[e] = cls; b.pair_extra[e] = extra;
+        if (b.canon) b.pair_hash[e] = cls ? pair_hash_final(dedup_acc, cls, best, Lh) : 0u;
         if (b.align_mode) b.pair_key[e] = key;
         const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
         cnt[e - pair0] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
@@ -636,13 +665,148 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
     st_trace = wave_sum(st_trace); st_cells = wave_sum(st_cells); st_pairs = wave_sum(st_pairs);
     if ((hw::thread_idx() & 63) == 0) {
         // counters are spread over kStatSlots cache lines (summed on the host) so that ~10^5 waves do not serialise on one line
-        unsigned long long* st = b.stats + (size_t)(hw::block_idx() % kStatSlots) * 8;
+        unsigned long long* st = b.stats + (size_t)(hw::block_idx() % kStatSlots) * kStatStride;
         if (st_cand)  hw::atomic_add_u64(st + 0, st_cand);
         if (st_fast)  hw::atomic_add_u64(st + 1, st_fast);
         if (st_score) hw::atomic_add_u64(st + 2, st_score);
         if (st_trace) hw::atomic_add_u64(st + 3, st_trace);
         if (st_cells) hw::atomic_add_u64(st + 4, st_cells);
         if (st_pairs) hw::atomic_add_u64(st + 5, st_pairs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Exact de-duplication of (read, haplotype) pairs. The haplotypes of a region are a few edits apart, so many of them show a read the very
+// same band window: same bases, same six penalty vectors, same place in a haplotype of the same length. Such pairs have the same
+// candidates, the same fast-path penalties, the same DP tasks and the same result - the reference computes each of them again.
+//   upload: canon[hoff[h] + off] = index of the first window of the region with the bytes of the window of haplotype h at off (length
+//           t_cap + 2 B - 1, cut at the haplotype's end; found through a hash table, CONFIRMED byte by byte)
+//   step:   k_classify leaves a hash per pair; k_dedup_match lets a read look at its pairs haplotype by haplotype and remember candidates;
+//           k_dedup_verify compares: a pair whose fast-path minimum, task classes, positions, haplotype length and canonical windows all
+//           equal those of an earlier pair of the same read drops its DP tasks and points at that pair (pair_rep); k_epilogue reads the
+//           result there.
+// Everything is decided by comparing the values themselves; hashes only find candidates.
+// ------------------------------------------------------------------------------------------------------------------
+
+// prefix[hoff[h] + h + x] = sum over y < x of mix(position y of haplotype h) * pw[y] (mod 2^64): one thread per haplotype
+OCT_KERNEL(k_window_prefix)(DevBatch b, const uint64_t* pw, uint64_t* prefix)
+{
+    const uint32_t h = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (h >= b.n_haps) return;
+    const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho;
+    uint64_t* out = prefix + (size_t)ho + h;
+    uint64_t sum = 0;
+    out[0] = 0;
+    for (uint32_t x = 0; x < Lh; ++x) {
+        const uint64_t v = (uint64_t)b.hbases[ho + x] | (uint64_t)(uint8_t)b.go[ho + x] << 8 | (uint64_t)(uint8_t)b.ge[ho + x] << 16 | (uint64_t)b.maskF[ho + x] << 24
+                         | (uint64_t)(uint8_t)b.priorF[ho + x] << 32 | (uint64_t)b.maskR[ho + x] << 40 | (uint64_t)(uint8_t)b.priorR[ho + x] << 48;
+        sum += mix64(v + 1) * pw[x];
+        out[x + 1] = sum;
+    }
+}
+
+// key of every window (never 0) and, per key, the smallest window index: open addressing, keys claimed with compare-and-swap
+OCT_KERNEL(k_window_insert)(DevBatch b, const uint64_t* pwinv, const uint64_t* prefix, uint32_t n_bases, unsigned long long* wkey,
+                            unsigned long long* tkeys, uint32_t* tvals, uint32_t tmask)
+{
+    const uint32_t x = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (x >= n_bases) return;
+    const uint32_t h = upper_bound_idx(b.hoff, b.n_haps + 1, x), ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, off = x - ho;
+    const uint32_t end = off + b.window_len < Lh ? off + b.window_len : Lh;
+    const uint64_t* pre = prefix + (size_t)ho + h;
+    const uint64_t sum = (pre[end] - pre[off]) * pwinv[off];                 // the window's polynomial, independent of where it starts
+    const unsigned long long key = mix64(sum ^ mix64((uint64_t)(end - off) << 32 | b.hap_region[h])) | 1ull;
+    wkey[x] = key;
+    for (uint32_t slot = (uint32_t)(key >> 20) & tmask; ; slot = (slot + 1) & tmask) {
+        const unsigned long long prev = hw::atomic_cas_u64(tkeys + slot, 0ull, key);
+        if (prev == 0ull || prev == key) { hw::atomic_min_u32(tvals + slot, x); break; }
+    }
+}
+
+OCT_DEVICE bool window_bytes_equal(const DevBatch& b, uint32_t a, uint32_t c, uint32_t n)   // n bytes of all seven arrays from a and from c
+{
+    return bytes_equal(b.hbases + a, b.hbases + c, n) && bytes_equal((const uint8_t*)b.go + a, (const uint8_t*)b.go + c, n)
+        && bytes_equal((const uint8_t*)b.ge + a, (const uint8_t*)b.ge + c, n) && bytes_equal(b.maskF + a, b.maskF + c, n)
+        && bytes_equal((const uint8_t*)b.priorF + a, (const uint8_t*)b.priorF + c, n) && bytes_equal(b.maskR + a, b.maskR + c, n)
+        && bytes_equal((const uint8_t*)b.priorR + a, (const uint8_t*)b.priorR + c, n);
+}
+
+// canon[x] = the table's window for x's key if its bytes (and region, and length) are those of x, else x itself
+OCT_KERNEL(k_window_resolve)(DevBatch b, uint32_t n_bases, const unsigned long long* wkey, const unsigned long long* tkeys, const uint32_t* tvals, uint32_t tmask)
+{
+    const uint32_t x = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (x >= n_bases) return;
+    const unsigned long long key = wkey[x];
+    uint32_t slot = (uint32_t)(key >> 20) & tmask;
+    while (tkeys[slot] != key) slot = (slot + 1) & tmask;
+    const uint32_t first = tvals[slot];
+    uint32_t canon = x;
+    if (first != x) {
+        const uint32_t h = upper_bound_idx(b.hoff, b.n_haps + 1, x), ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, off = x - ho;
+        const uint32_t h2 = upper_bound_idx(b.hoff, b.n_haps + 1, first), ho2 = b.hoff[h2], Lh2 = b.hoff[h2 + 1] - ho2, off2 = first - ho2;
+        const uint32_t n = (off + b.window_len < Lh ? off + b.window_len : Lh) - off, n2 = (off2 + b.window_len < Lh2 ? off2 + b.window_len : Lh2) - off2;
+        if (n == n2 && b.hap_region[h] == b.hap_region[h2] && window_bytes_equal(b, x, first, n)) canon = first;
+    }
+    b.canon[x] = canon;
+}
+
+// Match: one lane per read, 64 consecutive reads per wave (the pair arrays of a haplotype are read-major: coalesced), the haplotypes of the
+// segment one after the other. Each read remembers up to kDedupReps distinct pair hashes (+ haplotype) in LDS, column-major so that lanes
+// never collide; a pair whose hash it has seen becomes a CANDIDATE for sharing (pair_rep), nothing else changes yet.
+OCT_KERNEL(k_dedup_match)(DevBatch b, const DedupSeg* segs, uint32_t n_segs)
+{
+    OCT_DYN_SMEM(smem);
+    uint32_t* seen_hash = (uint32_t*)smem;                      // [kDedupReps][64]
+    uint32_t* seen_hap = seen_hash + kDedupReps * 64;           // [kDedupReps][64]
+    const uint32_t lane = hw::thread_idx() & 63, tile = hw::block_idx();
+    uint32_t lo = 0, hi = n_segs;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (segs[mid].tile0 <= tile) lo = mid; else hi = mid; }
+    const DedupSeg sg = segs[lo];
+    const uint32_t rl = (tile - sg.tile0) * 64 + lane;          // read within the region
+    if (rl >= sg.n_reads) return;
+    uint32_t n_seen = 0;
+    uint32_t key_next = b.pair_hash[b.hap_pair_off[sg.hap_lo] + rl];
+    for (uint32_t h = sg.hap_lo; h < sg.hap_hi; ++h) {
+        const uint32_t key = key_next;
+        if (h + 1 < sg.hap_hi) key_next = b.pair_hash[b.hap_pair_off[h + 1] + rl];
+        if (!key) continue;
+        uint32_t found = kNoPair;
+        for (uint32_t j = 0; j < n_seen; ++j) if (seen_hash[j * 64 + lane] == key) { found = seen_hap[j * 64 + lane]; break; }
+        if (found != kNoPair) b.pair_rep[b.hap_pair_off[h] + rl] = (uint32_t)(b.hap_pair_off[found] + rl);
+        else if (n_seen < kDedupReps) { seen_hash[n_seen * 64 + lane] = key; seen_hap[n_seen * 64 + lane] = h; ++n_seen; }
+    }
+}
+
+// Verify: one thread per pair. A candidate whose fast-path minimum, task classes, haplotype length, positions and canonical windows equal
+// those of the pair it points at drops its DP tasks (classes, scan counts) and keeps the pointer; any other candidate forgets it.
+OCT_KERNEL(k_dedup_verify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* cnt_late)
+{
+    const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    unsigned long long st_score = 0, st_trace = 0, st_cells = 0, st_pairs = 0;
+    if (e < pair1) {
+        const uint32_t shared = b.pair_rep[e];
+        if (shared != kNoPair) {
+            PairView v, w;
+            const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e), h2 = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, (uint64_t)shared);
+            v.e = e; v.cls = b.pair_cls[e]; v.best = b.pair_best[e]; v.ho = b.hoff[h]; v.Lh = b.hoff[h + 1] - v.ho;
+            w.e = shared; w.cls = b.pair_cls[shared]; w.best = b.pair_best[shared]; w.ho = b.hoff[h2]; w.Lh = b.hoff[h2 + 1] - w.ho;
+            if (v.cls && pair_views_same(b, v, w)) {
+                const uint32_t r = b.reg_read0[b.hap_region[h]] + (uint32_t)(e - b.hap_pair_off[h]), T = b.roff[r + 1] - b.roff[r];
+                uint32_t n_score = 0, n_trace = 0;
+                for (uint32_t slot = 0; slot <= (uint32_t)b.max_pos; ++slot) { const uint32_t kd = (v.cls >> (2 * slot)) & 3u; n_score += kd == 1u ? 1u : 0u; n_trace += kd >= 2u ? 1u : 0u; }
+                st_score = n_score; st_trace = n_trace; st_cells = (unsigned long long)(n_score + n_trace) * 2ull * (uint32_t)b.band * (T + (uint32_t)b.band); st_pairs = 1;
+                b.pair_cls[e] = 0;
+                cnt[e - pair0] = make_uint4(0, 0, 0, 0);
+                if (cnt_late) cnt_late[e - pair0] = make_uint4(0, 0, 0, 0);
+            } else {
+                b.pair_rep[e] = kNoPair;
+            }
+        }
+    }
+    st_score = wave_sum(st_score); st_trace = wave_sum(st_trace); st_cells = wave_sum(st_cells); st_pairs = wave_sum(st_pairs);
+    if ((hw::thread_idx() & 63) == 0 && st_pairs) {
+        unsigned long long* st = b.stats + (size_t)(hw::block_idx() % kStatSlots) * kStatStride;
+        hw::atomic_add_u64(st + 8, st_score); hw::atomic_add_u64(st + 9, st_trace); hw::atomic_add_u64(st + 10, st_cells); hw::atomic_add_u64(st + 11, st_pairs);
     }
 }
 
@@ -1744,7 +1908,8 @@ OCT_KERNEL(k_epilogue)(DevBatch b, double* out, uint64_t out0, uint64_t out1)
     double acc = 0;
     for (uint32_t r = r0; r < r1; ++r) {
         const uint64_t e = b.hap_pair_off[h] + (r - b.reg_read0[g]);
-        const int32_t pen = b.pair_best[e];
+        const uint32_t shared = b.pair_rep ? b.pair_rep[e] : kNoPair;              // k_dedup_verify: this pair's candidates equal another pair's
+        const int32_t pen = b.pair_best[shared != kNoPair ? (uint64_t)shared : e];
         const double ln_given_mapped = pen == kNoScore ? kLowest : -kLn10Div10 * (double)pen;
         double res;
         if (b.use_mapq) {                                   // model.cpp:285-300

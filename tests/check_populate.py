@@ -467,3 +467,63 @@ def check_leading_haplotypes_without_reads(backend, tol=0.0):
             os.environ.pop("OCT_PHMM_SLICES", None)
         else:
             os.environ["OCT_PHMM_SLICES"] = old
+
+
+def check_shared_pairs(backend, tol=0.0):
+    """Exact de-duplication of pairs (k_window_*, k_dedup_match, k_dedup_verify): regions whose haplotypes are copies of one another, copies with a far-away
+    edit, copies with an edit in one penalty vector only, and copies of different length. With OCT_PHMM_DEDUP=1 the matrix equals the oracle's
+    and the one computed with OCT_PHMM_DEDUP=0 bit for bit, the reference-equivalent counters do not move, and the shared counters show
+    that pairs were in fact not recomputed; one and several slices, given and device-mapped positions."""
+    import os
+    rng = np.random.default_rng(2024)
+    regions = []
+    for k, (R, H, T, Lh, B) in enumerate(((40, 6, 50, 170, 8), (70, 9, 60, 220, 8), (33, 3, 45, 150, 8))):
+        g = synth.make_region(rng, R, 3, T=T, Lh=Lh, B=B, flank=(20, 20) if k != 2 else None, positions="none")
+        haps = list(g["haps"])
+        while len(haps) < H:
+            src = haps[int(rng.integers(0, 3))].copy()
+            kind = len(haps) % 4
+            if kind == 1:                                   # an edit near one end: windows far from it stay shared
+                src[int(rng.integers(5, 25))] = ord("ACGT"[int(rng.integers(0, 4))])
+            elif kind == 2:                                 # shorter haplotype: the same windows, another length
+                src = src[:-int(rng.integers(1, 9))]
+            elif kind == 3 and len(haps) % 8 == 3:          # an 'N': generic kernels for this one, same windows elsewhere
+                src[int(rng.integers(Lh - 30, Lh - 5))] = ord("N")
+            haps.append(src)                                # kind 0: an exact copy
+        g["haps"] = haps
+        regions.append(g)
+    batch = synth.batch_from_regions(regions)
+    # one haplotype differs from its twin in a penalty vector only
+    o = int(batch.hap_offsets[4]); batch.gap_open = batch.gap_open.copy(); batch.gap_open[o + 60:o + 70] -= 3
+    import copy
+    given = mapper_positions(copy.copy(batch), rng=np.random.default_rng(5), junk=0.2)
+    assert batch.pos_offsets is None
+    old = {k: os.environ.get(k) for k in ("OCT_PHMM_DEDUP", "OCT_PHMM_SLICES")}
+    out = {}
+    try:
+        for slices in ("1", "3"):
+            os.environ["OCT_PHMM_SLICES"] = slices
+            for positions in ("device", "given"):
+                bt = batch if positions == "device" else given
+                res = {}
+                for mode in ("0", "1"):
+                    os.environ["OCT_PHMM_DEDUP"] = mode
+                    eng = make_engine(backend, max_indel_error=8)
+                    rb = eng.upload(bt); rb.run(); got = rb.download().copy(); st = rb.stats(); rb.free(); eng.close()
+                    res[mode] = (got, st)
+                stats = compare(backend, bt, tol, max_indel_error=8)         # against the oracle (OCT_PHMM_DEDUP=1 still set), counters included
+                assert np.array_equal(res["0"][0], res["1"][0])
+                for k in ("n_pairs", "n_candidates", "n_fast_path", "n_dp_score_only", "n_dp_traceback", "band_cells"):
+                    assert res["0"][1][k] == res["1"][1][k] == stats[k], k
+                s0, s1 = res["0"][1], res["1"][1]
+                assert s0["n_pairs_shared"] == 0 and s0["n_dp_score_only_shared"] + s0["n_dp_traceback_shared"] == 0 and s0["band_cells_shared"] == 0
+                assert s1["n_pairs_shared"] > 50 and s1["n_dp_score_only_shared"] + s1["n_dp_traceback_shared"] >= s1["n_pairs_shared"] and s1["band_cells_shared"] > 0
+                assert s1["n_dp_score_only_shared"] < s1["n_dp_score_only"] and 0 < s1["n_dp_traceback_shared"] < s1["n_dp_traceback"]
+                out[(slices, positions)] = s1
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return out

@@ -299,6 +299,11 @@ def test_gpu_patched_reference_class_equals_the_unpatched_one():
     assert ci.check("gpu", TOL) > 2000
 
 
+def test_gpu_pairs_with_equal_candidates_share_one_result():
+    """Exact de-duplication of pairs: identical matrices with and without it, reference-equivalent counters unchanged, shared counters > 0."""
+    assert len(cp.check_shared_pairs("gpu", TOL)) == 4
+
+
 def test_gpu_populate_generates_the_penalty_vectors_on_host_threads_and_on_the_device():
     """SURVEY 8f-3 in the product: NULL vectors + oct_phmm_set_error_model; both generation paths equal the reference's error-model classes."""
     if not oracle.have_ref():

@@ -96,3 +96,7 @@ def test_sim_streamed_upload_and_growing_calls():
 
 def test_sim_leading_slice_without_pairs_still_hashes_the_reads():
     cp.check_leading_haplotypes_without_reads("sim")
+
+
+def test_sim_pairs_with_equal_candidates_share_one_result():
+    assert len(cp.check_shared_pairs("sim")) == 4

@@ -1,19 +1,18 @@
+#!/bin/bash
+# round 2, step 5: all GPU tests with pair de-duplication in the default path, then the bench line with and without it
 cd /root/repo; export TMPDIR=/tmp
 O=gpurun_out/r02k; mkdir -p $O
-(cd /tmp && rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u > /root/repo/$O/sq_counters.txt); wc -l $O/sq_counters.txt
-export OCT_PHMM_SLICES=1
-P="--no-small-batch --no-cpu-baseline --no-extras --steps 1 --warmup 1"
-for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_BUSY_CYCLES"; do
-  D=pmc_$(echo $C | cut -d' ' -f2)
-  (cd /tmp && timeout 200 rocprofv3 --pmc $C --output-format csv -d /root/repo/$O/$D -o p -- python /root/repo/bench.py $P > /dev/null 2> /root/repo/$O/$D.err); echo "$D rc=$?"
-done
+timeout 1500 python -m pytest tests -x -q -m gpu --durations=5 > $O/pytest_gpu.log 2>&1; echo "pytest_gpu rc=$?" > $O/rc.log
+OCT_PHMM_DEDUP=0 timeout 600 python bench.py --no-cpu-baseline --steps 10 --warmup 2 > $O/bench_dedup0.json 2> $O/bench_dedup0.err; echo "bench0 rc=$?" >> $O/rc.log
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/rc.log
+cat $O/rc.log; tail -9 $O/pytest_gpu.log
 python - <<'PY'
-import csv, collections, glob
-for f in sorted(glob.glob('/root/repo/gpurun_out/r02k/pmc_*/p_counter_collection.csv')):
-    agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(lambda: collections.defaultdict(int))
-    for r in csv.DictReader(open(f)):
-        if int(r['Grid_Size'])<1000000: continue
-        k=r['Kernel_Name'].split('(')[0][-34:]; agg[k][r['Counter_Name']]+=float(r['Counter_Value']); n[k][r['Counter_Name']]+=1
-    for k,c in agg.items():
-        if 'kmer_map' in k or 'k_dp' in k or 'walk' in k or 'classify' in k: print(k, {a: '%.3g'%(v/n[k][a]) for a,v in c.items()})
+import json
+for m in ("bench_dedup0","bench"):
+    d=json.loads(open(f"gpurun_out/r02k/{m}.json").read().strip().splitlines()[-1])
+    s=d["stats"]; st=d.get("stream",{})
+    print(m, "ms", round(d["ms_per_step"],2), "value", round(d["value"],1), "ref_work", round(d["gcups_reference_work"],1), "loglik/s", round(d["loglik_per_s"]/1e6,1),
+          "shared pairs", s.get("n_pairs_shared"), "verified", d.get("verified_rows"), d.get("verified_max_abs_diff"),
+          "| stream ms", st.get("ms"), "regions/s", st.get("regions_per_s"), "shared", st.get("pairs_shared"), "verified", st.get("verified_rows"), st.get("verified_max_abs_diff"),
+          "e2e", d.get("e2e_ms_from_host"), "small", d.get("small_batch_ms"), "long", d.get("long_read",{}).get("ms"), "vs", d.get("vs_baseline"))
 PY
