@@ -114,6 +114,7 @@ struct oct_phmm_batch {
         DevTask* d_tasks = nullptr; size_t tasks_cap = 0; TraceEnd* d_ends = nullptr; size_t ends_cap = 0;
         unsigned long long* d_keys = nullptr; size_t keys_cap = 0;   // align mode: per traceback task
         uint32_t seg0 = 0, n_segs = 0, n_seg_tiles = 0;              // k_dedup_match: this slice's (region, haplotype range) segments and their 64-read tiles
+        bool resumes = false; rt::Event matched {};                  // its first region began in the previous slice: its matcher waits for that slice's, its epilogue for the earlier slices' results
         rt::Event done {};
     };
     std::vector<Slice> slices;
@@ -122,7 +123,7 @@ struct oct_phmm_batch {
     double* d_out = nullptr;
     uint32_t n_tasks[kNumKinds] = {0, 0, 0, 0};
     unsigned long long h_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bool dedup = false; std::vector<DedupSeg> h_segs; DedupSeg* d_segs = nullptr;   // exact de-duplication of pairs (phmm_kernels.hpp)
+    bool dedup = false, dedup_tables = false; std::vector<DedupSeg> h_segs; DedupSeg* d_segs = nullptr;   // exact de-duplication of pairs (phmm_kernels.hpp)
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
@@ -721,7 +722,7 @@ extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
     if (!h) h = b->owner;
     for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
     for (void* p : b->allocs) h->pool.release(p);
-    for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_ends); h->pool.release(sl.d_keys); h->put_event(sl.done); }
+    for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_ends); h->pool.release(sl.d_keys); h->put_event(sl.done); if (b->dedup) h->put_event(sl.matched); }
     if (b->ev_fork) { h->put_event(b->ev_fork); h->put_event(b->ev_join); h->put_event(b->ev_hashes); }
     delete b;
 }
@@ -973,10 +974,10 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     // Exact de-duplication of pairs (phmm_kernels.hpp): populate on the LDS-resident int16 path, where some region has several haplotypes and
     // the batch is big enough for the matcher's walk over a region's haplotypes (one after the other, ~1.5 us each) not to show: a 1k x 64
     // call went from 0.48 to 0.71 ms with it, the 100k x 128 batch from 32.4 to 30.9 ms, the 2,000-region stream from 49.6 to 44.5 ms.
-    d.canon = nullptr; d.pair_rep = nullptr; d.pair_hash = nullptr; d.window_len = b->t_cap + 2 * (uint32_t)h->band - 1;
+    d.canon = nullptr; d.pair_rep = nullptr; d.pair_hash = nullptr; d.pair_fast = nullptr; d.dd_hash = d.dd_hap = d.dd_n = nullptr; d.window_len = b->t_cap + 2 * (uint32_t)h->band - 1;
     b->dedup = !align_mode && !b->stream && !h->wide && H->n_haps > G && b->lh_cap <= 8192 && b->n_pairs >= 500000 && tune::dedup() != 0;
     if (tune::dedup() > 0) b->dedup = !align_mode && !b->stream && !h->wide && H->n_haps > G;
-    if (b->dedup) { pk.dalloc(&d.canon, (size_t)n_hap_bases + 1); pk.dalloc(&d.pair_rep, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_hash, (size_t)b->n_pairs + 1); }
+    if (b->dedup) { pk.dalloc(&d.canon, (size_t)n_hap_bases + 1); pk.dalloc(&d.pair_rep, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_hash, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_fast, (size_t)b->n_pairs + 1); }
     pk.dalloc(&d.stats, (size_t)kStatSlots * kStatStride + 8);
     pk.dalloc(&b->d_hap_base, (size_t)H->n_haps + 1);
     // late traceback start (k_dp): packed int16 kernels only, no lane can wrap (a failed traceback is then impossible,
@@ -990,8 +991,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     {
         // Slices of whole haplotypes, each on its own stream: while slice i is in its VALU-bound DP kernels, slice i+1 runs its
         // latency-bound mapper/classifier and slice i-1 its latency-bound walk. Small batches stay in one slice.
-        // (a pair only shares the result of a pair of its own slice: fewer, larger slices when de-duplicating)
-        int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / (b->dedup ? 3000000 : 1000000)));
+        int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / 1000000));
         { long long v; if (tune::number("OCT_PHMM_SLICES", &v)) n_slices = std::max(1, std::min(oct_phmm_handle::kMaxSlices, (int)v)); }
         n_slices = (int)std::min<uint32_t>((uint32_t)n_slices, std::max<uint32_t>(1, H->n_haps));
         pk.dalloc(&b->d_totals, (size_t)n_slices);
@@ -1016,10 +1016,17 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
                     const uint32_t g = hap_region[hp];
                     uint32_t e = hp; while (e < sl.hap1 && hap_region[e] == g) ++e;
                     const uint32_t nreads = first_read(g_row[g + 1]) - reg_read0[g];
-                    if (e - hp >= 2 && nreads) { b->h_segs.push_back(DedupSeg {g, hp, e, reg_read0[g], nreads, sl.n_seg_tiles}); sl.n_seg_tiles += (nreads + 63) / 64; }
+                    // a region cut by a slice border: its reads carry their tables over (a single haplotype on one side still takes part)
+                    const uint32_t resumes = hp > g_hap[g] ? 1u : 0u, continues = e < g_hap[g + 1] ? 1u : 0u;
+                    if ((e - hp >= 2 || resumes || continues) && nreads) {
+                        b->h_segs.push_back(DedupSeg {g, hp, e, reg_read0[g], nreads, sl.n_seg_tiles, resumes, continues}); sl.n_seg_tiles += (nreads + 63) / 64;
+                        if (resumes) sl.resumes = true;
+                        if (resumes || continues) b->dedup_tables = true;
+                    }
                     hp = e;
                 }
                 sl.n_segs = (uint32_t)b->h_segs.size() - sl.seg0;
+                RT(h->get_event(&sl.matched));
             }
             b->slices.push_back(sl);
             pk.dalloc(&b->slices.back().tile_sums, (size_t)sl.n_tiles + 1);
@@ -1027,6 +1034,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         }
     }
     if (b->dedup && !b->h_segs.empty()) pk.upload(b->h_segs.data(), b->h_segs.size(), (const DedupSeg**)&b->d_segs);
+    if (b->dedup_tables) { pk.dalloc(&d.dd_hash, (size_t)kDedupReps * R->n_reads + 1); pk.dalloc(&d.dd_hap, (size_t)kDedupReps * R->n_reads + 1); pk.dalloc(&d.dd_n, (size_t)R->n_reads + 1); }
     pk.dalloc(&b->d_out, (size_t)b->n_out);
     d.align_mode = align_mode ? 1 : 0; d.pair_key = nullptr;
     if (align_mode) {
@@ -1231,9 +1239,11 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         const uint32_t pair_blocks = (uint32_t)((np + 255) / 256);
         OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late); RT(rt::launch_ok());
         if (b->dedup && sl.n_seg_tiles) {                     // pairs whose candidates equal an earlier pair's of the same read drop their tasks
+            if (sl.resumes && i > 0) RT(rt::stream_wait_event(s, b->slices[i - 1].matched));     // its reads' tables and the earlier pairs' classes
             OCT_LAUNCH(k_dedup_match, sl.n_seg_tiles, 64, (size_t)kDedupReps * 64 * 2 * sizeof(uint32_t), s, d, (const DedupSeg*)b->d_segs + sl.seg0, sl.n_segs); RT(rt::launch_ok());
             OCT_LAUNCH(k_dedup_verify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late); RT(rt::launch_ok());
         }
+        if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one
         const uint64_t n_scan = np + 1;
         if (sl.n_tiles == 1) {
             OCT_LAUNCH(k_scan_tiles, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 2); RT(rt::launch_ok());
@@ -1311,7 +1321,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         }
         if (b->align_mode) {
             if (np) { OCT_LAUNCH(k_epilogue_align, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, b->d_aln_lik, b->d_aln_mpos, b->d_aln_n, b->d_aln_ops, b->cig_cap); RT(rt::launch_ok()); }
-        } else if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
+        } else if (sl.out1 > sl.out0) {
+            if (b->dedup && sl.resumes) for (int j = 0; j < i; ++j) RT(rt::stream_wait_event(s, b->slices[j].done));   // pairs of a resumed region may share results of earlier slices
+            OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
         if (b->early_out && sl.out1 > sl.out0)
             RT(rt::d2h((double*)h->out_stage + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
         RT(rt::event_record(sl.done, s));

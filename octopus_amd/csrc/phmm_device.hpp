@@ -76,6 +76,8 @@ struct DevBatch {
     // exact de-duplication of pairs (k_window_*, k_dedup_match, k_dedup_verify), null when off: canon[hoff[h] + off] = the first band window of the region
     // with the bytes of haplotype h's window at off (bases and the six vectors); pair_rep[e] = the pair whose result pair e shares, or kNoPair
     uint32_t* canon; uint32_t* pair_rep; uint32_t* pair_hash; uint32_t window_len;            // pair_hash: k_classify's hash of what decides a pair (0 = no DP task)
+    int32_t*  pair_fast;                                                                       // k_classify's fast-path minimum (pair_best before any DP result lands in it)
+    uint32_t* dd_hash; uint32_t* dd_hap; uint32_t* dd_n;                                       // [kDedupReps][n_reads] + [n_reads]: a read's table between the slices of its region
     // counters, kStatSlots stripes of kStatStride: [0] candidates [1] fast path [2] score-only DP [3] traceback DP [4] band cells [5] pairs
     // [6] [7] mapper diagnostics (OCT_PHMM_MAP_STATS) [8] score-only / [9] traceback DP tasks not run because their pair shares another pair's result [10] their band cells [11] such pairs
     unsigned long long* stats;
@@ -84,6 +86,7 @@ struct DevBatch {
 
 struct DedupSeg {     // the haplotypes [hap_lo, hap_hi) of one region inside one slice, and the reads of that region in tiles of 64
     uint32_t region, hap_lo, hap_hi, read0, n_reads, tile0;
+    uint32_t resumes, continues;   // the region's earlier haplotypes lie in the previous slice / its later ones in the next: the reads' tables travel (DevBatch::dd_*)
 };
 
 struct DpParams {

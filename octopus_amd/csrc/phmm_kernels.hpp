@@ -653,7 +653,7 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
             else { extra = (uint32_t)fin; visit((uint32_t)b.max_pos, extra); }
         }
         b.pair_best[e] = best; b.pair_cls[e] = cls; b.pair_extra[e] = extra;
-        if (b.canon) b.pair_hash[e] = cls ? pair_hash_final(dedup_acc, cls, best, Lh) : 0u;
+        if (b.canon) { b.pair_hash[e] = cls ? pair_hash_final(dedup_acc, cls, best, Lh) : 0u; b.pair_fast[e] = best; }
         if (b.align_mode) b.pair_key[e] = key;
         const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
         cnt[e - pair0] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
@@ -764,7 +764,12 @@ OCT_KERNEL(k_dedup_match)(DevBatch b, const DedupSeg* segs, uint32_t n_segs)
     const DedupSeg sg = segs[lo];
     const uint32_t rl = (tile - sg.tile0) * 64 + lane;          // read within the region
     if (rl >= sg.n_reads) return;
+    const uint32_t r = sg.read0 + rl;
     uint32_t n_seen = 0;
+    if (sg.resumes) {                                           // the table this read built over the region's haplotypes in the previous slice
+        n_seen = b.dd_n[r];
+        for (uint32_t j = 0; j < n_seen; ++j) { seen_hash[j * 64 + lane] = b.dd_hash[(size_t)j * b.n_reads + r]; seen_hap[j * 64 + lane] = b.dd_hap[(size_t)j * b.n_reads + r]; }
+    }
     uint32_t key_next = b.pair_hash[b.hap_pair_off[sg.hap_lo] + rl];
     for (uint32_t h = sg.hap_lo; h < sg.hap_hi; ++h) {
         const uint32_t key = key_next;
@@ -774,6 +779,10 @@ OCT_KERNEL(k_dedup_match)(DevBatch b, const DedupSeg* segs, uint32_t n_segs)
         for (uint32_t j = 0; j < n_seen; ++j) if (seen_hash[j * 64 + lane] == key) { found = seen_hap[j * 64 + lane]; break; }
         if (found != kNoPair) b.pair_rep[b.hap_pair_off[h] + rl] = (uint32_t)(b.hap_pair_off[found] + rl);
         else if (n_seen < kDedupReps) { seen_hash[n_seen * 64 + lane] = key; seen_hap[n_seen * 64 + lane] = h; ++n_seen; }
+    }
+    if (sg.continues) {
+        b.dd_n[r] = n_seen;
+        for (uint32_t j = 0; j < n_seen; ++j) { b.dd_hash[(size_t)j * b.n_reads + r] = seen_hash[j * 64 + lane]; b.dd_hap[(size_t)j * b.n_reads + r] = seen_hap[j * 64 + lane]; }
     }
 }
 
@@ -788,8 +797,9 @@ OCT_KERNEL(k_dedup_verify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cn
         if (shared != kNoPair) {
             PairView v, w;
             const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e), h2 = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, (uint64_t)shared);
-            v.e = e; v.cls = b.pair_cls[e]; v.best = b.pair_best[e]; v.ho = b.hoff[h]; v.Lh = b.hoff[h + 1] - v.ho;
-            w.e = shared; w.cls = b.pair_cls[shared]; w.best = b.pair_best[shared]; w.ho = b.hoff[h2]; w.Lh = b.hoff[h2 + 1] - w.ho;
+            // (fast-path minima from pair_fast: the other pair may lie in an earlier slice, whose DP results are already landing in pair_best)
+            v.e = e; v.cls = b.pair_cls[e]; v.best = b.pair_fast[e]; v.ho = b.hoff[h]; v.Lh = b.hoff[h + 1] - v.ho;
+            w.e = shared; w.cls = b.pair_cls[shared]; w.best = b.pair_fast[shared]; w.ho = b.hoff[h2]; w.Lh = b.hoff[h2 + 1] - w.ho;
             if (v.cls && pair_views_same(b, v, w)) {
                 const uint32_t r = b.reg_read0[b.hap_region[h]] + (uint32_t)(e - b.hap_pair_off[h]), T = b.roff[r + 1] - b.roff[r];
                 uint32_t n_score = 0, n_trace = 0;

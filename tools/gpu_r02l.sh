@@ -1,15 +1,20 @@
+#!/bin/bash
 cd /root/repo; export TMPDIR=/tmp
-timeout 600 python -m pytest tests -x -q -m gpu -k "mapper or config2 or slices or basic or fuzz or random_scenarios or 100k or server_batches or stream or ragged" > gpurun_out/r02l_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r02l_pytest.log
-bash tools/gpu_ab.sh r02l OCT_PHMM_LIB=/root/repo/octopus_amd/variants/v3.so
-O=gpurun_out/r02l
-export OCT_PHMM_SLICES=1
-(cd /tmp && timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /root/repo/$O/pmc1 -o p -- python /root/repo/bench.py --no-small-batch --no-cpu-baseline --no-extras --steps 1 --warmup 1 > /dev/null 2>&1)
+O=gpurun_out/r02l; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu -k "share or slices or 100k or stream" > $O/pytest.log 2>&1; echo "pytest rc=$?" > $O/rc.log
+for sl in 3 4 6 8; do
+    OCT_PHMM_SLICES=$sl timeout 300 python bench.py --no-cpu-baseline --no-small-batch --steps 10 --warmup 2 --no-extras 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('slices $sl ms', round(d['ms_per_step'],2), 'shared', d['stats']['n_pairs_shared'], 'loglik/s', round(d['loglik_per_s']/1e6,1))"
+done | tee $O/slices.txt
+timeout 600 python bench.py --no-cpu-baseline --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/rc.log
+cat $O/rc.log; tail -4 $O/pytest.log
 python - <<'PY'
-import csv, collections
-agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(lambda: collections.defaultdict(int))
-for r in csv.DictReader(open('/root/repo/gpurun_out/r02l/pmc1/p_counter_collection.csv')):
-    if int(r['Grid_Size'])<1000000: continue
-    k=r['Kernel_Name'].split('(')[0][-30:]; agg[k][r['Counter_Name']]+=float(r['Counter_Value']); n[k][r['Counter_Name']]+=1
-for k,c in agg.items():
-    if 'kmer_map' in k: print(k, {a: '%.3g'%(v/n[k][a]) for a,v in c.items()})
+import json
+d=json.loads(open("gpurun_out/r02l/bench.json").read().strip().splitlines()[-1])
+s=d["stats"]; st=d.get("stream",{})
+print("ms", round(d["ms_per_step"],2), "value", round(d["value"],1), "ref_work", round(d["gcups_reference_work"],1), "loglik/s", round(d["loglik_per_s"]/1e6,1),
+      "shared pairs", s.get("n_pairs_shared"), "verified", d.get("verified_rows"), d.get("verified_max_abs_diff"),
+      "| stream ms", st.get("ms"), "regions/s", st.get("regions_per_s"), "shared", st.get("pairs_shared"), "verified", st.get("verified_rows"), st.get("verified_max_abs_diff"),
+      "e2e", d.get("e2e_ms_from_host"), "small", d.get("small_batch_ms"))
 PY
