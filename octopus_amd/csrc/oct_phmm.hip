@@ -977,6 +977,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     d.canon = nullptr; d.pair_rep = nullptr; d.pair_hash = nullptr; d.pair_fast = nullptr; d.dd_hash = d.dd_hap = d.dd_n = nullptr; d.window_len = b->t_cap + 2 * (uint32_t)h->band - 1;
     b->dedup = !align_mode && !b->stream && !h->wide && H->n_haps > G && b->lh_cap <= 8192 && b->n_pairs >= 500000 && tune::dedup() != 0;
     if (tune::dedup() > 0) b->dedup = !align_mode && !b->stream && !h->wide && H->n_haps > G;
+    for (uint32_t g = 0; g < G && b->dedup; ++g) if (g_hap[g + 1] - g_hap[g] > 65535) b->dedup = false;     // (the matcher's table holds 16-bit haplotype numbers within a region)
     if (b->dedup) { pk.dalloc(&d.canon, (size_t)n_hap_bases + 1); pk.dalloc(&d.pair_rep, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_hash, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_fast, (size_t)b->n_pairs + 1); }
     pk.dalloc(&d.stats, (size_t)kStatSlots * kStatStride + 8);
     pk.dalloc(&b->d_hap_base, (size_t)H->n_haps + 1);
@@ -1019,7 +1020,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
                     // a region cut by a slice border: its reads carry their tables over (a single haplotype on one side still takes part)
                     const uint32_t resumes = hp > g_hap[g] ? 1u : 0u, continues = e < g_hap[g + 1] ? 1u : 0u;
                     if ((e - hp >= 2 || resumes || continues) && nreads) {
-                        b->h_segs.push_back(DedupSeg {g, hp, e, reg_read0[g], nreads, sl.n_seg_tiles, resumes, continues}); sl.n_seg_tiles += (nreads + 63) / 64;
+                        b->h_segs.push_back(DedupSeg {g, g_hap[g], hp, e, reg_read0[g], nreads, sl.n_seg_tiles, resumes, continues}); sl.n_seg_tiles += (nreads + 63) / 64;
                         if (resumes) sl.resumes = true;
                         if (resumes || continues) b->dedup_tables = true;
                     }
@@ -1240,7 +1241,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late); RT(rt::launch_ok());
         if (b->dedup && sl.n_seg_tiles) {                     // pairs whose candidates equal an earlier pair's of the same read drop their tasks
             if (sl.resumes && i > 0) RT(rt::stream_wait_event(s, b->slices[i - 1].matched));     // its reads' tables and the earlier pairs' classes
-            OCT_LAUNCH(k_dedup_match, sl.n_seg_tiles, 64, (size_t)kDedupReps * 64 * 2 * sizeof(uint32_t), s, d, (const DedupSeg*)b->d_segs + sl.seg0, sl.n_segs); RT(rt::launch_ok());
+            OCT_LAUNCH(k_dedup_match, sl.n_seg_tiles, 64, (size_t)kDedupSlots * 64 * (sizeof(uint32_t) + sizeof(uint16_t)), s, d, (const DedupSeg*)b->d_segs + sl.seg0, sl.n_segs); RT(rt::launch_ok());
             OCT_LAUNCH(k_dedup_verify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late); RT(rt::launch_ok());
         }
         if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one

@@ -85,7 +85,7 @@ struct DevBatch {
 };
 
 struct DedupSeg {     // the haplotypes [hap_lo, hap_hi) of one region inside one slice, and the reads of that region in tiles of 64
-    uint32_t region, hap_lo, hap_hi, read0, n_reads, tile0;
+    uint32_t region, hap_first, hap_lo, hap_hi, read0, n_reads, tile0;   // hap_first: the region's first haplotype (in whatever slice)
     uint32_t resumes, continues;   // the region's earlier haplotypes lie in the previous slice / its later ones in the next: the reads' tables travel (DevBatch::dd_*)
 };
 

@@ -751,13 +751,15 @@ OCT_KERNEL(k_window_resolve)(DevBatch b, uint32_t n_bases, const unsigned long l
 }
 
 // Match: one lane per read, 64 consecutive reads per wave (the pair arrays of a haplotype are read-major: coalesced), the haplotypes of the
-// segment one after the other. Each read remembers up to kDedupReps distinct pair hashes (+ haplotype) in LDS, column-major so that lanes
-// never collide; a pair whose hash it has seen becomes a CANDIDATE for sharing (pair_rep), nothing else changes yet.
+// segment one after the other. Each read keeps the distinct pair hashes it has met (+ haplotype) in a small open-addressing table in LDS,
+// column-major so that lanes never collide; a pair whose hash is in the table becomes a CANDIDATE for sharing (pair_rep), nothing else
+// changes yet. Where a region continues in the next slice the table's entries are left in dd_* and re-inserted there.
+constexpr uint32_t kDedupSlots = 64;                            // table slots per read (kDedupReps entries at most)
 OCT_KERNEL(k_dedup_match)(DevBatch b, const DedupSeg* segs, uint32_t n_segs)
 {
     OCT_DYN_SMEM(smem);
-    uint32_t* seen_hash = (uint32_t*)smem;                      // [kDedupReps][64]
-    uint32_t* seen_hap = seen_hash + kDedupReps * 64;           // [kDedupReps][64]
+    uint32_t* tab_hash = (uint32_t*)smem;                       // [kDedupSlots][64], 0 = empty (pair hashes are never 0)
+    uint16_t* tab_hap = (uint16_t*)(tab_hash + kDedupSlots * 64);   // [kDedupSlots][64] haplotype, counted from the region's first
     const uint32_t lane = hw::thread_idx() & 63, tile = hw::block_idx();
     uint32_t lo = 0, hi = n_segs;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (segs[mid].tile0 <= tile) lo = mid; else hi = mid; }
@@ -765,24 +767,41 @@ OCT_KERNEL(k_dedup_match)(DevBatch b, const DedupSeg* segs, uint32_t n_segs)
     const uint32_t rl = (tile - sg.tile0) * 64 + lane;          // read within the region
     if (rl >= sg.n_reads) return;
     const uint32_t r = sg.read0 + rl;
+    for (uint32_t j = 0; j < kDedupSlots; ++j) tab_hash[j * 64 + lane] = 0;
     uint32_t n_seen = 0;
-    if (sg.resumes) {                                           // the table this read built over the region's haplotypes in the previous slice
-        n_seen = b.dd_n[r];
-        for (uint32_t j = 0; j < n_seen; ++j) { seen_hash[j * 64 + lane] = b.dd_hash[(size_t)j * b.n_reads + r]; seen_hap[j * 64 + lane] = b.dd_hap[(size_t)j * b.n_reads + r]; }
+    // the haplotype that first showed `key`, or kNoPair after putting (key, hap) into the table (room permitting)
+    auto find_or_insert = [&](uint32_t key, uint32_t hap) -> uint32_t {
+        for (uint32_t slot = (key >> 8) % kDedupSlots; ; slot = (slot + 1) % kDedupSlots) {
+            const uint32_t at = tab_hash[slot * 64 + lane];
+            if (at == key) return sg.hap_first + tab_hap[slot * 64 + lane];
+            if (at == 0) {
+                if (n_seen < kDedupReps) { tab_hash[slot * 64 + lane] = key; tab_hap[slot * 64 + lane] = (uint16_t)(hap - sg.hap_first); ++n_seen; }
+                return kNoPair;
+            }
+        }
+    };
+    if (sg.resumes) {                                           // what this read met among the region's haplotypes in the previous slice
+        const uint32_t n = b.dd_n[r];
+        for (uint32_t j = 0; j < n; ++j) find_or_insert(b.dd_hash[(size_t)j * b.n_reads + r], b.dd_hap[(size_t)j * b.n_reads + r]);
     }
-    uint32_t key_next = b.pair_hash[b.hap_pair_off[sg.hap_lo] + rl];
-    for (uint32_t h = sg.hap_lo; h < sg.hap_hi; ++h) {
-        const uint32_t key = key_next;
-        if (h + 1 < sg.hap_hi) key_next = b.pair_hash[b.hap_pair_off[h + 1] + rl];
-        if (!key) continue;
-        uint32_t found = kNoPair;
-        for (uint32_t j = 0; j < n_seen; ++j) if (seen_hash[j * 64 + lane] == key) { found = seen_hap[j * 64 + lane]; break; }
-        if (found != kNoPair) b.pair_rep[b.hap_pair_off[h] + rl] = (uint32_t)(b.hap_pair_off[found] + rl);
-        else if (n_seen < kDedupReps) { seen_hash[n_seen * 64 + lane] = key; seen_hap[n_seen * 64 + lane] = h; ++n_seen; }
+    for (uint32_t h0 = sg.hap_lo; h0 < sg.hap_hi; h0 += 8) {    // eight haplotypes' hashes in flight at a time (a lone wave per SIMD hides no latency)
+        uint32_t keys[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) keys[u] = h0 + u < sg.hap_hi ? b.pair_hash[b.hap_pair_off[h0 + u] + rl] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            if (!keys[u]) continue;
+            const uint32_t found = find_or_insert(keys[u], h0 + u);
+            if (found != kNoPair) b.pair_rep[b.hap_pair_off[h0 + u] + rl] = (uint32_t)(b.hap_pair_off[found] + rl);
+        }
     }
     if (sg.continues) {
-        b.dd_n[r] = n_seen;
-        for (uint32_t j = 0; j < n_seen; ++j) { b.dd_hash[(size_t)j * b.n_reads + r] = seen_hash[j * 64 + lane]; b.dd_hap[(size_t)j * b.n_reads + r] = seen_hap[j * 64 + lane]; }
+        uint32_t n = 0;
+        for (uint32_t slot = 0; slot < kDedupSlots; ++slot) {
+            const uint32_t at = tab_hash[slot * 64 + lane];
+            if (at) { b.dd_hash[(size_t)n * b.n_reads + r] = at; b.dd_hap[(size_t)n * b.n_reads + r] = sg.hap_first + tab_hap[slot * 64 + lane]; ++n; }
+        }
+        b.dd_n[r] = n;
     }
 }
 

@@ -25,6 +25,9 @@ check_fuzz.check_fuzz("sim", seed=5, n=6)
 import check_server
 check_server.check_server("sim", n_threads=3, per_thread=5)
 cp.check_empty_batches("sim")
+cp.check_shared_pairs("sim")                       # canonical windows, matcher, verifier, tables across slices
+import check_error_model as ce
+ce.check_device_kernels_on_the_corpus("sim", 40)   # both penalty-vector kernels
 print("SANITIZED-OK")
 """
 
