@@ -492,6 +492,10 @@ def check_shared_pairs(backend, tol=0.0):
             haps.append(src)                                # kind 0: an exact copy
         g["haps"] = haps
         regions.append(g)
+    # more distinct haplotypes than a read's table holds (kDedupReps = 48), then copies of early and of late ones
+    g = synth.make_region(rng, 12, 58, T=45, Lh=160, B=8, flank=(15, 15), positions="none")
+    g["haps"] = list(g["haps"]) + [g["haps"][i].copy() for i in (0, 3, 50, 57, 20, 55)]
+    regions.append(g)
     batch = synth.batch_from_regions(regions)
     # one haplotype differs from its twin in a penalty vector only
     o = int(batch.hap_offsets[4]); batch.gap_open = batch.gap_open.copy(); batch.gap_open[o + 60:o + 70] -= 3
