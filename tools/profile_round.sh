@@ -7,6 +7,7 @@ python -c "from octopus_amd import engine; print(engine.kernel_source_sha())" > 
 if [ "$2" != "notests" ]; then
   timeout 900 python -m pytest tests -x -q -m gpu --durations=8 > $O/pytest_gpu.log 2>&1; echo "pytest_gpu rc=$?" >> $O/rc.log
 fi
+timeout 120 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/rc.log
 timeout 420 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/rc.log
 timeout 200 python bench.py --workload stream --no-cpu-baseline --no-small-batch > $O/bench_stream.json 2> $O/bench_stream.err; echo "bench_stream rc=$?" >> $O/rc.log
 export OCT_PHMM_SLICES=1
