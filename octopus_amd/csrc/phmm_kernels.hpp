@@ -38,6 +38,23 @@ OCT_DEVICE uint32_t upper_bound_idx(const T* a, uint32_t n, T v)   // largest i 
     return lo;
 }
 
+// The same for a kernel whose consecutive threads hold consecutive values (one thread per pair / output): the wave searches ONCE, for its first
+// value and in scalar registers; every lane then steps forward from there (a haplotype owns at least a read's worth of consecutive pairs, so
+// mostly not at all). `first` must be wave-uniform and <= v. A many-region batch has tens of thousands of haplotypes: 16 dependent loads per
+// thread otherwise.
+template <class T>
+OCT_DEVICE uint32_t upper_bound_near(const T* a, uint32_t n, T first, T v)
+{
+    uint32_t i = upper_bound_idx(a, n, first);
+    while (i + 1 < n && a[i + 1] <= v) ++i;
+    return i;
+}
+OCT_DEVICE uint64_t wave_first_index(uint64_t base)       // base + index of this wave's first thread in the grid, in scalar registers
+{
+    const uint32_t wave = hw::readfirstlane(hw::thread_idx() >> 6);
+    return base + (uint64_t)hw::block_idx() * hw::block_dim() + (uint64_t)wave * 64u;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // per-read flags, per-haplotype-base DP tables
 // ------------------------------------------------------------------------------------------------------------------
@@ -110,17 +127,17 @@ OCT_DEVICE uint32_t kmer_hash6(const uint8_t* s)               // perfect_kmer_h
 
 // make_kmer_hash_table (:85-106) for every haplotype: one workgroup per haplotype, CSR bins (order inside a bin does not
 // affect the vote counts). LDS: 4096 counters + 256 scan slots.
-OCT_DEVICE void read_hash_thread(const DevBatch& b, uint32_t g, uint32_t n_bases)   // compute_kmer_hashes<6> (:57-69), once per read base
+OCT_DEVICE void read_hash_wave(const DevBatch& b, uint32_t r, uint32_t lane)   // compute_kmer_hashes<6> (:57-69): one wave per read (no search for the read a base belongs to)
 {
-    if (g >= n_bases) return;
-    const uint32_t r = upper_bound_idx(b.roff, b.n_reads + 1, g);
-    if (g + kKmer <= b.roff[r + 1]) b.rhash[g] = (uint16_t)kmer_hash6(b.rbases + g);
+    if (r >= b.n_reads) return;
+    const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro;
+    for (uint32_t q = lane; q + kKmer <= T; q += 64) b.rhash[ro + q] = (uint16_t)kmer_hash6(b.rbases + ro + q);
 }
 
-// The workgroups past `n_hap_blocks` (slice 0 only) compute the read hashes of the whole batch in the same launch.
-OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint32_t n_read_bases)
+// The workgroups past `n_hap_blocks` (one slice only) compute the read hashes of the whole batch in the same launch, four reads each.
+OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks)
 {
-    if (hw::block_idx() >= n_hap_blocks) { read_hash_thread(b, (hw::block_idx() - n_hap_blocks) * hw::block_dim() + hw::thread_idx(), n_read_bases); return; }
+    if (hw::block_idx() >= n_hap_blocks) { read_hash_wave(b, (hw::block_idx() - n_hap_blocks) * (hw::block_dim() / 64) + (hw::thread_idx() >> 6), hw::thread_idx() & 63u); return; }
     OCT_DYN_SMEM(smem);
     uint32_t* hist = (uint32_t*)smem;            // [4096]
     uint32_t* part = hist + kKmerBins;           // [256]
@@ -134,32 +151,33 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint
         b.hhash[ho + p] = (uint16_t)hsh;                              // the haplotype's own hash sequence (k_kmer_map's exact-count shortcut)
     }
     hw::block_sync();
-    // exclusive scan of the 4096 counters: 16 per thread (256 threads)
-    const uint32_t per = kKmerBins / 256;
-    uint32_t sum = 0;
-    if (tid < 256) for (uint32_t i = 0; i < per; ++i) sum += hist[tid * per + i];
-    if (tid < 256) part[tid] = sum;
+    // exclusive scan of the 4096 counters: 16 per thread (256 threads = 4 waves); inside a wave by shuffles, across the waves through four
+    // LDS words - two workgroup barriers instead of seventeen (a many-region batch runs this once per haplotype: 49 k workgroups per step)
+    const uint32_t per = kKmerBins / 256, lane = tid & 63u, wv = tid >> 6;
+    uint32_t cnt16[kKmerBins / 256], sum = 0;
+    if (tid < 256) for (uint32_t i = 0; i < per; ++i) { cnt16[i] = hist[tid * per + i]; sum += cnt16[i]; }
+    uint32_t incl = sum;
+    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = hw::shfl(incl, (int)(lane >= d ? lane - d : lane)); if (lane >= d) incl += o; }
+    if (tid < 256 && lane == 63) part[wv] = incl;
     hw::block_sync();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-        uint32_t o = 0;
-        if (tid < 256 && tid >= d) o = part[tid - d];
-        hw::block_sync();
-        if (tid < 256) part[tid] += o;
-        hw::block_sync();
-    }
     if (tid < 256) {
-        uint32_t run = tid ? part[tid - 1] : 0;
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < wv; ++w) run += part[w];
         for (uint32_t i = 0; i < per; ++i) {
-            const uint32_t c = hist[tid * per + i]; hist[tid * per + i] = run;
-            b.bin_start[(size_t)h * (kKmerBins + 1) + tid * per + i] = (uint16_t)run;
-            if (b.bin32) b.bin32[(size_t)h * kKmerBins + tid * per + i] = run | c << 16;      // start and occupancy in one word, for k_kmer_map_lanes
+            const uint32_t c = cnt16[i]; hist[tid * per + i] = run | c << 16;                  // start and occupancy in one word (haplotypes are < 65,536 bases)
+            if (b.bin_start) b.bin_start[(size_t)h * (kKmerBins + 1) + tid * per + i] = (uint16_t)run;   // k_kmer_map_big's table (long haplotypes only)
             run += c;
         }
-        if (tid == 255) b.bin_start[(size_t)h * (kKmerBins + 1) + kKmerBins] = (uint16_t)run;
+        if (tid == 255 && b.bin_start) b.bin_start[(size_t)h * (kKmerBins + 1) + kKmerBins] = (uint16_t)run;
+    }
+    hw::block_sync();
+    if (b.bin32) {                                                                              // the table of k_kmer_map / k_kmer_map_lanes, 16 bytes per thread per store: whole lines
+        uint4* dst = (uint4*)(b.bin32 + (size_t)h * kKmerBins); const uint4* src = (const uint4*)hist;
+        for (uint32_t i = tid; i < kKmerBins / 4; i += nt) dst[i] = src[i];
     }
     hw::block_sync();
     for (uint32_t p = tid; p < nk; p += nt) {
-        const uint32_t slot = hw::atomic_add_lds_u32(&hist[kmer_hash6(b.hbases + ho + p)], 1u);
+        const uint32_t slot = hw::atomic_add_lds_u32(&hist[kmer_hash6(b.hbases + ho + p)], 1u) & 0xffffu;   // the start field counts up; it cannot reach the occupancy above it
         b.bin_idx[ho + slot] = (uint16_t)p;
     }
 }
@@ -599,9 +617,10 @@ OCT_DEVICE bool pair_views_same(const DevBatch& b, const PairView& v, const Pair
 OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* cnt_late)
 {
     const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    const uint64_t e_wave = wave_first_index(pair0);
     unsigned long long st_cand = 0, st_fast = 0, st_score = 0, st_trace = 0, st_cells = 0, st_pairs = 0;
     if (e < pair1) {
-        const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
+        const uint32_t h = upper_bound_near(b.hap_pair_off, b.n_haps + 1, e_wave, e);
         const uint32_t g = b.hap_region[h];
         const uint32_t r = b.reg_read0[g] + (uint32_t)(e - b.hap_pair_off[h]);
         const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, ho = b.hoff[h], Lh = b.hoff[h + 1] - ho;
@@ -810,12 +829,13 @@ OCT_KERNEL(k_dedup_match)(DevBatch b, const DedupSeg* segs, uint32_t n_segs)
 OCT_KERNEL(k_dedup_verify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* cnt_late)
 {
     const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    const uint64_t e_wave = wave_first_index(pair0);
     unsigned long long st_score = 0, st_trace = 0, st_cells = 0, st_pairs = 0;
     if (e < pair1) {
         const uint32_t shared = b.pair_rep[e];
         if (shared != kNoPair) {
             PairView v, w;
-            const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e), h2 = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, (uint64_t)shared);
+            const uint32_t h = upper_bound_near(b.hap_pair_off, b.n_haps + 1, e_wave, e), h2 = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, (uint64_t)shared);
             // (fast-path minima from pair_fast: the other pair may lie in an earlier slice, whose DP results are already landing in pair_best)
             v.e = e; v.cls = b.pair_cls[e]; v.best = b.pair_fast[e]; v.ho = b.hoff[h]; v.Lh = b.hoff[h + 1] - v.ho;
             w.e = shared; w.cls = b.pair_cls[shared]; w.best = b.pair_fast[shared]; w.ho = b.hoff[h2]; w.Lh = b.hoff[h2 + 1] - w.ho;
@@ -933,10 +953,11 @@ OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt,
                    const uint4* cnt_late, const uint4* hap_base_late, TaskArrays out_late)
 {
     const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    const uint64_t e_wave = wave_first_index(pair0);
     if (e >= pair1) return;
     const uint32_t cls = b.pair_cls[e];
     if (!cls) return;
-    const uint32_t h = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, e);
+    const uint32_t h = upper_bound_near(b.hap_pair_off, b.n_haps + 1, e_wave, e);
     const uint32_t r = b.reg_read0[b.hap_region[h]] + (uint32_t)(e - b.hap_pair_off[h]);
     const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
     const uint4 s = cnt[e - pair0], s0 = cnt[b.hap_pair_off[h] - pair0], hb = hap_base[h];
@@ -1929,8 +1950,9 @@ OCT_KERNEL(k_walk_cigar)(WalkParams w)
 OCT_KERNEL(k_epilogue)(DevBatch b, double* out, uint64_t out0, uint64_t out1)
 {
     const uint64_t o = out0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    const uint64_t o_wave = wave_first_index(out0);
     if (o >= out1) return;
-    const uint32_t h = upper_bound_idx(b.hap_out_off, b.n_haps + 1, o);
+    const uint32_t h = upper_bound_near(b.hap_out_off, b.n_haps + 1, o_wave, o);
     const uint32_t g = b.hap_region[h];
     const uint32_t row = b.reg_row0[g] + (uint32_t)(o - b.hap_out_off[h]);
     const uint32_t r0 = b.row_off ? b.row_off[row] : row, r1 = b.row_off ? b.row_off[row + 1] : row + 1;
