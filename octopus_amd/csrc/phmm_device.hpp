@@ -76,6 +76,7 @@ struct DevBatch {
     // exact de-duplication of pairs (k_window_*, k_dedup_match, k_dedup_verify), null when off: canon[hoff[h] + off] = the first band window of the region
     // with the bytes of haplotype h's window at off (bases and the six vectors); pair_rep[e] = the pair whose result pair e shares, or kNoPair
     uint32_t* canon; uint32_t* pair_rep; uint32_t* pair_hash; uint32_t window_len;            // pair_hash: k_classify's hash of what decides a pair (0 = no DP task)
+    uint32_t  dedup_hash_mask;                                                                 // all ones; a test hook narrows both hashes so that unequal windows / pairs collide (OCT_PHMM_DEDUP_HASH_BITS)
     int32_t*  pair_fast;                                                                       // k_classify's fast-path minimum (pair_best before any DP result lands in it)
     uint32_t* dd_hash; uint32_t* dd_hap; uint32_t* dd_n;                                       // [kDedupReps][n_reads] + [n_reads]: a read's table between the slices of its region
     // counters, kStatSlots stripes of kStatStride: [0] candidates [1] fast path [2] score-only DP [3] traceback DP [4] band cells [5] pairs

@@ -591,9 +591,9 @@ OCT_DEVICE uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull
 // haplotype length, and per DP task its position and the canonical window it starts in. k_classify leaves a 32-bit hash of these per pair
 // (0 = no DP task); `pair_views_same` compares two pairs of one read field by field.
 OCT_DEVICE uint64_t pair_hash_task(uint64_t acc, uint32_t p, uint32_t canon) { return mix64(acc ^ ((uint64_t)p << 32 | canon)); }
-OCT_DEVICE uint32_t pair_hash_final(uint64_t acc, uint32_t cls, int32_t best, uint32_t Lh)
+OCT_DEVICE uint32_t pair_hash_final(uint64_t acc, uint32_t cls, int32_t best, uint32_t Lh, uint32_t mask)
 {
-    const uint32_t k = (uint32_t)mix64(acc ^ mix64((uint64_t)cls << 32 | (uint32_t)best) ^ Lh);
+    const uint32_t k = (uint32_t)mix64(acc ^ mix64((uint64_t)cls << 32 | (uint32_t)best) ^ Lh) & mask;
     return k ? k : 1u;
 }
 struct PairView { uint32_t cls; int32_t best; uint32_t Lh; uint64_t e; uint32_t ho; };
@@ -672,7 +672,7 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
             else { extra = (uint32_t)fin; visit((uint32_t)b.max_pos, extra); }
         }
         b.pair_best[e] = best; b.pair_cls[e] = cls; b.pair_extra[e] = extra;
-        if (b.canon) { b.pair_hash[e] = cls ? pair_hash_final(dedup_acc, cls, best, Lh) : 0u; b.pair_fast[e] = best; }
+        if (b.canon) { b.pair_hash[e] = cls ? pair_hash_final(dedup_acc, cls, best, Lh, b.dedup_hash_mask) : 0u; b.pair_fast[e] = best; }
         if (b.align_mode) b.pair_key[e] = key;
         const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
         cnt[e - pair0] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
@@ -707,20 +707,29 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
 // Everything is decided by comparing the values themselves; hashes only find candidates.
 // ------------------------------------------------------------------------------------------------------------------
 
-// prefix[hoff[h] + h + x] = sum over y < x of mix(position y of haplotype h) * pw[y] (mod 2^64): one thread per haplotype
+// prefix[hoff[h] + h + x] = sum over y < x of mix(position y of haplotype h) * pw[y] (mod 2^64): one wave per haplotype, 64 positions per
+// round, an inclusive scan across the lanes (shuffles on the two halves of the 64-bit sums) and a carry from round to round
+OCT_DEVICE uint64_t shfl_u64(uint64_t v, uint32_t src) { return (uint64_t)hw::shfl((uint32_t)v, (int)src) | (uint64_t)hw::shfl((uint32_t)(v >> 32), (int)src) << 32; }
 OCT_KERNEL(k_window_prefix)(DevBatch b, const uint64_t* pw, uint64_t* prefix)
 {
-    const uint32_t h = hw::block_idx() * hw::block_dim() + hw::thread_idx();
-    if (h >= b.n_haps) return;
+    const uint32_t lane = hw::thread_idx() & 63u;
+    const uint32_t h = hw::block_idx() * (hw::block_dim() / 64) + hw::readfirstlane(hw::thread_idx() >> 6);
+    if (h >= b.n_haps) return;                                  // (whole waves)
     const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho;
     uint64_t* out = prefix + (size_t)ho + h;
-    uint64_t sum = 0;
-    out[0] = 0;
-    for (uint32_t x = 0; x < Lh; ++x) {
-        const uint64_t v = (uint64_t)b.hbases[ho + x] | (uint64_t)(uint8_t)b.go[ho + x] << 8 | (uint64_t)(uint8_t)b.ge[ho + x] << 16 | (uint64_t)b.maskF[ho + x] << 24
-                         | (uint64_t)(uint8_t)b.priorF[ho + x] << 32 | (uint64_t)b.maskR[ho + x] << 40 | (uint64_t)(uint8_t)b.priorR[ho + x] << 48;
-        sum += mix64(v + 1) * pw[x];
-        out[x + 1] = sum;
+    if (lane == 0) out[0] = 0;
+    uint64_t carry = 0;
+    for (uint32_t x0 = 0; x0 < Lh; x0 += 64) {
+        const uint32_t x = x0 + lane;
+        uint64_t sum = 0;
+        if (x < Lh) {
+            const uint64_t v = (uint64_t)b.hbases[ho + x] | (uint64_t)(uint8_t)b.go[ho + x] << 8 | (uint64_t)(uint8_t)b.ge[ho + x] << 16 | (uint64_t)b.maskF[ho + x] << 24
+                             | (uint64_t)(uint8_t)b.priorF[ho + x] << 32 | (uint64_t)b.maskR[ho + x] << 40 | (uint64_t)(uint8_t)b.priorR[ho + x] << 48;
+            sum = mix64(v + 1) * pw[x];
+        }
+        for (uint32_t d = 1; d < 64; d <<= 1) { const uint64_t o = shfl_u64(sum, lane >= d ? lane - d : lane); if (lane >= d) sum += o; }
+        if (x < Lh) out[x + 1] = carry + sum;
+        carry += shfl_u64(sum, 63);
     }
 }
 
@@ -734,7 +743,7 @@ OCT_KERNEL(k_window_insert)(DevBatch b, const uint64_t* pwinv, const uint64_t* p
     const uint32_t end = off + b.window_len < Lh ? off + b.window_len : Lh;
     const uint64_t* pre = prefix + (size_t)ho + h;
     const uint64_t sum = (pre[end] - pre[off]) * pwinv[off];                 // the window's polynomial, independent of where it starts
-    const unsigned long long key = mix64(sum ^ mix64((uint64_t)(end - off) << 32 | b.hap_region[h])) | 1ull;
+    const unsigned long long key = (mix64(sum ^ mix64((uint64_t)(end - off) << 32 | b.hap_region[h])) & ((uint64_t)b.dedup_hash_mask << 32 | b.dedup_hash_mask)) | 1ull;
     wkey[x] = key;
     for (uint32_t slot = (uint32_t)(key >> 20) & tmask; ; slot = (slot + 1) & tmask) {
         const unsigned long long prev = hw::atomic_cas_u64(tkeys + slot, 0ull, key);
@@ -811,7 +820,7 @@ OCT_KERNEL(k_dedup_match)(DevBatch b, const DedupSeg* segs, uint32_t n_segs)
         for (uint32_t u = 0; u < 8; ++u) {
             if (!keys[u]) continue;
             const uint32_t found = find_or_insert(keys[u], h0 + u);
-            if (found != kNoPair) b.pair_rep[b.hap_pair_off[h0 + u] + rl] = (uint32_t)(b.hap_pair_off[found] + rl);
+            if (found != kNoPair) b.pair_rep[b.hap_pair_off[h0 + u] + rl] = found;     // (the haplotype: k_dedup_verify turns it into the pair, or forgets it)
         }
     }
     if (sg.continues) {
@@ -832,10 +841,11 @@ OCT_KERNEL(k_dedup_verify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cn
     const uint64_t e_wave = wave_first_index(pair0);
     unsigned long long st_score = 0, st_trace = 0, st_cells = 0, st_pairs = 0;
     if (e < pair1) {
-        const uint32_t shared = b.pair_rep[e];
-        if (shared != kNoPair) {
+        const uint32_t h2 = b.pair_rep[e];                                     // the matcher's candidate: the HAPLOTYPE whose pair with this read looked the same
+        if (h2 != kNoPair) {
             PairView v, w;
-            const uint32_t h = upper_bound_near(b.hap_pair_off, b.n_haps + 1, e_wave, e), h2 = upper_bound_idx(b.hap_pair_off, b.n_haps + 1, (uint64_t)shared);
+            const uint32_t h = upper_bound_near(b.hap_pair_off, b.n_haps + 1, e_wave, e);
+            const uint64_t shared = b.hap_pair_off[h2] + (e - b.hap_pair_off[h]);
             // (fast-path minima from pair_fast: the other pair may lie in an earlier slice, whose DP results are already landing in pair_best)
             v.e = e; v.cls = b.pair_cls[e]; v.best = b.pair_fast[e]; v.ho = b.hoff[h]; v.Lh = b.hoff[h + 1] - v.ho;
             w.e = shared; w.cls = b.pair_cls[shared]; w.best = b.pair_fast[shared]; w.ho = b.hoff[h2]; w.Lh = b.hoff[h2 + 1] - w.ho;
@@ -845,6 +855,7 @@ OCT_KERNEL(k_dedup_verify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cn
                 for (uint32_t slot = 0; slot <= (uint32_t)b.max_pos; ++slot) { const uint32_t kd = (v.cls >> (2 * slot)) & 3u; n_score += kd == 1u ? 1u : 0u; n_trace += kd >= 2u ? 1u : 0u; }
                 st_score = n_score; st_trace = n_trace; st_cells = (unsigned long long)(n_score + n_trace) * 2ull * (uint32_t)b.band * (T + (uint32_t)b.band); st_pairs = 1;
                 b.pair_cls[e] = 0;
+                b.pair_rep[e] = (uint32_t)shared;                                     // from here on: the pair whose result this one reads
                 cnt[e - pair0] = make_uint4(0, 0, 0, 0);
                 if (cnt_late) cnt_late[e - pair0] = make_uint4(0, 0, 0, 0);
             } else {

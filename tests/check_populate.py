@@ -502,7 +502,7 @@ def check_shared_pairs(backend, tol=0.0):
     import copy
     given = mapper_positions(copy.copy(batch), rng=np.random.default_rng(5), junk=0.2)
     assert batch.pos_offsets is None
-    old = {k: os.environ.get(k) for k in ("OCT_PHMM_DEDUP", "OCT_PHMM_SLICES")}
+    old = {k: os.environ.get(k) for k in ("OCT_PHMM_DEDUP", "OCT_PHMM_SLICES", "OCT_PHMM_DEDUP_HASH_BITS")}
     out = {}
     try:
         for slices in ("1", "3"):
@@ -524,6 +524,14 @@ def check_shared_pairs(backend, tol=0.0):
                 assert s1["n_pairs_shared"] > 50 and s1["n_dp_score_only_shared"] + s1["n_dp_traceback_shared"] >= s1["n_pairs_shared"] and s1["band_cells_shared"] > 0
                 assert s1["n_dp_score_only_shared"] < s1["n_dp_score_only"] and 0 < s1["n_dp_traceback_shared"] < s1["n_dp_traceback"]
                 out[(slices, positions)] = s1
+                # hashes only FIND candidates: with both cut to two bits nearly every window and pair collides with an unequal one, every
+                # comparison must reject those, and the matrix must not move
+                os.environ["OCT_PHMM_DEDUP_HASH_BITS"] = "2"
+                eng = make_engine(backend, max_indel_error=8)
+                rb = eng.upload(bt); rb.run(); weak = rb.download().copy(); sw = rb.stats(); rb.free(); eng.close()
+                del os.environ["OCT_PHMM_DEDUP_HASH_BITS"]
+                assert np.array_equal(weak, res["0"][0])
+                assert 0 < sw["n_pairs_shared"] <= s1["n_pairs_shared"] and sw["n_dp_score_only"] == s1["n_dp_score_only"]
     finally:
         for k, v in old.items():
             if v is None:
