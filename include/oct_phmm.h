@@ -190,6 +190,10 @@ int  oct_phmm_batch_stats(const oct_phmm_batch* b, oct_phmm_stats* stats);
  * (utils/kmer_mapper.hpp:120-159) returns when the device mapped, the caller's own CSR otherwise. Entries past counts[pair] are undefined. */
 int  oct_phmm_batch_candidate_positions(oct_phmm_handle* h, oct_phmm_batch* b, uint8_t* counts, uint32_t* positions, oct_phmm_status* status);
 size_t oct_phmm_batch_out_size(const oct_phmm_batch* b); /* number of doubles `out` must hold */
+/* 1 when the batch runs with device-sized launches: one slice whose traceback scratch fits the host-known task bound, so that
+ * oct_phmm_batch_run enqueues the whole step without reading the task counts back (region-sized batches); 0 when the step reads them
+ * back to size its DP launches (big batches, alignment). Results are identical either way. Diagnostic / test seam. */
+int  oct_phmm_batch_device_sized(const oct_phmm_batch* b);
 /* Average device time (ms) of the last run's dominant DP kernel launches measured with HIP events on the
  * handle's stream, and the number of launches; for bench.py's roofline block. */
 int  oct_phmm_batch_kernel_time(const oct_phmm_batch* b, double* dp_kernel_ms, uint32_t* dp_launches);

@@ -127,6 +127,8 @@ struct oct_phmm_batch {
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
+    // device-sized launches (one slice, scratch for the host-known task bound fits): no host read-back of the task counts in the middle of a step
+    bool dsl = false; uint32_t dsl_list_bound = 0; size_t dsl_total_bound = 0; int dsl_flavours = 3;   // tasks one list / all six lists can hold at most (padding included)
     rt::Event ev_fork {}, ev_join {}, ev_hashes {};
     // align mode (oct_phmm_align)
     bool align_mode = false; uint32_t cig_cap = 0;
@@ -151,7 +153,7 @@ struct oct_phmm_batch {
 // production. They are read when a handle is created or a batch is uploaded - never by a kernel - and fall in three groups:
 //   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS
 //   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
-//                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP
+//                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions)
 // ---------------------------------------------------------------------------------------------------------------
@@ -169,6 +171,7 @@ inline bool big_mapper()      { return flag("OCT_PHMM_BIG_MAPPER"); }         //
 inline int  penalties_where() { const char* e = getenv("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' || e[0] == 'l' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
 inline int  dedup()           { const char* e = getenv("OCT_PHMM_DEDUP"); return !e ? -1 : atoi(e); }                                  // -1 by shape, 0 never, 1 wherever it is possible
 inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_HASH_BITS", &n) && n >= 1 && n < 32 ? (1u << n) - 1u : 0xffffffffu; }   // test hook: collisions
+inline int  device_sized()    { const char* e = getenv("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
 inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
 inline bool penalties_lane_kernel() { const char* e = getenv("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
 }
@@ -409,10 +412,15 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 }
 
 // Run one kind's task list through the DP kernel (+ walk for traceback kinds), chunked so the traceback scratch fits.
+// `ref` (device-sized launch): `tasks` is the array that holds all six lists, `n_tasks` the host's bound for one list; the kernels take the list itself
+// from the totals in device memory.
+constexpr uint32_t kDslMaxBlocks = 2048;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
 int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
-                int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false)
+                int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false,
+                TaskListRef ref = TaskListRef {nullptr, nullptr, 0})
 {
     if (!n_tasks) return OCT_PHMM_OK;
+    const bool dsl = ref.totals != nullptr;
     rt::Stream st = on_stream ? *on_stream : h->slice_stream(slice);
     const int B = h->band;
     const uint32_t C = (uint32_t)h->lanes_c;
@@ -421,6 +429,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     const size_t lds = b->stream ? 0 : dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr);
     if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
     DpParams p {};
+    p.ref = ref;
     p.rbases = b->d.rbases; p.rquals = b->d.rquals; p.roff = b->d.roff; p.rrev = b->d.rrev; p.hoff = b->d.hoff;
     p.rrec = b->d.rrec; p.rrec_stride = b->d.rrec_stride;
     p.tabF = gen ? b->d.tabGenF : b->d.tabFastF; p.tabR = gen ? b->d.tabGenR : b->d.tabFastR;
@@ -432,16 +441,17 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     // workgroups walk kGroupsPerWave groups per wave to amortise the haplotype-table staging; a small launch (one active region) instead
     // spreads over the chip: one group per wave until there are enough workgroups for every CU
     p.groups_per_block = kBlockWaves * std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerWave, n_groups / (kBlockWaves * 2048)));
+    if (dsl) p.groups_per_block = kBlockWaves;             // (region-sized by construction)
     p.late = late ? 1 : 0; p.hap_region = b->d.hap_region; p.reg_rhs = b->d.reg_rhs;
     uint32_t chunk_groups = n_groups;
     if (tr) {
         const size_t per_group = (size_t)p.k_cap * 4096 * (b->stream ? C : 1);
-        const size_t fit = std::max<size_t>(1, h->bp_budget / std::max<size_t>(1, b->slices.size()) / per_group);
+        const size_t fit = dsl ? n_groups : std::max<size_t>(1, h->bp_budget / std::max<size_t>(1, b->slices.size()) / per_group);   // (device-sized: the bound was checked at upload)
         chunk_groups = (uint32_t)std::min<size_t>(n_groups, fit);
         if (chunk_groups < n_groups) chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / p.groups_per_block * p.groups_per_block);   // several launches: whole workgroups each
         // the device may not have the budget free (other handles, other processes): fall back to smaller chunks of whole workgroups
         while (!ensure_bp(h, slice, (size_t)std::min(chunk_groups, n_groups) * per_group)) {
-            if (chunk_groups <= p.groups_per_block || b->align_mode) return fail(status, OCT_PHMM_EHIP, "traceback scratch allocation");
+            if (chunk_groups <= p.groups_per_block || b->align_mode || dsl) return fail(status, OCT_PHMM_EHIP, "traceback scratch allocation");
             chunk_groups = std::max<uint32_t>(p.groups_per_block, chunk_groups / 2 / p.groups_per_block * p.groups_per_block);
         }
     }
@@ -449,7 +459,8 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         const uint32_t ng = std::min(chunk_groups, n_groups - g0);
         p.tasks = tasks + (size_t)g0 * G; p.n_tasks = ng * G;
         p.bp = h->bp[slice]; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
-        const uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
+        uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
+        if (dsl) n_blocks = std::min(n_blocks, kDslMaxBlocks);
         rt::Event e0 {}, e1 {};
         if (h->timing) { RT(h->get_event(&e0)); RT(h->get_event(&e1)); RT(rt::event_record(e0, st)); }
         if (!(b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
@@ -459,6 +470,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         if (tr) {
             WalkParams w {};
             if (seam_walk) w = *seam_walk;
+            w.ref = ref;
             w.tasks = p.tasks; w.n_tasks = p.n_tasks; w.ends = p.ends; w.bp = h->bp[slice]; w.k_cap = p.k_cap; w.band = B;
             w.rbases = b->d.rbases; w.rquals = b->d.rquals; w.roff = b->d.roff; w.rrev = b->d.rrev;
             w.hbases = b->d.hbases; w.hoff = b->d.hoff; w.go = b->d.go; w.ge = b->d.ge;
@@ -1037,6 +1049,26 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             if (b->late_ok) pk.dalloc(&b->slices.back().tile_sums_late, (size_t)sl.n_tiles + 1);
         }
     }
+    {
+        // Device-sized launches: with ONE slice and traceback scratch for the most tasks the pairs can emit (max_mapping_positions + 1 each, plus the
+        // padding of every haplotype's runs), nothing on the host depends on the task counts: the step is a fixed launch sequence without a read-back.
+        const uint32_t Bw = (uint32_t)h->band, Gs = b->stream ? (Bw < 64 ? 64u / Bw : 1u) : (h->wide ? 1u : 2u) * (64u / Bw);
+        const uint64_t raw = b->n_pairs * (uint64_t)(S + 1), pad = (uint64_t)H->n_haps * (Gs - 1);
+        const uint64_t list_bound = (raw + pad + Gs - 1) / Gs * Gs, total_bound = raw + 6 * pad;
+        const uint64_t bp_bytes = list_bound / Gs * ((uint64_t)bp_tiles(b->t_cap, Bw) * 4096u * (b->stream ? (uint64_t)h->lanes_c : 1u));
+        const uint64_t cap = std::min<uint64_t>((uint64_t)8 << 30, h->bp_budget);
+        b->dsl = b->slices.size() == 1 && !align_mode && b->n_pairs > 0 && bp_bytes <= cap && list_bound < 0x7fffffffull && tune::device_sized() != 0;
+        b->dsl_list_bound = b->dsl ? (uint32_t)list_bound : 0; b->dsl_total_bound = b->dsl ? (size_t)total_bound : 0;
+        if (b->dsl && !gen_device && !d.wide) {
+            // which of the two cost flavours can occur at all (k_hap_tables / read_flags_thread decide per read and haplotype): a clean region launches no generic kernels
+            bool clean = true;
+            const uint8_t* rb = (const uint8_t*)R->bases; const uint8_t* hb = (const uint8_t*)H->bases;
+            auto acgt = [](uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; };
+            for (uint32_t i = 0; i < n_read_bases && clean; ++i) clean = acgt(rb[i]);
+            for (uint32_t i = 0; i < n_hap_bases && clean; ++i) clean = acgt(hb[i]) && H->snv_mask_fwd[i] != '0' && H->snv_mask_rev[i] != '0';
+            b->dsl_flavours = clean ? 1 : 3;
+        } else b->dsl_flavours = d.wide ? 2 : 3;            // bit 0: fast-cost lists may hold tasks, bit 1: generic lists may
+    }
     if (b->dedup && !b->h_segs.empty()) pk.upload(b->h_segs.data(), b->h_segs.size(), (const DedupSeg**)&b->d_segs);
     if (b->dedup_tables) { pk.dalloc(&d.dd_hash, (size_t)kDedupReps * R->n_reads + 1); pk.dalloc(&d.dd_hap, (size_t)kDedupReps * R->n_reads + 1); pk.dalloc(&d.dd_n, (size_t)R->n_reads + 1); }
     pk.dalloc(&b->d_out, (size_t)b->n_out);
@@ -1257,7 +1289,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 1); RT(rt::launch_ok());
         }
         OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, b->d_hap_base, sl.d_totals, G); RT(rt::launch_ok());
-        RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s));
+        if (!b->dsl) RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s));
         sl.totals_late = make_uint4(0, 0, 0, 0);
         if (sl.cnt_late) {                                    // the same scan for the late-start traceback tasks
             if (sl.n_tiles == 1) {
@@ -1268,8 +1300,47 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt_late, n_scan, sl.tile_sums_late, 1); RT(rt::launch_ok());
             }
             OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt_late, sl.pair0, b->d_hap_base_late, sl.d_totals_late, G); RT(rt::launch_ok());
-            RT(rt::d2h(&sl.totals_late, sl.d_totals_late, sizeof(uint4), s));
+            if (!b->dsl) RT(rt::d2h(&sl.totals_late, sl.d_totals_late, sizeof(uint4), s));
         }
+        return OCT_PHMM_OK;
+    };
+    // phase 2 of the one slice of a device-sized batch: the same launches with grids from the host's bound; the kernels find their task lists through
+    // the totals k_hap_bases left in device memory
+    auto phase2_device_sized = [&]() -> int {
+        rt::Range range_p2("phase 2 (device-sized): emit, DP, walk, epilogue");
+        oct_phmm_batch::Slice& sl = b->slices[0];
+        rt::Stream s = h->slice_stream(0);
+        const uint64_t np = sl.pair1 - sl.pair0;
+        if (np) {
+            if (b->dsl_total_bound > sl.tasks_cap) {
+                h->pool.release(sl.d_tasks); sl.d_tasks = nullptr; sl.tasks_cap = 0;
+                void* p = nullptr; RT(h->pool.alloc(&p, b->dsl_total_bound * sizeof(DevTask))); sl.d_tasks = (DevTask*)p; sl.tasks_cap = b->dsl_total_bound;
+            }
+            if (b->dsl_list_bound > sl.ends_cap) {
+                h->pool.release(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
+                void* p = nullptr; RT(h->pool.alloc(&p, (size_t)b->dsl_list_bound * sizeof(TraceEnd))); sl.d_ends = (TraceEnd*)p; sl.ends_cap = b->dsl_list_bound;
+            }
+            TaskArrays ta {}; ta.t[0] = sl.d_tasks; TaskArrays tl {};
+            TaskListRef ref {sl.d_totals, sl.cnt_late ? sl.d_totals_late : nullptr, 0};
+            OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
+                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, ref, G); RT(rt::launch_ok());
+            // region-sized and latency-bound: the score-only DP runs beside the traceback DP + walk on a second stream
+            rt::Stream aux = h->slice_stream(1);
+            RT(rt::event_record(b->ev_fork, s)); RT(rt::stream_wait_event(aux, b->ev_fork));
+            auto flavour_live = [&](int list) { const bool gen = list == kScoreGen || list == kTraceGen || list == 5; return (b->dsl_flavours & (gen ? 2 : 1)) != 0; };
+            for (int list : {4, 5, (int)kTraceFast, (int)kTraceGen, (int)kScoreFast, (int)kScoreGen}) {
+                if (list >= 4 && !sl.cnt_late) continue;
+                if (!flavour_live(list)) continue;
+                ref.list = list;
+                const int kind = list == 4 ? kTraceFast : list == 5 ? kTraceGen : list;
+                const bool score_kind = kind == kScoreFast || kind == kScoreGen;
+                const int rc = run_dp_kind(h, b, 0, kind, sl.d_tasks, b->dsl_list_bound, sl.d_ends, h->cfg.nuc_prior, nullptr, status, score_kind ? &aux : nullptr, list >= 4, ref);
+                if (rc != OCT_PHMM_OK) return rc;
+            }
+            RT(rt::event_record(b->ev_join, aux)); RT(rt::stream_wait_event(s, b->ev_join));
+        }
+        if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
+        RT(rt::event_record(sl.done, s));
         return OCT_PHMM_OK;
     };
     // phase 2: task emission, the DP kernels (+ traceback walk), epilogue for the slice's rows
@@ -1301,10 +1372,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             TaskArrays tl;                                       // late-start traceback tasks: [0] fast-cost kernel, [1] generic
             tl.t[0] = ta.t[3] + totals.w; tl.t[1] = tl.t[0] + late.x; tl.t[2] = tl.t[1] + late.y; tl.t[3] = tl.t[2];
             OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
-                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl); RT(rt::launch_ok());
-            const uint32_t pad_threads = (sl.hap1 - sl.hap0) * kNumKinds * G;
-            OCT_LAUNCH(k_emit_pad, (pad_threads + 255) / 256, 256, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, (const uint4*)b->d_hap_base, ta, G); RT(rt::launch_ok());
-            if (late.x + late.y) { OCT_LAUNCH(k_emit_pad, (pad_threads + 255) / 256, 256, 0, s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt_late, sl.pair0, (const uint4*)b->d_hap_base_late, tl, G); RT(rt::launch_ok()); }
+                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, TaskListRef {nullptr, nullptr, 0}, G); RT(rt::launch_ok());
             static const int order[kNumKinds] = {kTraceFast, kTraceGen, kScoreFast, kScoreGen};   // traceback first: its walk then overlaps the score-only DP of the next slice
             // A single-slice (region-sized) batch is latency-bound: its score-only DP runs beside the traceback DP + walk on a second stream.
             const bool side = S == 1 && total < 200000 && (totals.x + totals.z) > 0 && (totals.y + totals.w) > 0;   // big launches fill the chip on their own
@@ -1343,6 +1411,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     };
     // software pipeline over slices: phase 1 of slice i+1 is enqueued before the host waits for slice i's task counts
     int rc = S ? phase1(0) : OCT_PHMM_OK;
+    if (b->dsl) {                                             // one slice, no read-back: phase 2 follows at once
+        if (rc == OCT_PHMM_OK) rc = phase2_device_sized();
+    } else
     for (int i = 0; i < S && rc == OCT_PHMM_OK; ++i) {
         if (i + 1 < S) rc = phase1(i + 1);
         if (rc != OCT_PHMM_OK) break;
@@ -1441,6 +1512,8 @@ extern "C" int oct_phmm_batch_stats(const oct_phmm_batch* b, oct_phmm_stats* st)
 }
 
 extern "C" size_t oct_phmm_batch_out_size(const oct_phmm_batch* b) { return b ? (size_t)b->n_out : 0; }
+
+extern "C" int oct_phmm_batch_device_sized(const oct_phmm_batch* b) { return b && b->dsl ? 1 : 0; }
 
 extern "C" int oct_phmm_batch_kernel_time(const oct_phmm_batch* b, double* ms, uint32_t* launches)
 {

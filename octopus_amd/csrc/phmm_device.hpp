@@ -90,8 +90,19 @@ struct DedupSeg {     // the haplotypes [hap_lo, hap_hi) of one region inside on
     uint32_t resumes, continues;   // the region's earlier haplotypes lie in the previous slice / its later ones in the next: the reads' tables travel (DevBatch::dd_*)
 };
 
+// Device-sized launches (region-sized batches): the task counts of a step exist only in device memory (k_hap_bases' padded
+// totals: x score-only fast, y traceback fast, z score-only generic, w traceback generic; late-start traceback tasks x fast, y generic). The six task
+// lists lie one behind the other in that order in ONE array; a kernel that is handed `totals` finds its list there and the host never reads the counts
+// back in the middle of a step. Launch grids come from the host-known bound (pairs x (max_mapping_positions + 1)); surplus workgroups leave at once.
+struct TaskListRef {
+    const uint4* totals;        // null = host-sized launch: `tasks` / `n_tasks` of the parameter block are the list itself
+    const uint4* totals_late;   // may be null (no late-start lists)
+    int list;                   // 0..3 = Kind, 4 = late-start fast, 5 = late-start generic
+};
+
 struct DpParams {
-    const DevTask* tasks; uint32_t n_tasks;           // n_tasks is a multiple of the group size
+    const DevTask* tasks; uint32_t n_tasks;           // n_tasks is a multiple of the group size (device-sized launch: the array all six lists live in, n_tasks unused)
+    TaskListRef ref;
     const uint8_t* rbases; const uint8_t* rquals; const uint32_t* roff; const uint8_t* rrev;
     const uint32_t* hoff; const uint2* tabF; const uint2* tabR;
     const uint32_t* rrec; uint32_t rrec_stride;       // per-read record rows (fast-cost kernels): entry j = read position j - band
@@ -109,6 +120,7 @@ struct DpParams {
 
 struct WalkParams {
     const DevTask* tasks; uint32_t n_tasks; const TraceEnd* ends; const uint32_t* bp; uint32_t k_cap; int band;
+    TaskListRef ref;                                  // device-sized launch: see DpParams
     const uint8_t* rbases; const uint8_t* rquals; const uint32_t* roff; const uint8_t* rrev;
     const uint8_t* hbases; const uint32_t* hoff; const int8_t* go; const int8_t* ge;
     const uint8_t* maskF; const int8_t* priorF; const uint8_t* maskR; const int8_t* priorR;

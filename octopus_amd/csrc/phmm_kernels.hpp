@@ -959,51 +959,68 @@ OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* c
 
 struct TaskArrays { DevTask* t[kNumKinds]; };
 
+// Device-sized launches: first task and length of one of the six task lists, from k_hap_bases' totals in device memory (uniform: scalar loads)
+OCT_DEVICE void task_list_range(const TaskListRef& ref, uint32_t& first, uint32_t& n)
+{
+    const uint4 a = *ref.totals;
+    const uint4 l = ref.totals_late ? *ref.totals_late : make_uint4(0, 0, 0, 0);
+    const uint32_t c[6] = {a.x, a.y, a.z, a.w, l.x, l.y};
+    first = 0; n = 0;
+    for (int k = 0; k < 6; ++k) { if (k < ref.list) first += c[k]; if (k == ref.list) n = c[k]; }
+}
+
 // Pass 2: write the DP tasks of every pair at hap_base + (scanned count - scanned count at the haplotype's first pair).
 OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt, const uint4* hap_base, TaskArrays out,
-                   const uint4* cnt_late, const uint4* hap_base_late, TaskArrays out_late)
+                   const uint4* cnt_late, const uint4* hap_base_late, TaskArrays out_late, TaskListRef ref, uint32_t group)
 {
     const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
     const uint64_t e_wave = wave_first_index(pair0);
     if (e >= pair1) return;
+    if (ref.totals) {                                           // device-sized: the six lists one behind the other in out.t[0]
+        DevTask* base = out.t[0];
+        for (int k = 0; k < 6; ++k) {
+            TaskListRef q = ref; q.list = k;
+            uint32_t first, n; task_list_range(q, first, n);
+            if (k < kNumKinds) out.t[k] = base + first; else out_late.t[k - kNumKinds] = base + first;
+        }
+    }
     const uint32_t cls = b.pair_cls[e];
     if (!cls) return;
     const uint32_t h = upper_bound_near(b.hap_pair_off, b.n_haps + 1, e_wave, e);
     const uint32_t r = b.reg_read0[b.hap_region[h]] + (uint32_t)(e - b.hap_pair_off[h]);
     const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
-    const uint4 s = cnt[e - pair0], s0 = cnt[b.hap_pair_off[h] - pair0], hb = hap_base[h];
+    const uint4 s = cnt[e - pair0], s0 = cnt[b.hap_pair_off[h] - pair0], z = cnt[b.hap_pair_off[h + 1] - pair0], hb = hap_base[h];
     uint32_t at_score = generic ? hb.z + (s.z - s0.z) : hb.x + (s.x - s0.x);
     uint32_t at_trace = generic ? hb.w + (s.w - s0.w) : hb.y + (s.y - s0.y);
+    // one past the haplotype's last real task of each list: whoever writes the task before it also writes the padding copies behind it
+    const uint32_t end_score = generic ? hb.z + (z.z - s0.z) : hb.x + (z.x - s0.x), end_trace = generic ? hb.w + (z.w - s0.w) : hb.y + (z.y - s0.y);
     DevTask* ts = out.t[generic ? kScoreGen : kScoreFast]; DevTask* tt = out.t[generic ? kTraceGen : kTraceFast];
-    uint32_t at_late = 0; DevTask* tl = nullptr;
+    uint32_t at_late = 0, end_late = 0; DevTask* tl = nullptr;
     if (cnt_late) {
-        const uint4 q = cnt_late[e - pair0], q0 = cnt_late[b.hap_pair_off[h] - pair0], qb = hap_base_late[h];
+        const uint4 q = cnt_late[e - pair0], q0 = cnt_late[b.hap_pair_off[h] - pair0], qz = cnt_late[b.hap_pair_off[h + 1] - pair0], qb = hap_base_late[h];
         at_late = generic ? qb.y + (q.y - q0.y) : qb.x + (q.x - q0.x); tl = out_late.t[generic ? 1 : 0];
+        end_late = generic ? qb.y + (qz.y - q0.y) : qb.x + (qz.x - q0.x);
     }
     const uint32_t* P = b.pos + e * (uint64_t)b.max_pos;
     const uint32_t B = (uint32_t)b.band;
+    // Every haplotype's run in a list is padded to whole task groups (a DP task group never straddles two haplotypes): copies of its last task with
+    // pair = kPadTask. hap_base already counts them (k_hap_bases).
+    auto put = [&](DevTask* list, uint32_t& at, uint32_t end, uint32_t first, const DevTask& t) {
+        list[at++] = t;
+        if (at != end) return;
+        const uint32_t n = end - first, padded = (n + group - 1) / group * group;
+        DevTask q = t; q.pair = kPadTask;
+        for (uint32_t i = n; i < padded; ++i) list[first + i] = q;
+    };
     for (uint32_t slot = 0; slot <= (uint32_t)b.max_pos; ++slot) {
         const uint32_t k = (cls >> (2 * slot)) & 3u;
         if (!k) continue;
         const uint32_t p = slot < (uint32_t)b.max_pos ? P[slot] : b.pair_extra[e];
         DevTask t; t.pair = (uint32_t)e; t.read = r; t.hap = h; t.off = p > B ? p - B : 0;
-        if (k == 1) ts[at_score++] = t; else if (k == 2) tt[at_trace++] = t; else tl[at_late++] = t;
+        if (k == 1) put(ts, at_score, end_score, generic ? hb.z : hb.x, t);
+        else if (k == 2) put(tt, at_trace, end_trace, generic ? hb.w : hb.y, t);
+        else put(tl, at_late, end_late, generic ? hap_base_late[h].y : hap_base_late[h].x, t);
     }
-}
-
-OCT_KERNEL(k_emit_pad)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* scan, uint64_t pair0, const uint4* hap_base, TaskArrays out, uint32_t group)
-{
-    const uint32_t idx = hw::block_idx() * hw::block_dim() + hw::thread_idx();
-    const uint32_t h = hap0 + idx / (kNumKinds * group), rem = idx % (kNumKinds * group), kind = rem / group, slot = rem % group;
-    if (h >= hap1) return;
-    const uint4 a = scan[b.hap_pair_off[h] - pair0], z = scan[b.hap_pair_off[h + 1] - pair0], hb = hap_base[h];
-    const uint32_t cnt = kind == 0 ? z.x - a.x : kind == 1 ? z.y - a.y : kind == 2 ? z.z - a.z : z.w - a.w;
-    const uint32_t base = kind == 0 ? hb.x : kind == 1 ? hb.y : kind == 2 ? hb.z : hb.w;
-    const uint32_t padded = (cnt + group - 1) / group * group;
-    if (cnt == 0 || slot >= padded - cnt) return;
-    DevTask t = out.t[kind][base + cnt - 1];
-    t.pair = kPadTask;
-    out.t[kind][base + cnt + slot] = t;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1056,9 +1073,9 @@ OCT_KERNEL(k_dp)(DpParams p)
     uint2* rec_row = recs + (wave * ROWS + row) * rec_n;
     uint32_t* tile = tiles + wave * 16 * kTileStride;
 
-    const uint32_t n_groups = p.n_tasks / G;
-    const uint32_t g_begin = hw::block_idx() * p.groups_per_block;
-    const uint32_t g_end = g_begin + p.groups_per_block < n_groups ? g_begin + p.groups_per_block : n_groups;
+    const DevTask* tasks = p.tasks; uint32_t n_tasks = p.n_tasks;
+    if (p.ref.totals) { uint32_t first; task_list_range(p.ref, first, n_tasks); tasks += first; }   // device-sized launch: this kernel's list, from device memory
+    const uint32_t n_groups = n_tasks / G;
     const uint32_t NUC = p.nuc4;
     // State words are kept biased by 0x8000 per half (null_score_ -> 0x0000, infinity_ -> 0xF800): a wrapping add is bit-identical to the
     // reference's int16 add, the signed min becomes an unsigned min, and a half only carries into its neighbour where the reference's
@@ -1067,12 +1084,15 @@ OCT_KERNEL(k_dp)(DpParams p)
     constexpr uint32_t INFB = INF2 ^ 0x80008000u, NULB = NUL2 ^ 0x80008000u;
     auto sadd = [](uint32_t x, uint32_t y) -> uint32_t { if constexpr (FASTADD) return x + y; else return hw::pk_add(x, y); };
 
+    // (a host-sized launch has one workgroup per run of groups_per_block groups; a device-sized one a grid from the host's bound, strided)
+    for (uint32_t g_begin = hw::block_idx() * p.groups_per_block; g_begin < n_groups; g_begin += hw::grid_dim() * p.groups_per_block) {
+    const uint32_t g_end = g_begin + p.groups_per_block < n_groups ? g_begin + p.groups_per_block : n_groups;
     uint32_t seg = g_begin;
     while (seg < g_end) {
         // ---- haplotype segment [seg, seg_end): stage its two strand tables in LDS ----
-        const uint32_t hap = p.tasks[seg * G].hap;
+        const uint32_t hap = tasks[seg * G].hap;
         uint32_t seg_end = seg + 1;
-        while (seg_end < g_end && p.tasks[seg_end * G].hap == hap) ++seg_end;
+        while (seg_end < g_end && tasks[seg_end * G].hap == hap) ++seg_end;
         const uint32_t ho = p.hoff[hap], Lh = p.hoff[hap + 1] - ho;
         hw::block_sync();
         for (uint32_t x = tid; x < lh_n; x += kBlockWaves * 64) {
@@ -1083,7 +1103,7 @@ OCT_KERNEL(k_dp)(DpParams p)
         hw::block_sync();
 
         for (uint32_t g = seg + wave; g < seg_end; g += kBlockWaves) {
-            const DevTask tA = p.tasks[g * G + 2 * row], tB = p.tasks[g * G + 2 * row + 1];
+            const DevTask tA = tasks[g * G + 2 * row], tB = tasks[g * G + 2 * row + 1];
             const uint32_t roA = p.roff[tA.read], TA = p.roff[tA.read + 1] - roA;
             const uint32_t roB = p.roff[tB.read], TB = p.roff[tB.read + 1] - roB;
             uint32_t Tmax = TA > TB ? TA : TB, Tmin = TA < TB ? TA : TB;
@@ -1298,6 +1318,7 @@ OCT_KERNEL(k_dp)(DpParams p)
         }
         seg = seg_end;
     }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1327,16 +1348,18 @@ OCT_KERNEL(k_dp32)(DpParams p)
     uint32_t* tiles = (uint32_t*)(recs + kBlockWaves * ROWS * rec_n);
     uint2* rec_row = recs + (wave * ROWS + row) * rec_n;
     uint32_t* tile = tiles + wave * 16 * kTileStride;
-    const uint32_t n_groups = p.n_tasks / G;
-    const uint32_t g_begin = hw::block_idx() * p.groups_per_block;
-    const uint32_t g_end = g_begin + p.groups_per_block < n_groups ? g_begin + p.groups_per_block : n_groups;
+    const DevTask* tasks = p.tasks; uint32_t n_tasks = p.n_tasks;
+    if (p.ref.totals) { uint32_t first; task_list_range(p.ref, first, n_tasks); tasks += first; }   // device-sized launch (see k_dp)
+    const uint32_t n_groups = n_tasks / G;
     const uint32_t NUC = p.nuc4 & 0xffffu; const uint32_t NUC32 = (uint32_t)(int32_t)(int16_t)NUC;   // sign-extended (nuc_prior << 2)
 
+    for (uint32_t g_begin = hw::block_idx() * p.groups_per_block; g_begin < n_groups; g_begin += hw::grid_dim() * p.groups_per_block) {
+    const uint32_t g_end = g_begin + p.groups_per_block < n_groups ? g_begin + p.groups_per_block : n_groups;
     uint32_t seg = g_begin;
     while (seg < g_end) {
-        const uint32_t hap = p.tasks[seg * G].hap;
+        const uint32_t hap = tasks[seg * G].hap;
         uint32_t seg_end = seg + 1;
-        while (seg_end < g_end && p.tasks[seg_end * G].hap == hap) ++seg_end;
+        while (seg_end < g_end && tasks[seg_end * G].hap == hap) ++seg_end;
         const uint32_t ho = p.hoff[hap], Lh = p.hoff[hap + 1] - ho;
         hw::block_sync();
         for (uint32_t x = tid; x < lh_n; x += kBlockWaves * 64) {
@@ -1346,7 +1369,7 @@ OCT_KERNEL(k_dp32)(DpParams p)
         }
         hw::block_sync();
         for (uint32_t g = seg + wave; g < seg_end; g += kBlockWaves) {
-            const DevTask tA = p.tasks[g * G + row];
+            const DevTask tA = tasks[g * G + row];
             const uint32_t roA = p.roff[tA.read], TA = p.roff[tA.read + 1] - roA;
             uint32_t Tmax = TA;
             for (int m = B; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(Tmax, m); Tmax = o > Tmax ? o : Tmax; }
@@ -1436,6 +1459,7 @@ OCT_KERNEL(k_dp32)(DpParams p)
         }
         seg = seg_end;
     }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1461,9 +1485,11 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
     const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
     const uint32_t row = lane / BL, li = lane % BL;
     const uint32_t group = hw::block_idx() * kBlockWaves + wave;           // = the wave's task group (ROWS tasks)
-    if (group * ROWS >= p.n_tasks) return;                                 // whole waves only (n_tasks is a multiple of ROWS)
+    const DevTask* tasks = p.tasks; uint32_t n_tasks = p.n_tasks;
+    if (p.ref.totals) { uint32_t first; task_list_range(p.ref, first, n_tasks); tasks += first; }   // device-sized launch: the grid is the host's bound
+    if (group * ROWS >= n_tasks) return;                                   // whole waves only (n_tasks is a multiple of ROWS)
     const uint32_t task = group * ROWS + row;
-    const DevTask t = p.tasks[task];
+    const DevTask t = tasks[task];
     const uint32_t ro = p.roff[t.read], T = p.roff[t.read + 1] - ro;
     uint32_t K = T + B;
     if (ROWS > 1) { for (int m = BL; m < 64; m <<= 1) { const uint32_t o = hw::shfl_xor(K, m); K = o > K ? o : K; } K = hw::readfirstlane(K); }   // the rows iterate together
@@ -1749,8 +1775,13 @@ OCT_KERNEL(k_walk)(WalkParams w)
     OCT_DYN_SMEM(smem);
     uint32_t* evbuf = (uint32_t*)smem + hw::thread_idx() * kWalkEvents;
     const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    const DevTask* tasks = w.tasks; uint32_t n_tasks = w.n_tasks;
+    if (w.ref.totals) {                                                   // device-sized launch: the grid is the host's bound, surplus waves leave here
+        uint32_t first; task_list_range(w.ref, first, n_tasks); tasks += first;
+        if ((ti & ~63u) >= n_tasks) return;
+    }
     DevTask t; t.pair = kPadTask; t.read = 0; t.hap = 0; t.off = 0;
-    if (ti < w.n_tasks) t = w.tasks[ti];
+    if (ti < n_tasks) t = tasks[ti];
     const bool active = t.pair != kPadTask;
     TraceEnd end; end.score = 0; end.sidx = -1;
     if (active) end = w.ends[ti];

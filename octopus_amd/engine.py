@@ -74,6 +74,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_candidate_positions.argtypes = [pv, pv, pv, pv, pv]
         lib.oct_phmm_batch_out_size.argtypes = [pv]
         lib.oct_phmm_batch_out_size.restype = C.c_size_t
+        lib.oct_phmm_batch_device_sized.argtypes = [pv]
         lib.oct_phmm_batch_kernel_time.argtypes = [pv, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         lib.oct_phmm_batch_kernel_time_by_kind.argtypes = [pv, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32 * 4)]
         lib.oct_phmm_batch_genotype_likelihoods.argtypes = [pv, pv, pv, pv, pv]
@@ -193,6 +194,10 @@ class ResidentBatch:
         if code != abi.OK:
             raise EngineError(code, st, "batch_penalty_vectors")
         return go[:n], ge[:n], mf[:n], pf[:n], mr[:n], pr[:n]
+
+    def device_sized(self) -> bool:
+        """oct_phmm_batch_device_sized: the step runs without the mid-step read-back of the task counts."""
+        return bool(self.engine.lib.oct_phmm_batch_device_sized(self.ptr))
 
     def stats(self) -> dict:
         s = abi.Stats()

@@ -539,3 +539,50 @@ def check_shared_pairs(backend, tol=0.0):
             else:
                 os.environ[k] = v
     return out
+
+
+def check_launch_modes(backend, tol=0.0):
+    """A region-sized batch runs with device-sized launches (no mid-step read-back of the task counts, oct_phmm_batch_device_sized); the
+    host-sized path that big batches take (forced with OCT_PHMM_DEVICE_SIZED=0, or by a traceback-scratch budget the task bound does not fit)
+    must give the same bytes, and both must equal the oracle: packed int16, int32 lanes, the streaming kernels, generic bytes, several regions
+    with templates, and the late traceback start."""
+    import os
+    keep = {k: os.environ.get(k) for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_LATE_MIN_PAIRS")}
+    rng = np.random.default_rng(4711)
+    n = 0
+    try:
+        cases = []
+        for B, T, Lh, kw, late in ((16, 150, 300, {}, False), (8, 60, 150, {}, True), (16, 100, 260, dict(use_int_scores=1), False),
+                                   (128, 120, 600, {}, False), (16, 700, 1500, dict(use_int_scores=1), False), (32, 90, 300, {}, True)):
+            regs = [synth.make_region(rng, int(rng.integers(5, 30)), int(rng.integers(1, 6)), T=T, Lh=Lh, B=B, flank=(20, 30), positions="none",
+                                      indels_per_read=1) for _ in range(int(rng.integers(1, 4)))]
+            if B == 8:
+                for g in regs:
+                    g["reads"][rng.integers(0, g["reads"].shape[0], 3), rng.integers(0, T, 3)] = ord("N")
+            cases.append((B, kw, late, synth.batch_from_regions(regs)))
+        for B, kw, late, batch in cases:
+            os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = "0" if late else "1000000000000"
+            outs = []
+            for mode in ("default", "host", "budget"):
+                os.environ.pop("OCT_PHMM_DEVICE_SIZED", None); os.environ.pop("OCT_PHMM_BP_BUDGET_KB", None)
+                if mode == "host":
+                    os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"
+                if mode == "budget":
+                    os.environ["OCT_PHMM_BP_BUDGET_KB"] = "600"
+                eng = make_engine(backend, max_indel_error=B, **kw)
+                rb = eng.upload(batch)
+                assert rb.device_sized() == (mode == "default"), (mode, B)
+                rb.run(); outs.append(rb.download().copy())
+                rb.run(); assert np.array_equal(rb.download(), outs[-1])       # a resident batch can be run again
+                rb.free(); eng.close()
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+            os.environ.pop("OCT_PHMM_DEVICE_SIZED", None); os.environ.pop("OCT_PHMM_BP_BUDGET_KB", None)
+            compare(backend, batch, tol, max_indel_error=B, **kw)
+            n += 1
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return n

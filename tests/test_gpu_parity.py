@@ -238,6 +238,16 @@ def test_gpu_late_traceback_start_equals_oracle_and_plain_path(monkeypatch):
     cp.compare("gpu", batch, TOL, max_indel_error=16)
 
 
+def test_gpu_device_sized_and_host_sized_launches_agree(monkeypatch):
+    """Region-sized batches take the device-sized launches (no mid-step read-back); the host-sized single-slice path on the same inputs."""
+    assert cp.check_launch_modes("gpu", TOL) == 6
+    import check_fuzz
+    monkeypatch.setenv("OCT_PHMM_DEVICE_SIZED", "0")
+    assert check_fuzz.check_fuzz("gpu", seed=77, n=60, tol=TOL) == 60
+    cp.check_basic("gpu", TOL)
+    cp.check_generic_bytes("gpu", TOL)
+
+
 def test_gpu_chunked_traceback_launches():
     cp.check_chunked_traceback("gpu", TOL)
 

@@ -100,3 +100,16 @@ def test_sim_leading_slice_without_pairs_still_hashes_the_reads():
 
 def test_sim_pairs_with_equal_candidates_share_one_result():
     assert len(cp.check_shared_pairs("sim")) == 4
+
+
+def test_sim_device_sized_and_host_sized_launches_agree():
+    assert cp.check_launch_modes("sim") == 6
+
+
+def test_sim_populate_host_sized_launches(monkeypatch):
+    """Region-sized batches run with device-sized launches by default; the single-slice host-sized path (the mid-step read-back) on the same checks."""
+    monkeypatch.setenv("OCT_PHMM_DEVICE_SIZED", "0")
+    cp.check_basic("sim")
+    cp.check_generic_bytes("sim")
+    cp.check_templates_and_regions("sim")
+    cp.check_ragged_and_edges("sim")
