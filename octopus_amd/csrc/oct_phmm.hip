@@ -153,7 +153,8 @@ struct oct_phmm_batch {
 // production. They are read when a handle is created or a batch is uploaded - never by a kernel - and fall in three groups:
 //   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS
 //   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
-//                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED
+//                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED,
+//                OCT_PHMM_WALK_STAGE
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions)
 // ---------------------------------------------------------------------------------------------------------------
@@ -172,6 +173,7 @@ inline int  penalties_where() { const char* e = getenv("OCT_PHMM_PENALTIES"); re
 inline int  dedup()           { const char* e = getenv("OCT_PHMM_DEDUP"); return !e ? -1 : atoi(e); }                                  // -1 by shape, 0 never, 1 wherever it is possible
 inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_HASH_BITS", &n) && n >= 1 && n < 32 ? (1u << n) - 1u : 0xffffffffu; }   // test hook: collisions
 inline int  device_sized()    { const char* e = getenv("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
+inline int  walk_stage()      { const char* e = getenv("OCT_PHMM_WALK_STAGE"); return !e ? -1 : atoi(e); }                             // -1 by launch size, 0 never, 1 always: the walk with its tiles staged in LDS
 inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
 inline bool penalties_lane_kernel() { const char* e = getenv("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
 }
@@ -355,24 +357,31 @@ bool launch_dp32(int band, bool tr, const DpParams& p, uint32_t n_blocks, size_t
     }
 }
 template <int B, int TPR, int C>
-bool launch_walk_inst(const WalkParams& w, rt::Stream s)
+bool launch_walk_inst(const WalkParams& w, rt::Stream s, bool stage)
 {
     const uint32_t blocks = (w.n_tasks + 255) / 256;
     const size_t lds = 256 * kWalkEvents * sizeof(uint32_t);
+    if constexpr (C == 1) {
+        const size_t stage_lds = walk_stage_lds_bytes(B, TPR);
+        if (stage && stage_lds <= rt::kMaxLdsBytes) {          // region-sized launch: one wave per workgroup, the tiles staged in LDS
+            if (stage_lds > 64 * 1024 && !rt::allow_lds((k_walk<B, TPR, C, true>), stage_lds)) return false;
+            OCT_LAUNCH((k_walk<B, TPR, C, true>), (w.n_tasks + 63) / 64, 64, stage_lds, s, w);
+        } else OCT_LAUNCH((k_walk<B, TPR, C, false>), blocks, 256, lds, s, w);
+    } else
     OCT_LAUNCH((k_walk<B, TPR, C>), blocks, 256, lds, s, w);
     if (w.out_align1 != nullptr) OCT_LAUNCH((k_walk_strings<B, TPR, C>), blocks, 256, 0, s, w);   // test seam: gapped strings from the simple per-step walker
     if (w.pair_key != nullptr) OCT_LAUNCH((k_walk_cigar<B, TPR, C>), blocks, 256, 0, s, w);       // align mode: the pairs' winning tasks write their CIGARs
     return rt::launch_ok();
 }
-bool launch_walk(int band, bool one_per_row, const WalkParams& w, rt::Stream s)
+bool launch_walk(int band, bool one_per_row, const WalkParams& w, rt::Stream s, bool stage)
 {
     switch (band) {
-        case 8:   return one_per_row ? launch_walk_inst<8, 1, 1>(w, s) : launch_walk_inst<8, 2, 1>(w, s);
-        case 16:  return one_per_row ? launch_walk_inst<16, 1, 1>(w, s) : launch_walk_inst<16, 2, 1>(w, s);
-        case 32:  return one_per_row ? launch_walk_inst<32, 1, 1>(w, s) : launch_walk_inst<32, 2, 1>(w, s);
-        case 64:  return one_per_row ? launch_walk_inst<64, 1, 1>(w, s) : launch_walk_inst<64, 2, 1>(w, s);
-        case 128: return launch_walk_inst<128, 1, 2>(w, s);
-        case 256: return launch_walk_inst<256, 1, 4>(w, s);
+        case 8:   return one_per_row ? launch_walk_inst<8, 1, 1>(w, s, stage) : launch_walk_inst<8, 2, 1>(w, s, stage);
+        case 16:  return one_per_row ? launch_walk_inst<16, 1, 1>(w, s, stage) : launch_walk_inst<16, 2, 1>(w, s, stage);
+        case 32:  return one_per_row ? launch_walk_inst<32, 1, 1>(w, s, stage) : launch_walk_inst<32, 2, 1>(w, s, stage);
+        case 64:  return one_per_row ? launch_walk_inst<64, 1, 1>(w, s, stage) : launch_walk_inst<64, 2, 1>(w, s, stage);
+        case 128: return launch_walk_inst<128, 1, 2>(w, s, false);
+        case 256: return launch_walk_inst<256, 1, 4>(w, s, false);
         default: return false;
     }
 }
@@ -488,7 +497,9 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
                 w.pair_key = b->d.pair_key; w.task_key = b->slices[slice].d_keys; w.pos = b->d.pos; w.npos = b->d.npos; w.max_pos = b->d.max_pos;
                 w.err_flags = b->d_err_flags; w.cig_ops = b->d_aln_ops; w.cig_n = b->d_aln_n; w.cig_mpos = b->d_aln_mpos; w.cig_cap = b->cig_cap;
             }
-            if (!launch_walk(B, h->wide || b->stream, w, st)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
+            // region-sized launches (a few hundred waves at most) stage their tiles in LDS; big ones hide the line fetches behind other waves
+            const bool stage = tune::walk_stage() >= 0 ? tune::walk_stage() != 0 : (dsl || (size_t)p.n_tasks <= 64 * 1024);
+            if (!launch_walk(B, h->wide || b->stream, w, st, stage)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
         }
     }
     return OCT_PHMM_OK;
@@ -1281,6 +1292,11 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         }
         if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one
         const uint64_t n_scan = np + 1;
+        if (b->dsl && n_scan <= kScanBasesMaxItems) {         // region-sized: scans and per-haplotype bases of both count arrays in one launch
+            OCT_LAUNCH(k_scan_bases, sl.cnt_late ? 2 : 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, sl.cnt, sl.cnt_late, sl.pair0, (uint32_t)n_scan,
+                       b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G); RT(rt::launch_ok());
+            return OCT_PHMM_OK;
+        }
         if (sl.n_tiles == 1) {
             OCT_LAUNCH(k_scan_tiles, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 2); RT(rt::launch_ok());
         } else {

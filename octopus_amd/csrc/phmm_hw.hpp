@@ -15,6 +15,7 @@
 #define OCT_DEVICE_NOINLINE __device__ __noinline__
 #define OCT_HD __host__ __device__ __forceinline__
 #define OCT_KERNEL(name) __global__ void name
+#define OCT_MAX_THREADS(n) __launch_bounds__(n)
 #define OCT_DYN_SMEM(ptr) extern __shared__ __attribute__((aligned(16))) unsigned char ptr[]
 
 namespace octphmm { namespace hw {

@@ -957,6 +957,53 @@ OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* c
     if (tid == kHapBaseThreads - 1) *totals = sh[tid];
 }
 
+// Region-sized batches: the scan of the per-pair counts and the per-haplotype bases in ONE single-workgroup launch instead of four (three scan
+// launches + k_hap_bases), for both count arrays at once (workgroup 0: cnt, workgroup 1: cnt_late). A call is a chain of dependent launches and each
+// link costs ~5 us however little it does.
+constexpr uint32_t kScanBasesMaxItems = 64 * 1024;
+OCT_KERNEL(k_scan_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, uint4* cnt1, uint64_t pair0, uint32_t n_scan,
+                         uint4* hap_base0, uint4* hap_base1, uint4* totals0, uint4* totals1, uint32_t group)
+{
+    OCT_DYN_SMEM(smem);
+    uint4* sh = (uint4*)smem;                                   // [kHapBaseThreads]
+    uint4* cnt = hw::block_idx() ? cnt1 : cnt0; uint4* hap_base = hw::block_idx() ? hap_base1 : hap_base0; uint4* totals = hw::block_idx() ? totals1 : totals0;
+    const uint32_t tid = hw::thread_idx();
+    auto block_scan = [&](uint4 sum) -> uint4 {                 // exclusive prefix of the threads' sums; sh[last] = the total
+        sh[tid] = sum;
+        hw::block_sync();
+        for (uint32_t d = 1; d < kHapBaseThreads; d <<= 1) {
+            uint4 o = make_uint4(0, 0, 0, 0);
+            if (tid >= d) o = sh[tid - d];
+            hw::block_sync();
+            sh[tid] = add4(sh[tid], o);
+            hw::block_sync();
+        }
+        return tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0);
+    };
+    {   // exclusive scan of cnt[0, n_scan), in place
+        const uint32_t per = (n_scan + kHapBaseThreads - 1) / kHapBaseThreads;
+        const uint32_t lo = tid * per < n_scan ? tid * per : n_scan, hi = lo + per < n_scan ? lo + per : n_scan;
+        uint4 sum = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = lo; i < hi; ++i) sum = add4(sum, cnt[i]);
+        uint4 run = block_scan(sum);
+        for (uint32_t i = lo; i < hi; ++i) { const uint4 v = cnt[i]; cnt[i] = run; run = add4(run, v); }
+        hw::block_sync();                                       // the scanned counts are read across threads below
+    }
+    const uint32_t n = hap1 - hap0;
+    const uint32_t per = (n + kHapBaseThreads - 1) / kHapBaseThreads;
+    const uint32_t lo = hap0 + (tid * per < n ? tid * per : n), hi = hap0 + ((tid + 1) * per < n ? (tid + 1) * per : n);
+    auto up = [&](uint32_t c) { return (c + group - 1) / group * group; };
+    auto padded = [&](uint32_t h) {
+        const uint4 a = cnt[b.hap_pair_off[h] - pair0], z = cnt[b.hap_pair_off[h + 1] - pair0];
+        return make_uint4(up(z.x - a.x), up(z.y - a.y), up(z.z - a.z), up(z.w - a.w));
+    };
+    uint4 sum = make_uint4(0, 0, 0, 0);
+    for (uint32_t h = lo; h < hi; ++h) sum = add4(sum, padded(h));
+    uint4 run = block_scan(sum);
+    for (uint32_t h = lo; h < hi; ++h) { hap_base[h] = run; run = add4(run, padded(h)); }
+    if (tid == kHapBaseThreads - 1) *totals = sh[tid];
+}
+
 struct TaskArrays { DevTask* t[kNumKinds]; };
 
 // Device-sized launches: first task and length of one of the six task lists, from k_hap_bases' totals in device memory (uniform: scalar loads)
@@ -1768,12 +1815,23 @@ OCT_DEVICE_NOINLINE int32_t walk_price_event(WalkPricing p, uint32_t e)
 // rare, and both are queued as events in LDS and priced in a second uniform loop.
 constexpr uint32_t kWalkEvents = 12;
 
-template <int B, int TPR, int C>
-OCT_KERNEL(k_walk)(WalkParams w)
+// STAGE (region-sized launches, one wave per workgroup): a launch of ~100 waves has nothing to hide a memory round trip behind, and every change of
+// band lane (an indel column) in any of a wave's 64 walks used to stall the whole lockstep sweep for a line fetch (half of the old kernel's time on a
+// 300 x 24 region). Here the wave copies the current tile of all its task groups into LDS first (64 / G blocks of 4 KB, coalesced) and every step
+// reads its word from there: a lane change is just another LDS address. Task row r keeps its B lines at stride 17 words, rows B * 17 + 1 words apart:
+// walkers on the same band lane and iteration (the usual case) hit 32 different banks.
+constexpr uint32_t walk_stage_row_words(uint32_t B) { return B * 17 + 1; }
+inline size_t walk_stage_lds_bytes(uint32_t B, uint32_t tpr) { return (64 * kWalkEvents + (64 / tpr) * walk_stage_row_words(B)) * sizeof(uint32_t); }
+
+template <int B, int TPR, int C, bool STAGE = false>
+OCT_MAX_THREADS(STAGE ? 64 : 256) OCT_KERNEL(k_walk)(WalkParams w)
 {
     constexpr uint32_t ROWS = 64 * C / B, G = TPR * ROWS;   // C > 1: band 64 x C on one wave, diagonal i lives in lane i / C, plane i % C
+    static_assert(!STAGE || C == 1, "staged walk: bands up to 64");
     OCT_DYN_SMEM(smem);
     uint32_t* evbuf = (uint32_t*)smem + hw::thread_idx() * kWalkEvents;
+    uint32_t* tbuf = (uint32_t*)smem + 64 * kWalkEvents;                  // STAGE: [64 / TPR task rows][B lines x 17 words + 1]
+    constexpr uint32_t RS = walk_stage_row_words(B);
     const uint32_t ti = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     const DevTask* tasks = w.tasks; uint32_t n_tasks = w.n_tasks;
     if (w.ref.totals) {                                                   // device-sized launch: the grid is the host's bound, surplus waves leave here
@@ -1875,6 +1933,35 @@ OCT_KERNEL(k_walk)(WalkParams w)
         if (hw::ballot(!(fl & kFin)) == 0) break;                                              // every walk of the wave is over (early stops)
         uint32_t c[16];
         int32_t line_i = INT32_MIN;                                                             // no band lane: a walker outside the band takes the rare path below
+        if constexpr (STAGE) {
+            constexpr uint32_t NG = 64 / G;                                                     // task groups of this wave
+            const uint32_t lane = hw::thread_idx() & 63u, group0 = (ti & ~63u) / G, n_groups = n_tasks / G;
+            hw::wave_lds_fence();                                                               // the previous tile's reads are done
+            constexpr uint32_t GB = NG < 8 ? NG : 8;                                            // groups per batch: up to 32 loads per lane in flight (a one-wave workgroup has the registers)
+            for (uint32_t gl0 = 0; gl0 < NG; gl0 += GB) {
+                uint4 v[GB][4];
+#pragma unroll
+                for (uint32_t a = 0; a < GB; ++a) {
+                    const uint32_t gl = gl0 + a;
+                    const bool in = gl < NG && group0 + gl < n_groups;
+                    const uint4* src = (const uint4*)(w.bp + ((size_t)(group0 + (in ? gl : 0)) * w.k_cap + (uint32_t)kt) * 1024);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) v[a][j] = in ? src[lane + 64 * j] : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (uint32_t a = 0; a < GB; ++a) {
+                    const uint32_t gl = gl0 + a;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t u = lane + 64 * j, line = u >> 2, q = u & 3u;            // line = row * B + band lane, q = which four iterations
+                        uint32_t* dst = tbuf + (gl * ROWS + line / B) * RS + (line % B) * 17 + 4 * q;
+                        dst[0] = v[a][j].x; dst[1] = v[a][j].y; dst[2] = v[a][j].z; dst[3] = v[a][j].w;
+                    }
+                }
+            }
+            hw::wave_lds_fence();
+        }
+        const uint32_t* my_row = tbuf + ((hw::thread_idx() & 63u) / TPR) * RS;                  // STAGE: this walk's task row
         auto load_line = [&]() {
             const size_t line = C == 1 ? (size_t)kt * 64 + row * B + (uint32_t)i : ((size_t)kt * C + (uint32_t)i % C) * 64 + (uint32_t)i / C;
             const uint4* l = bpg + line * 4;
@@ -1883,21 +1970,31 @@ OCT_KERNEL(k_walk)(WalkParams w)
             c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w; c[12] = q3.x; c[13] = q3.y; c[14] = q3.z; c[15] = q3.w;
             line_i = i;
         };
-        if (!(fl & kFin) && i >= 0 && i < B) load_line(); else { for (int q = 0; q < 16; ++q) c[q] = 0; }
+        if constexpr (!STAGE) { if (!(fl & kFin) && i >= 0 && i < B) load_line(); else { for (int q = 0; q < 16; ++q) c[q] = 0; } }
 #pragma nounroll
         for (int kk = 15; kk >= 0; --kk) {                                                      // kk is wave-uniform: c[kk] is an indexed register read (M0), and
             const int32_t k = kt * 16 + kk;                                                     // the loop body stays small enough for the instruction cache
 #pragma unroll
             for (int rep = 0; rep < 2; ++rep) {                                                 // an insertion/deletion can add a second step at the same k
                 if (!(fl & kFin) && (sidx >> 1) == k) {                                         // (a negative sidx never equals k >= 0)
-                    uint32_t wv = c[kk];
+                    uint32_t wv = 0;
                     bool go = true;
+                    if constexpr (STAGE) {
+                        if (i >= 0 && i < B) wv = my_row[(uint32_t)i * 17 + (uint32_t)kk];
+                        else if (i < 0) { fl = (fl & ~kOk) | kFin; go = false; }                // :195-199
+                        else {                                                                  // the reference indexes its array flat: lane overflow reads the next diagonal
+                            const int64_t f = (int64_t)sidx * B + i;
+                            if (f >= n_flat) { fl = (fl & ~kOk) | kFin; go = false; } else wv = slow_word(f);
+                        }
+                    } else {
+                    wv = c[kk];
                     if (i != line_i) {                                                          // rare: the walk changed its band lane (an indel), or left the band
                         if (i < 0) { fl = (fl & ~kOk) | kFin; go = false; }                     // :195-199
                         else if (i >= B) {                                                      // the reference indexes its array flat: lane overflow reads the next diagonal
                             const int64_t f = (int64_t)sidx * B + i;
                             if (f >= n_flat) { fl = (fl & ~kOk) | kFin; go = false; } else wv = slow_word(f);
                         } else { load_line(); wv = c[kk]; }
+                    }
                     }
                     if (go) step(wv);
                 }

@@ -16,6 +16,7 @@
 #define OCT_DEVICE_NOINLINE inline
 #define OCT_HD inline
 #define OCT_KERNEL(name) inline void name
+#define OCT_MAX_THREADS(n)
 #define OCT_DYN_SMEM(ptr) unsigned char* ptr = hipsim::S().smem
 #define __shared__ static   /* workgroups run one after another in the simulator */
 

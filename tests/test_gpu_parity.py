@@ -248,6 +248,20 @@ def test_gpu_device_sized_and_host_sized_launches_agree(monkeypatch):
     cp.check_generic_bytes("gpu", TOL)
 
 
+def test_gpu_staged_and_unstaged_walk_agree(monkeypatch):
+    """Region-sized traceback launches walk out of LDS-staged tiles; big launches keep one line per lane in registers. Both on small inputs."""
+    import check_fuzz
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OCT_PHMM_WALK_STAGE", mode)
+        cp.check_basic("gpu", TOL)
+        cp.check_templates_and_regions("gpu", TOL)
+        cp.check_late_traceback_start("gpu", TOL)
+        cp.check_int32_lanes("gpu", TOL)
+        assert check_fuzz.check_fuzz("gpu", seed=90 + int(mode), n=40, tol=TOL) == 40
+    batch = synth.config_batch("1kx64", seed=45, B=16, positions="none")
+    cp.compare("gpu", batch, TOL, max_indel_error=16)
+
+
 def test_gpu_chunked_traceback_launches():
     cp.check_chunked_traceback("gpu", TOL)
 

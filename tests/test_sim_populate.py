@@ -113,3 +113,11 @@ def test_sim_populate_host_sized_launches(monkeypatch):
     cp.check_generic_bytes("sim")
     cp.check_templates_and_regions("sim")
     cp.check_ragged_and_edges("sim")
+
+
+def test_sim_populate_unstaged_walk(monkeypatch):
+    """Small traceback launches stage their tiles in LDS (k_walk<..., STAGE>); the line-per-lane walker that big launches use, on the same checks."""
+    monkeypatch.setenv("OCT_PHMM_WALK_STAGE", "0")
+    cp.check_basic("sim")
+    cp.check_templates_and_regions("sim")
+    cp.check_late_traceback_start("sim")

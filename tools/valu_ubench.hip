@@ -4,9 +4,11 @@
 #include <stdio.h>
 #include <vector>
 #define REP 64
-#define ITER 2000
-template <int OP> __global__ void k(unsigned* out, unsigned seed)
+#define ITER 20000
+// clk[2 * wave] = shader cycles (s_memtime), clk[2 * wave + 1] = ticks of the constant reference clock (s_memrealtime) the wave's loop took
+template <int OP> __global__ void k(unsigned* out, unsigned seed, unsigned long long* clk)
 {
+    const unsigned long long t0 = clock64(), r0 = wall_clock64();
     unsigned a[8];
     for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + i + 1);
     unsigned b = seed ^ 0x00030003u, c = 0x00040004u;
@@ -63,18 +65,27 @@ template <int OP> __global__ void k(unsigned* out, unsigned seed)
     }
     unsigned s = 0; for (int i = 0; i < 8; ++i) s ^= a[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    const unsigned long long t1 = clock64(), r1 = wall_clock64();
+    if ((threadIdx.x & 63) == 0) { const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; clk[2 * w] = t1 - t0; clk[2 * w + 1] = r1 - r0; }
 }
 template <int OP> void run(const char* name, unsigned* d)
 {
     for (int wps : {4}) {       // waves per SIMD (256 CUs x 4 SIMDs)
         const int blocks = 256 * wps, threads = 256;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        k<OP><<<blocks, threads>>>(d, 12345u); hipDeviceSynchronize();
-        hipEventRecord(e0); k<OP><<<blocks, threads>>>(d, 12345u); hipEventRecord(e1); hipEventSynchronize(e1);
+        static unsigned long long* clk = nullptr; if (!clk) hipMalloc(&clk, 256 * 8 * 4 * 2 * sizeof(unsigned long long));
+        int wall_khz = 0; hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+        k<OP><<<blocks, threads>>>(d, 12345u, clk); hipDeviceSynchronize();
+        hipEventRecord(e0); k<OP><<<blocks, threads>>>(d, 12345u, clk); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
+        const int n_waves = blocks * threads / 64;
+        std::vector<unsigned long long> h(2 * n_waves); hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+        double cyc = 0, ref = 0; for (int w = 0; w < n_waves; ++w) { cyc += (double)h[2 * w]; ref += (double)h[2 * w + 1]; }
+        const double ghz = cyc / ref * wall_khz * 1e-6;              // shader cycles per second while the loop ran, from the two in-kernel clocks
         const double insts_per_simd = (double)wps * ITER * REP;      // wave-instructions issued on one SIMD
-        printf("%-28s waves/SIMD=%d  %.3f ms  -> %.2f ns per wave-instr per SIMD (%.2f cycles @2.4GHz)\n", name, wps, ms,
-               ms * 1e6 / insts_per_simd, ms * 1e6 / insts_per_simd * 2.4);
+        // true issue cost: the wps waves of a SIMD run side by side, so a wave's own s_memtime span covers wps x its instructions
+        printf("%-28s waves/SIMD=%d  %.3f ms  -> %.2f ns per wave-instr per SIMD (%.2f cycles @2.4GHz nominal; measured shader clock %.3f GHz -> %.2f shader cycles by s_memtime)\n",
+               name, wps, ms, ms * 1e6 / insts_per_simd, ms * 1e6 / insts_per_simd * 2.4, ghz, cyc / n_waves / insts_per_simd);
     }
 }
 int main()
