@@ -52,6 +52,7 @@ struct DevPool {
         auto it = free_blocks.lower_bound(c);             // the smallest cached block that fits, if it is not wastefully large
         if (it != free_blocks.end() && it->first <= c + c / 2) { *p = it->second; const size_t got = it->first; free_blocks.erase(it); cached -= got; live[*p] = got; return true; }
         if (!rt::dev_malloc(p, c)) {
+            rt::clear_error();
             trim();                                     // give cached blocks back and retry once
             if (!rt::dev_malloc(p, c)) return false;
         }
@@ -128,7 +129,8 @@ struct oct_phmm_batch {
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false;
     // device-sized launches (one slice, scratch for the host-known task bound fits): no host read-back of the task counts in the middle of a step
-    bool dsl = false; uint32_t dsl_list_bound = 0; size_t dsl_total_bound = 0; int dsl_flavours = 3;   // tasks one list / all six lists can hold at most (padding included)
+    bool dsl = false; uint32_t dsl_list_bound = 0; size_t dsl_total_bound = 0; int dsl_flavours = 3;
+    uint32_t dsl_trace_cap = 0;   // tasks a traceback list may hold (the scratch provisioned for it); a batch that needs more is repeated with host-sized launches   // tasks one list / all six lists can hold at most (padding included)
     rt::Event ev_fork {}, ev_join {}, ev_hashes {};
     // align mode (oct_phmm_align)
     bool align_mode = false; uint32_t cig_cap = 0;
@@ -156,7 +158,8 @@ struct oct_phmm_batch {
 //                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED,
 //                OCT_PHMM_WALK_STAGE
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
-//                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions)
+//                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
+//                OCT_PHMM_DSL_TRACE_PER_PAIR
 // ---------------------------------------------------------------------------------------------------------------
 namespace tune {
 inline bool flag(const char* name) { return getenv(name) != nullptr; }
@@ -173,6 +176,7 @@ inline int  penalties_where() { const char* e = getenv("OCT_PHMM_PENALTIES"); re
 inline int  dedup()           { const char* e = getenv("OCT_PHMM_DEDUP"); return !e ? -1 : atoi(e); }                                  // -1 by shape, 0 never, 1 wherever it is possible
 inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_HASH_BITS", &n) && n >= 1 && n < 32 ? (1u << n) - 1u : 0xffffffffu; }   // test hook: collisions
 inline int  device_sized()    { const char* e = getenv("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
+inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
 inline int  walk_stage()      { const char* e = getenv("OCT_PHMM_WALK_STAGE"); return !e ? -1 : atoi(e); }                             // -1 by launch size, 0 never, 1 always: the walk with its tiles staged in LDS
 inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
 inline bool penalties_lane_kernel() { const char* e = getenv("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
@@ -410,13 +414,17 @@ bool launch_dp_wide(int band, bool tr, bool w16, const DpParams& p, rt::Stream s
 bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 {
     if (h->bp_bytes[slice] >= bytes) return true;
+    // grow by half at least (below 4 GB): a region thread's calls differ in size, and every regrowth is a hipFree + hipMalloc that stalls the device
+    const size_t old = h->bp_bytes[slice], roomy = old < ((size_t)4 << 30) ? std::max(bytes, old + old / 2) : bytes;
     rt::dev_free(h->bp[slice]); h->bp[slice] = nullptr; h->bp_bytes[slice] = 0;
-    void* p = nullptr;
-    if (!rt::dev_malloc(&p, bytes)) {
+    void* p = nullptr; size_t got = roomy;
+    if (!rt::dev_malloc(&p, roomy)) {
+        rt::clear_error();
         h->pool.trim();                                 // cached blocks of earlier batches may be in the way
-        if (!rt::dev_malloc(&p, bytes)) return false;
+        got = bytes;
+        if (!rt::dev_malloc(&p, bytes)) { rt::clear_error(); return false; }
     }
-    h->bp[slice] = (uint32_t*)p; h->bp_bytes[slice] = bytes;
+    h->bp[slice] = (uint32_t*)p; h->bp_bytes[slice] = got;
     return true;
 }
 
@@ -426,7 +434,7 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 constexpr uint32_t kDslMaxBlocks = 2048;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
 int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
                 int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false,
-                TaskListRef ref = TaskListRef {nullptr, nullptr, 0})
+                TaskListRef ref = TaskListRef {nullptr, nullptr, 0, nullptr}, const rt::Event* after_first_dp = nullptr)
 {
     if (!n_tasks) return OCT_PHMM_OK;
     const bool dsl = ref.totals != nullptr;
@@ -476,6 +484,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
                         : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         if (h->timing) { RT(rt::event_record(e1, st)); b->timers.emplace_back(e0, e1); b->timer_kind.push_back(kind); }
+        if (after_first_dp && g0 == 0) RT(rt::event_record(*after_first_dp, st));      // whoever waits for it runs beside this launch's walk, not beside its DP
         if (tr) {
             WalkParams w {};
             if (seam_walk) w = *seam_walk;
@@ -1066,18 +1075,22 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         const uint32_t Bw = (uint32_t)h->band, Gs = b->stream ? (Bw < 64 ? 64u / Bw : 1u) : (h->wide ? 1u : 2u) * (64u / Bw);
         const uint64_t raw = b->n_pairs * (uint64_t)(S + 1), pad = (uint64_t)H->n_haps * (Gs - 1);
         const uint64_t list_bound = (raw + pad + Gs - 1) / Gs * Gs, total_bound = raw + 6 * pad;
-        const uint64_t bp_bytes = list_bound / Gs * ((uint64_t)bp_tiles(b->t_cap, Bw) * 4096u * (b->stream ? (uint64_t)h->lanes_c : 1u));
+        // Traceback scratch is provisioned for two traceback tasks per pair, not for the bound of eleven (a 300 x 24 region: 86 MB instead of 475 MB per
+        // handle; this generator's regions need 0.9): the scan flags a batch that needs more and oct_phmm_batch_wait repeats it host-sized.
+        long long per_pair = 2; tune::trace_per_pair(&per_pair);
+        const uint64_t trace_cap = per_pair < 0 ? Gs : std::min<uint64_t>(list_bound, (b->n_pairs * (uint64_t)per_pair + pad + Gs - 1) / Gs * Gs + Gs);   // (negative: one task group, test hook)
+        const uint64_t bp_bytes = trace_cap / Gs * ((uint64_t)bp_tiles(b->t_cap, Bw) * 4096u * (b->stream ? (uint64_t)h->lanes_c : 1u));
         const uint64_t cap = std::min<uint64_t>((uint64_t)8 << 30, h->bp_budget);
         b->dsl = b->slices.size() == 1 && !align_mode && b->n_pairs > 0 && bp_bytes <= cap && list_bound < 0x7fffffffull && tune::device_sized() != 0;
-        b->dsl_list_bound = b->dsl ? (uint32_t)list_bound : 0; b->dsl_total_bound = b->dsl ? (size_t)total_bound : 0;
+        b->dsl_list_bound = b->dsl ? (uint32_t)list_bound : 0; b->dsl_total_bound = b->dsl ? (size_t)total_bound : 0; b->dsl_trace_cap = b->dsl ? (uint32_t)trace_cap : 0;
         if (b->dsl && !gen_device && !d.wide) {
             // which of the two cost flavours can occur at all (k_hap_tables / read_flags_thread decide per read and haplotype): a clean region launches no generic kernels
-            bool clean = true;
             const uint8_t* rb = (const uint8_t*)R->bases; const uint8_t* hb = (const uint8_t*)H->bases;
-            auto acgt = [](uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; };
-            for (uint32_t i = 0; i < n_read_bases && clean; ++i) clean = acgt(rb[i]);
-            for (uint32_t i = 0; i < n_hap_bases && clean; ++i) clean = acgt(hb[i]) && H->snv_mask_fwd[i] != '0' && H->snv_mask_rev[i] != '0';
-            b->dsl_flavours = clean ? 1 : 3;
+            uint32_t dirty = 0;                                  // branch-free: these loops run over every base of the call and must vectorise
+            auto not_acgt = [](uint8_t c) -> uint32_t { return ((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')) ? 0u : 1u; };
+            for (uint32_t i = 0; i < n_read_bases; ++i) dirty |= not_acgt(rb[i]);
+            for (uint32_t i = 0; i < n_hap_bases; ++i) dirty |= not_acgt(hb[i]) | (H->snv_mask_fwd[i] == '0' ? 1u : 0u) | (H->snv_mask_rev[i] == '0' ? 1u : 0u);
+            b->dsl_flavours = dirty ? 3 : 1;
         } else b->dsl_flavours = d.wide ? 2 : 3;            // bit 0: fast-cost lists may hold tasks, bit 1: generic lists may
     }
     if (b->dedup && !b->h_segs.empty()) pk.upload(b->h_segs.data(), b->h_segs.size(), (const DedupSeg**)&b->d_segs);
@@ -1095,7 +1108,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     pk.upload(ones.data(), (size_t)H->n_haps, (const uint32_t**)&d.hclean);
     RT(h->get_event(&b->ev_fork)); RT(h->get_event(&b->ev_join)); RT(h->get_event(&b->ev_hashes));
     RT(pk.commit(h, bp, s));
-    d.err_key = d.stats + (size_t)kStatSlots * kStatStride;
+    d.err_key = d.stats + (size_t)kStatSlots * kStatStride; d.dsl_overflow = d.err_key + 1; d.dsl_trace_cap = b->dsl_trace_cap;
     for (size_t i = 0; i < b->slices.size(); ++i) {
         b->slices[i].cnt = d.pair_cnt + b->slices[i].pair0 + i;      // each slice owns pair1 - pair0 + 1 scan entries
         b->slices[i].d_totals = b->d_totals + i;
@@ -1229,7 +1242,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     b->timers.clear(); b->timer_kind.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
     const uint32_t G = b->stream ? (h->band < 64 ? 64u / (uint32_t)h->band : 1u) : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
     const int S = (int)b->slices.size();
-    RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 1) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key behind them
+    d.dsl_trace_cap = b->dsl ? b->dsl_trace_cap : 0;
+    RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
     if (b->dedup) RT(rt::dev_memset(d.pair_rep, 0xff, (size_t)b->n_pairs * sizeof(uint32_t), s0));      // kNoPair: every pair is computed itself until k_dedup_verify says otherwise
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
@@ -1293,7 +1307,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one
         const uint64_t n_scan = np + 1;
         if (b->dsl && n_scan <= kScanBasesMaxItems) {         // region-sized: scans and per-haplotype bases of both count arrays in one launch
-            OCT_LAUNCH(k_scan_bases, sl.cnt_late ? 2 : 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, sl.cnt, sl.cnt_late, sl.pair0, (uint32_t)n_scan,
+            OCT_LAUNCH(k_scan_bases, sl.cnt_late ? 2 : 1, kHapBaseThreads, 16 * sizeof(uint4), s, d, sl.hap0, sl.hap1, sl.cnt, sl.cnt_late, sl.pair0, (uint32_t)n_scan,
                        b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G); RT(rt::launch_ok());
             return OCT_PHMM_OK;
         }
@@ -1304,7 +1318,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.tile_sums, sl.n_tiles); RT(rt::launch_ok());
             OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 1); RT(rt::launch_ok());
         }
-        OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, b->d_hap_base, sl.d_totals, G); RT(rt::launch_ok());
+        OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, b->d_hap_base, sl.d_totals, G, 0); RT(rt::launch_ok());
         if (!b->dsl) RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s));
         sl.totals_late = make_uint4(0, 0, 0, 0);
         if (sl.cnt_late) {                                    // the same scan for the late-start traceback tasks
@@ -1315,7 +1329,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.tile_sums_late, sl.n_tiles); RT(rt::launch_ok());
                 OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt_late, n_scan, sl.tile_sums_late, 1); RT(rt::launch_ok());
             }
-            OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt_late, sl.pair0, b->d_hap_base_late, sl.d_totals_late, G); RT(rt::launch_ok());
+            OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt_late, sl.pair0, b->d_hap_base_late, sl.d_totals_late, G, 1); RT(rt::launch_ok());
             if (!b->dsl) RT(rt::d2h(&sl.totals_late, sl.d_totals_late, sizeof(uint4), s));
         }
         return OCT_PHMM_OK;
@@ -1332,25 +1346,35 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 h->pool.release(sl.d_tasks); sl.d_tasks = nullptr; sl.tasks_cap = 0;
                 void* p = nullptr; RT(h->pool.alloc(&p, b->dsl_total_bound * sizeof(DevTask))); sl.d_tasks = (DevTask*)p; sl.tasks_cap = b->dsl_total_bound;
             }
-            if (b->dsl_list_bound > sl.ends_cap) {
+            if (b->dsl_trace_cap > sl.ends_cap) {
                 h->pool.release(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
-                void* p = nullptr; RT(h->pool.alloc(&p, (size_t)b->dsl_list_bound * sizeof(TraceEnd))); sl.d_ends = (TraceEnd*)p; sl.ends_cap = b->dsl_list_bound;
+                void* p = nullptr; RT(h->pool.alloc(&p, (size_t)b->dsl_trace_cap * sizeof(TraceEnd))); sl.d_ends = (TraceEnd*)p; sl.ends_cap = b->dsl_trace_cap;
             }
             TaskArrays ta {}; ta.t[0] = sl.d_tasks; TaskArrays tl {};
-            TaskListRef ref {sl.d_totals, sl.cnt_late ? sl.d_totals_late : nullptr, 0};
+            TaskListRef ref {sl.d_totals, sl.cnt_late ? sl.d_totals_late : nullptr, 0, d.dsl_overflow};
             OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
                        (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, ref, G); RT(rt::launch_ok());
-            // region-sized and latency-bound: the score-only DP runs beside the traceback DP + walk on a second stream
+            // Region-sized and latency-bound: the score-only DP runs on a second stream beside the traceback WALK (a few hundred waves that mostly wait
+            // for LDS and memory), not beside the traceback DP (both are VALU-bound and would only share the issue slots): it starts when the first
+            // traceback DP launch is over.
             rt::Stream aux = h->slice_stream(1);
-            RT(rt::event_record(b->ev_fork, s)); RT(rt::stream_wait_event(aux, b->ev_fork));
             auto flavour_live = [&](int list) { const bool gen = list == kScoreGen || list == kTraceGen || list == 5; return (b->dsl_flavours & (gen ? 2 : 1)) != 0; };
-            for (int list : {4, 5, (int)kTraceFast, (int)kTraceGen, (int)kScoreFast, (int)kScoreGen}) {
+            bool forked = false;
+            for (int list : {4, 5, (int)kTraceFast, (int)kTraceGen}) {
                 if (list >= 4 && !sl.cnt_late) continue;
                 if (!flavour_live(list)) continue;
                 ref.list = list;
-                const int kind = list == 4 ? kTraceFast : list == 5 ? kTraceGen : list;
-                const bool score_kind = kind == kScoreFast || kind == kScoreGen;
-                const int rc = run_dp_kind(h, b, 0, kind, sl.d_tasks, b->dsl_list_bound, sl.d_ends, h->cfg.nuc_prior, nullptr, status, score_kind ? &aux : nullptr, list >= 4, ref);
+                const int rc = run_dp_kind(h, b, 0, list == 4 ? kTraceFast : list == 5 ? kTraceGen : list, sl.d_tasks, b->dsl_trace_cap, sl.d_ends, h->cfg.nuc_prior, nullptr, status,
+                                           nullptr, list >= 4, ref, forked ? nullptr : &b->ev_fork);
+                if (rc != OCT_PHMM_OK) return rc;
+                forked = true;
+            }
+            if (!forked) RT(rt::event_record(b->ev_fork, s));
+            RT(rt::stream_wait_event(aux, b->ev_fork));
+            for (int list : {(int)kScoreFast, (int)kScoreGen}) {
+                if (!flavour_live(list)) continue;
+                ref.list = list;
+                const int rc = run_dp_kind(h, b, 0, list, sl.d_tasks, b->dsl_list_bound, sl.d_ends, h->cfg.nuc_prior, nullptr, status, &aux, false, ref);
                 if (rc != OCT_PHMM_OK) return rc;
             }
             RT(rt::event_record(b->ev_join, aux)); RT(rt::stream_wait_event(s, b->ev_join));
@@ -1388,22 +1412,28 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             TaskArrays tl;                                       // late-start traceback tasks: [0] fast-cost kernel, [1] generic
             tl.t[0] = ta.t[3] + totals.w; tl.t[1] = tl.t[0] + late.x; tl.t[2] = tl.t[1] + late.y; tl.t[3] = tl.t[2];
             OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
-                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, TaskListRef {nullptr, nullptr, 0}, G); RT(rt::launch_ok());
+                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, TaskListRef {nullptr, nullptr, 0, nullptr}, G); RT(rt::launch_ok());
             static const int order[kNumKinds] = {kTraceFast, kTraceGen, kScoreFast, kScoreGen};   // traceback first: its walk then overlaps the score-only DP of the next slice
             // A single-slice (region-sized) batch is latency-bound: its score-only DP runs beside the traceback DP + walk on a second stream.
             const bool side = S == 1 && total < 200000 && (totals.x + totals.z) > 0 && (totals.y + totals.w) > 0;   // big launches fill the chip on their own
             rt::Stream aux = h->slice_stream(1);
-            if (side) { RT(rt::event_record(b->ev_fork, s)); RT(rt::stream_wait_event(aux, b->ev_fork)); }
+            bool forked = false;                                 // (side) the score-only DP starts beside the first traceback launch's walk: see phase2_device_sized
             for (int lk = 0; lk < 2; ++lk) {                     // late-start traceback launches first (the longest walks of the slice start earliest)
                 const uint32_t n = lk ? late.y : late.x;
-                const int rc = run_dp_kind(h, b, i, lk ? kTraceGen : kTraceFast, tl.t[lk], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, nullptr, true);
+                const int rc = run_dp_kind(h, b, i, lk ? kTraceGen : kTraceFast, tl.t[lk], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, nullptr, true,
+                                           TaskListRef {nullptr, nullptr, 0, nullptr}, side && !forked && n ? &b->ev_fork : nullptr);
                 if (rc != OCT_PHMM_OK) return rc;
+                forked = forked || (side && n);
             }
             for (int k : order) {
                 const bool score_kind = k == kScoreFast || k == kScoreGen;
-                const int rc = run_dp_kind(h, b, i, k, ta.t[k], (k == 0 ? totals.x : k == 1 ? totals.y : k == 2 ? totals.z : totals.w), sl.d_ends, h->cfg.nuc_prior, nullptr, status,
-                                           side && score_kind ? &aux : nullptr);
+                const uint32_t n = k == 0 ? totals.x : k == 1 ? totals.y : k == 2 ? totals.z : totals.w;
+                if (side && score_kind && !forked) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
+                if (side && score_kind && n) RT(rt::stream_wait_event(aux, b->ev_fork));
+                const int rc = run_dp_kind(h, b, i, k, ta.t[k], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, side && score_kind ? &aux : nullptr, false,
+                                           TaskListRef {nullptr, nullptr, 0, nullptr}, side && !score_kind && !forked && n ? &b->ev_fork : nullptr);
                 if (rc != OCT_PHMM_OK) return rc;
+                forked = forked || (side && !score_kind && n);
             }
             if (side) { RT(rt::event_record(b->ev_join, aux)); RT(rt::stream_wait_event(s, b->ev_join)); }
         }
@@ -1440,8 +1470,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     if (rc != OCT_PHMM_OK) return rc;
     for (int i = std::max(0, S - 2); i < S; ++i) { rc = deliver(i); if (rc != OCT_PHMM_OK) return rc; }
     for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(s0, b->slices[i].done));
-    b->h_stat_stripes.assign((size_t)kStatSlots * kStatStride + 1, 0);  // counters + the inverted error key, one copy
-    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, ((size_t)kStatSlots * kStatStride + 1) * sizeof(unsigned long long), s0));
+    b->h_stat_stripes.assign((size_t)kStatSlots * kStatStride + 2, 0);  // counters + the inverted error key + the overflow flag, one copy
+    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));
     b->ran = true;
     return ok(status);
 }
@@ -1451,6 +1481,13 @@ extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_ph
     if (!h || !b || b->owner != h || !b->ran) return fail(status, OCT_PHMM_EINVAL, "batch was not run");
     RT(rt::set_device(h->cfg.device_id));
     RT(rt::stream_sync(h->stream));
+    if (b->dsl && b->h_stat_stripes[(size_t)kStatSlots * kStatStride + 1]) {
+        // a traceback list outgrew the scratch provisioned for the device-sized launches: every list read as empty. Once more, host-sized.
+        b->dsl = false;
+        const int rc = oct_phmm_batch_run(h, b, status);
+        if (rc != OCT_PHMM_OK) return rc;
+        RT(rt::stream_sync(h->stream));
+    }
     for (int k = 0; k < 12; ++k) { b->h_stats[k] = 0; for (uint32_t sl = 0; sl < kStatSlots; ++sl) b->h_stats[k] += b->h_stat_stripes[(size_t)sl * kStatStride + k]; }
     b->h_err_key = ~b->h_stat_stripes[(size_t)kStatSlots * kStatStride];
     if (tune::map_stats()) {

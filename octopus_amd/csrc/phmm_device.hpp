@@ -83,6 +83,8 @@ struct DevBatch {
     // [6] [7] mapper diagnostics (OCT_PHMM_MAP_STATS) [8] score-only / [9] traceback DP tasks not run because their pair shares another pair's result [10] their band cells [11] such pairs
     unsigned long long* stats;
     unsigned long long* err_key;                      // min over failing pairs of (hap << 32 | read); ~0 = none
+    unsigned long long* dsl_overflow;                 // device-sized launches: a traceback list is longer than `dsl_trace_cap` tasks (TaskListRef::overflow)
+    uint32_t dsl_trace_cap;                           // 0 = no limit (host-sized launches)
 };
 
 struct DedupSeg {     // the haplotypes [hap_lo, hap_hi) of one region inside one slice, and the reads of that region in tiles of 64
@@ -98,6 +100,8 @@ struct TaskListRef {
     const uint4* totals;        // null = host-sized launch: `tasks` / `n_tasks` of the parameter block are the list itself
     const uint4* totals_late;   // may be null (no late-start lists)
     int list;                   // 0..3 = Kind, 4 = late-start fast, 5 = late-start generic
+    const unsigned long long* overflow;   // set by the scan when a traceback list outgrew the scratch the host provisioned: every list then reads as empty
+                                          // and the host repeats the step with host-sized launches (oct_phmm_batch_wait)
 };
 
 struct DpParams {

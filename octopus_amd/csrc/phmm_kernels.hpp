@@ -927,7 +927,7 @@ OCT_KERNEL(k_scan_tile_sums)(uint4* tile_sums, uint32_t n_tiles)   // one block 
 constexpr uint32_t kHapBaseThreads = 1024;
 // Per haplotype and kind: first task slot, with every haplotype's task run padded to a multiple of the group size so
 // that a DP task group never straddles two haplotypes. hap_base[n_haps] = padded totals.
-OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* cnt, uint64_t pair0, uint4* hap_base, uint4* totals, uint32_t group)
+OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* cnt, uint64_t pair0, uint4* hap_base, uint4* totals, uint32_t group, int late)
 {
     // one block of kHapBaseThreads threads: each sums a contiguous run of haplotypes, the block scans the thread sums, each writes its run
     // (a slice of the many-region workload holds tens of thousands of haplotypes: one serial thread took 4.6 ms per launch)
@@ -954,41 +954,53 @@ OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* c
     }
     uint4 run = tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0);
     for (uint32_t h = lo; h < hi; ++h) { hap_base[h] = run; run = add4(run, padded(h)); }
-    if (tid == kHapBaseThreads - 1) *totals = sh[tid];
+    if (tid == kHapBaseThreads - 1) {
+        const uint4 all = sh[tid];
+        *totals = all;
+        const uint32_t t0 = late ? all.x : all.y, t1 = late ? all.y : all.w;          // the traceback lists (see k_scan_bases)
+        if (b.dsl_trace_cap && (t0 > b.dsl_trace_cap || t1 > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
+    }
 }
 
 // Region-sized batches: the scan of the per-pair counts and the per-haplotype bases in ONE single-workgroup launch instead of four (three scan
 // launches + k_hap_bases), for both count arrays at once (workgroup 0: cnt, workgroup 1: cnt_late). A call is a chain of dependent launches and each
-// link costs ~5 us however little it does.
+// link costs ~5 us however little it does. Tiles of 4096 items (four consecutive per thread: a wave reads 4 KB in one piece), the thread sums
+// scanned with shuffles inside a wave and through 16 LDS words across the waves: two workgroup barriers per tile.
 constexpr uint32_t kScanBasesMaxItems = 64 * 1024;
+OCT_DEVICE uint4 shfl4(uint4 v, uint32_t src) { return make_uint4(hw::shfl(v.x, (int)src), hw::shfl(v.y, (int)src), hw::shfl(v.z, (int)src), hw::shfl(v.w, (int)src)); }
+OCT_DEVICE uint4 sub4(uint4 a, uint4 b) { return make_uint4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+// exclusive prefix of `v` over the kHapBaseThreads threads of the workgroup; *total = the sum over all of them. sh: 16 words of LDS.
+OCT_DEVICE uint4 block_scan_excl(uint4 v, uint4* sh, uint4* total)
+{
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63u, wv = tid >> 6;
+    uint4 inc = v;
+    for (uint32_t d = 1; d < 64; d <<= 1) { const uint4 o = shfl4(inc, lane >= d ? lane - d : lane); if (lane >= d) inc = add4(inc, o); }
+    hw::block_sync();                                           // (an earlier round's reads of sh are over)
+    if (lane == 63) sh[wv] = inc;
+    hw::block_sync();
+    uint4 before = make_uint4(0, 0, 0, 0), all = make_uint4(0, 0, 0, 0);
+    for (uint32_t w = 0; w < kHapBaseThreads / 64; ++w) { const uint4 s = sh[w]; if (w < wv) before = add4(before, s); all = add4(all, s); }
+    *total = all;
+    return add4(before, sub4(inc, v));
+}
 OCT_KERNEL(k_scan_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, uint4* cnt1, uint64_t pair0, uint32_t n_scan,
                          uint4* hap_base0, uint4* hap_base1, uint4* totals0, uint4* totals1, uint32_t group)
 {
     OCT_DYN_SMEM(smem);
-    uint4* sh = (uint4*)smem;                                   // [kHapBaseThreads]
+    uint4* sh = (uint4*)smem;                                   // [16]
     uint4* cnt = hw::block_idx() ? cnt1 : cnt0; uint4* hap_base = hw::block_idx() ? hap_base1 : hap_base0; uint4* totals = hw::block_idx() ? totals1 : totals0;
     const uint32_t tid = hw::thread_idx();
-    auto block_scan = [&](uint4 sum) -> uint4 {                 // exclusive prefix of the threads' sums; sh[last] = the total
-        sh[tid] = sum;
-        hw::block_sync();
-        for (uint32_t d = 1; d < kHapBaseThreads; d <<= 1) {
-            uint4 o = make_uint4(0, 0, 0, 0);
-            if (tid >= d) o = sh[tid - d];
-            hw::block_sync();
-            sh[tid] = add4(sh[tid], o);
-            hw::block_sync();
-        }
-        return tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0);
-    };
-    {   // exclusive scan of cnt[0, n_scan), in place
-        const uint32_t per = (n_scan + kHapBaseThreads - 1) / kHapBaseThreads;
-        const uint32_t lo = tid * per < n_scan ? tid * per : n_scan, hi = lo + per < n_scan ? lo + per : n_scan;
-        uint4 sum = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = lo; i < hi; ++i) sum = add4(sum, cnt[i]);
-        uint4 run = block_scan(sum);
-        for (uint32_t i = lo; i < hi; ++i) { const uint4 v = cnt[i]; cnt[i] = run; run = add4(run, v); }
-        hw::block_sync();                                       // the scanned counts are read across threads below
+    uint4 carry = make_uint4(0, 0, 0, 0);
+    for (uint32_t base = 0; base < n_scan; base += kHapBaseThreads * 4) {      // exclusive scan of cnt[0, n_scan), in place
+        const uint32_t i0 = base + tid * 4;
+        uint4 v[4], sum = make_uint4(0, 0, 0, 0);
+        for (uint32_t j = 0; j < 4; ++j) { v[j] = i0 + j < n_scan ? cnt[i0 + j] : make_uint4(0, 0, 0, 0); sum = add4(sum, v[j]); }
+        uint4 tile_total;
+        uint4 run = add4(carry, block_scan_excl(sum, sh, &tile_total));
+        for (uint32_t j = 0; j < 4; ++j) if (i0 + j < n_scan) { cnt[i0 + j] = run; run = add4(run, v[j]); }
+        carry = add4(carry, tile_total);
     }
+    hw::block_sync();                                           // the scanned counts are read across threads below
     const uint32_t n = hap1 - hap0;
     const uint32_t per = (n + kHapBaseThreads - 1) / kHapBaseThreads;
     const uint32_t lo = hap0 + (tid * per < n ? tid * per : n), hi = hap0 + ((tid + 1) * per < n ? (tid + 1) * per : n);
@@ -999,9 +1011,15 @@ OCT_KERNEL(k_scan_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, 
     };
     uint4 sum = make_uint4(0, 0, 0, 0);
     for (uint32_t h = lo; h < hi; ++h) sum = add4(sum, padded(h));
-    uint4 run = block_scan(sum);
+    uint4 all;
+    uint4 run = block_scan_excl(sum, sh, &all);
     for (uint32_t h = lo; h < hi; ++h) { hap_base[h] = run; run = add4(run, padded(h)); }
-    if (tid == kHapBaseThreads - 1) *totals = sh[tid];
+    if (tid == 0) {
+        *totals = all;
+        // the traceback lists (y, w of the main counts; x, y of the late-start ones) must fit the scratch the host provisioned
+        const uint32_t t0 = hw::block_idx() ? all.x : all.y, t1 = hw::block_idx() ? all.y : all.w;
+        if (b.dsl_trace_cap && (t0 > b.dsl_trace_cap || t1 > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
+    }
 }
 
 struct TaskArrays { DevTask* t[kNumKinds]; };
@@ -1014,6 +1032,7 @@ OCT_DEVICE void task_list_range(const TaskListRef& ref, uint32_t& first, uint32_
     const uint32_t c[6] = {a.x, a.y, a.z, a.w, l.x, l.y};
     first = 0; n = 0;
     for (int k = 0; k < 6; ++k) { if (k < ref.list) first += c[k]; if (k == ref.list) n = c[k]; }
+    if (ref.overflow && *ref.overflow) { first = 0; n = 0; }
 }
 
 // Pass 2: write the DP tasks of every pair at hap_base + (scanned count - scanned count at the haplotype's first pair).
@@ -1024,6 +1043,7 @@ OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt,
     const uint64_t e_wave = wave_first_index(pair0);
     if (e >= pair1) return;
     if (ref.totals) {                                           // device-sized: the six lists one behind the other in out.t[0]
+        if (ref.overflow && *ref.overflow) return;
         DevTask* base = out.t[0];
         for (int k = 0; k < 6; ++k) {
             TaskListRef q = ref; q.list = k;

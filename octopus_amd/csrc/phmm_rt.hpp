@@ -46,6 +46,7 @@ inline bool event_sync(Event e) { OCT_RT_CHECK(hipEventSynchronize(e)); return t
 inline bool stream_wait_event(Stream s, Event e) { OCT_RT_CHECK(hipStreamWaitEvent(s, e, 0)); return true; }
 inline bool event_elapsed_ms(float* ms, Event a, Event b) { OCT_RT_CHECK(hipEventElapsedTime(ms, a, b)); return true; }
 inline bool launch_ok() { OCT_RT_CHECK(hipGetLastError()); return true; }
+inline void clear_error() { (void)hipGetLastError(); }       // after a failed allocation that the caller recovers from: the runtime's last-error slot is sticky and the next launch_ok() would report it
 template <class K> inline bool allow_lds(K kernel, size_t bytes)
 {
     OCT_RT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

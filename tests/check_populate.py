@@ -547,15 +547,19 @@ def check_launch_modes(backend, tol=0.0):
     must give the same bytes, and both must equal the oracle: packed int16, int32 lanes, the streaming kernels, generic bytes, several regions
     with templates, and the late traceback start."""
     import os
-    keep = {k: os.environ.get(k) for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_LATE_MIN_PAIRS")}
+    keep = {k: os.environ.get(k) for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_LATE_MIN_PAIRS", "OCT_PHMM_DSL_TRACE_PER_PAIR")}
     rng = np.random.default_rng(4711)
-    n = 0
+    n = repeated = 0
     try:
         cases = []
-        for B, T, Lh, kw, late in ((16, 150, 300, {}, False), (8, 60, 150, {}, True), (16, 100, 260, dict(use_int_scores=1), False),
-                                   (128, 120, 600, {}, False), (16, 700, 1500, dict(use_int_scores=1), False), (32, 90, 300, {}, True)):
-            regs = [synth.make_region(rng, int(rng.integers(5, 30)), int(rng.integers(1, 6)), T=T, Lh=Lh, B=B, flank=(20, 30), positions="none",
-                                      indels_per_read=1) for _ in range(int(rng.integers(1, 4)))]
+        shapes = ((16, 150, 300, {}, False), (8, 60, 150, {}, True), (16, 100, 260, dict(use_int_scores=1), False),
+                  (128, 120, 600, {}, False), (16, 700, 1500, dict(use_int_scores=1), False), (32, 90, 300, {}, True))
+        if backend == "sim":                                       # the simulator runs every lane as a coroutine: the same paths on smaller shapes
+            shapes = ((16, 80, 200, {}, False), (8, 50, 130, {}, True), (16, 60, 180, dict(use_int_scores=1), False),
+                      (128, 40, 360, {}, False), (16, 260, 700, dict(use_int_scores=1), False), (32, 60, 220, {}, True))
+        for B, T, Lh, kw, late in shapes:
+            regs = [synth.make_region(rng, int(rng.integers(5, 30 if backend != "sim" else 12)), int(rng.integers(1, 6 if backend != "sim" else 4)), T=T, Lh=Lh, B=B, flank=(20, 30),
+                                      positions="none", indels_per_read=1) for _ in range(int(rng.integers(1, 4)))]
             if B == 8:
                 for g in regs:
                     g["reads"][rng.integers(0, g["reads"].shape[0], 3), rng.integers(0, T, 3)] = ord("N")
@@ -563,20 +567,30 @@ def check_launch_modes(backend, tol=0.0):
         for B, kw, late, batch in cases:
             os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = "0" if late else "1000000000000"
             outs = []
-            for mode in ("default", "host", "budget"):
-                os.environ.pop("OCT_PHMM_DEVICE_SIZED", None); os.environ.pop("OCT_PHMM_BP_BUDGET_KB", None)
+            for mode in ("default", "host", "budget", "overflow"):
+                for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR"):
+                    os.environ.pop(k, None)
                 if mode == "host":
                     os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"
                 if mode == "budget":
-                    os.environ["OCT_PHMM_BP_BUDGET_KB"] = "600"
+                    os.environ["OCT_PHMM_BP_BUDGET_KB"] = "8"
+                if mode == "overflow":                              # scratch for one task group: the scan flags the batch, the wait repeats it host-sized
+                    os.environ["OCT_PHMM_DSL_TRACE_PER_PAIR"] = "-1"
                 eng = make_engine(backend, max_indel_error=B, **kw)
                 rb = eng.upload(batch)
-                assert rb.device_sized() == (mode == "default"), (mode, B)
+                assert rb.device_sized() == (mode in ("default", "overflow")), (mode, B)
                 rb.run(); outs.append(rb.download().copy())
+                if mode == "overflow":
+                    repeated += 0 if rb.device_sized() else 1
+                    assert not rb.device_sized() or rb.stats()["n_dp_traceback"] <= 64        # (one task group per list may hold a tiny case)
                 rb.run(); assert np.array_equal(rb.download(), outs[-1])       # a resident batch can be run again
-                rb.free(); eng.close()
-            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
-            os.environ.pop("OCT_PHMM_DEVICE_SIZED", None); os.environ.pop("OCT_PHMM_BP_BUDGET_KB", None)
+                rb.free()
+                one_shot, _ = eng.populate(batch)
+                assert np.array_equal(one_shot, outs[-1])
+                eng.close()
+            assert all(np.array_equal(outs[0], o) for o in outs[1:])
+            for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR"):
+                os.environ.pop(k, None)
             compare(backend, batch, tol, max_indel_error=B, **kw)
             n += 1
     finally:
@@ -585,4 +599,5 @@ def check_launch_modes(backend, tol=0.0):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+    assert repeated >= 4, repeated
     return n

@@ -32,6 +32,7 @@ inline bool event_sync(Event) { return true; }
 inline bool stream_wait_event(Stream, Event) { return true; }
 inline bool event_elapsed_ms(float* ms, Event, Event) { *ms = 0.f; return true; }
 inline bool launch_ok() { return true; }
+inline void clear_error() {}
 template <class K> inline bool allow_lds(K, size_t) { return true; }
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 struct Range { explicit Range(const char*) {} };

@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <vector>
 #define REP 64
-#define ITER 20000
+#define ITER 8000
 // clk[2 * wave] = shader cycles (s_memtime), clk[2 * wave + 1] = ticks of the constant reference clock (s_memrealtime) the wave's loop took
 template <int OP> __global__ void k(unsigned* out, unsigned seed, unsigned long long* clk)
 {
@@ -68,29 +68,32 @@ template <int OP> __global__ void k(unsigned* out, unsigned seed, unsigned long 
     const unsigned long long t1 = clock64(), r1 = wall_clock64();
     if ((threadIdx.x & 63) == 0) { const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; clk[2 * w] = t1 - t0; clk[2 * w + 1] = r1 - r0; }
 }
+// One workgroup of 1024 threads per CU, forced by a dynamic LDS request only one workgroup fits beside: every SIMD then holds exactly four waves for
+// the whole kernel (a plain grid of small workgroups is NOT spread evenly over the CUs: the wall time then measures the most crowded CU, and the
+// first version of this bench overstated every cost by ~1.5x that way).
 template <int OP> void run(const char* name, unsigned* d)
 {
-    for (int wps : {4}) {       // waves per SIMD (256 CUs x 4 SIMDs)
-        const int blocks = 256 * wps, threads = 256;
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        static unsigned long long* clk = nullptr; if (!clk) hipMalloc(&clk, 256 * 8 * 4 * 2 * sizeof(unsigned long long));
-        int wall_khz = 0; hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
-        k<OP><<<blocks, threads>>>(d, 12345u, clk); hipDeviceSynchronize();
-        hipEventRecord(e0); k<OP><<<blocks, threads>>>(d, 12345u, clk); hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        const int n_waves = blocks * threads / 64;
-        std::vector<unsigned long long> h(2 * n_waves); hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
-        double cyc = 0, ref = 0; for (int w = 0; w < n_waves; ++w) { cyc += (double)h[2 * w]; ref += (double)h[2 * w + 1]; }
-        const double ghz = cyc / ref * wall_khz * 1e-6;              // shader cycles per second while the loop ran, from the two in-kernel clocks
-        const double insts_per_simd = (double)wps * ITER * REP;      // wave-instructions issued on one SIMD
-        // true issue cost: the wps waves of a SIMD run side by side, so a wave's own s_memtime span covers wps x its instructions
-        printf("%-28s waves/SIMD=%d  %.3f ms  -> %.2f ns per wave-instr per SIMD (%.2f cycles @2.4GHz nominal; measured shader clock %.3f GHz -> %.2f shader cycles by s_memtime)\n",
-               name, wps, ms, ms * 1e6 / insts_per_simd, ms * 1e6 / insts_per_simd * 2.4, ghz, cyc / n_waves / insts_per_simd);
-    }
+    const int wps = 4, blocks = 256, threads = 1024; const size_t lds = 96 * 1024;
+    static bool once = false;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    static unsigned long long* clk = nullptr; if (!clk) hipMalloc(&clk, 256 * 16 * 2 * sizeof(unsigned long long));
+    int wall_khz = 0; hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+    k<OP><<<blocks, threads, lds>>>(d, 12345u, clk); hipDeviceSynchronize();
+    hipEventRecord(e0); k<OP><<<blocks, threads, lds>>>(d, 12345u, clk); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const int n_waves = blocks * threads / 64;
+    std::vector<unsigned long long> h(2 * n_waves); hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, ref = 0, cmax = 0; for (int w = 0; w < n_waves; ++w) { cyc += (double)h[2 * w]; ref += (double)h[2 * w + 1]; if ((double)h[2 * w] > cmax) cmax = (double)h[2 * w]; }
+    const double ghz = cyc / ref * wall_khz * 1e-6;              // shader cycles per second while the loops ran, from the two in-kernel clocks
+    const double insts_per_simd = (double)wps * ITER * REP;      // wave-instructions issued on one SIMD
+    if (!once) { once = true; printf("# 256 workgroups x 1024 threads, one per CU (LDS-forced): 4 waves per SIMD; ITER %d x REP %d\n", ITER, REP); }
+    printf("%-28s %.3f ms wall -> %.2f cycles per wave-instr per SIMD at the measured %.3f GHz (%.2f at nominal 2.4); by s_memtime: mean wave span %.2f, slowest %.2f cycles per instr\n",
+           name, ms, ms * 1e6 / insts_per_simd * ghz, ghz, ms * 1e6 / insts_per_simd * 2.4, cyc / n_waves / insts_per_simd, cmax / insts_per_simd);
 }
 int main()
 {
-    unsigned* d; hipMalloc(&d, 256 * 8 * 256 * 4);
+    unsigned* d; hipMalloc(&d, 256 * 1024 * 4);
     run<0>("v_pk_add_u16", d); run<1>("v_pk_min_i16", d); run<13>("v_pk_min_u16", d); run<10>("v_pk_add_i16 clamp", d); run<5>("v_pk_mad_u16", d);
     run<4>("v_perm_b32", d); run<6>("v_mov_b32_dpp row_shr:1", d); run<2>("v_add_u32", d); run<3>("v_min_i32", d); run<9>("v_min3_i32", d);
     run<8>("v_and_b32", d); run<11>("v_lshl_or_b32", d); run<14>("v_cndmask_b32", d); run<7>("v_fma_f32", d); run<12>("v_pk_fma_f32", d);
