@@ -137,6 +137,7 @@ struct oct_phmm_batch {
     double* d_aln_lik = nullptr; uint32_t* d_aln_mpos = nullptr; uint32_t* d_aln_n = nullptr; uint32_t* d_aln_ops = nullptr; uint32_t* d_err_flags = nullptr;
     double* early_out = nullptr;  // oct_phmm_populate: copy every slice's rows to the caller as soon as its epilogue is done
     bool stream = false;          // streaming DP path (k_dp_wide): band 128/256, or band 64 with reads/haplotypes too long for LDS
+    bool multi_wave = false;      // ... its multi-wave form k_dp_mw: bands 128 / 256 with int32 lanes (one task per workgroup, fast-cost and generic lists)
     bool map_big = false;         // haplotypes too long for the LDS-resident k-mer mapper
     int  map_lanes = 0;           // > 0: k_kmer_map_lanes with this many lanes (= reads) per workgroup
     bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
@@ -156,7 +157,7 @@ struct oct_phmm_batch {
 //   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS
 //   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
 //                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED,
-//                OCT_PHMM_WALK_STAGE
+//                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
 //                OCT_PHMM_DSL_TRACE_PER_PAIR
@@ -177,6 +178,7 @@ inline int  dedup()           { const char* e = getenv("OCT_PHMM_DEDUP"); return
 inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_HASH_BITS", &n) && n >= 1 && n < 32 ? (1u << n) - 1u : 0xffffffffu; }   // test hook: collisions
 inline int  device_sized()    { const char* e = getenv("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
 inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
+inline bool multi_wave()      { const char* e = getenv("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
 inline int  walk_stage()      { const char* e = getenv("OCT_PHMM_WALK_STAGE"); return !e ? -1 : atoi(e); }                             // -1 by launch size, 0 never, 1 always: the walk with its tiles staged in LDS
 inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
 inline bool penalties_lane_kernel() { const char* e = getenv("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
@@ -371,8 +373,11 @@ bool launch_walk_inst(const WalkParams& w, rt::Stream s, bool stage)
             if (stage_lds > 64 * 1024 && !rt::allow_lds((k_walk<B, TPR, C, true>), stage_lds)) return false;
             OCT_LAUNCH((k_walk<B, TPR, C, true>), (w.n_tasks + 63) / 64, 64, stage_lds, s, w);
         } else OCT_LAUNCH((k_walk<B, TPR, C, false>), blocks, 256, lds, s, w);
-    } else
-    OCT_LAUNCH((k_walk<B, TPR, C>), blocks, 256, lds, s, w);
+    } else {
+        // bands 128 / 256: one wave walks one task out of LDS-staged lines (k_walk_long) unless the launch is big enough for the lockstep walker to fill its waves
+        if (stage) OCT_LAUNCH((k_walk_long<B, C>), w.n_tasks, 64, walk_long_lds_bytes(), s, w);
+        else OCT_LAUNCH((k_walk<B, TPR, C>), blocks, 256, lds, s, w);
+    }
     if (w.out_align1 != nullptr) OCT_LAUNCH((k_walk_strings<B, TPR, C>), blocks, 256, 0, s, w);   // test seam: gapped strings from the simple per-step walker
     if (w.pair_key != nullptr) OCT_LAUNCH((k_walk_cigar<B, TPR, C>), blocks, 256, 0, s, w);       // align mode: the pairs' winning tasks write their CIGARs
     return rt::launch_ok();
@@ -384,8 +389,8 @@ bool launch_walk(int band, bool one_per_row, const WalkParams& w, rt::Stream s, 
         case 16:  return one_per_row ? launch_walk_inst<16, 1, 1>(w, s, stage) : launch_walk_inst<16, 2, 1>(w, s, stage);
         case 32:  return one_per_row ? launch_walk_inst<32, 1, 1>(w, s, stage) : launch_walk_inst<32, 2, 1>(w, s, stage);
         case 64:  return one_per_row ? launch_walk_inst<64, 1, 1>(w, s, stage) : launch_walk_inst<64, 2, 1>(w, s, stage);
-        case 128: return launch_walk_inst<128, 1, 2>(w, s, false);
-        case 256: return launch_walk_inst<256, 1, 4>(w, s, false);
+        case 128: return launch_walk_inst<128, 1, 2>(w, s, stage);
+        case 256: return launch_walk_inst<256, 1, 4>(w, s, stage);
         default: return false;
     }
 }
@@ -411,6 +416,19 @@ bool launch_dp_wide(int band, bool tr, bool w16, const DpParams& p, rt::Stream s
     }
 }
 
+template <int B>
+bool launch_dp_mw_band(bool tr, bool gen, const DpParams& p, rt::Stream s)
+{
+    const uint32_t blocks = p.n_tasks;                                   // one task per workgroup of B threads
+    if (tr) { if (gen) OCT_LAUNCH((k_dp_mw<B, true, true>), blocks, B, 0, s, p); else OCT_LAUNCH((k_dp_mw<B, true, false>), blocks, B, 0, s, p); }
+    else    { if (gen) OCT_LAUNCH((k_dp_mw<B, false, true>), blocks, B, 0, s, p); else OCT_LAUNCH((k_dp_mw<B, false, false>), blocks, B, 0, s, p); }
+    return rt::launch_ok();
+}
+bool launch_dp_mw(int band, bool tr, bool gen, const DpParams& p, rt::Stream s)
+{
+    return band == 128 ? launch_dp_mw_band<128>(tr, gen, p, s) : band == 256 ? launch_dp_mw_band<256>(tr, gen, p, s) : false;
+}
+
 bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 {
     if (h->bp_bytes[slice] >= bytes) return true;
@@ -431,7 +449,7 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 // Run one kind's task list through the DP kernel (+ walk for traceback kinds), chunked so the traceback scratch fits.
 // `ref` (device-sized launch): `tasks` is the array that holds all six lists, `n_tasks` the host's bound for one list; the kernels take the list itself
 // from the totals in device memory.
-constexpr uint32_t kDslMaxBlocks = 2048;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
+constexpr uint32_t kDslMaxBlocks = 1024;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
 int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
                 int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false,
                 TaskListRef ref = TaskListRef {nullptr, nullptr, 0, nullptr}, const rt::Event* after_first_dp = nullptr)
@@ -448,7 +466,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     DpParams p {};
     p.ref = ref;
     p.rbases = b->d.rbases; p.rquals = b->d.rquals; p.roff = b->d.roff; p.rrev = b->d.rrev; p.hoff = b->d.hoff;
-    p.rrec = b->d.rrec; p.rrec_stride = b->d.rrec_stride;
+    p.rrec = b->d.rrec; p.rrec_stride = b->d.rrec_stride; p.rrecW = b->d.rrecW;
     p.tabF = gen ? b->d.tabGenF : b->d.tabFastF; p.tabR = gen ? b->d.tabGenR : b->d.tabFastR;
     p.pair_best = b->d.pair_best;
     p.k_cap = bp_tiles(b->t_cap, (uint32_t)B); p.t_cap = b->t_cap; p.lh_cap = b->lh_cap;
@@ -480,7 +498,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         if (dsl) n_blocks = std::min(n_blocks, kDslMaxBlocks);
         rt::Event e0 {}, e1 {};
         if (h->timing) { RT(h->get_event(&e0)); RT(h->get_event(&e1)); RT(rt::event_record(e0, st)); }
-        if (!(b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
+        if (!(b->multi_wave ? launch_dp_mw(B, tr, gen, p, st) : b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
                         : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         if (h->timing) { RT(rt::event_record(e1, st)); b->timers.emplace_back(e0, e1); b->timer_kind.push_back(kind); }
@@ -867,6 +885,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     {
         const bool fits = h->band <= 64 && dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)h->band, true) <= rt::kMaxLdsBytes;
         b->stream = h->band > 64 || !fits;      // long reads at any band stream their operands (PacBioCCS.config: max-indel-errors=16 with 10-20 kb reads)
+        b->multi_wave = h->band >= 128 && h->wide && tune::multi_wave();
         if (b->t_cap + 2 * (uint32_t)h->band >= 32768) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long (walk events hold 15-bit coordinates)");
     }
     {
@@ -931,7 +950,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     rt::Stream s = h->stream;
     DevBatch& d = b->d;
     d.n_reads = R->n_reads; d.n_rows = n_rows; d.n_haps = H->n_haps; d.n_regions = G; d.n_pairs = b->n_pairs;
-    d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions; d.wide = (h->wide || b->stream) ? 1 : 0;
+    d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions; d.wide = ((h->wide || b->stream) && !b->multi_wave) ? 1 : 0;   // 1: every task takes the generic lists
     d.use_mapq = h->cfg.use_mapping_quality; d.mapq_cap = h->cfg.mapping_quality_cap; d.mapq_trigger = h->cfg.mapping_quality_cap_trigger;
     oct_phmm_batch* bp = b.get();
     Packer pk;
@@ -996,13 +1015,17 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         pk.upload(b->h_blk_read0.data(), b->h_blk_read0.size(), (const uint32_t**)&b->d_blk_read0);
     }
     pk.dalloc(&d.racgt, (size_t)R->n_reads);
-    d.rrec = nullptr; d.rrec_stride = 0;
+    d.rrec = nullptr; d.rrec_stride = 0; d.rrecW = nullptr;
     if (!b->stream && !h->wide && R->n_reads) {           // the LDS-resident int16 kernels read their read-side operands from per-read record rows
         d.rrec_stride = dp_rec_n(b->t_cap, (uint32_t)h->band);
         pk.dalloc(&d.rrec, (size_t)R->n_reads * d.rrec_stride);
     }
-    pk.dalloc(&d.tabFastF, (size_t)n_hap_bases); pk.dalloc(&d.tabFastR, (size_t)n_hap_bases);
-    pk.dalloc(&d.tabGenF, (size_t)n_hap_bases);  pk.dalloc(&d.tabGenR, (size_t)n_hap_bases);
+    if (b->multi_wave && R->n_reads) {                    // ... and so does the multi-wave streaming kernel (16 bytes per entry: both cost flavours)
+        d.rrec_stride = dp_rec_n(b->t_cap, (uint32_t)h->band);
+        pk.dalloc(&d.rrecW, (size_t)R->n_reads * d.rrec_stride);
+    }
+    pk.dalloc(&d.tabFastF, (size_t)n_hap_bases + 16); pk.dalloc(&d.tabFastR, (size_t)n_hap_bases + 16);      // (+16: k_dp_mw's last operand chunks run past a window)
+    pk.dalloc(&d.tabGenF, (size_t)n_hap_bases + 16);  pk.dalloc(&d.tabGenR, (size_t)n_hap_bases + 16);
     pk.dalloc(&d.pair_best, (size_t)b->n_pairs); pk.dalloc(&d.pair_cls, (size_t)b->n_pairs);
     pk.dalloc(&d.pair_extra, (size_t)b->n_pairs); pk.dalloc(&d.pair_cnt, (size_t)b->n_pairs + oct_phmm_handle::kMaxSlices + 1);
     // Exact de-duplication of pairs (phmm_kernels.hpp): populate on the LDS-resident int16 path, where some region has several haplotypes and
@@ -1178,7 +1201,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     // per-read flags and per-base DP tables (once per batch; HaplotypeLikelihoodModel::reset analogue)
     {
         const uint32_t table_blocks = (n_hap_bases + 255) / 256, flag_blocks = (R->n_reads + 255) / 256;
-        const uint64_t rec_blocks64 = d.rrec ? ((uint64_t)R->n_reads * d.rrec_stride + 255) / 256 : 0;
+        const uint64_t rec_blocks64 = (d.rrec || d.rrecW) ? ((uint64_t)R->n_reads * d.rrec_stride + 255) / 256 : 0;
         if (table_blocks + flag_blocks + rec_blocks64 >= 0x7fffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "batch too large for one table launch");
         const uint32_t rec_blocks = (uint32_t)rec_blocks64;
         if (table_blocks + flag_blocks + rec_blocks) { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok()); }
@@ -1360,6 +1383,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             rt::Stream aux = h->slice_stream(1);
             auto flavour_live = [&](int list) { const bool gen = list == kScoreGen || list == kTraceGen || list == 5; return (b->dsl_flavours & (gen ? 2 : 1)) != 0; };
             bool forked = false;
+            if (b->stream) { RT(rt::event_record(b->ev_fork, s)); forked = true; }     // (long reads: see the host-sized path)
             for (int list : {4, 5, (int)kTraceFast, (int)kTraceGen}) {
                 if (list >= 4 && !sl.cnt_late) continue;
                 if (!flavour_live(list)) continue;
@@ -1418,6 +1442,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             const bool side = S == 1 && total < 200000 && (totals.x + totals.z) > 0 && (totals.y + totals.w) > 0;   // big launches fill the chip on their own
             rt::Stream aux = h->slice_stream(1);
             bool forked = false;                                 // (side) the score-only DP starts beside the first traceback launch's walk: see phase2_device_sized
+            // ... except for long reads: a traceback launch of ~10^2 tasks is a few hundred latency-bound waves that leave the chip's issue slots to the score-only DP
+            if (side && b->stream) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
             for (int lk = 0; lk < 2; ++lk) {                     // late-start traceback launches first (the longest walks of the slice start earliest)
                 const uint32_t n = lk ? late.y : late.x;
                 const int rc = run_dp_kind(h, b, i, lk ? kTraceGen : kTraceFast, tl.t[lk], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, nullptr, true,
@@ -2032,7 +2058,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
     // every window is its own haplotype and a DP task group must stay within one haplotype: give each window a whole
     // group (one real task + G-1 padding copies). This is a test seam, not the throughput path.
     for (uint32_t i = 0; i < n; ++i) {
-        const int gen = h->wide || b->stream || !(racgt[i] && hclean[i]);
+        const int gen = ((h->wide || b->stream) && !b->multi_wave) || !(racgt[i] && hclean[i]);
         tasks[gen].push_back(DevTask {i, i, i, 0}); origin[gen].push_back(i);
         for (uint32_t k = 1; k < G; ++k) tasks[gen].push_back(DevTask {kPadTask, i, i, 0});
     }

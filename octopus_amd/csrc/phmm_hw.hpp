@@ -110,6 +110,10 @@ OCT_DEVICE unsigned long long atomic_add_u64(unsigned long long* p, unsigned lon
 OCT_DEVICE uint32_t atomic_and_u32(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
 OCT_DEVICE uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 OCT_DEVICE unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long expected, unsigned long long v) { return atomicCAS(p, expected, v); }
+// 64-bit mailboxes in LDS between the waves of a workgroup (k_dp_mw): value and tag travel in ONE store / ONE load, re-read until the tag is right
+OCT_DEVICE void lds_store_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+OCT_DEVICE unsigned long long lds_load_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+OCT_DEVICE void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 OCT_DEVICE uint32_t thread_idx() { return threadIdx.x; }
 OCT_DEVICE uint32_t block_idx() { return blockIdx.x; }
 OCT_DEVICE uint32_t block_dim() { return blockDim.x; }

@@ -85,7 +85,12 @@ OCT_DEVICE void read_record_thread(const DevBatch& b, uint64_t g)
     const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro;
     const int32_t t = (int32_t)j - b.band;
     const bool in = t >= 0 && (uint32_t)t < T;
-    const uint32_t sel = in ? base_code(b.rbases[ro + t]) : 0x0du, q = in ? (uint32_t)b.rquals[ro + t] : 64u;
+    const uint32_t base = in ? (uint32_t)b.rbases[ro + t] : 0u;
+    const uint32_t sel = in ? base_code(base) : 0x0du, q = in ? (uint32_t)b.rquals[ro + t] : 64u;
+    if (b.rrecW) {      // k_dp_mw: one task per band row, 32-bit words (fast cost: selector word + quality; generic: raw base as k_dp_wide pads it + quality << 2)
+        b.rrecW[g] = make_uint4(sel | 0x0c0c0c00u, q, in ? base : (t < 0 ? 0x100u : (uint32_t)'0'), q << 2);
+        return;
+    }
     b.rrec[g] = sel | 0x0c00u | q << 16;
 }
 
@@ -1693,6 +1698,159 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Long reads at bands 128 / 256, int32 lanes (BASELINE.json configs[4]): ONE TASK PER WORKGROUP, its B band diagonals over B / 64 waves, one diagonal
+// per lane. A long-read batch holds ~10^3 tasks of ~10^4 dependent iterations: with one wave per task (k_dp_wide) a SIMD holds one wave and the launch
+// runs at the latency of a 4-diagonal dependency chain per lane; here the same batch puts four waves on every SIMD and a wave's chain is a quarter
+// as long. Inside a wave D and I move between neighbouring lanes with a DPP shift as everywhere else; across the wave border they travel through
+// 64-bit mailboxes in LDS, {value, iteration}, written by the border lane as soon as the value exists and read (re-read until the iteration tag
+// matches) by the neighbour wave's border lane where it is needed:
+//   dsh(k), the D hand-down, depends only on iteration k - 1: posted FIRST in iteration k, consumed after the M / I updates of the same iteration;
+//   ish(k), the I hand-up, exists after the even diagonal: posted there, consumed at the end of the iteration.
+// So neither wave waits in the steady state, no workgroup barrier is involved, and a wave can run at most one iteration ahead of its neighbours (ring of
+// four slots per mailbox). Operands come from per-read record rows (DevBatch::rrecW) and the per-base tables in chunks of eight iterations, the next chunk in
+// flight while this one computes; the fast-cost form (pure ACGT read on a clean haplotype) is perm + min + shift-add per cell like k_dp's.
+// Same recurrence, same traceback words and layout as k_dp_wide<B, TRACE, false>: k_walk<B, 1, B / 64> serves both.
+// ------------------------------------------------------------------------------------------------------------------
+template <int B, bool TRACE, bool GENERIC>
+OCT_MAX_THREADS(B) OCT_KERNEL(k_dp_mw)(DpParams p)
+{
+    constexpr int NW = B / 64, C = NW;
+    static_assert(B == 128 || B == 256, "multi-wave streaming kernel: bands 128 and 256");
+    __shared__ unsigned long long mbox_up[NW][4], mbox_dn[NW][4];        // [producer wave][iteration & 3]
+    __shared__ uint32_t red_v[NW], red_s[NW];
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = hw::readfirstlane(tid >> 6);
+    const DevTask* tasks = p.tasks; uint32_t n_tasks = p.n_tasks;
+    if (p.ref.totals) { uint32_t first; task_list_range(p.ref, first, n_tasks); tasks += first; }   // device-sized launch: the grid is the host's bound
+    const uint32_t task = hw::block_idx();
+    if (task >= n_tasks) return;                                           // (whole workgroups)
+    if (lane < 4) { mbox_up[wave][lane] = ~0ull; mbox_dn[wave][lane] = ~0ull; }   // no iteration carries this tag
+    hw::block_sync();
+    const DevTask t = tasks[task];
+    const uint32_t ro = p.roff[t.read], T = p.roff[t.read + 1] - ro;
+    const uint32_t K = T + B, K8 = (K + 7) & ~7u;
+    const uint32_t i = wave * 64 + lane;                                   // this lane's band diagonal
+    const uint2* tab = (p.rrev[t.read] ? p.tabR : p.tabF) + p.hoff[t.hap] + t.off;
+    const uint2* rrow = (const uint2*)(p.rrecW + (size_t)t.read * p.rrec_stride) + (GENERIC ? 1 : 0);   // entry j (stride 2 uint2) = read position j - B
+    const uint32_t NUCW = (uint32_t)(int32_t)(int16_t)(p.nuc4 & 0xffffu);
+    uint32_t M1 = INF32, I1 = INF32, D1 = INF32, M2 = INF32, I2 = INF32, D2 = INF32;
+    uint32_t best = INF32, best_s = 0; bool have = false;
+
+    constexpr int CH = 8;
+    struct Chunk { uint2 e[CH]; uint2 r[CH]; };
+    // what iterations k0 .. k0 + 7 newly need: table entry x + 1 = k + i + 1 and read record t = k - i. Two running pointers per lane, the eight loads at
+    // constant offsets (no address arithmetic per load). The last chunks run a few entries past the task's window: the tables carry slack for that
+    // (upload) and those iterations feed no end cell.
+    const uint2* tab_next = tab + i + 1;
+    const uint2* rec_next = rrow + 2 * (size_t)((uint32_t)B - i);
+    auto fetch = [&]() -> Chunk {
+        Chunk ch;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { ch.e[u] = tab_next[u]; ch.r[u] = rec_next[2 * u]; }
+        tab_next += CH; rec_next += 2 * CH;
+        return ch;
+    };
+    auto cost = [&](const uint2 r2, const uint2 a, uint32_t& flag) -> uint32_t {       // update_match_state (:121-132), already shifted by the trace bits
+        if constexpr (GENERIC) {
+            const uint32_t h = a.x & 0xffu, m = (a.x >> 8) & 0xffu, p4 = ((a.x >> 16) & 0xffu) << 2, isn = a.x >> 24;
+            const uint32_t inner = r2.x == m ? p4 : r2.y;
+            uint32_t c = min_i32(r2.y, inner);
+            if (r2.x == h) c = 0;
+            flag = r2.x != h ? 0x8000u : 0u;
+            return min_i32(c, isn ? 8u : INF32);
+        } else {
+            const uint32_t cp = hw::perm(a.x, a.x, r2.x);                          // this read base's cap at this haplotype position (0xff: none)
+            const uint32_t c = cp < r2.y ? cp : r2.y;                              // min(quality, cap)
+            flag = c ? 0x8000u : 0u;                                               // the walk charges exactly c inside a flank
+            return c << 2;
+        }
+    };
+    auto post = [&](unsigned long long* box, uint32_t v, uint32_t k) { hw::lds_store_u64(box + (k & 3u), (unsigned long long)k << 32 | v); };
+    // every lane of the wave reads the one mailbox word (a broadcast) and re-reads it until it carries iteration k: the test is wave-uniform, no
+    // exec-mask round trip; the border lane then selects the value
+    auto take = [&](const unsigned long long* box, uint32_t k) -> uint32_t {
+        unsigned long long v = hw::lds_load_u64(box + (k & 3u));
+        while (hw::readfirstlane((uint32_t)(v >> 32)) != k) { hw::spin_pause(); v = hw::lds_load_u64(box + (k & 3u)); }
+        return (uint32_t)v;
+    };
+    const bool first_lane = wave > 0 && lane == 0, last_lane = wave + 1 < (uint32_t)NW && lane == 63;   // this lane's D / I neighbour lives in another wave
+    const uint32_t inf_lo = lane == 0 ? INF32 : 0u, inf_hi = lane == 63 ? INF32 : 0u;                   // infinity_ into the band's first / last diagonal
+    uint32_t* bpt = TRACE ? p.bp + (size_t)task * p.k_cap * C * 1024 + ((size_t)(i % C) * 64 + i / C) * 16 : nullptr;   // + tile * C * 1024 + (k & 15)
+
+    uint2 cE = tab[i];                                                     // table entry of x = k + i
+    uint32_t GO = cE.y & 0xffffu, GE = cE.y >> 16;
+    Chunk nxt = fetch();
+    auto run_chunk = [&](uint32_t k0, auto init_c, auto cap_c) {
+        constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value;
+        const Chunk cur = nxt;
+        if (k0 + CH < K8) nxt = fetch();
+        uint32_t bw[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const uint32_t k = k0 + (uint32_t)u;
+            const uint2 nE = cur.e[u], rr = cur.r[u];
+            const uint32_t GOn = nE.y & 0xffffu, GEn = nE.y >> 16;
+            if constexpr (INIT) { if (k == i) { M1 = NUL32; M2 = NUL32; } }                  // rolling initialiser
+            // the D hand-down of this iteration needs nothing of it: first, so that the next wave finds it early
+            const uint32_t x2 = min_i32(M2, I2);
+            const uint32_t dsh = min_i32(D2 + GEn, x2 + GOn);                                 // :293
+            if (wave + 1 < (uint32_t)NW && lane == 63) post(mbox_up[wave], dsh, k);
+            uint32_t fE, fO;
+            const uint32_t m1 = min_i32(M1, min_i32(I1, D1));                                 // :284
+            if constexpr (CAP) { if (k == T + i && (int32_t)m1 < (int32_t)best) { best = m1; best_s = 2 * k; have = true; } }   // :285-291
+            M1 = m1 + cost(rr, cE, fE);                                                       // :292
+            I1 = min_i32(I2 + GE, M2 + GO) + NUCW;                                            // :295
+            uint32_t bpe = 0;
+            if constexpr (TRACE) { const uint32_t tm = M1 & 3u, ti = I1 & 3u; M1 ^= tm; I1 = (I1 & ~3u) | 1u; bpe = tm | ti << 2 | fE; }
+            const uint32_t ish = min_i32(I1 + GE, M1 + GO) + NUCW;                            // :318
+            if (wave > 0 && lane == 0) post(mbox_dn[wave], ish, k);
+            D1 = hw::dpp_wave_shr1_z(dsh) | inf_lo;                                           // :294 one diagonal up, infinity_ into diagonal 0
+            if (wave > 0) { const uint32_t v = take(mbox_up[wave - 1], k); D1 = first_lane ? v : D1; }
+            if constexpr (TRACE) { const uint32_t td = D1 & 3u; D1 |= 3u; bpe |= td << 4; }
+            const uint32_t m2 = min_i32(x2, D2);                                              // :308
+            if constexpr (CAP) { if (k == T + i && (int32_t)m2 < (int32_t)best) { best = m2; best_s = 2 * k + 1; have = true; } }
+            M2 = m2 + cost(rr, nE, fO);                                                       // :316
+            const uint32_t y1 = min_i32(M1, I1);
+            D2 = min_i32(D1 + GEn, y1 + GOn);                                                 // :317
+            I2 = hw::dpp_wave_shl1_z(ish) | inf_hi;                                           // :318-319 one diagonal down, infinity_ into the last one
+            if (wave + 1 < (uint32_t)NW) { const uint32_t v = take(mbox_dn[wave + 1], k); I2 = last_lane ? v : I2; }
+            if constexpr (TRACE) {
+                const uint32_t tm = M2 & 3u, ti = I2 & 3u, td = D2 & 3u;
+                M2 ^= tm; I2 = (I2 & ~3u) | 1u; D2 |= 3u;
+                bw[u] = bpe | (tm | ti << 2 | td << 4) << 6 | fO >> 1;
+            }
+            cE = nE; GO = GOn; GE = GEn;
+        }
+        if constexpr (TRACE) {                                                               // this lane's eight words of the tile: half of its 64-byte line
+            uint4* dst = (uint4*)(bpt + (size_t)(k0 >> 4) * C * 1024 + (k0 & 15u));
+            dst[0] = make_uint4(bw[0], bw[1], bw[2], bw[3]); dst[1] = make_uint4(bw[4], bw[5], bw[6], bw[7]);
+        }
+    };
+    const uint32_t t_lo = (T & ~7u) > (uint32_t)B ? (T & ~7u) : (uint32_t)B;         // no end cell before iteration T
+    uint32_t k = 0;
+    if (T < (uint32_t)B) { for (; k < (uint32_t)B; k += CH) run_chunk(k, BoolC<true>{}, BoolC<true>{}); }
+    for (; k < (uint32_t)B; k += CH) run_chunk(k, BoolC<true>{}, BoolC<false>{});
+    for (; k < t_lo; k += CH) run_chunk(k, BoolC<false>{}, BoolC<false>{});
+    for (; k < K8; k += CH) run_chunk(k, BoolC<false>{}, BoolC<true>{});
+
+    // first minimum over the end cells: per lane the candidates came in increasing diagonal order (strict < kept the first); lanes, then waves
+    uint32_t kv = have ? (best ^ 0x80000000u) : 0xffffffffu, ks = have ? best_s : 0xffffffffu;
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint32_t ov = hw::shfl_xor(kv, m), os = hw::shfl_xor(ks, m);
+        if (ov < kv || (ov == kv && os < ks)) { kv = ov; ks = os; }
+    }
+    if (lane == 0) { red_v[wave] = kv; red_s[wave] = ks; }
+    hw::block_sync();
+    if (tid == 0) {
+        for (int w = 1; w < NW; ++w) { const uint32_t ov = red_v[w], os = red_s[w]; if (ov < kv || (ov == kv && os < ks)) { kv = ov; ks = os; } }
+        const bool none = kv == 0xffffffffu;                                                  // no end cell below infinity_: minscore stays infinity_, minscoreidx -1 (:269-270)
+        const uint32_t biased = none ? (INF32 ^ 0x80000000u) : kv;
+        const int32_t score = (int32_t)biased >> 2;
+        if constexpr (TRACE) { TraceEnd e; e.score = score; e.sidx = none ? -1 : (int32_t)ks; p.ends[task] = e; }
+        else if (t.pair != kPadTask) hw::atomic_min_i32(p.pair_best + t.pair, score);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // traceback walk + flank score
 // ------------------------------------------------------------------------------------------------------------------
 template <int B, int TPR, int C>
@@ -2043,6 +2201,168 @@ OCT_MAX_THREADS(STAGE ? 64 : 256) OCT_KERNEL(k_walk)(WalkParams w)
         const uint32_t p = t.off + (uint32_t)B;             // in-range positions are >= B, so alignment_offset = position - B
         const uint32_t* P = w.pos + (size_t)t.pair * (uint32_t)w.max_pos; const uint32_t np = w.npos[t.pair];
         unsigned long long order = 0;                       // not in the mapped list: the original (or shifted original) position
+        for (uint32_t j = 0; j < np; ++j) if (P[j] == p) { order = j + 1; break; }
+        const unsigned long long key = (unsigned long long)(uint32_t)pen << 32 | order << 8;
+        w.task_key[ti] = key;
+        hw::atomic_min_u64(w.pair_key + t.pair, key);
+        return;
+    }
+    hw::atomic_min_i32(w.pair_best + t.pair, pen);
+}
+
+// Long reads at bands 128 / 256 (one task per band row, C = B / 64 planes): a batch holds ~10^2 traceback tasks of ~10^4 columns, so the
+// lockstep walker above would run two or three waves of mostly idle lanes at a memory round trip per band-lane change. Here ONE WAVE WALKS ONE TASK:
+// all 64 lanes carry the same walker state (every branch is wave-uniform, so a step is plain branches instead of selects) and share the memory work -
+// lane l keeps the 64-byte line of band lane (base + l) of the current tile in LDS, the lines of the next tile are in flight while this one is
+// walked (base = the walk's lane - 32 when they were requested; a walk that drifts out of the 64 staged lanes reads its word from memory), and the
+// in-flank events are collected in LDS and priced by all lanes together at the end. Same steps, same events, same result as k_walk.
+constexpr uint32_t kWalkLongEvents = 2048;
+inline size_t walk_long_lds_bytes() { return (kWalkLongEvents + 2 * 64 * 16) * sizeof(uint32_t); }
+
+template <int B, int C>
+OCT_MAX_THREADS(64) OCT_KERNEL(k_walk_long)(WalkParams w)
+{
+    static_assert(C > 1 && B == 64 * C, "one task per band row of 64 x C diagonals");
+    OCT_DYN_SMEM(smem);
+    uint32_t* evbuf = (uint32_t*)smem;                                    // [kWalkLongEvents]
+    uint32_t* tbuf = evbuf + kWalkLongEvents;                             // [2][64 lines][16 words]
+    const uint32_t lane = hw::thread_idx() & 63u, ti = hw::block_idx();
+    const DevTask* tasks = w.tasks; uint32_t n_tasks = w.n_tasks;
+    if (w.ref.totals) { uint32_t first; task_list_range(w.ref, first, n_tasks); tasks += first; }
+    if (ti >= n_tasks) return;
+    const DevTask t = tasks[ti];
+    if (t.pair == kPadTask) return;
+    const TraceEnd end = w.ends[ti];
+    const uint32_t ro = w.roff[t.read]; const int32_t T = (int32_t)(w.roff[t.read + 1] - ro);
+    const uint32_t ho = w.hoff[t.hap]; const int32_t Lh = (int32_t)(w.hoff[t.hap + 1] - ho);
+    const int32_t L = T + 2 * B - 1, off = (int32_t)t.off;
+    const bool seam = w.out_first_pos != nullptr;
+    int32_t lhs = 0, rhs = 0; bool want_flank = true;                     // flank sizes in window coordinates (pair_hmm.hpp:572-587)
+    if (seam) {
+        want_flank = w.seam_lhs != nullptr;
+        if (want_flank) { lhs = w.seam_lhs[ti]; rhs = w.seam_rhs[ti]; }
+    } else {
+        const uint32_t g = w.hap_region[t.hap];
+        lhs = (int32_t)w.reg_lhs[g];
+        if (lhs < off) lhs = 0; else { lhs -= off; if (lhs < 0) lhs = 0; }
+        rhs = (int32_t)w.reg_rhs[g];
+        if (off + L < Lh - rhs) rhs = 0; else { rhs += off + L; rhs -= Lh; if (rhs < 0) rhs = 0; }
+    }
+    const int32_t rhs_begin = L - rhs;
+    const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
+    const uint32_t* bpg = w.bp + (size_t)ti * w.k_cap * C * 1024;        // this task's tiles: [tile][plane i % C][lane i / C][16 iterations]
+
+    int32_t sidx = end.sidx, i = sidx / 2 - T, y = T, x = sidx - T;       // walker state (set_alignments :180-193), the same in every lane
+    int32_t flank = 0, msz = 0; uint32_t nev = 0, state = 0;
+    bool ok = sidx >= 0, fin = !ok;
+    if (ok) { const int64_t f0 = (int64_t)sidx * B + i; if (f0 < 0 || f0 >= n_flat) { ok = false; fin = true; } }   // :186-190
+
+    WalkPricing pricing;
+    {
+        const bool fwd = !w.rrev[t.read];
+        const size_t hb0 = (size_t)ho + (uint32_t)off;
+        pricing.rbases = w.rbases + ro; pricing.rquals = (const int8_t*)w.rquals + ro; pricing.hbases = w.hbases + hb0;
+        pricing.mask = (fwd ? w.maskF : w.maskR) + hb0; pricing.prior = (fwd ? w.priorF : w.priorR) + hb0;
+        pricing.go = w.go + hb0; pricing.ge = w.ge + hb0;
+    }
+    auto push_event = [&](uint32_t kind, int32_t ex, int32_t ey) {
+        const uint32_t e = kind << 30 | (uint32_t)ey << 15 | (uint32_t)ex;
+        if (nev < kWalkLongEvents) { if (lane == 0) evbuf[nev] = e; ++nev; } else flank += walk_price_event(pricing, e);
+    };
+    auto in_flank = [&]() { return want_flank && (x < lhs || x >= rhs_begin); };   // calculate_flank_score_helper :383-424
+    auto step = [&](uint32_t wv) {                                        // one alignment column from backpointer word `wv` of cell (sidx, i)
+        const uint32_t par = (uint32_t)sidx & 1u;
+        const uint32_t bits = (wv >> (6 * par)) & 63u, mism = (wv >> (15 - par)) & 1u;
+        const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;                 // :200
+        if (state == 0) {                                                                       // match :201-204
+            sidx -= 2; --x; --y;
+            if (in_flank()) { ++msz; if (mism) push_event(0u, x, y); }
+        } else if (state == 1) {                                                                // insert :205-209
+            i += sidx & 1; sidx -= 1; --y;
+            if (in_flank()) { ++msz; flank += w.nuc_prior; push_event((y != 0 && new_state == 1) ? 2u : 1u, x - 1 < 0 ? 0 : x - 1, 0); }   // (x - 1 == -1: UB in the reference, clamped)
+        } else {                                                                                // delete :210-215
+            sidx -= 1; i -= sidx & 1; --x;
+            if (in_flank()) push_event(new_state == 3 ? 2u : 1u, x, 0);
+        }
+        state = new_state;
+        if (y <= 0) fin = true;                                                                 // :194
+    };
+    auto word_from_memory = [&](int64_t flat) -> uint32_t {                                     // any cell by flat index = diagonal * B + lane
+        const int32_t s = (int32_t)(flat / B), li = (int32_t)(flat % B);
+        if (s >= 2 * (T + B)) return 0;                                                         // last row of the reference's array is never written
+        const uint32_t k = (uint32_t)s >> 1;
+        return bpg[(((size_t)(k >> 4) * C + (uint32_t)li % C) * 64 + (uint32_t)li / C) * 16 + (k & 15)];
+    };
+    if (ok) {                                                                                   // the first move only reads the end cell's own label (:191-192)
+        const uint32_t wv = word_from_memory((int64_t)sidx * B + i);
+        state = (wv >> (6 * ((uint32_t)sidx & 1u))) & 3u;
+        sidx -= 2;
+    }
+    // staging: lane l fetches the line of band lane base + l of tile kt (four 16-byte loads), later parks it in one of the two LDS buffers
+    struct Lines { uint4 q[4]; int32_t base; };
+    auto request = [&](int32_t kt) -> Lines {
+        Lines r;
+        r.base = i - 32 < 0 ? 0 : (i - 32 > B - 64 ? B - 64 : i - 32);
+        const uint32_t li = (uint32_t)r.base + lane;
+        const uint4* l = (const uint4*)(bpg + (((size_t)kt * C + li % C) * 64 + li / C) * 16);
+        r.q[0] = l[0]; r.q[1] = l[1]; r.q[2] = l[2]; r.q[3] = l[3];
+        return r;
+    };
+    auto park = [&](const Lines& r, uint32_t buf) {
+        uint4* dst = (uint4*)(tbuf + buf * 1024 + lane * 16);
+        dst[0] = r.q[0]; dst[1] = r.q[1]; dst[2] = r.q[2]; dst[3] = r.q[3];
+    };
+    const int32_t kt_top = (ok && sidx >= 0) ? (sidx >> 1) >> 4 : -1;
+    uint32_t cur = 0; int32_t base_cur = 0;
+    if (kt_top >= 0) { const Lines r = request(kt_top); park(r, 0); base_cur = r.base; }
+    hw::wave_lds_fence();
+    for (int32_t kt = kt_top; kt >= 0 && !fin; --kt) {
+        Lines nxt; nxt.base = 0;
+        if (kt > 0) nxt = request(kt - 1);                                                      // in flight while this tile is walked
+        const uint32_t* tile = tbuf + cur * 1024;
+        for (int32_t kk = 15; kk >= 0 && !fin; --kk) {
+            const int32_t k = kt * 16 + kk;
+            for (int rep = 0; rep < 2 && !fin && (sidx >> 1) == k; ++rep) {                      // an insertion/deletion can add a second step at the same k
+                uint32_t wv;
+                const int32_t rel = i - base_cur;
+                if (rel >= 0 && rel < 64 && i < B) wv = tile[rel * 16 + kk];
+                else if (i < 0) { ok = false; fin = true; break; }                              // :195-199
+                else {
+                    const int64_t f = (int64_t)sidx * B + i;                                    // i >= B: the reference indexes its array flat (lane overflow reads the next diagonal)
+                    if (f >= n_flat) { ok = false; fin = true; break; }
+                    wv = word_from_memory(f);
+                }
+                step(wv);
+            }
+        }
+        if (kt > 0) { hw::wave_lds_fence(); park(nxt, cur ^ 1u); base_cur = nxt.base; cur ^= 1u; hw::wave_lds_fence(); }
+    }
+    if (!fin) ok = false;                                                                       // ran off the first diagonal with target bases left (:195-199)
+    const int32_t first_pos = ok ? x : -1;
+    if (ok) {                                                                                   // the queued events, priced by all lanes together
+        hw::wave_lds_fence();
+        int32_t part = 0;
+        const uint32_t n_q = nev < kWalkLongEvents ? nev : kWalkLongEvents;
+        for (uint32_t e = lane; e < n_q; e += 64) part += walk_price_event(pricing, evbuf[e]);
+        flank += (int32_t)hw::wave_sum_u32((uint32_t)part);
+    }
+    if (lane != 0) return;
+    if (seam) {
+        w.out_first_pos[ti] = first_pos;
+        if (want_flank) { w.out_flank[ti] = ok ? flank : 0; w.out_mask_size[ti] = ok ? msz : 0; }
+        return;
+    }
+    if (!ok) {
+        if (w.pair_key) { w.task_key[ti] = ~0ull; hw::atomic_or_u32(w.err_flags, 1u); }       // simd_align throws HMMOverflow (:811-813)
+        return;                                             // populate: lowest(), contributes nothing to the max (pair_hmm.hpp:750-752)
+    }
+    if (T - msz < 2) flank = 0;                             // :757-759 / :664-665
+    const int32_t score = end.score;
+    const int32_t pen = flank <= score ? score - flank : flank + score;   // :760-764 / :666-670
+    if (w.pair_key) {                                       // align mode: compete for the pair under the reference's tie rules
+        const uint32_t p = t.off + (uint32_t)B;
+        const uint32_t* P = w.pos + (size_t)t.pair * (uint32_t)w.max_pos; const uint32_t np = w.npos[t.pair];
+        unsigned long long order = 0;
         for (uint32_t j = 0; j < np; ++j) if (P[j] == p) { order = j + 1; break; }
         const unsigned long long key = (unsigned long long)(uint32_t)pen << 32 | order << 8;
         w.task_key[ti] = key;

@@ -262,6 +262,18 @@ def test_gpu_staged_and_unstaged_walk_agree(monkeypatch):
     cp.compare("gpu", batch, TOL, max_indel_error=16)
 
 
+@pytest.mark.parametrize("band,n", [(128, 60), (256, 60)])
+def test_gpu_multi_wave_kernel_fast_cost_and_one_wave_form(band, n, monkeypatch):
+    check_l1.check_random("gpu", band, n, seed=500 + band, t_lo=30, t_hi=700, with_n=False, score_bits=32)
+    check_l1.check_random("gpu", band, n, seed=510 + band, t_lo=30, t_hi=700, with_n=True, score_bits=32)
+    check_l1.check_random("gpu", band, n // 2, seed=520 + band, t_lo=200, t_hi=900, q_max=125, junk=True, with_n=False, score_bits=32)   # walks that wander over the band
+    cp.check_wide_and_long("gpu", TOL)
+    monkeypatch.setenv("OCT_PHMM_MULTI_WAVE", "0")
+    monkeypatch.setenv("OCT_PHMM_WALK_STAGE", "0")        # ... and the lockstep walker instead of k_walk_long
+    check_l1.check_random("gpu", band, n // 2, seed=600 + band, t_lo=40, t_hi=400, with_n=True, score_bits=32)
+    cp.check_wide_and_long("gpu", TOL)
+
+
 def test_gpu_chunked_traceback_launches():
     cp.check_chunked_traceback("gpu", TOL)
 

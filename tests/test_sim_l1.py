@@ -50,3 +50,14 @@ def test_sim_exact_add_mode_gives_same_results(monkeypatch):
 @pytest.mark.parametrize("band,bits,n", [(128, 16, 4), (128, 32, 3), (256, 32, 2), (256, 16, 2)])
 def test_sim_wide_bands_streaming_kernel(band, bits, n):
     check_l1.check_random("sim", band, n, seed=400 + band + bits, t_lo=40, t_hi=200, with_n=True, score_bits=bits)
+
+
+@pytest.mark.parametrize("band,n", [(128, 4), (256, 3)])
+def test_sim_multi_wave_kernel_fast_cost_and_one_wave_form(band, n, monkeypatch):
+    """Bands 128 / 256 on int32 lanes run one task per workgroup (k_dp_mw: B / 64 waves, border cells through LDS mailboxes); pure-ACGT windows
+    take its fast-cost form. OCT_PHMM_MULTI_WAVE=0 keeps the one-wave-per-task kernel (k_dp_wide) covered."""
+    check_l1.check_random("sim", band, n, seed=500 + band, t_lo=30, t_hi=300, with_n=False, score_bits=32)
+    check_l1.check_random("sim", band, 2, seed=520 + band, t_lo=200, t_hi=330, q_max=125, junk=True, with_n=False, score_bits=32)   # unrelated sequences: walks that wander over the band
+    monkeypatch.setenv("OCT_PHMM_MULTI_WAVE", "0")
+    monkeypatch.setenv("OCT_PHMM_WALK_STAGE", "0")        # ... and the lockstep walker instead of k_walk_long
+    check_l1.check_random("sim", band, 2, seed=600 + band, t_lo=40, t_hi=200, with_n=True, score_bits=32)
