@@ -157,7 +157,7 @@ struct oct_phmm_batch {
 //   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS
 //   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
 //                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED,
-//                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE
+//                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
 //                OCT_PHMM_DSL_TRACE_PER_PAIR
@@ -179,6 +179,7 @@ inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_H
 inline int  device_sized()    { const char* e = getenv("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
 inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
 inline bool multi_wave()      { const char* e = getenv("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
+inline int  mw_planes()       { const char* e = getenv("OCT_PHMM_MW_PLANES"); return !e ? -1 : atoi(e); }                              // k_dp_mw: -1 by task count, 0 one plane per wave (B / 64 waves per task), 1 all planes in one wave
 inline int  walk_stage()      { const char* e = getenv("OCT_PHMM_WALK_STAGE"); return !e ? -1 : atoi(e); }                             // -1 by launch size, 0 never, 1 always: the walk with its tiles staged in LDS
 inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
 inline bool penalties_lane_kernel() { const char* e = getenv("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
@@ -416,17 +417,20 @@ bool launch_dp_wide(int band, bool tr, bool w16, const DpParams& p, rt::Stream s
     }
 }
 
-template <int B>
+template <int B, int PL>
 bool launch_dp_mw_band(bool tr, bool gen, const DpParams& p, rt::Stream s)
 {
-    const uint32_t blocks = p.n_tasks;                                   // one task per workgroup of B threads
-    if (tr) { if (gen) OCT_LAUNCH((k_dp_mw<B, true, true>), blocks, B, 0, s, p); else OCT_LAUNCH((k_dp_mw<B, true, false>), blocks, B, 0, s, p); }
-    else    { if (gen) OCT_LAUNCH((k_dp_mw<B, false, true>), blocks, B, 0, s, p); else OCT_LAUNCH((k_dp_mw<B, false, false>), blocks, B, 0, s, p); }
+    const uint32_t blocks = p.n_tasks, threads = B / PL;                 // one task per workgroup of B / (64 PL) waves
+    if (tr) { if (gen) OCT_LAUNCH((k_dp_mw<B, PL, true, true>), blocks, threads, 0, s, p); else OCT_LAUNCH((k_dp_mw<B, PL, true, false>), blocks, threads, 0, s, p); }
+    else    { if (gen) OCT_LAUNCH((k_dp_mw<B, PL, false, true>), blocks, threads, 0, s, p); else OCT_LAUNCH((k_dp_mw<B, PL, false, false>), blocks, threads, 0, s, p); }
     return rt::launch_ok();
 }
-bool launch_dp_mw(int band, bool tr, bool gen, const DpParams& p, rt::Stream s)
+// one_wave: all planes of a task in one wave (a launch with a task for every SIMD of the chip), else one plane per wave (few tasks: spread them out)
+bool launch_dp_mw(int band, bool one_wave, bool tr, bool gen, const DpParams& p, rt::Stream s)
 {
-    return band == 128 ? launch_dp_mw_band<128>(tr, gen, p, s) : band == 256 ? launch_dp_mw_band<256>(tr, gen, p, s) : false;
+    if (band == 128) return one_wave ? launch_dp_mw_band<128, 2>(tr, gen, p, s) : launch_dp_mw_band<128, 1>(tr, gen, p, s);
+    if (band == 256) return one_wave ? launch_dp_mw_band<256, 4>(tr, gen, p, s) : launch_dp_mw_band<256, 1>(tr, gen, p, s);
+    return false;
 }
 
 bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
@@ -498,7 +502,9 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         if (dsl) n_blocks = std::min(n_blocks, kDslMaxBlocks);
         rt::Event e0 {}, e1 {};
         if (h->timing) { RT(h->get_event(&e0)); RT(h->get_event(&e1)); RT(rt::event_record(e0, st)); }
-        if (!(b->multi_wave ? launch_dp_mw(B, tr, gen, p, st) : b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
+        // (a device-sized launch does not know its task count: region-sized, so the spread-out form)
+        const bool one_wave = tune::mw_planes() >= 0 ? tune::mw_planes() != 0 : (!dsl && p.n_tasks >= 640);
+        if (!(b->multi_wave ? launch_dp_mw(B, one_wave, tr, gen, p, st) : b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
                         : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         if (h->timing) { RT(rt::event_record(e1, st)); b->timers.emplace_back(e0, e1); b->timer_kind.push_back(kind); }

@@ -40,8 +40,8 @@ struct DevBatch {
     const uint8_t*  rmapq;    const uint8_t* rrev;    const int64_t*  rbegin;
     uint8_t*        racgt;                            // [n_reads] 1 = only A/C/G/T
     uint32_t*       rrec; uint32_t rrec_stride;       // [n_reads][rrec_stride] read-side DP records of the fast-cost kernels (k_hap_tables), null when unused
-    uint4*          rrecW;                            // [n_reads][rrec_stride] the same for the multi-wave streaming kernel k_dp_mw (int32 lanes, bands 128 / 256):
-                                                      // {v_perm selector word of the base's cap byte, quality, raw base (0x100 before / '0' after the read), quality << 2}
+    uint32_t*       rrecW;                            // [n_reads][rrec_stride] the same for the multi-wave streaming kernel k_dp_mw (int32 lanes, bands 128 / 256):
+                                                      // v_perm selector of the base's cap byte | raw base (0x100 before / '0' after the read) << 8 | quality << 24
     uint32_t n_rows;          const uint32_t* row_off; // may be null (row == read)
     // haplotypes + the six vectors of HaplotypeLikelihoodModel::reset
     uint32_t n_haps;
@@ -112,7 +112,7 @@ struct DpParams {
     const uint8_t* rbases; const uint8_t* rquals; const uint32_t* roff; const uint8_t* rrev;
     const uint32_t* hoff; const uint2* tabF; const uint2* tabR;
     const uint32_t* rrec; uint32_t rrec_stride;       // per-read record rows (fast-cost kernels): entry j = read position j - band
-    const uint4* rrecW;                               // the rows of k_dp_mw (DevBatch::rrecW), same stride
+    const uint32_t* rrecW;                            // the rows of k_dp_mw (DevBatch::rrecW), same stride
     int32_t*  pair_best;                              // score-only kernels: atomicMin target
     uint32_t* bp; TraceEnd* ends;                     // traceback kernels
     uint32_t  k_cap;                                  // 16-iteration backpointer tiles (4 KB each) per task group in the bp scratch

@@ -87,8 +87,8 @@ OCT_DEVICE void read_record_thread(const DevBatch& b, uint64_t g)
     const bool in = t >= 0 && (uint32_t)t < T;
     const uint32_t base = in ? (uint32_t)b.rbases[ro + t] : 0u;
     const uint32_t sel = in ? base_code(base) : 0x0du, q = in ? (uint32_t)b.rquals[ro + t] : 64u;
-    if (b.rrecW) {      // k_dp_mw: one task per band row, 32-bit words (fast cost: selector word + quality; generic: raw base as k_dp_wide pads it + quality << 2)
-        b.rrecW[g] = make_uint4(sel | 0x0c0c0c00u, q, in ? base : (t < 0 ? 0x100u : (uint32_t)'0'), q << 2);
+    if (b.rrecW) {      // k_dp_mw, one task per band row: byte 0 the v_perm selector of the base's cap byte, bits 8-16 the raw base as k_dp_wide pads it, byte 3 the quality
+        b.rrecW[g] = sel | (in ? base : (t < 0 ? 0x100u : (uint32_t)'0')) << 8 | q << 24;
         return;
     }
     b.rrec[g] = sel | 0x0c00u | q << 16;
@@ -1711,11 +1711,16 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
 // flight while this one computes; the fast-cost form (pure ACGT read on a clean haplotype) is perm + min + shift-add per cell like k_dp's.
 // Same recurrence, same traceback words and layout as k_dp_wide<B, TRACE, false>: k_walk<B, 1, B / 64> serves both.
 // ------------------------------------------------------------------------------------------------------------------
-template <int B, bool TRACE, bool GENERIC>
-OCT_MAX_THREADS(B) OCT_KERNEL(k_dp_mw)(DpParams p)
+// PL = planes per wave: a wave owns PL runs of 64 adjacent diagonals (diagonal (wave * PL + c) * 64 + lane in plane c), a task B / (64 PL) waves.
+//   PL = 1: four waves per task at band 256, borders through the mailboxes - the form for FEW tasks (a traceback launch of ~10^2 tasks, any batch below
+//           ~10^3 tasks): it spreads a task over four SIMDs and quarters the dependency chain.
+//   PL = B / 64: one wave per task, the planes' borders cross with a DPP rotate (lane 63 of plane c meets lane 0 of plane c + 1 inside the wave), no mailbox,
+//           no scalar-unit work per iteration - the form for a launch that has a task for every SIMD: the planes give the lone wave four independent chains.
+template <int B, int PL, bool TRACE, bool GENERIC>
+OCT_MAX_THREADS(B / PL) OCT_KERNEL(k_dp_mw)(DpParams p)
 {
-    constexpr int NW = B / 64, C = NW;
-    static_assert(B == 128 || B == 256, "multi-wave streaming kernel: bands 128 and 256");
+    constexpr int C = B / 64, NW = C / PL;
+    static_assert((B == 128 || B == 256) && (PL == 1 || PL == C), "multi-wave streaming kernel: bands 128 and 256, one plane or all planes per wave");
     __shared__ unsigned long long mbox_up[NW][4], mbox_dn[NW][4];        // [producer wave][iteration & 3]
     __shared__ uint32_t red_v[NW], red_s[NW];
     const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = hw::readfirstlane(tid >> 6);
@@ -1723,123 +1728,170 @@ OCT_MAX_THREADS(B) OCT_KERNEL(k_dp_mw)(DpParams p)
     if (p.ref.totals) { uint32_t first; task_list_range(p.ref, first, n_tasks); tasks += first; }   // device-sized launch: the grid is the host's bound
     const uint32_t task = hw::block_idx();
     if (task >= n_tasks) return;                                           // (whole workgroups)
-    if (lane < 4) { mbox_up[wave][lane] = ~0ull; mbox_dn[wave][lane] = ~0ull; }   // no iteration carries this tag
-    hw::block_sync();
+    if constexpr (NW > 1) {
+        if (lane < 4) { mbox_up[wave][lane] = ~0ull; mbox_dn[wave][lane] = ~0ull; }   // no iteration carries this tag
+        hw::block_sync();
+    }
     const DevTask t = tasks[task];
     const uint32_t ro = p.roff[t.read], T = p.roff[t.read + 1] - ro;
-    const uint32_t K = T + B, K8 = (K + 7) & ~7u;
-    const uint32_t i = wave * 64 + lane;                                   // this lane's band diagonal
+    const uint32_t K = T + B;
+    constexpr int CH = PL == 1 ? 8 : 4;                                    // iterations per operand chunk
+    const uint32_t KC = (K + CH - 1) / CH * CH;
+    const uint32_t i0 = wave * PL * 64 + lane;                             // this lane's band diagonal in plane 0 (plane c: + 64 c)
     const uint2* tab = (p.rrev[t.read] ? p.tabR : p.tabF) + p.hoff[t.hap] + t.off;
-    const uint2* rrow = (const uint2*)(p.rrecW + (size_t)t.read * p.rrec_stride) + (GENERIC ? 1 : 0);   // entry j (stride 2 uint2) = read position j - B
+    const uint32_t* rrow = p.rrecW + (size_t)t.read * p.rrec_stride;          // entry j = read position j - B: selector | base << 8 | quality << 24
     const uint32_t NUCW = (uint32_t)(int32_t)(int16_t)(p.nuc4 & 0xffffu);
-    uint32_t M1 = INF32, I1 = INF32, D1 = INF32, M2 = INF32, I2 = INF32, D2 = INF32;
+    uint32_t M1[PL], I1[PL], D1[PL], M2[PL], I2[PL], D2[PL];
+#pragma unroll
+    for (int c = 0; c < PL; ++c) M1[c] = I1[c] = D1[c] = M2[c] = I2[c] = D2[c] = INF32;
     uint32_t best = INF32, best_s = 0; bool have = false;
 
-    constexpr int CH = 8;
-    struct Chunk { uint2 e[CH]; uint2 r[CH]; };
-    // what iterations k0 .. k0 + 7 newly need: table entry x + 1 = k + i + 1 and read record t = k - i. Two running pointers per lane, the eight loads at
+    struct Chunk { uint2 e[PL][CH]; uint32_t r[PL][CH]; };
+    // what iterations k0 .. k0 + CH - 1 newly need: table entry x + 1 = k + i + 1 and read record t = k - i. Two running pointers per lane, the loads at
     // constant offsets (no address arithmetic per load). The last chunks run a few entries past the task's window: the tables carry slack for that
     // (upload) and those iterations feed no end cell.
-    const uint2* tab_next = tab + i + 1;
-    const uint2* rec_next = rrow + 2 * (size_t)((uint32_t)B - i);
-    auto fetch = [&]() -> Chunk {
-        Chunk ch;
+    const uint2* tab_next = tab + i0 + 1;
+    const uint32_t* rec_next = rrow + ((uint32_t)B - i0);
+    auto fetch = [&](Chunk& ch) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) { ch.e[u] = tab_next[u]; ch.r[u] = rec_next[2 * u]; }
-        tab_next += CH; rec_next += 2 * CH;
-        return ch;
+        for (int c = 0; c < PL; ++c) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { ch.e[c][u] = tab_next[64 * c + u]; ch.r[c][u] = (rec_next - 64 * c)[u]; }
+        }
+        tab_next += CH; rec_next += CH;
     };
-    auto cost = [&](const uint2 r2, const uint2 a, uint32_t& flag) -> uint32_t {       // update_match_state (:121-132), already shifted by the trace bits
+    auto cost = [&](const uint32_t rec, const uint2 a, uint32_t& flag) -> uint32_t {   // update_match_state (:121-132), already shifted by the trace bits
         if constexpr (GENERIC) {
+            const uint32_t rc = (rec >> 8) & 0x1ffu, q4 = (rec >> 24) << 2;
             const uint32_t h = a.x & 0xffu, m = (a.x >> 8) & 0xffu, p4 = ((a.x >> 16) & 0xffu) << 2, isn = a.x >> 24;
-            const uint32_t inner = r2.x == m ? p4 : r2.y;
-            uint32_t c = min_i32(r2.y, inner);
-            if (r2.x == h) c = 0;
-            flag = r2.x != h ? 0x8000u : 0u;
+            const uint32_t inner = rc == m ? p4 : q4;
+            uint32_t c = min_i32(q4, inner);
+            if (rc == h) c = 0;
+            flag = rc != h ? 0x8000u : 0u;
             return min_i32(c, isn ? 8u : INF32);
         } else {
-            const uint32_t cp = hw::perm(a.x, a.x, r2.x);                          // this read base's cap at this haplotype position (0xff: none)
-            const uint32_t c = cp < r2.y ? cp : r2.y;                              // min(quality, cap)
+            const uint32_t cp = hw::perm(a.x, a.x, rec) & 0xffu;                   // this read base's cap at this haplotype position (0xff: none); only selector byte 0 counts
+            const uint32_t q = rec >> 24;
+            const uint32_t c = cp < q ? cp : q;                                    // min(quality, cap): one sub-dword-select min
             flag = c ? 0x8000u : 0u;                                               // the walk charges exactly c inside a flank
             return c << 2;
         }
     };
-    auto post = [&](unsigned long long* box, uint32_t v, uint32_t k) { hw::lds_store_u64(box + (k & 3u), (unsigned long long)k << 32 | v); };
-    // every lane of the wave reads the one mailbox word (a broadcast) and re-reads it until it carries iteration k: the test is wave-uniform, no
-    // exec-mask round trip; the border lane then selects the value
-    auto take = [&](const unsigned long long* box, uint32_t k) -> uint32_t {
-        unsigned long long v = hw::lds_load_u64(box + (k & 3u));
-        while (hw::readfirstlane((uint32_t)(v >> 32)) != k) { hw::spin_pause(); v = hw::lds_load_u64(box + (k & 3u)); }
+    // Mailboxes (NW > 1). A post is one 64-bit LDS store by the border lane (a store by every lane into private sink words, to spare the exec-mask round trip,
+    // made the value visible later and cost the latency-bound traceback launch 5 %). A take is a broadcast read of the neighbour's mailbox by the whole wave,
+    // repeated until it carries iteration k - a wave-uniform test (waves without that neighbour compare under a zero mask and never wait) - after which the
+    // border lane selects the value.
+    const bool first_lane = wave > 0 && lane == 0, last_lane = wave + 1 < (uint32_t)NW && lane == 63;   // this lane's D / I neighbour lives in another wave
+    const unsigned long long* const take_up = &mbox_up[wave > 0 ? wave - 1 : 0][0];
+    const unsigned long long* const take_dn = &mbox_dn[wave + 1 < (uint32_t)NW ? wave + 1 : wave][0];
+    const uint32_t need_up = wave > 0 ? ~0u : 0u, need_dn = wave + 1 < (uint32_t)NW ? ~0u : 0u;
+    auto take = [&](const unsigned long long* box, uint32_t need, uint32_t k) -> uint32_t {
+        unsigned long long v = hw::lds_load_u64(box);
+        while (((hw::readfirstlane((uint32_t)(v >> 32)) ^ k) & need) != 0) { hw::spin_pause(); v = hw::lds_load_u64(box); }
         return (uint32_t)v;
     };
-    const bool first_lane = wave > 0 && lane == 0, last_lane = wave + 1 < (uint32_t)NW && lane == 63;   // this lane's D / I neighbour lives in another wave
     const uint32_t inf_lo = lane == 0 ? INF32 : 0u, inf_hi = lane == 63 ? INF32 : 0u;                   // infinity_ into the band's first / last diagonal
-    uint32_t* bpt = TRACE ? p.bp + (size_t)task * p.k_cap * C * 1024 + ((size_t)(i % C) * 64 + i / C) * 16 : nullptr;   // + tile * C * 1024 + (k & 15)
+    uint32_t* bpt[PL];                                                     // this lane's 16-word line of plane c in tile 0 (+ tile * C * 1024 + (k & 15))
+#pragma unroll
+    for (int c = 0; c < PL; ++c) { const uint32_t i = i0 + 64 * c; bpt[c] = TRACE ? p.bp + (size_t)task * p.k_cap * C * 1024 + ((size_t)(i % C) * 64 + i / C) * 16 : nullptr; }
 
-    uint2 cE = tab[i];                                                     // table entry of x = k + i
-    uint32_t GO = cE.y & 0xffffu, GE = cE.y >> 16;
-    Chunk nxt = fetch();
-    auto run_chunk = [&](uint32_t k0, auto init_c, auto cap_c) {
+    uint2 cE[PL]; uint32_t GO[PL], GE[PL];                                 // table entry of x = k + i per plane, its gap penalties unpacked
+#pragma unroll
+    for (int c = 0; c < PL; ++c) { cE[c] = tab[i0 + 64 * c]; GO[c] = cE[c].y & 0xffffu; GE[c] = cE[c].y >> 16; }
+    auto run_chunk = [&](uint32_t k0, const Chunk& cur, auto init_c, auto cap_c) __attribute__((always_inline)) {   // iterations k0 .. k0 + CH - 1 (k0 a multiple of CH); inlined at every call site: the state stays in registers
         constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value;
-        const Chunk cur = nxt;
-        if (k0 + CH < K8) nxt = fetch();
-        uint32_t bw[CH];
+        uint32_t bw[PL][CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const uint32_t k = k0 + (uint32_t)u;
-            const uint2 nE = cur.e[u], rr = cur.r[u];
-            const uint32_t GOn = nE.y & 0xffffu, GEn = nE.y >> 16;
-            if constexpr (INIT) { if (k == i) { M1 = NUL32; M2 = NUL32; } }                  // rolling initialiser
+            uint32_t x2[PL], dsh[PL], ish[PL], bpe[PL], GOn[PL], GEn[PL], fO[PL];
             // the D hand-down of this iteration needs nothing of it: first, so that the next wave finds it early
-            const uint32_t x2 = min_i32(M2, I2);
-            const uint32_t dsh = min_i32(D2 + GEn, x2 + GOn);                                 // :293
-            if (wave + 1 < (uint32_t)NW && lane == 63) post(mbox_up[wave], dsh, k);
-            uint32_t fE, fO;
-            const uint32_t m1 = min_i32(M1, min_i32(I1, D1));                                 // :284
-            if constexpr (CAP) { if (k == T + i && (int32_t)m1 < (int32_t)best) { best = m1; best_s = 2 * k; have = true; } }   // :285-291
-            M1 = m1 + cost(rr, cE, fE);                                                       // :292
-            I1 = min_i32(I2 + GE, M2 + GO) + NUCW;                                            // :295
-            uint32_t bpe = 0;
-            if constexpr (TRACE) { const uint32_t tm = M1 & 3u, ti = I1 & 3u; M1 ^= tm; I1 = (I1 & ~3u) | 1u; bpe = tm | ti << 2 | fE; }
-            const uint32_t ish = min_i32(I1 + GE, M1 + GO) + NUCW;                            // :318
-            if (wave > 0 && lane == 0) post(mbox_dn[wave], ish, k);
-            D1 = hw::dpp_wave_shr1_z(dsh) | inf_lo;                                           // :294 one diagonal up, infinity_ into diagonal 0
-            if (wave > 0) { const uint32_t v = take(mbox_up[wave - 1], k); D1 = first_lane ? v : D1; }
-            if constexpr (TRACE) { const uint32_t td = D1 & 3u; D1 |= 3u; bpe |= td << 4; }
-            const uint32_t m2 = min_i32(x2, D2);                                              // :308
-            if constexpr (CAP) { if (k == T + i && (int32_t)m2 < (int32_t)best) { best = m2; best_s = 2 * k + 1; have = true; } }
-            M2 = m2 + cost(rr, nE, fO);                                                       // :316
-            const uint32_t y1 = min_i32(M1, I1);
-            D2 = min_i32(D1 + GEn, y1 + GOn);                                                 // :317
-            I2 = hw::dpp_wave_shl1_z(ish) | inf_hi;                                           // :318-319 one diagonal down, infinity_ into the last one
-            if (wave + 1 < (uint32_t)NW) { const uint32_t v = take(mbox_dn[wave + 1], k); I2 = last_lane ? v : I2; }
-            if constexpr (TRACE) {
-                const uint32_t tm = M2 & 3u, ti = I2 & 3u, td = D2 & 3u;
-                M2 ^= tm; I2 = (I2 & ~3u) | 1u; D2 |= 3u;
-                bw[u] = bpe | (tm | ti << 2 | td << 4) << 6 | fO >> 1;
+#pragma unroll
+            for (int c = 0; c < PL; ++c) {
+                GOn[c] = cur.e[c][u].y & 0xffffu; GEn[c] = cur.e[c][u].y >> 16;
+                if constexpr (INIT) { if (k == i0 + 64 * c) { M1[c] = NUL32; M2[c] = NUL32; } }   // rolling initialiser
+                x2[c] = min_i32(M2[c], I2[c]);
+                dsh[c] = min_i32(D2[c] + GEn[c], x2[c] + GOn[c]);                             // :293
             }
-            cE = nE; GO = GOn; GE = GEn;
+            if constexpr (NW > 1) { if (last_lane) hw::lds_store_u64(&mbox_up[wave][u & 3], (unsigned long long)k << 32 | dsh[PL - 1]); }
+#pragma unroll
+            for (int c = 0; c < PL; ++c) {
+                uint32_t fE;
+                const uint32_t m1 = min_i32(M1[c], min_i32(I1[c], D1[c]));                    // :284
+                if constexpr (CAP) { if (k == T + i0 + 64 * c && (int32_t)m1 < (int32_t)best) { best = m1; best_s = 2 * k; have = true; } }   // :285-291
+                M1[c] = m1 + cost(cur.r[c][u], cE[c], fE);                                    // :292
+                I1[c] = min_i32(I2[c] + GE[c], M2[c] + GO[c]) + NUCW;                         // :295
+                bpe[c] = 0;
+                if constexpr (TRACE) { const uint32_t tm = M1[c] & 3u, ti = I1[c] & 3u; M1[c] ^= tm; I1[c] = (I1[c] & ~3u) | 1u; bpe[c] = tm | ti << 2 | fE; }
+                ish[c] = min_i32(I1[c] + GE[c], M1[c] + GO[c]) + NUCW;                        // :318
+            }
+            if constexpr (NW > 1) { if (first_lane) hw::lds_store_u64(&mbox_dn[wave][u & 3], (unsigned long long)k << 32 | ish[0]); }
+            // :294 one diagonal up: inside a plane a DPP shift; lane 0 takes lane 63 of the plane below (a DPP rotate of it is the fill of the shift), the
+            // wave's first plane the neighbour wave's mailbox, the band's first diagonal infinity_
+            D1[0] = hw::dpp_wave_shr1_z(dsh[0]) | inf_lo;
+            if constexpr (NW > 1) { const uint32_t v = take(take_up + (u & 3), need_up, k); D1[0] = first_lane ? v : D1[0]; }
+#pragma unroll
+            for (int c = 1; c < PL; ++c) D1[c] = hw::dpp_wave_shr1(hw::dpp_wave_ror1(dsh[c - 1]), dsh[c]);
+#pragma unroll
+            for (int c = 0; c < PL; ++c) {
+                if constexpr (TRACE) { const uint32_t td = D1[c] & 3u; D1[c] |= 3u; bpe[c] |= td << 4; }
+                const uint32_t m2 = min_i32(x2[c], D2[c]);                                    // :308
+                if constexpr (CAP) { if (k == T + i0 + 64 * c && (int32_t)m2 < (int32_t)best) { best = m2; best_s = 2 * k + 1; have = true; } }
+                M2[c] = m2 + cost(cur.r[c][u], cur.e[c][u], fO[c]);                           // :316
+                const uint32_t y1 = min_i32(M1[c], I1[c]);
+                D2[c] = min_i32(D1[c] + GEn[c], y1 + GOn[c]);                                 // :317
+            }
+            // :318-319 one diagonal down, the mirror image
+            I2[PL - 1] = hw::dpp_wave_shl1_z(ish[PL - 1]) | inf_hi;
+            if constexpr (NW > 1) { const uint32_t v = take(take_dn + (u & 3), need_dn, k); I2[PL - 1] = last_lane ? v : I2[PL - 1]; }
+#pragma unroll
+            for (int c = 0; c + 1 < PL; ++c) I2[c] = hw::dpp_wave_shl1(hw::dpp_wave_rol1(ish[c + 1]), ish[c]);
+#pragma unroll
+            for (int c = 0; c < PL; ++c) {
+                if constexpr (TRACE) {
+                    const uint32_t tm = M2[c] & 3u, ti = I2[c] & 3u, td = D2[c] & 3u;
+                    M2[c] ^= tm; I2[c] = (I2[c] & ~3u) | 1u; D2[c] |= 3u;
+                    bw[c][u] = bpe[c] | (tm | ti << 2 | td << 4) << 6 | fO[c] >> 1;
+                }
+                cE[c] = cur.e[c][u]; GO[c] = GOn[c]; GE[c] = GEn[c];
+            }
         }
-        if constexpr (TRACE) {                                                               // this lane's eight words of the tile: half of its 64-byte line
-            uint4* dst = (uint4*)(bpt + (size_t)(k0 >> 4) * C * 1024 + (k0 & 15u));
-            dst[0] = make_uint4(bw[0], bw[1], bw[2], bw[3]); dst[1] = make_uint4(bw[4], bw[5], bw[6], bw[7]);
+        if constexpr (TRACE) {                                                               // this lane's CH words of the tile per plane: a piece of its 64-byte line
+#pragma unroll
+            for (int c = 0; c < PL; ++c) {
+                uint4* dst = (uint4*)(bpt[c] + (size_t)(k0 >> 4) * C * 1024 + (k0 & 15u));
+                dst[0] = make_uint4(bw[c][0], bw[c][1], bw[c][2], bw[c][3]);
+                if constexpr (CH == 8) dst[1] = make_uint4(bw[c][4], bw[c][5], bw[c][6], bw[c][7]);
+            }
         }
     };
-    const uint32_t t_lo = (T & ~7u) > (uint32_t)B ? (T & ~7u) : (uint32_t)B;         // no end cell before iteration T
+    // two operand chunks, used in turn: the one not being consumed is in flight (no register copies between them)
+    Chunk ca, cb;
+    fetch(ca);
+    bool flip = false;
+    auto advance = [&](uint32_t k0, auto init_c, auto cap_c) __attribute__((always_inline)) {
+        const bool more = k0 + CH < KC;
+        if (!flip) { if (more) fetch(cb); run_chunk(k0, ca, init_c, cap_c); }
+        else       { if (more) fetch(ca); run_chunk(k0, cb, init_c, cap_c); }
+        flip = !flip;
+    };
+    const uint32_t t_lo = (T / CH * CH) > (uint32_t)B ? (T / CH * CH) : (uint32_t)B;         // no end cell before iteration T
     uint32_t k = 0;
-    if (T < (uint32_t)B) { for (; k < (uint32_t)B; k += CH) run_chunk(k, BoolC<true>{}, BoolC<true>{}); }
-    for (; k < (uint32_t)B; k += CH) run_chunk(k, BoolC<true>{}, BoolC<false>{});
-    for (; k < t_lo; k += CH) run_chunk(k, BoolC<false>{}, BoolC<false>{});
-    for (; k < K8; k += CH) run_chunk(k, BoolC<false>{}, BoolC<true>{});
+    if (T < (uint32_t)B) { for (; k < (uint32_t)B; k += CH) advance(k, BoolC<true>{}, BoolC<true>{}); }
+    for (; k < (uint32_t)B; k += CH) advance(k, BoolC<true>{}, BoolC<false>{});
+    for (; k < t_lo; k += CH) advance(k, BoolC<false>{}, BoolC<false>{});
+    for (; k < KC; k += CH) advance(k, BoolC<false>{}, BoolC<true>{});
 
-    // first minimum over the end cells: per lane the candidates came in increasing diagonal order (strict < kept the first); lanes, then waves
+    // first minimum over the end cells: per lane the candidates came in increasing diagonal order WITHIN a plane; across planes, lanes and waves by (value, diagonal index)
     uint32_t kv = have ? (best ^ 0x80000000u) : 0xffffffffu, ks = have ? best_s : 0xffffffffu;
     for (int m = 1; m < 64; m <<= 1) {
         const uint32_t ov = hw::shfl_xor(kv, m), os = hw::shfl_xor(ks, m);
         if (ov < kv || (ov == kv && os < ks)) { kv = ov; ks = os; }
     }
-    if (lane == 0) { red_v[wave] = kv; red_s[wave] = ks; }
-    hw::block_sync();
+    if constexpr (NW > 1) {
+        if (lane == 0) { red_v[wave] = kv; red_s[wave] = ks; }
+        hw::block_sync();
+    }
     if (tid == 0) {
         for (int w = 1; w < NW; ++w) { const uint32_t ov = red_v[w], os = red_s[w]; if (ov < kv || (ov == kv && os < ks)) { kv = ov; ks = os; } }
         const bool none = kv == 0xffffffffu;                                                  // no end cell below infinity_: minscore stays infinity_, minscoreidx -1 (:269-270)
@@ -2294,50 +2346,59 @@ OCT_MAX_THREADS(64) OCT_KERNEL(k_walk_long)(WalkParams w)
         return bpg[(((size_t)(k >> 4) * C + (uint32_t)li % C) * 64 + (uint32_t)li / C) * 16 + (k & 15)];
     };
     if (ok) {                                                                                   // the first move only reads the end cell's own label (:191-192)
-        const uint32_t wv = word_from_memory((int64_t)sidx * B + i);
+        const uint32_t wv = hw::readfirstlane(word_from_memory((int64_t)sidx * B + i));
         state = (wv >> (6 * ((uint32_t)sidx & 1u))) & 3u;
         sidx -= 2;
     }
     // staging: lane l fetches the line of band lane base + l of tile kt (four 16-byte loads), later parks it in one of the two LDS buffers
-    struct Lines { uint4 q[4]; int32_t base; };
-    auto request = [&](int32_t kt) -> Lines {
-        Lines r;
-        r.base = i - 32 < 0 ? 0 : (i - 32 > B - 64 ? B - 64 : i - 32);
-        const uint32_t li = (uint32_t)r.base + lane;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0; int32_t q_base = 0;      // the requested line and the band lane the request started at
+    auto request = [&](int32_t kt) __attribute__((always_inline)) {
+        q_base = i - 32 < 0 ? 0 : (i - 32 > B - 64 ? B - 64 : i - 32);
+        const uint32_t li = (uint32_t)q_base + lane;
         const uint4* l = (const uint4*)(bpg + (((size_t)kt * C + li % C) * 64 + li / C) * 16);
-        r.q[0] = l[0]; r.q[1] = l[1]; r.q[2] = l[2]; r.q[3] = l[3];
-        return r;
+        q0 = l[0]; q1 = l[1]; q2 = l[2]; q3 = l[3];
     };
-    auto park = [&](const Lines& r, uint32_t buf) {
+    auto park = [&](uint32_t buf) __attribute__((always_inline)) {
         uint4* dst = (uint4*)(tbuf + buf * 1024 + lane * 16);
-        dst[0] = r.q[0]; dst[1] = r.q[1]; dst[2] = r.q[2]; dst[3] = r.q[3];
+        dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
     };
-    const int32_t kt_top = (ok && sidx >= 0) ? (sidx >> 1) >> 4 : -1;
-    uint32_t cur = 0; int32_t base_cur = 0;
-    if (kt_top >= 0) { const Lines r = request(kt_top); park(r, 0); base_cur = r.base; }
+    // One step per loop iteration (no sweep over iterations that hold no step): the walk's own position names the tile it needs; when that changes - always to the
+    // tile below - the lines requested a tile ago are parked and the next request goes out.
+    uint32_t cur = 0; int32_t base_cur = 0, kt_cur = (ok && sidx >= 0) ? (sidx >> 1) >> 4 : -1;
+    if (kt_cur >= 0) { request(kt_cur); park(0); base_cur = q_base; if (kt_cur > 0) request(kt_cur - 1); }
     hw::wave_lds_fence();
-    for (int32_t kt = kt_top; kt >= 0 && !fin; --kt) {
-        Lines nxt; nxt.base = 0;
-        if (kt > 0) nxt = request(kt - 1);                                                      // in flight while this tile is walked
-        const uint32_t* tile = tbuf + cur * 1024;
-        for (int32_t kk = 15; kk >= 0 && !fin; --kk) {
-            const int32_t k = kt * 16 + kk;
-            for (int rep = 0; rep < 2 && !fin && (sidx >> 1) == k; ++rep) {                      // an insertion/deletion can add a second step at the same k
-                uint32_t wv;
-                const int32_t rel = i - base_cur;
-                if (rel >= 0 && rel < 64 && i < B) wv = tile[rel * 16 + kk];
-                else if (i < 0) { ok = false; fin = true; break; }                              // :195-199
-                else {
-                    const int64_t f = (int64_t)sidx * B + i;                                    // i >= B: the reference indexes its array flat (lane overflow reads the next diagonal)
-                    if (f >= n_flat) { ok = false; fin = true; break; }
-                    wv = word_from_memory(f);
-                }
-                step(wv);
-            }
+    while (!fin) {
+        if (sidx < 0) { ok = false; break; }                                                    // ran off the first diagonal with target bases left (:195-199)
+        const int32_t k = sidx >> 1, kt = k >> 4;
+        if (kt != kt_cur) {                                                                     // (kt == kt_cur - 1: a step lowers sidx by at most 2)
+            hw::wave_lds_fence(); park(cur ^ 1u); base_cur = q_base; cur ^= 1u; kt_cur = kt; hw::wave_lds_fence();
+            if (kt > 0) request(kt - 1);                                                        // in flight while this tile is walked
         }
-        if (kt > 0) { hw::wave_lds_fence(); park(nxt, cur ^ 1u); base_cur = nxt.base; cur ^= 1u; hw::wave_lds_fence(); }
+        uint32_t wv;
+        const int32_t rel = i - base_cur;
+        if (state == 0 && rel >= 0 && rel < 64 && i < B) {
+            // A run of match columns walks straight down ONE band lane at ONE diagonal parity: its backpointer words are the words kk, kk - 1, ... 0 of the
+            // staged line. Lanes 0 .. kk look at one word each; up to the first whose M label is not "match" (or to the line's end) the steps only count
+            // down - sidx by 2, x and y by 1 each - as long as none of them lies inside a flank and the read does not end among them. Long reads spend
+            // nearly all of their ~10^4 columns in such runs: the walk then costs a few iterations per tile instead of sixteen.
+            const int32_t kk = k & 15;
+            const uint32_t par = (uint32_t)sidx & 1u;
+            const uint32_t mine = tbuf[cur * 1024 + (uint32_t)rel * 16 + (lane & 15u)];
+            const unsigned long long turns = hw::ballot((int32_t)lane <= kk && ((mine >> (6 * par)) & 3u) != 0u) & 0xffffull;
+            int32_t n = turns ? kk - (63 - (int32_t)__builtin_clzll(turns)) : kk + 1;               // match steps before the first other label, walking down from kk
+            if (want_flank) { const int32_t room_r = x <= rhs_begin ? n : 0, room_l = x - lhs; n = n < room_r ? n : room_r; n = n < room_l ? n : room_l; }   // x - 1 .. x - n outside both flanks
+            n = n < y - 1 ? n : y - 1;                                                              // (the step that consumes the last read base takes the plain path)
+            if (n > 0) { sidx -= 2 * n; x -= n; y -= n; continue; }
+        }
+        if (rel >= 0 && rel < 64 && i < B) wv = hw::readfirstlane(tbuf[cur * 1024 + (uint32_t)rel * 16 + ((uint32_t)k & 15u)]);
+        else if (i < 0) { ok = false; break; }                                                  // :195-199
+        else {
+            const int64_t f = (int64_t)sidx * B + i;                                            // i >= B: the reference indexes its array flat (lane overflow reads the next diagonal)
+            if (f >= n_flat) { ok = false; break; }
+            wv = hw::readfirstlane(word_from_memory(f));                                        // (waited for inside this branch: the lines in flight are not)
+        }
+        step(wv);               // the same word in every lane, and the compiler knows it: the walker's state lives in scalar registers
     }
-    if (!fin) ok = false;                                                                       // ran off the first diagonal with target bases left (:195-199)
     const int32_t first_pos = ok ? x : -1;
     if (ok) {                                                                                   // the queued events, priced by all lanes together
         hw::wave_lds_fence();

@@ -122,6 +122,8 @@ inline uint32_t dpp_wave_shl1_z(uint32_t v);
 inline uint32_t dpp_wave_shr1(uint32_t fill, uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return l == 0 ? -1 : (int)l - 1; }, fill); }
 inline uint32_t dpp_wave_shl1(uint32_t fill, uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return l == 63 ? -1 : (int)l + 1; }, fill); }
 inline uint32_t dpp_wave_shr1_z(uint32_t v) { return dpp_wave_shr1(0u, v); }
+inline uint32_t dpp_wave_ror1(uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return (int)((l + 63) & 63); }, 0u); }
+inline uint32_t dpp_wave_rol1(uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return (int)((l + 1) & 63); }, 0u); }
 inline uint32_t dpp_wave_shl1_z(uint32_t v) { return dpp_wave_shl1(0u, v); }
 
 inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
@@ -134,7 +136,7 @@ inline uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
         if (s < 8) byte = (uint32_t)(src >> (8 * s)) & 0xff;
         else if (s == 0x0c) byte = 0;
         else if (s > 0x0c) byte = 0xff;
-        else { fprintf(stderr, "hipsim: v_perm_b32 selector %u not modelled\n", s); abort(); }
+        else byte = ((src >> (8 * (2 * (s - 8) + 1) + 7)) & 1) ? 0xffu : 0u;      // 8..11: sign of source byte 1, 3, 5, 7
         r |= byte << (8 * n);
     }
     return r;

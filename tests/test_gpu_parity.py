@@ -268,6 +268,11 @@ def test_gpu_multi_wave_kernel_fast_cost_and_one_wave_form(band, n, monkeypatch)
     check_l1.check_random("gpu", band, n, seed=510 + band, t_lo=30, t_hi=700, with_n=True, score_bits=32)
     check_l1.check_random("gpu", band, n // 2, seed=520 + band, t_lo=200, t_hi=900, q_max=125, junk=True, with_n=False, score_bits=32)   # walks that wander over the band
     cp.check_wide_and_long("gpu", TOL)
+    monkeypatch.setenv("OCT_PHMM_MW_PLANES", "1")         # all planes of a task in one wave (what a launch of >= 640 tasks takes)
+    check_l1.check_random("gpu", band, n, seed=530 + band, t_lo=30, t_hi=700, with_n=False, score_bits=32)
+    check_l1.check_random("gpu", band, n, seed=540 + band, t_lo=30, t_hi=700, with_n=True, score_bits=32)
+    cp.check_wide_and_long("gpu", TOL)
+    monkeypatch.delenv("OCT_PHMM_MW_PLANES")
     monkeypatch.setenv("OCT_PHMM_MULTI_WAVE", "0")
     monkeypatch.setenv("OCT_PHMM_WALK_STAGE", "0")        # ... and the lockstep walker instead of k_walk_long
     check_l1.check_random("gpu", band, n // 2, seed=600 + band, t_lo=40, t_hi=400, with_n=True, score_bits=32)

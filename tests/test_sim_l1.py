@@ -58,6 +58,10 @@ def test_sim_multi_wave_kernel_fast_cost_and_one_wave_form(band, n, monkeypatch)
     take its fast-cost form. OCT_PHMM_MULTI_WAVE=0 keeps the one-wave-per-task kernel (k_dp_wide) covered."""
     check_l1.check_random("sim", band, n, seed=500 + band, t_lo=30, t_hi=300, with_n=False, score_bits=32)
     check_l1.check_random("sim", band, 2, seed=520 + band, t_lo=200, t_hi=330, q_max=125, junk=True, with_n=False, score_bits=32)   # unrelated sequences: walks that wander over the band
+    monkeypatch.setenv("OCT_PHMM_MW_PLANES", "1")         # all planes of a task in one wave (what a launch of >= 640 tasks takes)
+    check_l1.check_random("sim", band, n, seed=530 + band, t_lo=30, t_hi=300, with_n=False, score_bits=32)
+    check_l1.check_random("sim", band, 2, seed=540 + band, t_lo=40, t_hi=200, with_n=True, score_bits=32)
+    monkeypatch.delenv("OCT_PHMM_MW_PLANES")
     monkeypatch.setenv("OCT_PHMM_MULTI_WAVE", "0")
     monkeypatch.setenv("OCT_PHMM_WALK_STAGE", "0")        # ... and the lockstep walker instead of k_walk_long
     check_l1.check_random("sim", band, 2, seed=600 + band, t_lo=40, t_hi=200, with_n=True, score_bits=32)
