@@ -4,10 +4,10 @@ classification + scalar fast path, banded pair-HMM DP with and without traceback
 one synthetic batch that is already resident in HBM.
 
 Workload at N=1: BASELINE.json configs[2] — 100k Illumina-like 150 bp reads x 128 300 bp haplotypes, band 16, int16 lanes,
-flank state 40/40 (the largest single-GPU short-read configuration). N>1: one process per GPU, each with its own region of the
-same shape (weak scaling, no collective: regions are independent), value = sum over ranks / max-over-ranks time.
-`--workload stream` is BASELINE configs[3]: ONE fixed stream of --regions synthetic active regions, region i on rank i mod N
-(strong scaling, no collective).
+flank state 40/40 (the largest single-GPU short-read configuration). N>1: BASELINE configs[3], the split north_star names — ONE fixed
+stream of --regions synthetic active regions (default 50,000), region i on rank i mod N, one process per GPU, no
+collective (strong scaling; value = the whole stream's cells / max-over-ranks time). `--workload 100kx128` at N>1 keeps the weak-scaling
+mode (every rank its own 100k x 128 region); `--workload stream` at N=1 runs the stream on one GPU.
 
 After the timed region rank 0 (i) verifies the matrix the timed loop produced against the reference's own populate on a 5 % sample
 of its rows, (ii) re-runs the batch single-slice with HIP events for the roofline block, (iii) at N=1 adds the PCIe-inclusive
@@ -32,9 +32,11 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU issue peak per MI355X_MICROARCH.md (SIMD-32: a wave64 VALU instruction issues in 2 cycles): 256 CU x 4 SIMD x 2.4 GHz / 2
 VALU_PEAK_2CYCLE = 256 * 4 * 2.4e9 / 2
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
-# Measured issue cost per wave64 instruction on one SIMD in cycles of the nominal 2.4 GHz clock (profiles/r01_step16_valu_issue_rates.log):
-# v_add_u32 / v_and / v_or / v_mov 2.6 ("cheap"), everything packed, VOP3, DPP, perm, min 4.4 ("dear").
-CHEAP_CYCLES, DEAR_CYCLES = 2.6, 4.4
+# Measured issue cost per wave64 instruction on one SIMD in SHADER cycles (tools/valu_ubench.hip with one 1024-thread workgroup pinned per CU, i.e.
+# exactly four waves per SIMD for the whole kernel; s_memtime against the wall clock; profiles/r03_valu_issue_rates.log): plain VOP2 adds / logic / moves
+# 2.40 ("cheap"), everything packed, VOP3, DPP, perm, min / max, shifts 4.25 ("dear"). (Rounds 1-2 quoted 2.6 / 4.4 "nominal 2.4 GHz cycles" from a
+# grid that was not spread evenly over the CUs.)
+CHEAP_CYCLES, DEAR_CYCLES = 2.40, 4.25
 # Fallback instruction budget (main-loop ISA count of the shipped build, VALU wave-instructions per DP iteration per wave = 8 tasks at
 # B = 16, and the share of cheap ones) for when no committed counter summary matches the kernels being timed.
 VALU_PER_ITER = {"score": 29.25, "trace": 51.75}
@@ -180,6 +182,70 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12):
+    """What a caller gets who hands over HOST buffers: (i) one oct_phmm_populate of the many-region batch, PCIe both ways; (ii) the same batch
+    over and over from two host threads with a handle each - while one handle's batch computes, the other's next batch is validated, packed, copied up and
+    its results stream back - the sustained rate over n_batches consecutive batches. Every result is compared with the resident run's matrix (which is
+    verified against the reference's own populate on a sample of regions)."""
+    import threading
+    from octopus_amd import engine
+    out = np.empty(batch.out_size())
+    eng.populate(batch, out=out)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.populate(batch, out=out)
+    one = (time.perf_counter() - t0) / 3
+    same = bool(np.array_equal(out, resident))
+    eng2 = engine.Engine(cfg)
+    outs = [out, np.empty(batch.out_size())]
+    engs = [eng, eng2]
+    eng2.populate(batch, out=outs[1])                       # warm the second handle's pools
+    done = [0, 0]
+
+    def work(t):
+        for _ in range(n_batches // 2):
+            engs[t].populate(batch, out=outs[t]); done[t] += 1
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    t0 = time.perf_counter()
+    [t.start() for t in ths]; [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    same = same and bool(np.array_equal(outs[0], resident)) and bool(np.array_equal(outs[1], resident))
+    eng2.close()
+    n = done[0] + done[1]
+    return {"e2e_ms_from_host": one * 1e3, "e2e_regions_per_s": n_regions / one,
+            "e2e_pipelined_regions_per_s": n * n_regions / dt, "e2e_pipelined_ms_per_batch": dt / n * 1e3, "e2e_pipelined_batches": n,
+            "e2e_pipelined_how": "two host threads, one handle each, oct_phmm_populate from host buffers back to back",
+            "e2e_results_equal_resident_run": same}
+
+
+def region_call_legs():
+    """The reference's calling pattern (one populate per active region from each region-task thread, caller.cpp:1159-1196) through the C ABI, without an
+    interpreter in the way: tools/region_calls_bench (built by __graft_entry__.build()) makes 1,000 regions of 300 reads x 24 haplotypes and issues
+    one call per region (i) from one thread on one handle, (ii) from 16 threads through the region server; the server's answers are compared with plain calls."""
+    import subprocess
+    exe = ROOT / "tools" / "region_calls_bench"
+    if not exe.exists():
+        return {"region_calls": {"error": "tools/region_calls_bench is not built (python -c 'import __graft_entry__ as g; g.build()')"}}
+    try:
+        r = subprocess.run([str(exe), "1000", "300", "24", "1", "16"], capture_output=True, text=True, timeout=300)
+    except Exception as e:      # noqa: BLE001
+        return {"region_calls": {"error": repr(e)}}
+    rows = []
+    for line in r.stdout.splitlines():
+        try:
+            rows.append(json.loads(line))
+        except ValueError:
+            pass
+    pick = lambda mode, th: next((x for x in rows if x.get("mode") == mode and x.get("threads") == th), {})
+    check = next((x for x in rows if x.get("mode") == "server vs plain calls"), {})
+    one, srv16, srv1, h16 = pick("handle per thread", 1), pick("server", 16), pick("server", 1), pick("handle per thread", 16)
+    legs = {"region_call_ms": one.get("ms_per_call"), "region_server_regions_per_s": srv16.get("regions_per_s"),
+            "region_calls": {"regions": "1,000 synthetic active regions of 300 reads x 24 haplotypes (150 bp x 300 bp, flank 40/40), one oct_phmm call per region from host buffers",
+                             "one_thread_one_handle": one, "server_1_caller": srv1, "server_16_callers": srv16, "handle_per_thread_16": h16,
+                             "server_answers_equal_plain_calls": check, "rc": r.returncode}}
+    return legs
+
+
 def timed_resident(rb, steps: int, warmup: int = 1):
     for _ in range(warmup):
         rb.run(); rb.wait()
@@ -194,9 +260,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="100kx128")
+    ap.add_argument("--workload", default=None, help="100kx128 (default at --gpus 1) or stream (default at --gpus N > 1)")
     ap.add_argument("--band", type=int, default=16)
-    ap.add_argument("--regions", type=int, default=2000, help="--workload stream: regions of the ONE stream that is sharded over the ranks (BASELINE configs[3] stand-in)")
+    ap.add_argument("--regions", type=int, default=None, help="--workload stream: regions of the ONE stream that is sharded over the ranks (BASELINE configs[3]; "
+                                                              "default 50000 at N > 1 = SURVEY.md 8d config 4, 2000 on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the 1k x 64 latency leg (for rocprof runs: keeps every k_dp launch full-size)")
     ap.add_argument("--stream-cap", type=int, nargs=2, default=None, metavar=("READS", "HAPS"), help="test hook: cap every stream region's size (simulator runs)")
@@ -206,6 +273,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.workload is None:
+        args.workload = "stream" if world > 1 else "100kx128"
+    if args.regions is None:
+        args.regions = 50000 if (world > 1 and args.workload == "stream") else 2000
     # OCT_BENCH_BACKEND=sim: test hook of the CPU suite (tests/test_bench_gloo.py) - the same launch, barrier and reduction logic on two gloo
     # ranks with the library's wave simulator in place of the GPU; never a measurement
     sim = os.environ.get("OCT_BENCH_BACKEND") == "sim"
@@ -234,7 +305,8 @@ def main():
         eng = engine.Engine(cfg)                  # fails loudly if liboct_phmm.so / a gfx950 device is missing
     stream = args.workload == "stream"
     if stream:        # configs[3]: ONE stream of independent active regions, region i -> rank i mod N, one flat batch per rank per step
-        regions = synth.region_stream_shard(seed=42, n_regions=args.regions, rank=rank, world=world, B=B, positions="none", cap=args.stream_cap)
+        regions = synth.region_stream_shard(seed=42, n_regions=args.regions, rank=rank, world=world, B=B, positions="none", cap=args.stream_cap,
+                                            workers=max(1, min(8, (os.cpu_count() or 1) // max(world, 1))))
     else:             # candidate positions come from the device k-mer mapper
         regions = [synth.config_region(args.workload, seed=42 + rank, B=B, positions="none")]
     batch = synth.batch_from_regions(regions)
@@ -264,8 +336,13 @@ def main():
     n_trace_run = stats["n_dp_traceback"] - stats.get("n_dp_traceback_shared", 0)
     n_tasks = n_score_run + n_trace_run
     n_regions_all = len(regions)
+    rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         import torch
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -289,10 +366,27 @@ def main():
         del os.environ["OCT_PHMM_SLICES"]
         rb1.run(); rb1.wait()
         kind_ms = {k: [0.0, 0] for k in ("score_fast", "trace_fast", "score_generic", "trace_generic")}
+        # the shader clock while these very launches run: a one-wave probe on its own stream (oct_phmm_probe_clock), 4 ms windows, from a second thread
+        clock_samples, probing = [], [True]
+
+        def probe():
+            while probing[0]:
+                try:
+                    clock_samples.append(eng.probe_clock(4.0))
+                except Exception:      # the simulator backend has no clock
+                    return
+        import threading
+        prober = threading.Thread(target=probe)
+        if not sim:
+            prober.start()
         for _ in range(3):
             rb1.run(); rb1.wait()
             for k, (ms, n) in rb1.kernel_time_by_kind().items():
                 kind_ms[k][0] += ms; kind_ms[k][1] += n
+        probing[0] = False
+        if not sim:
+            prober.join()
+        measured_ghz = float(np.median(clock_samples)) if clock_samples else None
         rb1.free()
         eng.set_timing(False)
         tr_ms, tr_n = kind_ms["trace_fast"]
@@ -321,6 +415,8 @@ def main():
         valu_instr = instr["score"] + instr["trace"]
         issue_cycles = instr["score"] * issue_cycles_per_instr("score") + instr["trace"] * issue_cycles_per_instr("trace")
         instr_rate = valu_instr / dp_s_per_step if dp_s_per_step > 0 else 0.0
+        clock_hz = (measured_ghz or 2.4) * 1e9
+        peak_at_clock = 256 * 4 * clock_hz / 2            # the 2-cycle issue peak at the clock the DP launches were measured at
         out = {
             "metric": "pair-HMM band cell-updates/s", "value": cells / per_step / 1e9, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
@@ -335,7 +431,8 @@ def main():
             "gcups_reference_work": cells_ref / per_step / 1e9,
             "value_note": ("value counts the band cells the DP kernels updated; gcups_reference_work also counts the cells of pairs that share another "
                            "pair's result (stats *_shared: same read, candidates equal byte for byte), which the reference computes again"),
-            **({"regions_per_s": n_regions_all / per_step} if stream else {}),
+            **({"regions_per_s": n_regions_all / per_step, "regions_per_step": n_regions_all} if stream else {}),
+            "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
             "stats": stats,
             **verified,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -350,12 +447,17 @@ def main():
                          "score_only_kernel_avg_launch_ms": (sc_ms / max(sc_n, 1)),
                          "valu": {"achieved_wave_instr_per_s": instr_rate,
                                   "peak_wave_instr_per_s": VALU_PEAK_2CYCLE, "frac": instr_rate / VALU_PEAK_2CYCLE,
-                                  "issue_weighted_frac": (issue_cycles / SIMD_CYCLES_PER_S / dp_s_per_step) if dp_s_per_step > 0 else 0.0,
+                                  "measured_clock_ghz": measured_ghz, "clock_samples": len(clock_samples),
+                                  "frac_at_measured_clock": instr_rate / peak_at_clock,
+                                  "issue_weighted_frac": (issue_cycles / (256 * 4 * clock_hz) / dp_s_per_step) if dp_s_per_step > 0 else 0.0,
                                   "note": "the DP is integer-VALU issue bound, not HBM bound (SURVEY.md 8d). frac = " + valu_src + " / DP kernel time vs the "
-                                          "2-cycle issue peak of MI355X_MICROARCH.md (256 CU x 4 SIMD x 2.4 GHz / 2): this instruction mix (packed int16, "
-                                          "min, perm, DPP = 4.4 measured cycles, plain 32-bit add/and/or/mov 2.6, profiles/r01_step16_valu_issue_rates.log) cannot "
-                                          "exceed ~0.55 of it; issue_weighted_frac prices every instruction at its measured cost = the share of DP kernel time "
-                                          "the instruction stream itself accounts for (the rest: staging latency, reductions, tile flushes, tails)"}},
+                                          "2-cycle issue peak of MI355X_MICROARCH.md at the nominal 2.4 GHz (256 CU x 4 SIMD x 2.4 GHz / 2); frac_at_measured_clock "
+                                          "uses the shader clock sampled while these launches ran (oct_phmm_probe_clock: s_memtime against the reference clock, "
+                                          "one wave on its own stream). Per instruction the SIMD needs 2.40 shader cycles for plain VOP2 add / logic / mov and 4.25 "
+                                          "for packed int16, min / max, perm, DPP and every VOP3 (tools/valu_ubench.hip, four waves pinned per SIMD, "
+                                          "profiles/r03_valu_issue_rates.log) - not the guide's 2 -, so this mix cannot exceed ~0.55 of the 2-cycle peak; "
+                                          "issue_weighted_frac prices every instruction at its measured cost = the share of DP kernel time the instruction "
+                                          "stream itself accounts for (the rest: staging latency, reductions, tile flushes, tails)"}},
         }
         if world == 1 and extras and not sim:
             # PCIe-inclusive: one oct_phmm_populate of the same batch from host buffers (H2D, table build, run, results streamed back)
@@ -370,14 +472,17 @@ def main():
             if not stream:
                 # configs[3]: the 2,000-region stream in one flat batch (resident), verified like the main batch
                 sregs = synth.region_stream_shard(seed=42, n_regions=args.regions, B=B, positions="none")
-                sb = eng.upload(synth.batch_from_regions(sregs))
+                sbatch = synth.batch_from_regions(sregs)
+                sb = eng.upload(sbatch)
                 dt = timed_resident(sb, 5)
                 ss = sb.stats()
-                sv = verify_against_reference(sb.download(), sregs, B, frac=0.05)
+                resident = sb.download().copy()
+                sv = verify_against_reference(resident, sregs, B, frac=0.05)
                 sb.free()
                 out["stream"] = {"ms": dt * 1e3, "regions": len(sregs), "regions_per_s": len(sregs) / dt, "gcups": (ss["band_cells"] - ss.get("band_cells_shared", 0)) / dt / 1e9,
                                  "gcups_reference_work": ss["band_cells"] / dt / 1e9, "pairs_shared": ss.get("n_pairs_shared", 0),
                                  "loglik_per_s": ss["n_pairs"] / dt, "verified_rows": sv["verified_rows"], "verified_max_abs_diff": sv["verified_max_abs_diff"]}
+                out["stream"].update(stream_from_host(eng, cfg, sbatch, resident, len(sregs)))
                 # configs[4]: 64 x 10 kb reads, 8 x 20 kb haplotypes, band 256, int32 lanes (streaming DP kernels, traceback in HBM)
                 lcfg = abi.Config.default(max_indel_error=256, use_int_scores=1, device_id=local_rank)
                 leng = engine.Engine(lcfg)
@@ -388,6 +493,8 @@ def main():
                 lb.free(); leng.close()
                 out["long_read"] = {"ms": dt * 1e3, "gcups": ls["band_cells"] / dt / 1e9, "dtype": "int32", "band": 256,
                                     "workload": "long64x8: 64 x 10 kb reads x 8 x 20 kb haplotypes (BASELINE configs[4])", "dp_tasks": ls["n_dp_score_only"] + ls["n_dp_traceback"]}
+        if world == 1 and extras and not sim:
+            out.update(region_call_legs())
         if world == 1 and not args.no_small_batch:
             small = eng.upload(synth.config_batch("1kx64", seed=42, B=B, positions="none"))
             for _ in range(3):

@@ -99,6 +99,10 @@ typedef struct oct_phmm_haplotypes {
     const int8_t*   snv_prior_fwd;    /* haplotype_snv_forward_priors_, each in [0,127] */
     const char*     snv_mask_rev;     /* haplotype_snv_reverse_mask_ */
     const int8_t*   snv_prior_rev;    /* haplotype_snv_reverse_priors_ */
+    const uint8_t*  substitution_mask;/* optional, only read when the six vectors above are NULL (generated by the library): 1 where the haplotype's
+                                         own CIGAR against the reference holds a substitution - those bases keep the maximum SNV prior
+                                         (repeat_based_snv_error_model.cpp:168-172). NULL = no haplotype carries substitutions. Travels with the call, so
+                                         it reaches the region server's batches too. */
 } oct_phmm_haplotypes;
 
 /* HaplotypeLikelihoodModel::FlankState (haplotype_likelihood_model.hpp:46-49). */
@@ -194,6 +198,10 @@ size_t oct_phmm_batch_out_size(const oct_phmm_batch* b); /* number of doubles `o
  * oct_phmm_batch_run enqueues the whole step without reading the task counts back (region-sized batches); 0 when the step reads them
  * back to size its DP launches (big batches, alignment). Results are identical either way. Diagnostic / test seam. */
 int  oct_phmm_batch_device_sized(const oct_phmm_batch* b);
+/* Diagnostic: the shader clock (GHz) the device sustains over `window_ms` milliseconds, measured by a one-wave kernel on a stream of its own that
+ * compares the shader cycle counter with the constant reference clock - i.e. while whatever else is enqueued on the device runs (bench.py prices the
+ * VALU roofline of the DP kernels at the clock they actually get). Blocks for the window. */
+int  oct_phmm_probe_clock(oct_phmm_handle* h, double window_ms, double* shader_ghz);
 /* Average device time (ms) of the last run's dominant DP kernel launches measured with HIP events on the
  * handle's stream, and the number of launches; for bench.py's roofline block. */
 int  oct_phmm_batch_kernel_time(const oct_phmm_batch* b, double* dp_kernel_ms, uint32_t* dp_launches);
@@ -225,8 +233,9 @@ void oct_phmm_server_destroy(oct_phmm_server* s);
 int  oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
                               const oct_phmm_flank_state* flank, const oct_phmm_positions* positions,
                               double* out, oct_phmm_status* status);
-/* oct_phmm_set_error_model for every handle of the server: callers may then leave their six penalty-vector pointers NULL. Call it before the
- * region threads start calling (a worker that is mid-batch keeps the model it started with). */
+/* oct_phmm_set_error_model for every handle of the server: callers may then leave their six penalty-vector pointers NULL. The model is handed to each
+ * worker thread, which installs it on its own handle before the next device batch it starts: a batch that is running keeps the model it started with,
+ * calls that are enqueued after this returns are answered with the new one. */
 int  oct_phmm_server_set_error_model(oct_phmm_server* s, const struct oct_phmm_error_model* model);
 /* calls answered and device batches run so far (calls / batches = achieved batching) */
 int  oct_phmm_server_stats(const oct_phmm_server* s, uint64_t* n_calls, uint64_t* n_batches);
@@ -290,8 +299,6 @@ int  oct_phmm_penalty_vectors(const oct_phmm_error_model* model, uint32_t n_haps
  * oct_phmm_haplotypes whose SIX vector pointers are all NULL and generate the vectors inside the call (HaplotypeLikelihoodModel::reset
  * for every haplotype): on host threads for region-sized calls, on the device (one haplotype per lane) from a few thousand haplotypes. */
 int  oct_phmm_set_error_model(oct_phmm_handle* h, const oct_phmm_error_model* model);
-/* Haplotype substitution masks for the in-call generation (see oct_phmm_penalty_vectors): borrowed for the NEXT upload on this handle only; NULL = none. */
-int  oct_phmm_set_substitution_mask(oct_phmm_handle* h, const uint8_t* substitution_mask);
 /* Test seam: the vectors the last upload of this batch generated (device or host path), concatenated like the haplotypes. */
 int  oct_phmm_batch_penalty_vectors(oct_phmm_handle* h, oct_phmm_batch* b, int8_t* gap_open, int8_t* gap_extend, char* snv_mask_fwd,
                                     int8_t* snv_prior_fwd, char* snv_mask_rev, int8_t* snv_prior_rev, oct_phmm_status* status);

@@ -67,6 +67,7 @@ class Haplotypes(C.Structure):
         ("snv_prior_fwd", C.c_void_p),
         ("snv_mask_rev", C.c_void_p),
         ("snv_prior_rev", C.c_void_p),
+        ("substitution_mask", C.c_void_p),
     ]
 
 
@@ -260,9 +261,12 @@ class Batch:
                      "snv_prior_fwd", "snv_mask_rev", "snv_prior_rev"):
             if getattr(self, name) is not None:
                 setattr(self, name, np.ascontiguousarray(getattr(self, name)))
+        sub = getattr(self, "substitution_mask", None)
+        if sub is not None:
+            self.substitution_mask = sub = np.ascontiguousarray(sub, dtype=np.uint8)
         return Haplotypes(self.n_haps, _ptr(self.hap_bases), _ptr(self.hap_offsets), _ptr(self.hap_ref_begin),
                           _ptr(self.gap_open), _ptr(self.gap_extend), _ptr(self.snv_mask_fwd), _ptr(self.snv_prior_fwd),
-                          _ptr(self.snv_mask_rev), _ptr(self.snv_prior_rev))
+                          _ptr(self.snv_mask_rev), _ptr(self.snv_prior_rev), _ptr(sub))
 
     def c_regions(self) -> Optional[Regions]:
         if self.region_row_offsets is None:

@@ -92,8 +92,9 @@ struct oct_phmm_handle {
     // traceback scratch budget: large, so that all traceback tasks of a batch run in ONE DP launch and ONE walk launch (the walk
     // is a latency-bound pointer chase that needs every task in flight to hide it); MI355X has 288 GB. OCT_PHMM_BP_BUDGET_GB overrides.
     size_t bp_budget = (size_t)96 << 30;
-    // error model for in-call penalty vectors (oct_phmm_set_error_model); sub_mask is borrowed for the next upload only
-    bool has_model = false; oct_phmm_error_model model {}; const uint8_t* sub_mask = nullptr;
+    // error model for in-call penalty vectors (oct_phmm_set_error_model)
+    bool has_model = false; oct_phmm_error_model model {};
+    int fail_bp_allocs = 0;                              // test hook, see ensure_bp
     oct_phmm_error_model* d_model = nullptr;             // device copy, made on first use
     // canonical-window pass of an upload (exact de-duplication of pairs): scratch and the two power tables, kept and grown on demand
     void* dedup_scratch = nullptr; size_t dedup_scratch_bytes = 0; uint64_t* d_pw = nullptr; uint64_t* d_pwinv = nullptr; size_t pw_n = 0;
@@ -143,7 +144,6 @@ struct oct_phmm_batch {
     bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
     uint32_t* d_blk_hap = nullptr; uint32_t* d_blk_read0 = nullptr; uint32_t n_map_blocks = 0;
     uint32_t map_reads_per_block = 64;   // reads one k_kmer_map workgroup walks with the haplotype's bins staged once; fewer for small batches (latency)
-    std::vector<int8_t> gen_go, gen_ge, gen_pf, gen_pr; std::vector<char> gen_mf, gen_mr;   // penalty vectors generated on the host for this batch
     double dp_ms = 0; uint32_t dp_launches = 0;
     std::vector<std::pair<rt::Event, rt::Event>> timers;       // one (start, stop) pair per DP launch
     std::vector<int> timer_kind;
@@ -160,7 +160,7 @@ struct oct_phmm_batch {
 //                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
-//                OCT_PHMM_DSL_TRACE_PER_PAIR
+//                OCT_PHMM_DSL_TRACE_PER_PAIR, OCT_PHMM_TEST_FAIL_BP_ALLOCS (the first traceback-scratch allocations "fail")
 // ---------------------------------------------------------------------------------------------------------------
 namespace tune {
 inline bool flag(const char* name) { return getenv(name) != nullptr; }
@@ -440,6 +440,7 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
     const size_t old = h->bp_bytes[slice], roomy = old < ((size_t)4 << 30) ? std::max(bytes, old + old / 2) : bytes;
     rt::dev_free(h->bp[slice]); h->bp[slice] = nullptr; h->bp_bytes[slice] = 0;
     void* p = nullptr; size_t got = roomy;
+    if (h->fail_bp_allocs > 0) { --h->fail_bp_allocs; return false; }      // test hook (OCT_PHMM_TEST_FAIL_BP_ALLOCS): the device "has no room": the caller halves its chunk
     if (!rt::dev_malloc(&p, roomy)) {
         rt::clear_error();
         h->pool.trim();                                 // cached blocks of earlier batches may be in the way
@@ -609,10 +610,14 @@ void host_penalty_vectors(const oct_phmm_error_model& m, uint32_t n_haps, const 
     for (auto& x : th) x.join();
 }
 
-bool model_is_valid(const oct_phmm_error_model* m)
+bool model_is_valid(const oct_phmm_error_model* m)       // every table entry a penalty in [0, 127]; table by table (the struct's padding bytes are the caller's)
 {
-    const int8_t* p = (const int8_t*)m; bool ok = true;
-    for (size_t i = 0; i < offsetof(oct_phmm_error_model, use_snv_model); ++i) ok = ok && p[i] >= 0;
+    bool ok = true;
+    auto table = [&](const int8_t* t, size_t n) { for (size_t i = 0; i < n; ++i) ok = ok && t[i] >= 0; };
+    table(m->at_homopolymer_open, OCT_PHMM_INDEL_TABLE); table(m->cg_homopolymer_open, OCT_PHMM_INDEL_TABLE);
+    table(m->dinucleotide_open, OCT_PHMM_INDEL_TABLE); table(m->trinucleotide_open, OCT_PHMM_INDEL_TABLE);
+    table(m->homopolymer_extend, OCT_PHMM_INDEL_TABLE); table(m->dinucleotide_extend, OCT_PHMM_INDEL_TABLE); table(m->trinucleotide_extend, OCT_PHMM_INDEL_TABLE);
+    for (int k = 0; k < 3; ++k) table(m->snv_caps[k], OCT_PHMM_SNV_TABLE);
     return ok;
 }
 
@@ -670,13 +675,6 @@ extern "C" int oct_phmm_set_error_model(oct_phmm_handle* h, const oct_phmm_error
     h->has_model = model != nullptr;
     if (model) h->model = *model;
     if (h->d_model) { rt::set_device(h->cfg.device_id); rt::stream_sync(h->stream); h->pool.release(h->d_model); h->d_model = nullptr; }
-    return OCT_PHMM_OK;
-}
-
-extern "C" int oct_phmm_set_substitution_mask(oct_phmm_handle* h, const uint8_t* substitution_mask)
-{
-    if (!h) return OCT_PHMM_EINVAL;
-    h->sub_mask = substitution_mask;
     return OCT_PHMM_OK;
 }
 
@@ -738,6 +736,7 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     }
     { long long v; if (tune::number("OCT_PHMM_BP_BUDGET_GB", &v) && v > 0) h->bp_budget = (size_t)v << 30;
       if (tune::number("OCT_PHMM_BP_BUDGET_KB", &v) && v > 0) h->bp_budget = (size_t)v << 10; }   // KB: test hook, forces chunked traceback launches on small batches
+    { long long v; if (tune::number("OCT_PHMM_TEST_FAIL_BP_ALLOCS", &v) && v > 0) h->fail_bp_allocs = (int)v; }
     if (!rt::stream_create(&h->stream)) return OCT_PHMM_EHIP;
     for (auto& es : h->extra_streams) if (!rt::stream_create(&es)) return OCT_PHMM_EHIP;
     if (!rt::event_create(&h->ev_ready)) return OCT_PHMM_EHIP;
@@ -806,7 +805,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     rt::Range range_("oct_phmm upload");
     oct_phmm_haplotypes Hv = *H_in;
     const oct_phmm_haplotypes* H = &Hv;
-    const uint8_t* sub_mask = h->sub_mask; h->sub_mask = nullptr;          // borrowed for this upload only
+    const uint8_t* sub_mask = H->substitution_mask;                          // only read where the library makes the vectors
     const int n_vec = (H->gap_open ? 1 : 0) + (H->gap_extend ? 1 : 0) + (H->snv_mask_fwd ? 1 : 0) + (H->snv_prior_fwd ? 1 : 0) + (H->snv_mask_rev ? 1 : 0) + (H->snv_prior_rev ? 1 : 0);
     const bool generate = H->n_haps && n_vec == 0;                           // HaplotypeLikelihoodModel::reset inside the call (oct_phmm_set_error_model)
     if (generate && !h->has_model) return fail(status, OCT_PHMM_EINVAL, "penalty vectors are NULL and the handle has no error model");
@@ -1271,6 +1270,10 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     b->timers.clear(); b->timer_kind.clear(); b->dp_ms = 0; b->dp_launches = 0; b->ran = false;
     const uint32_t G = b->stream ? (h->band < 64 ? 64u / (uint32_t)h->band : 1u) : (h->wide ? 1u : 2u) * (64 / (uint32_t)h->band);
     const int S = (int)b->slices.size();
+    if (b->dsl && b->dsl_trace_cap) {     // the scratch of the device-sized launches, before anything is enqueued: without it the batch simply runs host-sized (chunked if need be)
+        const size_t per_group = (size_t)bp_tiles(b->t_cap, (uint32_t)h->band) * 4096 * (b->stream ? (size_t)h->lanes_c : 1);
+        if (!ensure_bp(h, 0, (size_t)b->dsl_trace_cap / G * per_group)) b->dsl = false;
+    }
     d.dsl_trace_cap = b->dsl ? b->dsl_trace_cap : 0;
     RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
@@ -1600,6 +1603,39 @@ extern "C" size_t oct_phmm_batch_out_size(const oct_phmm_batch* b) { return b ? 
 
 extern "C" int oct_phmm_batch_device_sized(const oct_phmm_batch* b) { return b && b->dsl ? 1 : 0; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// diagnostic: the shader clock while other work runs (bench.py prices its VALU roofline at the clock the DP kernels actually get)
+// ---------------------------------------------------------------------------------------------------------------
+#if !defined(OCTPHMM_SIM)
+__global__ void k_clock_probe(unsigned long long* out, unsigned long long ticks)
+{
+    const unsigned long long t0 = clock64(), r0 = wall_clock64();          // s_memtime: shader cycles; s_memrealtime: the constant reference clock
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(32); r1 = wall_clock64(); }
+    const unsigned long long t1 = clock64();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+#endif
+extern "C" int oct_phmm_probe_clock(oct_phmm_handle* h, double window_ms, double* shader_ghz)
+{
+    if (!h || !shader_ghz || !(window_ms > 0) || window_ms > 1000) return OCT_PHMM_EINVAL;
+#if defined(OCTPHMM_SIM)
+    return OCT_PHMM_EUNSUPPORTED;
+#else
+    if (!rt::set_device(h->cfg.device_id)) return OCT_PHMM_EHIP;
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id) != hipSuccess || khz <= 0) return OCT_PHMM_EHIP;
+    rt::Stream s; if (!rt::stream_create(&s)) return OCT_PHMM_EHIP;       // its own stream: the probe wave runs beside whatever the handle's streams are doing
+    unsigned long long* d = nullptr; unsigned long long v[2] = {0, 0};
+    bool ok = rt::dev_malloc((void**)&d, 16);
+    if (ok) { hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, d, (unsigned long long)(window_ms * khz)); ok = rt::launch_ok() && rt::d2h(v, d, 16, s) && rt::stream_sync(s); }
+    rt::dev_free(d); rt::stream_destroy(s);
+    if (!ok || !v[1]) return OCT_PHMM_EHIP;
+    *shader_ghz = (double)v[0] / (double)v[1] * khz * 1e-6;
+    return OCT_PHMM_OK;
+#endif
+}
+
 extern "C" int oct_phmm_batch_kernel_time(const oct_phmm_batch* b, double* ms, uint32_t* launches)
 {
     if (!b) return OCT_PHMM_EINVAL;
@@ -1750,6 +1786,8 @@ struct oct_phmm_server {
     uint64_t n_calls = 0, n_batches = 0;
     std::vector<uint64_t> n_calls_by_device;
     std::atomic<bool> has_model {false};                 // oct_phmm_server_set_error_model: calls may leave their penalty vectors NULL
+    // the model travels to the handles through their own worker threads (under mu): a handle is only ever touched by its worker
+    oct_phmm_error_model pending_model {}; bool pending_has_model = false; uint64_t model_version = 0; std::vector<uint64_t> worker_version;
     // OCT_PHMM_SERVER_PROFILE=1: where a worker's time goes (ns, summed over workers), printed by oct_phmm_server_destroy
     bool profile = tune::server_profile();
     std::atomic<uint64_t> ns_idle {0}, ns_concat {0}, ns_upload {0}, ns_run {0}, ns_download {0}, ns_scatter {0}, ns_single {0};
@@ -1763,7 +1801,8 @@ struct oct_phmm_server {
     // concatenate the calls' arrays into one flat batch with one region per call
     void serve_many(oct_phmm_handle* h, std::vector<Request*>& qs)
     {
-        std::string rb, hb, mf, mr; std::vector<uint8_t> rq, mq, rv, has_flank; std::vector<uint32_t> roff {0}, hoff {0}, row_off {0}, reg_rows {0}, reg_haps {0};
+        std::string rb, hb, mf, mr; std::vector<uint8_t> rq, mq, rv, has_flank, sub; bool any_sub = false;
+        for (Request* q : qs) if (q->H->substitution_mask) any_sub = true; std::vector<uint32_t> roff {0}, hoff {0}, row_off {0}, reg_rows {0}, reg_haps {0};
         std::vector<int64_t> rbeg, hbeg; std::vector<int8_t> go, ge, pf, pr; std::vector<oct_phmm_flank_state> fl;
         bool templates = false;
         for (Request* q : qs) if (q->R->row_offsets) templates = true;
@@ -1781,6 +1820,7 @@ struct oct_phmm_server {
             hb.append(H->bases, hn);
             for (uint32_t k = 0; k < H->n_haps; ++k) hoff.push_back(hoff.back() + (H->offsets[k + 1] - H->offsets[k]));
             hbeg.insert(hbeg.end(), H->ref_begin, H->ref_begin + H->n_haps);
+            if (any_sub) { if (H->substitution_mask) sub.insert(sub.end(), H->substitution_mask, H->substitution_mask + hn); else sub.insert(sub.end(), hn, (uint8_t)0); }
             if (H->gap_open) {                             // (a device batch holds either calls with vectors or calls without, run())
                 go.insert(go.end(), H->gap_open, H->gap_open + hn); ge.insert(ge.end(), H->gap_extend, H->gap_extend + hn);
                 mf.append(H->snv_mask_fwd, hn); mr.append(H->snv_mask_rev, hn);
@@ -1794,7 +1834,8 @@ struct oct_phmm_server {
         oct_phmm_reads R {n_reads, rb.data(), rq.data(), roff.data(), mq.data(), rv.data(), rbeg.data(), templates ? n_rows : 0, templates ? row_off.data() : nullptr};
         const bool given = qs.front()->H->gap_open != nullptr;
         oct_phmm_haplotypes H {(uint32_t)hbeg.size(), hb.data(), hoff.data(), hbeg.data(), given ? go.data() : nullptr, given ? ge.data() : nullptr,
-                               given ? mf.data() : nullptr, given ? pf.data() : nullptr, given ? mr.data() : nullptr, given ? pr.data() : nullptr};
+                               given ? mf.data() : nullptr, given ? pf.data() : nullptr, given ? mr.data() : nullptr, given ? pr.data() : nullptr,
+                               !given && any_sub ? sub.data() : nullptr};
         oct_phmm_regions G {(uint32_t)qs.size(), reg_rows.data(), reg_haps.data(), has_flank.data(), fl.data()};
         std::vector<double> out(n_out + 1);
         oct_phmm_status st;
@@ -1834,6 +1875,10 @@ struct oct_phmm_server {
                 cv_work.wait(lk, [&] { return stop || !queue.empty(); });
                 if (profile) ns_idle += now_ns() - t_idle;
                 if (queue.empty() && stop) return;
+                if (worker_version[(size_t)w] != model_version) {          // a new error model since this worker's last batch: install it before taking calls
+                    oct_phmm_set_error_model(h, pending_has_model ? &pending_model : nullptr);
+                    worker_version[(size_t)w] = model_version;
+                }
                 while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
             }
             std::vector<Request*> batchable, single;
@@ -1887,7 +1932,7 @@ extern "C" int oct_phmm_server_create_multi(const oct_phmm_config* cfg, const in
             s->hs.push_back(h); s->device_of.push_back((int)dv);
         }
     }
-    s->n_calls_by_device.assign(n_devices, 0);
+    s->n_calls_by_device.assign(n_devices, 0); s->worker_version.assign(s->hs.size(), 0);
     if (max_regions_per_batch) s->max_regions = max_regions_per_batch;
     for (size_t w = 0; w < s->hs.size(); ++w) s->workers.emplace_back([s, w] { s->run((int)w); });
     *out = s;
@@ -1951,8 +1996,11 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
 extern "C" int oct_phmm_server_set_error_model(oct_phmm_server* s, const oct_phmm_error_model* model)
 {
     if (!s) return OCT_PHMM_EINVAL;
+    if (model && !model_is_valid(model)) return OCT_PHMM_EINVAL;
     std::lock_guard<std::mutex> lk(s->mu);
-    for (auto* h : s->hs) { const int rc = oct_phmm_set_error_model(h, model); if (rc != OCT_PHMM_OK) return rc; }
+    s->pending_has_model = model != nullptr;
+    if (model) s->pending_model = *model;
+    ++s->model_version;                                    // every worker installs it on its own handle before its next batch (run())
     s->has_model = model != nullptr;
     return OCT_PHMM_OK;
 }

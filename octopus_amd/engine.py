@@ -75,6 +75,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_out_size.argtypes = [pv]
         lib.oct_phmm_batch_out_size.restype = C.c_size_t
         lib.oct_phmm_batch_device_sized.argtypes = [pv]
+        lib.oct_phmm_probe_clock.argtypes = [pv, C.c_double, C.POINTER(C.c_double)]
         lib.oct_phmm_batch_kernel_time.argtypes = [pv, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         lib.oct_phmm_batch_kernel_time_by_kind.argtypes = [pv, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32 * 4)]
         lib.oct_phmm_batch_genotype_likelihoods.argtypes = [pv, pv, pv, pv, pv]
@@ -90,7 +91,6 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_error_model_default.argtypes = [C.POINTER(abi.ErrorModel)]
         lib.oct_phmm_penalty_vectors.argtypes = [C.POINTER(abi.ErrorModel), C.c_uint32] + [pv] * 10
         lib.oct_phmm_set_error_model.argtypes = [pv, C.POINTER(abi.ErrorModel)]
-        lib.oct_phmm_set_substitution_mask.argtypes = [pv, pv]
         lib.oct_phmm_batch_penalty_vectors.argtypes = [pv] * 9
         lib.oct_phmm_server_set_error_model.argtypes = [pv, C.POINTER(abi.ErrorModel)]
         _LIBS[key] = lib
@@ -282,9 +282,13 @@ class Engine:
         if code != abi.OK:
             raise EngineError(code, None, "set_error_model")
 
-    def set_substitution_mask(self, mask: Optional[np.ndarray]):
-        self._sub_mask = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)      # borrowed until the next upload
-        self.lib.oct_phmm_set_substitution_mask(self.handle, _ptr(self._sub_mask))
+    def probe_clock(self, window_ms: float = 5.0) -> float:
+        """oct_phmm_probe_clock: shader clock (GHz) sustained over the window, beside whatever else runs on the device."""
+        g = C.c_double(0)
+        code = self.lib.oct_phmm_probe_clock(self.handle, float(window_ms), C.byref(g))
+        if code != abi.OK:
+            raise EngineError(code, None, "probe_clock")
+        return g.value
 
     def set_timing(self, enabled: bool = True):
         """Bracket the DP launches with HIP events (ResidentBatch.kernel_time*); off by default."""

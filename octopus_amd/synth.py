@@ -222,6 +222,38 @@ def stream_region(seed: int, i: int, B: int = 16, positions: str = "true", cap=N
     return make_region(rng, R, max(H, 1), Lh=Lh, B=B, positions=positions)
 
 
-def region_stream_shard(seed: int, n_regions: int, rank: int = 0, world: int = 1, B: int = 16, positions: str = "true", cap=None) -> List[dict]:
-    """BASELINE.json configs[3]: the regions i = rank (mod world) of a stream of n_regions regions (round-robin over the GPUs, no exchange)."""
-    return [stream_region(seed, i, B=B, positions=positions, cap=cap) for i in range(rank, n_regions, world)]
+def _stream_regions(args):
+    seed, idx, B, positions, cap = args
+    return [stream_region(seed, i, B=B, positions=positions, cap=cap) for i in idx]
+
+
+def region_stream_shard(seed: int, n_regions: int, rank: int = 0, world: int = 1, B: int = 16, positions: str = "true", cap=None, workers: int = 1) -> List[dict]:
+    """BASELINE.json configs[3]: the regions i = rank (mod world) of a stream of n_regions regions (round-robin over the GPUs, no exchange).
+    A big shard (the 50,000-region stream of bench.py at N > 1) is generated by `workers` spawned processes: every region has its own generator state,
+    so the result does not depend on who makes it."""
+    idx = list(range(rank, n_regions, world))
+    if workers <= 1 or len(idx) < 4000:
+        return _stream_regions((seed, idx, B, positions, cap))
+    # plain child interpreters (no multiprocessing: its spawn mode re-imports the parent's __main__, and the parent may hold a HIP context that must not be forked)
+    import pickle
+    import subprocess
+    import sys
+    root = str(__import__("pathlib").Path(__file__).resolve().parents[1])
+    code = ("import sys, pickle; sys.path.insert(0, %r); from octopus_amd import synth; "
+            "a = pickle.load(sys.stdin.buffer); pickle.dump(synth._stream_regions(a), sys.stdout.buffer, protocol=4)" % root)
+    chunks = [idx[k::workers] for k in range(workers)]
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE) for _ in chunks]
+    import threading
+    parts = [None] * len(chunks)
+
+    def talk(k):
+        out, _ = procs[k].communicate(pickle.dumps((seed, chunks[k], B, positions, cap), protocol=4))
+        if procs[k].returncode != 0:
+            raise RuntimeError("region generator child failed")
+        parts[k] = pickle.loads(out)
+    ths = [threading.Thread(target=talk, args=(k,)) for k in range(len(chunks))]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    by_index = {}
+    for c, regs in zip(chunks, parts):
+        by_index.update(zip(c, regs))
+    return [by_index[i] for i in idx]

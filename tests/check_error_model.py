@@ -113,7 +113,7 @@ def check_device_kernels_on_the_corpus(backend, n_strings=600, where=("device", 
             os.environ["OCT_PHMM_PENALTIES"] = path
             eng = make_engine(backend, max_indel_error=8)
             eng.set_error_model(m)
-            eng.set_substitution_mask(sub)
+            batch.substitution_mask = sub                           # oct_phmm_haplotypes::substitution_mask: travels with the call
             rb = eng.upload(batch)
             got = rb.penalty_vectors()
             rb.free(); eng.close()
@@ -136,9 +136,8 @@ def check_align_and_server_generate_the_vectors(backend, tol=0.0):
     m = engine.default_error_model(lib_path)
     rng = np.random.default_rng(91)
 
-    def with_model_vectors(batch):
-        given = synth.batch_from_regions([])  if False else batch
-        vec = engine.penalty_vectors(m, batch.hap_bases, batch.hap_offsets, lib_path=lib_path)
+    def with_model_vectors(batch, model=None):
+        vec = engine.penalty_vectors(model if model is not None else m, batch.hap_bases, batch.hap_offsets, getattr(batch, "substitution_mask", None), lib_path=lib_path)
         import copy
         g = copy.copy(batch); g._keep = []
         g.gap_open, g.gap_extend, g.snv_mask_fwd, g.snv_prior_fwd, g.snv_mask_rev, g.snv_prior_rev = vec
@@ -155,32 +154,40 @@ def check_align_and_server_generate_the_vectors(backend, tol=0.0):
     assert got["cigar_strings"] == want["cigar_strings"] and np.array_equal(got["mapping_position"], want["mapping_position"])
     assert np.max(np.abs(got["likelihood"] - want["likelihood"]), initial=0.0) <= tol
     # region server: callers with and without vectors at the same time
-    reqs = [r for r in make_requests(rng, 10, 8) if r.pos_offsets is None]
+    # ... and every third caller's haplotypes carry substitutions (oct_phmm_haplotypes::substitution_mask travels with the call into the server's batches)
+    reqs = [r for r in make_requests(rng, 12, 8) if r.pos_offsets is None]
+    for i, r in enumerate(reqs):
+        if i % 3 == 0:
+            r.substitution_mask = (rng.random(int(r.hap_offsets[-1])) < 0.15).astype(np.uint8)
     cfg = abi.Config.default(max_indel_error=8)
-    ref_eng = make_engine(backend, max_indel_error=8)
-    want = [ref_eng.populate(with_model_vectors(r), raise_on_error=False) for r in reqs]
-    want = [(o.copy(), st.code) for o, st in want]
-    ref_eng.close()
+    m2 = engine.default_error_model(lib_path)                          # a second model, installed while the server is up
+    for k in range(len(m2.at_homopolymer_open)):
+        m2.at_homopolymer_open[k] = max(3, m2.at_homopolymer_open[k] - 2); m2.dinucleotide_extend[k] = 4
     srv = engine.Server(cfg, lib_path=lib_path)
-    srv.set_error_model(m)
-    got = [None] * len(reqs)
-    errors = []
+    for model in (m, m2):
+        ref_eng = make_engine(backend, max_indel_error=8)
+        want = [ref_eng.populate(with_model_vectors(r, model), raise_on_error=False) for r in reqs]
+        want = [(o.copy(), st.code) for o, st in want]
+        ref_eng.close()
+        srv.set_error_model(model)
+        got = [None] * len(reqs)
+        errors = []
 
-    def worker(t):
-        try:
-            for i in range(t, len(reqs), 3):
-                r = reqs[i].without_penalty_vectors() if i % 2 == 0 else with_model_vectors(reqs[i])
-                o, st = srv.populate(r, raise_on_error=False)
-                got[i] = (o.copy(), st.code)
-        except Exception as e:  # noqa: BLE001
-            errors.append(e)
+        def worker(t):
+            try:
+                for i in range(t, len(reqs), 3):
+                    r = reqs[i].without_penalty_vectors() if i % 2 == 0 else with_model_vectors(reqs[i], model)
+                    o, st = srv.populate(r, raise_on_error=False)
+                    got[i] = (o.copy(), st.code)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
 
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
-    [t.start() for t in ths]; [t.join() for t in ths]
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        assert not errors, errors
+        for (go, gc), (wo, wc) in zip(got, want):
+            assert gc == wc
+            if gc == abi.OK:
+                assert np.max(np.abs(go - wo), initial=0.0) <= tol
     srv.close()
-    assert not errors, errors
-    for (go, gc), (wo, wc) in zip(got, want):
-        assert gc == wc
-        if gc == abi.OK:
-            assert np.max(np.abs(go - wo), initial=0.0) <= tol
     return len(reqs)

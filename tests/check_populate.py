@@ -388,6 +388,35 @@ def check_chunked_traceback(backend, tol=0.0):
                 os.environ[k] = v
 
 
+def check_scratch_allocation_failures(backend, tol=0.0):
+    """The traceback scratch is the one large allocation of a step. When the device has no room for it (other handles, other processes) a device-sized
+    batch falls back to host-sized launches and those halve their chunks until an allocation succeeds; the failed attempts must not leave an error behind
+    (the runtime's last-error slot is sticky). Test hook: the first N scratch allocations of a handle fail."""
+    import os
+    keep = os.environ.get("OCT_PHMM_TEST_FAIL_BP_ALLOCS")
+    try:
+        for B, fails in ((8, 1), (16, 3)):
+            g, rng = small_region(700 + B, R=40, H=6, T=90, Lh=220, B=B, flank=(25, 60))
+            batch = synth.batch_from_regions([g])
+            os.environ["OCT_PHMM_TEST_FAIL_BP_ALLOCS"] = str(fails)
+            stats = compare(backend, batch, tol, max_indel_error=B)
+            assert stats["n_dp_traceback"] > 64
+            eng = make_engine(backend, max_indel_error=B)
+            rb = eng.upload(batch)
+            assert rb.device_sized()
+            rb.run(); a = rb.download().copy()
+            assert not rb.device_sized()                          # the scratch of the device-sized form could not be had
+            os.environ.pop("OCT_PHMM_TEST_FAIL_BP_ALLOCS")
+            rb2 = eng.upload(batch); rb2.run()
+            assert np.array_equal(a, rb2.download())
+            rb.free(); rb2.free(); eng.close()
+    finally:
+        if keep is None:
+            os.environ.pop("OCT_PHMM_TEST_FAIL_BP_ALLOCS", None)
+        else:
+            os.environ["OCT_PHMM_TEST_FAIL_BP_ALLOCS"] = keep
+
+
 def check_against_reference_array(backend, tol=0.0):
     """The product pipeline against the REFERENCE's own HaplotypeLikelihoodArray::populate (haplotype_likelihood_array.cpp built in place,
     oracle/_ref/libref_array.so): reads and templates, several samples' rows, device k-mer mapping, with no oracle restatement in between."""

@@ -55,3 +55,14 @@ def test_bench_stream_mode_shards_one_fixed_stream_over_the_ranks():
     assert two["config"]["pairs_per_step"] == one["config"]["pairs_per_step"]
     assert two["stats"]["n_pairs"] < one["stats"]["n_pairs"]                     # rank 0 of two holds regions 0, 2, 4 only
     assert abs(two["value"] * two["ms_per_step"] / (one["value"] * one["ms_per_step"]) - 1.0) < 1e-6
+
+
+def test_bench_defaults_to_the_stream_split_on_more_than_one_rank():
+    """Without --workload, N > 1 runs BASELINE configs[3] (one stream sharded round-robin, strong scaling), N = 1 the 100k x 128 headline batch.
+    (--regions / --stream-cap only shrink the stream to simulator size; the default size is 50,000 regions.)"""
+    two = _run(2, ("--regions", "6", "--stream-cap", "12", "3"))
+    assert two["scaling"] == "strong" and two["regions_per_step"] == 6 and two["regions_per_s"] > 0
+    assert two["rank_ms_per_step"]["min"] > 0 and two["rank_ms_per_step"]["max"] >= two["rank_ms_per_step"]["min"]
+    assert "stream" in two["config"]["workload"]
+    src = (ROOT / "bench.py").read_text()
+    assert 'args.regions = 50000 if (world > 1 and args.workload == "stream") else 2000' in src

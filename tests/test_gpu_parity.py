@@ -279,6 +279,10 @@ def test_gpu_multi_wave_kernel_fast_cost_and_one_wave_form(band, n, monkeypatch)
     cp.check_wide_and_long("gpu", TOL)
 
 
+def test_gpu_scratch_allocation_failures_fall_back_and_leave_no_error():
+    cp.check_scratch_allocation_failures("gpu", TOL)
+
+
 def test_gpu_chunked_traceback_launches():
     cp.check_chunked_traceback("gpu", TOL)
 

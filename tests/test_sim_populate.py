@@ -121,3 +121,7 @@ def test_sim_populate_unstaged_walk(monkeypatch):
     cp.check_basic("sim")
     cp.check_templates_and_regions("sim")
     cp.check_late_traceback_start("sim")
+
+
+def test_sim_scratch_allocation_failures_fall_back_and_leave_no_error():
+    cp.check_scratch_allocation_failures("sim")

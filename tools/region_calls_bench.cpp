@@ -80,6 +80,22 @@ int main(int argc, char** argv)
             if (pass) printf("{\"mode\": \"server\", \"devices\": %d, \"threads\": %d, \"regions_per_s\": %.1f, \"M_loglik_per_s\": %.2f, \"regions_per_device_batch\": %.2f, \"failures\": %d}\n",
                              (int)devs.size(), T, n_regions / dt, (double)n_regions * R * H / dt / 1e6, (double)(c1 - c0) / (double)std::max<uint64_t>(1, b1 - b0), failures);
         }
+        if (T == threads.back()) {                                  // the server's answers against plain populate calls on a handle of our own, bit for bit
+            oct_phmm_handle* hv = nullptr;
+            if (oct_phmm_create(&c, &hv) != OCT_PHMM_OK) { fprintf(stderr, "no device\n"); return 1; }
+            const int n_check = std::min(n_regions, 64); int bad = 0;
+            for (int i = 0; i < n_check; ++i) {
+                Region& g = regions[i];
+                std::vector<double> want(g.out.size());
+                oct_phmm_reads rd {(uint32_t)g.mq.size(), g.rb.data(), g.q.data(), g.ro.data(), g.mq.data(), g.rev.data(), g.rbeg.data(), 0, nullptr};
+                oct_phmm_haplotypes hp {(uint32_t)g.hbeg.size(), g.hb.data(), g.ho.data(), g.hbeg.data(), g.go.data(), g.ge.data(), g.mf.data(), g.pf.data(), g.mr.data(), g.pr.data()};
+                oct_phmm_flank_state fl {40, 40}; oct_phmm_status st;
+                if (oct_phmm_populate(hv, &rd, &hp, nullptr, &fl, nullptr, want.data(), &st) != OCT_PHMM_OK || want != g.out) ++bad;
+            }
+            oct_phmm_destroy(hv);
+            printf("{\"mode\": \"server vs plain calls\", \"regions_compared\": %d, \"regions_that_differ\": %d}\n", n_check, bad);
+            if (bad) failures += bad;
+        }
         oct_phmm_server_destroy(srv);
     }
     for (int T : threads) {                                     // ---- one handle per calling thread ----
