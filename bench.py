@@ -182,11 +182,11 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12):
+def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12, in_flight: int = 3):
     """What a caller gets who hands over HOST buffers: (i) one oct_phmm_populate of the many-region batch, PCIe both ways; (ii) the same batch
-    over and over from two host threads with a handle each - while one handle's batch computes, the other's next batch is validated, packed, copied up and
-    its results stream back - the sustained rate over n_batches consecutive batches. Every result is compared with the resident run's matrix (which is
-    verified against the reference's own populate on a sample of regions)."""
+    over and over from `in_flight` host threads with a handle each - while one handle's batch computes, the others' next batches are validated, packed,
+    copied up and their results stream back - the sustained rate over n_batches consecutive batches. Every result is compared with the resident run's
+    matrix (which is verified against the reference's own populate on a sample of regions)."""
     import threading
     from octopus_amd import engine
     out = np.empty(batch.out_size())
@@ -196,26 +196,30 @@ def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12):
         eng.populate(batch, out=out)
     one = (time.perf_counter() - t0) / 3
     same = bool(np.array_equal(out, resident))
-    eng2 = engine.Engine(cfg)
-    outs = [out, np.empty(batch.out_size())]
-    engs = [eng, eng2]
-    eng2.populate(batch, out=outs[1])                       # warm the second handle's pools
-    done = [0, 0]
+    res = {"e2e_ms_from_host": one * 1e3, "e2e_regions_per_s": n_regions / one}
+    for k in sorted({2, in_flight}):
+        engs = [eng] + [engine.Engine(cfg) for _ in range(k - 1)]
+        outs = [out] + [np.empty(batch.out_size()) for _ in range(k - 1)]
+        for e, o in zip(engs[1:], outs[1:]):
+            e.populate(batch, out=o)                        # warm the other handles' pools
+        done = [0] * k
 
-    def work(t):
-        for _ in range(n_batches // 2):
-            engs[t].populate(batch, out=outs[t]); done[t] += 1
-    ths = [threading.Thread(target=work, args=(t,)) for t in range(2)]
-    t0 = time.perf_counter()
-    [t.start() for t in ths]; [t.join() for t in ths]
-    dt = time.perf_counter() - t0
-    same = same and bool(np.array_equal(outs[0], resident)) and bool(np.array_equal(outs[1], resident))
-    eng2.close()
-    n = done[0] + done[1]
-    return {"e2e_ms_from_host": one * 1e3, "e2e_regions_per_s": n_regions / one,
-            "e2e_pipelined_regions_per_s": n * n_regions / dt, "e2e_pipelined_ms_per_batch": dt / n * 1e3, "e2e_pipelined_batches": n,
-            "e2e_pipelined_how": "two host threads, one handle each, oct_phmm_populate from host buffers back to back",
-            "e2e_results_equal_resident_run": same}
+        def work(t):
+            for _ in range(n_batches // k):
+                engs[t].populate(batch, out=outs[t]); done[t] += 1
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(k)]
+        t0 = time.perf_counter()
+        [t.start() for t in ths]; [t.join() for t in ths]
+        dt = time.perf_counter() - t0
+        same = same and all(bool(np.array_equal(o, resident)) for o in outs)
+        for e in engs[1:]:
+            e.close()
+        n = sum(done)
+        tag = "e2e_pipelined" if k == in_flight else f"e2e_pipelined_{k}_in_flight"
+        res.update({f"{tag}_regions_per_s": n * n_regions / dt, f"{tag}_ms_per_batch": dt / n * 1e3, f"{tag}_batches": n})
+    res["e2e_pipelined_how"] = f"{in_flight} host threads, one handle each, oct_phmm_populate from host buffers back to back ({in_flight} batches in flight)"
+    res["e2e_results_equal_resident_run"] = same
+    return res
 
 
 def region_call_legs():

@@ -285,6 +285,14 @@ typedef struct oct_phmm_error_model {
     int32_t use_snv_model;                     /* 0: no SNV model (PacBio sequencers, error_model_factory.cpp:480-483): masks = the haplotype itself, priors = 100 (model.cpp:69-73) */
 } oct_phmm_error_model;
 void oct_phmm_error_model_default(oct_phmm_error_model* model);
+/* Every parameter set the reference's factory holds (error_model_factory.cpp:220-517), by the names --sequence-error-model takes (option_parser.cpp:571-573;
+ * matched like the reference's operator>>: case-insensitive, "PCR-free" also as "PCRF"):
+ *   library preparation  PCR, PCR-free, 10X, MDA;  sequencer  HiSeq-2000, HiSeq-2500, HiSeq-4000, X10, NovaSeq, BGISEQ-500, PacBio, PacBioCCS.
+ * NULL or "" stands for the default part (PCR-free / HiSeq-2500). The PacBio sequencers have no SNV model (use_snv_model = 0, :480-483).
+ * OCT_PHMM_EINVAL: unknown name (the reference's UnknownLibraryPreparation / UnknownSequencer), or a pair the factory has no entry for (10X and MDA on
+ * the PacBio sequencers: the reference's map lookup throws there). _by_label parses the option's own "<library>[.<sequencer>]" form (parse_model_config). */
+int  oct_phmm_error_model_by_name(const char* library_preparation, const char* sequencer, oct_phmm_error_model* model);
+int  oct_phmm_error_model_by_label(const char* label, oct_phmm_error_model* model);
 /* dst[0 .. capacity) = src[0 .. min(n, capacity)) then the last source entry repeated; n >= 1 */
 void oct_phmm_error_model_expand(int8_t* dst, uint32_t capacity, const int8_t* src, uint32_t n);
 /* The vectors of n_haps haplotypes (concatenated like oct_phmm_haplotypes, same offsets) into caller-allocated arrays of offsets[n_haps]

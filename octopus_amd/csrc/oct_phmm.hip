@@ -23,6 +23,7 @@
 #include "phmm_kernels.hpp"
 #include "phmm_readout.hpp"
 #include "phmm_error_model.hpp"
+#include "phmm_error_model_tables.hpp"
 
 using namespace octphmm;
 
@@ -95,6 +96,7 @@ struct oct_phmm_handle {
     // error model for in-call penalty vectors (oct_phmm_set_error_model)
     bool has_model = false; oct_phmm_error_model model {};
     int fail_bp_allocs = 0;                              // test hook, see ensure_bp
+    bool probe_ready = false; rt::Stream probe_stream {}; unsigned long long* d_probe = nullptr; unsigned long long* h_probe = nullptr;   // oct_phmm_probe_clock
     oct_phmm_error_model* d_model = nullptr;             // device copy, made on first use
     // canonical-window pass of an upload (exact de-duplication of pairs): scratch and the two power tables, kept and grown on demand
     void* dedup_scratch = nullptr; size_t dedup_scratch_bytes = 0; uint64_t* d_pw = nullptr; uint64_t* d_pwinv = nullptr; size_t pw_n = 0;
@@ -629,28 +631,59 @@ extern "C" void oct_phmm_error_model_expand(int8_t* dst, uint32_t capacity, cons
     for (uint32_t i = 0; i < capacity; ++i) dst[i] = src[i < n ? i : n - 1];
 }
 
+// The reference's built-in parameter sets (error_model_factory.cpp:220-517) as data: phmm_error_model_tables.hpp, generated from the reference's source by
+// tools/make_error_model_tables.py. Names are matched the way the reference's operator>> does (:88-104, :158-182): capitalised, "PCR-FREE" also "PCRF".
+namespace {
+int library_by_name(const char* name)
+{
+    if (!name || !*name) return emt::kDefaultLibrary;
+    std::string t(name); for (char& c : t) c = (char)toupper((unsigned char)c);          // utils::capitalise
+    if (t == "PCR") return emt::pcr;
+    if (t == "PCR-FREE" || t == "PCRF") return emt::pcr_free;
+    if (t == "10X") return emt::tenx;
+    if (t == "MDA") return emt::mda;
+    return -1;                                                                            // UnknownLibraryPreparation
+}
+int sequencer_by_name(const char* name)
+{
+    if (!name || !*name) return emt::kDefaultSequencer;
+    std::string t(name); for (char& c : t) c = (char)toupper((unsigned char)c);
+    static const char* const names[emt::kSequencers] = {"HISEQ-2000", "HISEQ-2500", "HISEQ-4000", "X10", "NOVASEQ", "BGISEQ-500", "PACBIO", "PACBIOCCS"};
+    for (int i = 0; i < emt::kSequencers; ++i) if (t == names[i]) return i;
+    return -1;                                                                            // UnknownSequencer
+}
+int builtin_model(int lib, int seq, oct_phmm_error_model* m)
+{
+    if (!m || lib < 0 || seq < 0) return OCT_PHMM_EINVAL;
+    if (emt::indel_open[lib][seq][0] < 0) return OCT_PHMM_EINVAL;                          // builtin_indel_models.at() throws: 10X / MDA have no PacBio entries (:366-473)
+    memset(m, 0, sizeof(*m));
+    auto put = [&](int8_t* dst, uint32_t cap, int row) { const emt::Row& r = emt::rows[row]; oct_phmm_error_model_expand(dst, cap, r.v, r.n); };
+    put(m->at_homopolymer_open, OCT_PHMM_INDEL_TABLE, emt::indel_open[lib][seq][0]); put(m->cg_homopolymer_open, OCT_PHMM_INDEL_TABLE, emt::indel_open[lib][seq][1]);
+    put(m->dinucleotide_open, OCT_PHMM_INDEL_TABLE, emt::indel_open[lib][seq][2]); put(m->trinucleotide_open, OCT_PHMM_INDEL_TABLE, emt::indel_open[lib][seq][3]);
+    put(m->homopolymer_extend, OCT_PHMM_INDEL_TABLE, emt::extend[0]); put(m->dinucleotide_extend, OCT_PHMM_INDEL_TABLE, emt::extend[1]); put(m->trinucleotide_extend, OCT_PHMM_INDEL_TABLE, emt::extend[2]);
+    for (int k = 0; k < 3; ++k) put(m->snv_caps[k], OCT_PHMM_SNV_TABLE, emt::snv_caps[lib][k]);
+    m->use_snv_model = (seq == emt::pacbio || seq == emt::pacbio_ccs) ? 0 : 1;             // use_snv_error_model :480-483
+    return OCT_PHMM_OK;
+}
+} // namespace
+
 extern "C" void oct_phmm_error_model_default(oct_phmm_error_model* m)
 {
-    if (!m) return;
-    // default_model_config = {PCR-free, HiSeq-2500} (error_model_factory.hpp:26-28): indel open tables error_model_factory.cpp:231-238, extension
-    // tables = BasicRepeatBasedIndelErrorModel::Parameters' defaults (basic_repeat_based_indel_error_model.hpp:26-28), SNV caps :488-495
-    static const int8_t at[] = {45,45,43,43,41,38,35,32,29,25,21,20,19,18,17,17,16,16,15,14,14,13,12,12,11,10,9,9,8,7,7,7,6,6,6,6,6,6,6,6,6,6,6,6,6,6,6,6,6,5};
-    static const int8_t cg[] = {45,45,45,41,39,34,30,24,21,18,15,13,12,10,8,7,7,6,6,6,6,6,6,5,5,5,5,5,5,5,5,5,5,5,5,5,5,5,5,5,3};
-    static const int8_t di[] = {45,45,42,40,35,29,26,24,22,21,20,19,18,18,17,17,16,16,15,15,15,14,13,13,12,12,11,11,10,10,9,9,9,7,7,7,6,6,5,4,4,4,4,4,4,4,4,4,3};
-    static const int8_t tri[] = {45,45,40,36,30,28,26,25,23,22,22,22,21,21,20,20,20,18,17,16,14,14,14,14,12,11,11,11,10,10,10,7,7,7,4,4,4,4,4,4,4,3};
-    static const int8_t he[] = {3,3,3,3,3,3,4,5,6,6,8,8,7,6,5,4,3};
-    static const int8_t de[] = {3,3,5,4,3,2};
-    static const int8_t s1[] = {125,125,60,55,50,30,20,15,12,12,10,10,10,10,8,7,6,6,6,6,6,6,5,5,5,5,5,5,5,5,5,5,5,4,4,4,3,3,3,3,2,2,2,2,2,1,1,1,1,1,1};
-    static const int8_t s2[] = {125,125,60,60,52,52,38,38,22,22,17,17,15,15,13,13,10,10,10,10,8,8,7,6,6,6,6,6,6,5,5,5,5,4,4,4,3,3,3,3,2,2,2,2,2,1,1,1,1,1,1};
-    static const int8_t s3[] = {125,125,125,55,55,55,40,40,40,25,25,25,19,19,19,11,11,11,9,9,9,7,7,6,6,6,6,6,6,5,5,5,5,4,4,4,3,3,3,3,2,2,2,2,2,1,1,1,1,1,1};
-    memset(m, 0, sizeof(*m));
-#define OCT_EXPAND(field, cap, src) oct_phmm_error_model_expand(m->field, cap, src, (uint32_t)sizeof(src))
-    OCT_EXPAND(at_homopolymer_open, OCT_PHMM_INDEL_TABLE, at); OCT_EXPAND(cg_homopolymer_open, OCT_PHMM_INDEL_TABLE, cg);
-    OCT_EXPAND(dinucleotide_open, OCT_PHMM_INDEL_TABLE, di); OCT_EXPAND(trinucleotide_open, OCT_PHMM_INDEL_TABLE, tri);
-    OCT_EXPAND(homopolymer_extend, OCT_PHMM_INDEL_TABLE, he); OCT_EXPAND(dinucleotide_extend, OCT_PHMM_INDEL_TABLE, de); OCT_EXPAND(trinucleotide_extend, OCT_PHMM_INDEL_TABLE, de);
-    OCT_EXPAND(snv_caps[0], OCT_PHMM_SNV_TABLE, s1); OCT_EXPAND(snv_caps[1], OCT_PHMM_SNV_TABLE, s2); OCT_EXPAND(snv_caps[2], OCT_PHMM_SNV_TABLE, s3);
-#undef OCT_EXPAND
-    m->use_snv_model = 1;
+    if (m) builtin_model(emt::kDefaultLibrary, emt::kDefaultSequencer, m);                 // default_model_config = {PCR-free, HiSeq-2500} (error_model_factory.hpp:26-28)
+}
+
+extern "C" int oct_phmm_error_model_by_name(const char* library_preparation, const char* sequencer, oct_phmm_error_model* m)
+{
+    return builtin_model(library_by_name(library_preparation), sequencer_by_name(sequencer), m);
+}
+
+extern "C" int oct_phmm_error_model_by_label(const char* label, oct_phmm_error_model* m)   // parse_model_config :628-644: "<library>[.<sequencer>]", either part may be empty
+{
+    if (!label) return OCT_PHMM_EINVAL;
+    const std::string l(label);
+    const size_t dot = l.find('.');
+    const std::string lib = l.substr(0, dot), seq = dot == std::string::npos ? std::string() : l.substr(dot + 1);
+    return builtin_model(library_by_name(lib.c_str()), sequencer_by_name(seq.c_str()), m);
 }
 
 extern "C" int oct_phmm_penalty_vectors(const oct_phmm_error_model* model, uint32_t n_haps, const char* bases, const uint32_t* offsets,
@@ -753,6 +786,7 @@ extern "C" void oct_phmm_destroy(oct_phmm_handle* h)
     for (auto& kv : h->pool.live) rt::dev_free(kv.first);
     h->pool.live.clear(); h->pool.trim();
     rt::host_pinned_free(h->stage);
+    if (h->probe_ready) { rt::stream_sync(h->probe_stream); rt::stream_destroy(h->probe_stream); rt::dev_free(h->d_probe); rt::host_pinned_free(h->h_probe); }
     for (rt::Event e : h->ev_pool) rt::event_destroy(e);
     rt::event_destroy(h->ev_ready);
     rt::stream_destroy(h->stream);
@@ -1625,11 +1659,15 @@ extern "C" int oct_phmm_probe_clock(oct_phmm_handle* h, double window_ms, double
     if (!rt::set_device(h->cfg.device_id)) return OCT_PHMM_EHIP;
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id) != hipSuccess || khz <= 0) return OCT_PHMM_EHIP;
-    rt::Stream s; if (!rt::stream_create(&s)) return OCT_PHMM_EHIP;       // its own stream: the probe wave runs beside whatever the handle's streams are doing
-    unsigned long long* d = nullptr; unsigned long long v[2] = {0, 0};
-    bool ok = rt::dev_malloc((void**)&d, 16);
-    if (ok) { hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, d, (unsigned long long)(window_ms * khz)); ok = rt::launch_ok() && rt::d2h(v, d, 16, s) && rt::stream_sync(s); }
-    rt::dev_free(d); rt::stream_destroy(s);
+    // its own stream (made once per handle: creating one, like hipMalloc, synchronises the device): the probe wave runs beside whatever the handle's streams are doing
+    if (!h->probe_ready) {
+        if (!rt::stream_create(&h->probe_stream) || !rt::dev_malloc((void**)&h->d_probe, 16) || !rt::host_pinned_malloc((void**)&h->h_probe, 16)) return OCT_PHMM_EHIP;
+        h->probe_ready = true;
+    }
+    rt::Stream s = h->probe_stream; unsigned long long* v = h->h_probe;
+    v[0] = v[1] = 0;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, h->d_probe, (unsigned long long)(window_ms * khz));
+    const bool ok = rt::launch_ok() && rt::d2h(v, h->d_probe, 16, s) && rt::stream_sync(s);
     if (!ok || !v[1]) return OCT_PHMM_EHIP;
     *shader_ghz = (double)v[0] / (double)v[1] * khz * 1e-6;
     return OCT_PHMM_OK;

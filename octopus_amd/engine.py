@@ -116,6 +116,27 @@ def default_error_model(lib_path: Optional[Path] = None) -> abi.ErrorModel:
     return m
 
 
+def error_model_by_name(library: Optional[str], sequencer: Optional[str], lib_path: Optional[Path] = None) -> abi.ErrorModel:
+    """oct_phmm_error_model_by_name: one of the reference's built-in parameter sets (error_model_factory.cpp:220-517)."""
+    m = abi.ErrorModel()
+    lib = load(lib_path)
+    lib.oct_phmm_error_model_by_name.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(abi.ErrorModel)]
+    code = lib.oct_phmm_error_model_by_name(None if library is None else library.encode(), None if sequencer is None else sequencer.encode(), C.byref(m))
+    if code != abi.OK:
+        raise EngineError(code, None, f"error_model_by_name({library}, {sequencer})")
+    return m
+
+
+def error_model_by_label(label: str, lib_path: Optional[Path] = None) -> abi.ErrorModel:
+    m = abi.ErrorModel()
+    lib = load(lib_path)
+    lib.oct_phmm_error_model_by_label.argtypes = [C.c_char_p, C.POINTER(abi.ErrorModel)]
+    code = lib.oct_phmm_error_model_by_label(label.encode(), C.byref(m))
+    if code != abi.OK:
+        raise EngineError(code, None, f"error_model_by_label({label})")
+    return m
+
+
 def penalty_vectors(model: abi.ErrorModel, hap_bases: np.ndarray, hap_offsets: np.ndarray, substitution_mask=None, lib_path: Optional[Path] = None):
     """oct_phmm_penalty_vectors (host entry, no device): (gap_open, gap_extend, mask_fwd, prior_fwd, mask_rev, prior_rev), concatenated like the haplotypes."""
     lib = load(lib_path)
