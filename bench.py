@@ -364,10 +364,10 @@ def main():
         # Roofline leg (outside the timed region): the pipeline above overlaps launches of different slices, so per-launch
         # durations are taken from a single-slice run of the same batch, where every launch has the device to itself.
         # Dominant kernel = k_dp<B, TRACE=true, fast cost, FASTADD> (the traceback DP); HIP events on the library's stream.
-        os.environ["OCT_PHMM_SLICES"] = "1"
+        engine.test_set("OCT_PHMM_SLICES", "1", lib_path)
         eng.set_timing(True)
         rb1 = eng.upload(batch)
-        del os.environ["OCT_PHMM_SLICES"]
+        engine.test_set("OCT_PHMM_SLICES", None, lib_path)
         rb1.run(); rb1.wait()
         kind_ms = {k: [0.0, 0] for k in ("score_fast", "trace_fast", "score_generic", "trace_generic")}
         # the shader clock while these very launches run: a one-wave probe on its own stream (oct_phmm_probe_clock), 4 ms windows, from a second thread

@@ -198,6 +198,10 @@ size_t oct_phmm_batch_out_size(const oct_phmm_batch* b); /* number of doubles `o
  * oct_phmm_batch_run enqueues the whole step without reading the task counts back (region-sized batches); 0 when the step reads them
  * back to size its DP launches (big batches, alignment). Results are identical either way. Diagnostic / test seam. */
 int  oct_phmm_batch_device_sized(const oct_phmm_batch* b);
+/* Test / A-B switches (the OCT_PHMM_* names of INTEGRATION.md section 7): a process-wide table consulted when a handle is created or a batch is uploaded.
+ * value NULL removes the entry. The library reads such switches from the ENVIRONMENT only when OCT_PHMM_ENV_SWITCHES is set there (the test suite and the
+ * tools set it): a caller's environment does not steer the product by accident. None is needed in production. */
+int  oct_phmm_test_set(const char* name, const char* value);
 /* Diagnostic: the shader clock (GHz) the device sustains over `window_ms` milliseconds, measured by a one-wave kernel on a stream of its own that
  * compares the shader cycle counter with the constant reference clock - i.e. while whatever else is enqueued on the device runs (bench.py prices the
  * VALU roofline of the DP kernels at the clock they actually get). Blocks for the window. */

@@ -156,7 +156,7 @@ struct oct_phmm_batch {
 // ---------------------------------------------------------------------------------------------------------------
 // Every environment switch of the library, in one place (documented for callers in INTEGRATION.md section 7). None is needed in
 // production. They are read when a handle is created or a batch is uploaded - never by a kernel - and fall in three groups:
-//   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS
+//   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS, OCT_PHMM_UPLOAD_PROFILE
 //   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
 //                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED,
 //                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES
@@ -165,26 +165,44 @@ struct oct_phmm_batch {
 //                OCT_PHMM_DSL_TRACE_PER_PAIR, OCT_PHMM_TEST_FAIL_BP_ALLOCS (the first traceback-scratch allocations "fail")
 // ---------------------------------------------------------------------------------------------------------------
 namespace tune {
-inline bool flag(const char* name) { return getenv(name) != nullptr; }
-inline bool number(const char* name, long long* v) { const char* e = getenv(name); if (!e) return false; *v = atoll(e); return true; }
-inline bool timing()          { return flag("OCT_PHMM_TIMING"); }             // HIP events around every DP launch (bench.py's roofline leg)
-inline bool server_profile()  { return flag("OCT_PHMM_SERVER_PROFILE"); }     // region server: where the workers' time goes, printed at destroy
-inline bool map_stats()       { return flag("OCT_PHMM_MAP_STATS"); }          // k-mer mapper: pairs decided by the shortcut / counted, printed per run
+// Switches reach the library in two ways, neither by accident:
+//   oct_phmm_test_set(name, value)   a process-wide override table (tests, bench.py's single-slice roofline leg, A/B tools);
+//   the environment                  ONLY when OCT_PHMM_ENV_SWITCHES is set in it (tests/conftest.py, tools/*.sh): a variant caller's environment that happens to
+//                                    hold an OCT_PHMM_* variable does not steer the product.
+// The profiling switches (stderr reports, HIP-event timing, roctx ranges) are read from the environment directly: they change no result and no code path.
+inline std::mutex& switch_mu() { static std::mutex m; return m; }
+inline std::map<std::string, std::string>& switch_table() { static std::map<std::string, std::string> t; return t; }
+inline const char* get(const char* name)
+{
+    {
+        std::lock_guard<std::mutex> lk(switch_mu());
+        auto it = switch_table().find(name);
+        if (it != switch_table().end()) return it->second.c_str();          // (entries are only ever replaced between runs: tests and tools are single-threaded there)
+    }
+    static const bool env_ok = getenv("OCT_PHMM_ENV_SWITCHES") != nullptr;
+    return env_ok ? getenv(name) : nullptr;
+}
+inline bool prof_flag(const char* name) { return getenv(name) != nullptr; }
+inline bool flag(const char* name) { return get(name) != nullptr; }
+inline bool number(const char* name, long long* v) { const char* e = get(name); if (!e) return false; *v = atoll(e); return true; }
+inline bool timing()          { return prof_flag("OCT_PHMM_TIMING"); }             // HIP events around every DP launch (bench.py's roofline leg)
+inline bool server_profile()  { return prof_flag("OCT_PHMM_SERVER_PROFILE"); }     // region server: where the workers' time goes, printed at destroy
+inline bool map_stats()       { return prof_flag("OCT_PHMM_MAP_STATS"); }          // k-mer mapper: pairs decided by the shortcut / counted, printed per run
 inline bool exact_adds()      { return flag("OCT_PHMM_EXACT_ADDS"); }         // keep v_pk_add_u16 even where the host bound allows v_add_u32
 inline bool pageable_h2d()    { return flag("OCT_PHMM_PAGEABLE_H2D"); }       // big batches: copy from the caller's arrays instead of the pinned staging halves
 inline bool map_count_only()  { return flag("OCT_PHMM_MAP_COUNT_ONLY"); }     // k-mer mapper without the exact shortcut
 inline bool lane_mapper()     { return flag("OCT_PHMM_LANE_MAPPER"); }        // the (slower) lane-per-pair mapper
 inline bool big_mapper()      { return flag("OCT_PHMM_BIG_MAPPER"); }         // test hook: the long-haplotype mapper on short haplotypes
-inline int  penalties_where() { const char* e = getenv("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' || e[0] == 'l' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
-inline int  dedup()           { const char* e = getenv("OCT_PHMM_DEDUP"); return !e ? -1 : atoi(e); }                                  // -1 by shape, 0 never, 1 wherever it is possible
+inline int  penalties_where() { const char* e = get("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' || e[0] == 'l' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
+inline int  dedup()           { const char* e = get("OCT_PHMM_DEDUP"); return !e ? -1 : atoi(e); }                                  // -1 by shape, 0 never, 1 wherever it is possible
 inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_HASH_BITS", &n) && n >= 1 && n < 32 ? (1u << n) - 1u : 0xffffffffu; }   // test hook: collisions
-inline int  device_sized()    { const char* e = getenv("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
+inline int  device_sized()    { const char* e = get("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
 inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
-inline bool multi_wave()      { const char* e = getenv("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
-inline int  mw_planes()       { const char* e = getenv("OCT_PHMM_MW_PLANES"); return !e ? -1 : atoi(e); }                              // k_dp_mw: -1 by task count, 0 one plane per wave (B / 64 waves per task), 1 all planes in one wave
-inline int  walk_stage()      { const char* e = getenv("OCT_PHMM_WALK_STAGE"); return !e ? -1 : atoi(e); }                             // -1 by launch size, 0 never, 1 always: the walk with its tiles staged in LDS
+inline bool multi_wave()      { const char* e = get("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
+inline int  mw_planes()       { const char* e = get("OCT_PHMM_MW_PLANES"); return !e ? -1 : atoi(e); }                              // k_dp_mw: -1 by task count, 0 one plane per wave (B / 64 waves per task), 1 all planes in one wave
+inline int  walk_stage()      { const char* e = get("OCT_PHMM_WALK_STAGE"); return !e ? -1 : atoi(e); }                             // -1 by launch size, 0 never, 1 always: the walk with its tiles staged in LDS
 inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
-inline bool penalties_lane_kernel() { const char* e = getenv("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
+inline bool penalties_lane_kernel() { const char* e = get("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
 }
 
 namespace {
@@ -837,6 +855,10 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     if (!h || !R || !H_in || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
     *out = nullptr;
     rt::Range range_("oct_phmm upload");
+    // OCT_PHMM_UPLOAD_PROFILE: where a big upload's host time goes (one stderr line per upload)
+    const bool up_prof = tune::prof_flag("OCT_PHMM_UPLOAD_PROFILE");
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_up0 = up_prof ? now_ms() : 0; double t_up1 = 0, t_up2 = 0;
     oct_phmm_haplotypes Hv = *H_in;
     const oct_phmm_haplotypes* H = &Hv;
     const uint8_t* sub_mask = H->substitution_mask;                          // only read where the library makes the vectors
@@ -1169,7 +1191,9 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     std::vector<uint32_t> ones(H->n_haps + 1, 1u);
     pk.upload(ones.data(), (size_t)H->n_haps, (const uint32_t**)&d.hclean);
     RT(h->get_event(&b->ev_fork)); RT(h->get_event(&b->ev_join)); RT(h->get_event(&b->ev_hashes));
+    if (up_prof) t_up1 = now_ms();
     RT(pk.commit(h, bp, s));
+    if (up_prof) t_up2 = now_ms();
     d.err_key = d.stats + (size_t)kStatSlots * kStatStride; d.dsl_overflow = d.err_key + 1; d.dsl_trace_cap = b->dsl_trace_cap;
     for (size_t i = 0; i < b->slices.size(); ++i) {
         b->slices[i].cnt = d.pair_cnt + b->slices[i].pair0 + i;      // each slice owns pair1 - pair0 + 1 scan entries
@@ -1286,6 +1310,8 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     // right away, so they must have landed. A one-shot call (populate, align) runs on the same stream at once and does not return before its
     // results are back, which covers the pinned buffer; it only waits here when it brought pageable position arrays.
     if (!one_shot || positions) RT(rt::stream_sync(s));
+    if (up_prof) fprintf(stderr, "{\"upload_profile_ms\": {\"validate_and_tables\": %.2f, \"pack_and_copy\": %.2f, \"kernels_enqueue%s\": %.2f, \"input_MB\": %.1f}}\n",
+                         t_up1 - t_up0, t_up2 - t_up1, (!one_shot || positions) ? "_and_wait" : "", now_ms() - t_up2, (double)pk.in_bytes / 1e6);
     *out = b.release();
     return ok(status);
 }
@@ -1636,6 +1662,14 @@ extern "C" int oct_phmm_batch_stats(const oct_phmm_batch* b, oct_phmm_stats* st)
 extern "C" size_t oct_phmm_batch_out_size(const oct_phmm_batch* b) { return b ? (size_t)b->n_out : 0; }
 
 extern "C" int oct_phmm_batch_device_sized(const oct_phmm_batch* b) { return b && b->dsl ? 1 : 0; }
+
+extern "C" int oct_phmm_test_set(const char* name, const char* value)
+{
+    if (!name || strncmp(name, "OCT_PHMM_", 9) != 0) return OCT_PHMM_EINVAL;
+    std::lock_guard<std::mutex> lk(tune::switch_mu());
+    if (value) tune::switch_table()[name] = value; else tune::switch_table().erase(name);
+    return OCT_PHMM_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // diagnostic: the shader clock while other work runs (bench.py prices its VALU roofline at the clock the DP kernels actually get)

@@ -26,15 +26,37 @@ class EngineError(RuntimeError):
         super().__init__(f"oct_phmm error {code} {what}: {msg}")
 
 
+def source_digest(files, flags) -> str:
+    """sha256 over the contents of `files` and the compiler flags: what a built artefact is stamped with (a sidecar `<artefact>.srchash`), so that a
+    stale binary is never reused because its mtime happens to be newer than the sources' (a checkout, a copied tree, a clock step)."""
+    import hashlib
+    m = hashlib.sha256()
+    for f in files:
+        m.update(Path(f).name.encode()); m.update(Path(f).read_bytes())
+    m.update(" ".join(flags).encode())
+    return m.hexdigest()
+
+
+def up_to_date(artefact: Path, digest: str) -> bool:
+    stamp = Path(str(artefact) + ".srchash")
+    return artefact.exists() and stamp.exists() and stamp.read_text().strip() == digest
+
+
+def stamp(artefact: Path, digest: str) -> None:
+    Path(str(artefact) + ".srchash").write_text(digest + "\n")
+
+
 def build(force: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 the kernels + host API into octopus_amd/liboct_phmm.so (in-tree)."""
+    """hipcc --offload-arch=gfx950 the kernels + host API into octopus_amd/liboct_phmm.so (in-tree). Rebuilt whenever the sources' digest differs from
+    the one the library was stamped with."""
     srcs = [PKG_DIR / "csrc" / "oct_phmm.hip"] + sorted((PKG_DIR / "csrc").glob("*.hpp"))      # every header the one translation unit includes
     srcs.append(PKG_DIR.parent / "include" / "oct_phmm.h")
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+    digest = source_digest(srcs, flags)
+    if not force and up_to_date(LIB_PATH, digest):
         return LIB_PATH
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           str(srcs[0]), "-o", str(LIB_PATH)]
-    subprocess.run(cmd, check=True)
+    subprocess.run([HIPCC] + flags + [str(srcs[0]), "-o", str(LIB_PATH)], check=True)
+    stamp(LIB_PATH, digest)
     return LIB_PATH
 
 
@@ -76,6 +98,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_out_size.restype = C.c_size_t
         lib.oct_phmm_batch_device_sized.argtypes = [pv]
         lib.oct_phmm_probe_clock.argtypes = [pv, C.c_double, C.POINTER(C.c_double)]
+        lib.oct_phmm_test_set.argtypes = [C.c_char_p, C.c_char_p]
         lib.oct_phmm_batch_kernel_time.argtypes = [pv, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         lib.oct_phmm_batch_kernel_time_by_kind.argtypes = [pv, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32 * 4)]
         lib.oct_phmm_batch_genotype_likelihoods.argtypes = [pv, pv, pv, pv, pv]
@@ -114,6 +137,13 @@ def default_error_model(lib_path: Optional[Path] = None) -> abi.ErrorModel:
     m = abi.ErrorModel()
     load(lib_path).oct_phmm_error_model_default(C.byref(m))
     return m
+
+
+def test_set(name: str, value: Optional[str], lib_path: Optional[Path] = None) -> None:
+    """oct_phmm_test_set: a test / A-B switch by its OCT_PHMM_* name (None removes it); read when a handle is created or a batch is uploaded."""
+    code = load(lib_path).oct_phmm_test_set(name.encode(), None if value is None else str(value).encode())
+    if code != abi.OK:
+        raise EngineError(code, None, f"test_set({name})")
 
 
 def error_model_by_name(library: Optional[str], sequencer: Optional[str], lib_path: Optional[Path] = None) -> abi.ErrorModel:

@@ -14,12 +14,14 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def build_sim() -> Path:
-    srcs = list((ROOT / "octopus_amd" / "csrc").glob("*")) + list((ROOT / "tests" / "sim").glob("*.hpp")) + [ROOT / "include" / "oct_phmm.h"]
-    if SIM_LIB.exists() and all(SIM_LIB.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+    srcs = sorted((ROOT / "octopus_amd" / "csrc").glob("*.h*")) + sorted((ROOT / "tests" / "sim").glob("*.hpp")) + [ROOT / "include" / "oct_phmm.h"]
+    flags = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DOCTPHMM_SIM", "-Wno-unused-function"]
+    digest = engine.source_digest(srcs, flags)                 # content, not mtimes: see engine.build
+    if engine.up_to_date(SIM_LIB, digest):
         return SIM_LIB
-    subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DOCTPHMM_SIM",
-                    f"-I{ROOT / 'tests' / 'sim'}", f"-I{ROOT / 'octopus_amd' / 'csrc'}", "-Wno-unused-function",
-                    str(ROOT / "octopus_amd" / "csrc" / "oct_phmm.hip"), "-o", str(SIM_LIB)], check=True)
+    subprocess.run([CLANG] + flags + [f"-I{ROOT / 'tests' / 'sim'}", f"-I{ROOT / 'octopus_amd' / 'csrc'}",
+                                      str(ROOT / "octopus_amd" / "csrc" / "oct_phmm.hip"), "-o", str(SIM_LIB)], check=True)
+    engine.stamp(SIM_LIB, digest)
     return SIM_LIB
 
 

@@ -29,7 +29,7 @@ def sample(ms, n):
 
 
 res = {"idle_ghz": sample(5.0, 5)}
-os.environ["OCT_PHMM_SLICES"] = "1"
+os.environ["OCT_PHMM_ENV_SWITCHES"] = "1"; os.environ["OCT_PHMM_SLICES"] = "1"
 eng = engine.Engine(abi.Config.default(max_indel_error=16))
 rb = eng.upload(synth.config_batch("100kx128", seed=42, B=16, positions="none"))
 rb.run(); rb.wait()

@@ -1,6 +1,6 @@
 # A/B of environment switches on the GPU box: bash tools/gpu_ab.sh <tag> "VAR=1" "VAR2=x" ... (first run = no switch)
 set -x
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/$1; mkdir -p $O; shift
 P="--no-small-batch --no-cpu-baseline --no-extras"
 timeout 300 python bench.py $P > $O/bench_default.json 2> $O/bench_default.err

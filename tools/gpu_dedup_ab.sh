@@ -1,6 +1,6 @@
 # Exact de-duplication of pairs on and off, over slice counts, bench batch + stream, with the bench's own verification:
 #   bash tools/gpu_dedup_ab.sh <tag>      -> gpurun_out/<tag>/dedup_ab.txt
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/${1:-dedup_ab}; mkdir -p $O
 show() { python -c "
 import sys, json

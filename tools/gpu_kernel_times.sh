@@ -1,6 +1,6 @@
 # Per-kernel time of one single-slice bench run (every launch has the device to itself), from rocprofv3's kernel trace:
 #   bash tools/gpu_kernel_times.sh <tag> ["VAR=value" ...]      -> gpurun_out/<tag>/kernel_times.txt
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/${1:-ktimes}; mkdir -p $O; shift
 env OCT_PHMM_SLICES=1 "$@" timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o b -- python bench.py --no-cpu-baseline --no-small-batch --steps 3 --warmup 1 --no-extras > $O/bench_prof.json 2> $O/err.log
 python - "$O" <<'PY' | tee $O/kernel_times.txt

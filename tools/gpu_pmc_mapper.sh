@@ -1,6 +1,6 @@
 # PMC passes with the instruction-mix and wait counters (all kernels of a single-slice run): where do the issue cycles go?
 set -x
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/${1:-pmcmap}; mkdir -p $O
 export OCT_PHMM_SLICES=1
 (cd /tmp && timeout 200 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d /root/repo/$O/pmc_a -o p -- python /root/repo/bench.py --no-small-batch --no-cpu-baseline --steps 1 --warmup 1 > /root/repo/$O/pmc_a.json 2> /root/repo/$O/pmc_a.err); echo "pmc_a rc=$?" >> $O/rc.log

@@ -1,6 +1,6 @@
 # Region-sized calls on the final build: per-call latency breakdown (Python binding) and the C++ region-call bench (C ABI, region server)
 #   bash tools/gpu_region_calls.sh <tag>   -> gpurun_out/<tag>/region_calls.log
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/${1:-region_calls}; mkdir -p $O
 {
 timeout 200 python tools/latency_breakdown.py

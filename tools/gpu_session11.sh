@@ -1,4 +1,4 @@
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/r03_s11; mkdir -p $O
 python -c "from octopus_amd import engine; print(engine.kernel_source_sha())" > $O/kernel_source_sha
 timeout 1200 python -m pytest tests -x -q -m gpu --durations=10 > $O/pytest_gpu.log 2>&1; echo "pytest_gpu rc=$?" >> $O/rc.log

@@ -1,4 +1,4 @@
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/r03_s12; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q > $O/pytest_parity.log 2>&1; echo "pytest rc=$?" >> $O/rc.log
 timeout 100 python tools/latency_breakdown.py > $O/latency.json 2>&1

@@ -1,5 +1,5 @@
 # round 3, GPU session 2: staged walk + fused scan on the GPU; region-call A/B
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/r03_s2; mkdir -p $O
 python -c "from octopus_amd import engine; print(engine.kernel_source_sha())" > $O/kernel_source_sha
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "device_sized or staged or populate_basic or templates or random_scenarios or late_traceback or server or chunked or empty or align or int32 or wide" > $O/pytest_subset.log 2>&1; echo "pytest rc=$?" >> $O/rc.log

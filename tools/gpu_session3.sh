@@ -1,5 +1,5 @@
 # round 3, GPU session 3: why do device-sized launches hurt multi-region (server) batches?
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/r03_s3; mkdir -p $O
 g++ -O2 -std=c++17 tools/region_calls_bench.cpp -o tools/region_calls_bench -Iinclude -Loctopus_amd -loct_phmm -Wl,-rpath,/root/repo/octopus_amd -lpthread 2>&1 | tail -3
 for N in 1 4 8; do

@@ -1,4 +1,4 @@
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/r03_s4; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "device_sized or staged or populate_basic or templates or random_scenarios or late_traceback or server or chunked or empty or align" > $O/pytest_subset.log 2>&1; echo "pytest rc=$?" >> $O/rc.log
 g++ -O2 -std=c++17 tools/region_calls_bench.cpp -o tools/region_calls_bench -Iinclude -Loctopus_amd -loct_phmm -Wl,-rpath,/root/repo/octopus_amd -lpthread 2>&1 | tail -3

@@ -1,7 +1,7 @@
 # One gpurun call's worth of tests + bench + profiles for a round (summaries are copied into profiles/ afterwards):
 #   bash tools/profile_round.sh <tag> [notests]   -> gpurun_out/<tag>/{bench*.json, kstats/, pmc_*/, pytest_gpu.log, kernel_source_sha}
 set -x
-cd /root/repo; export TMPDIR=/tmp
+cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/${1:-prof}; mkdir -p $O
 python -c "from octopus_amd import engine; print(engine.kernel_source_sha())" > $O/kernel_source_sha
 if [ "$2" != "notests" ]; then
