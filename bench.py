@@ -182,7 +182,7 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12, in_flight: int = 3):
+def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12, in_flight: int = 2):
     """What a caller gets who hands over HOST buffers: (i) one oct_phmm_populate of the many-region batch, PCIe both ways; (ii) the same batch
     over and over from `in_flight` host threads with a handle each - while one handle's batch computes, the others' next batches are validated, packed,
     copied up and their results stream back - the sustained rate over n_batches consecutive batches. Every result is compared with the resident run's
@@ -197,7 +197,7 @@ def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12, 
     one = (time.perf_counter() - t0) / 3
     same = bool(np.array_equal(out, resident))
     res = {"e2e_ms_from_host": one * 1e3, "e2e_regions_per_s": n_regions / one}
-    for k in sorted({2, in_flight}):
+    for k in sorted({in_flight, 3}):
         engs = [eng] + [engine.Engine(cfg) for _ in range(k - 1)]
         outs = [out] + [np.empty(batch.out_size()) for _ in range(k - 1)]
         for e, o in zip(engs[1:], outs[1:]):

@@ -130,7 +130,7 @@ struct oct_phmm_batch {
     bool dedup = false, dedup_tables = false; std::vector<DedupSeg> h_segs; DedupSeg* d_segs = nullptr;   // exact de-duplication of pairs (phmm_kernels.hpp)
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long h_err_key = ~0ull;
-    bool ran = false, device_map = false;
+    bool ran = false, device_map = false, stats_clear = false;       // stats_clear: the upload's table kernel left the counters zeroed (the first run skips its memset)
     // device-sized launches (one slice, scratch for the host-known task bound fits): no host read-back of the task counts in the middle of a step
     bool dsl = false; uint32_t dsl_list_bound = 0; size_t dsl_total_bound = 0; int dsl_flavours = 3;
     uint32_t dsl_trace_cap = 0;   // tasks a traceback list may hold (the scratch provisioned for it); a batch that needs more is repeated with host-sized launches   // tasks one list / all six lists can hold at most (padding included)
@@ -1263,11 +1263,14 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     }
     // per-read flags and per-base DP tables (once per batch; HaplotypeLikelihoodModel::reset analogue)
     {
-        const uint32_t table_blocks = (n_hap_bases + 255) / 256, flag_blocks = (R->n_reads + 255) / 256;
+        const uint32_t table_blocks = (n_hap_bases + 255) / 256, flag_blocks = (R->n_reads + 3) / 4;      // tables: a thread per base; flags: a wave per read
         const uint64_t rec_blocks64 = (d.rrec || d.rrecW) ? ((uint64_t)R->n_reads * d.rrec_stride + 255) / 256 : 0;
         if (table_blocks + flag_blocks + rec_blocks64 >= 0x7fffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "batch too large for one table launch");
         const uint32_t rec_blocks = (uint32_t)rec_blocks64;
-        if (table_blocks + flag_blocks + rec_blocks) { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok()); }
+        if (table_blocks + flag_blocks + rec_blocks) {
+            OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok());
+            b->stats_clear = true;                             // (the kernel's last workgroup cleared the counters)
+        }
     }
     if (b->dedup) {
         // canonical band windows: polynomial prefix sums per haplotype, a hash table from window key to the first window with that key,
@@ -1335,7 +1338,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         if (!ensure_bp(h, 0, (size_t)b->dsl_trace_cap / G * per_group)) b->dsl = false;
     }
     d.dsl_trace_cap = b->dsl ? b->dsl_trace_cap : 0;
-    RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
+    if (!b->stats_clear) RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
+    b->stats_clear = false;
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
     if (b->dedup) RT(rt::dev_memset(d.pair_rep, 0xff, (size_t)b->n_pairs * sizeof(uint32_t), s0));      // kNoPair: every pair is computed itself until k_dedup_verify says otherwise
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;

@@ -58,12 +58,14 @@ OCT_DEVICE uint64_t wave_first_index(uint64_t base)       // base + index of thi
 // ------------------------------------------------------------------------------------------------------------------
 // per-read flags, per-haplotype-base DP tables
 // ------------------------------------------------------------------------------------------------------------------
-OCT_DEVICE void read_flags_thread(const DevBatch& b, uint32_t r)
-{
+OCT_DEVICE void read_flags_wave(const DevBatch& b, uint32_t r, uint32_t lane)      // one wave per read: 64 bases per trip (a thread per read walked its 150 bases one
+{                                                                                  // dependent load after the other: 25 us of a region-sized upload)
     if (r >= b.n_reads) return;
-    uint32_t ok = 1;
-    for (uint32_t i = b.roff[r]; i < b.roff[r + 1]; ++i) ok &= is_acgt(b.rbases[i]) ? 1u : 0u;
-    b.racgt[r] = (uint8_t)ok;
+    const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro;
+    uint32_t bad = 0;
+    for (uint32_t i = lane; i < T; i += 64) bad |= is_acgt(b.rbases[ro + i]) ? 0u : 1u;
+    const uint64_t any = hw::ballot(bad != 0);
+    if (lane == 0) b.racgt[r] = any ? 0 : 1;
 }
 
 OCT_DEVICE uint32_t cap_of(uint32_t r, uint32_t h, uint32_t m, uint32_t p)
@@ -98,8 +100,10 @@ OCT_DEVICE void read_record_thread(const DevBatch& b, uint64_t g)
 // "pure ACGT" flags, those past `table_blocks + flag_blocks` build the read record rows, in the same launch.
 OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks, uint32_t flag_blocks)
 {
+    // the last workgroup also clears the step's counters (+ error key + overflow flag behind them), so that the first run after an upload needs no memset launch
+    if (hw::block_idx() + 1 == hw::grid_dim()) for (uint32_t i = hw::thread_idx(); i < kStatSlots * kStatStride + 2; i += hw::block_dim()) b.stats[i] = 0ull;
     if (hw::block_idx() >= table_blocks + flag_blocks) { read_record_thread(b, (uint64_t)(hw::block_idx() - table_blocks - flag_blocks) * hw::block_dim() + hw::thread_idx()); return; }
-    if (hw::block_idx() >= table_blocks) { read_flags_thread(b, (hw::block_idx() - table_blocks) * hw::block_dim() + hw::thread_idx()); return; }
+    if (hw::block_idx() >= table_blocks) { read_flags_wave(b, (hw::block_idx() - table_blocks) * (hw::block_dim() / 64) + (hw::thread_idx() >> 6), hw::thread_idx() & 63u); return; }
     const uint32_t g = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (g >= n_bases) return;
     const uint32_t h = b.hbases[g], mf = b.maskF[g], mr = b.maskR[g];
