@@ -1,5 +1,5 @@
 cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
-O=gpurun_out/r03_s10; mkdir -p $O
+O=gpurun_out/r03_s14; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "multi_wave or wide or long_reads" > $O/pytest_mw.log 2>&1; echo "pytest rc=$?" >> $O/rc.log
 for V in "A=1" "OCT_PHMM_MW_PLANES=0" "OCT_PHMM_MW_PLANES=1"; do
   echo "## $V" >> $O/long_read_ab.log
