@@ -2001,7 +2001,11 @@ extern "C" int oct_phmm_server_create_multi(const oct_phmm_config* cfg, const in
     if (!s) return OCT_PHMM_EHIP;
     for (uint32_t dv = 0; dv < n_devices; ++dv) {
         oct_phmm_config c = *cfg; c.device_id = device_ids[dv];
-        for (int w = 0; w < oct_phmm_server::kWorkers; ++w) {
+        int n_workers = oct_phmm_server::kWorkers;
+#if !defined(OCTPHMM_SIM)
+        { long long v; if (tune::number("OCT_PHMM_SERVER_WORKERS", &v) && v >= 1 && v <= 8) n_workers = (int)v; }      // A/B switch: device queues (worker threads + handles) per device
+#endif
+        for (int w = 0; w < n_workers; ++w) {
             oct_phmm_handle* h = nullptr;
             const int rc = oct_phmm_create(&c, &h);
             if (rc != OCT_PHMM_OK) { for (auto* k : s->hs) oct_phmm_destroy(k); delete s; return rc; }
