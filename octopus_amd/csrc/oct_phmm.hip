@@ -76,7 +76,9 @@ struct oct_phmm_handle {
     oct_phmm_config cfg;
     DevPool pool;
     void* stage = nullptr; size_t stage_bytes = 0;       // pinned host staging: all input arrays of a batch go up in ONE copy
-    void* out_stage = nullptr; size_t out_stage_bytes = 0;   // pinned landing zone for slice-wise result copies (oct_phmm_populate)
+    void* out_stage = nullptr; size_t out_stage_bytes = 0;   // pinned landing zone for result copies (oct_phmm_populate)
+    std::vector<void*> stat_stage_free;                  // pinned landing blocks for a run's counters (one per batch in flight, recycled)
+    void* get_stat_stage(size_t bytes) { if (!stat_stage_free.empty()) { void* p = stat_stage_free.back(); stat_stage_free.pop_back(); return p; } void* p = nullptr; return rt::host_pinned_malloc(&p, bytes) ? p : nullptr; }
     std::vector<rt::Event> ev_pool;                      // recycled timing / completion events
     bool timing = false;                                 // HIP-event timing of the DP launches (oct_phmm_set_timing; bench.py's roofline leg)
     bool get_event(rt::Event* e) { if (!ev_pool.empty()) { *e = ev_pool.back(); ev_pool.pop_back(); return true; } return rt::event_create(e); }
@@ -129,6 +131,8 @@ struct oct_phmm_batch {
     unsigned long long h_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool dedup = false, dedup_tables = false; std::vector<DedupSeg> h_segs; DedupSeg* d_segs = nullptr;   // exact de-duplication of pairs (phmm_kernels.hpp)
     std::vector<unsigned long long> h_stat_stripes;
+    unsigned long long* stat_stage = nullptr;                   // pinned landing block of the counters' copy (the handle's; pageable destinations cost a staged copy per call)
+    bool synced = false;                                        // oct_phmm_batch_wait has seen the handle's streams idle since the last run
     unsigned long long h_err_key = ~0ull;
     bool ran = false, device_map = false, stats_clear = false;       // stats_clear: the upload's table kernel left the counters zeroed (the first run skips its memset)
     // device-sized launches (one slice, scratch for the host-known task bound fits): no host read-back of the task counts in the middle of a step
@@ -159,7 +163,7 @@ struct oct_phmm_batch {
 //   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS, OCT_PHMM_UPLOAD_PROFILE
 //   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
 //                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED,
-//                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES
+//                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES, OCT_PHMM_DSL_FORK_EARLY, OCT_PHMM_DSL_MERGE_DP, OCT_PHMM_SERVER_WORKERS
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
 //                OCT_PHMM_DSL_TRACE_PER_PAIR, OCT_PHMM_TEST_FAIL_BP_ALLOCS (the first traceback-scratch allocations "fail")
@@ -200,7 +204,10 @@ inline int  device_sized()    { const char* e = get("OCT_PHMM_DEVICE_SIZED"); re
 inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
 inline bool multi_wave()      { const char* e = get("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
 inline int  mw_planes()       { const char* e = get("OCT_PHMM_MW_PLANES"); return !e ? -1 : atoi(e); }                              // k_dp_mw: -1 by task count, 0 one plane per wave (B / 64 waves per task), 1 all planes in one wave
-inline int  walk_stage()      { const char* e = get("OCT_PHMM_WALK_STAGE"); return !e ? -1 : atoi(e); }                             // -1 by launch size, 0 never, 1 always: the walk with its tiles staged in LDS
+inline int  dsl_merge_dp()    { const char* e = get("OCT_PHMM_DSL_MERGE_DP"); return !e ? -1 : atoi(e); }                                         // device-sized step: traceback and score-only list of a flavour in one launch (k_dp_pair): -1 by batch size, 0 never (two launches on two streams), 1 always
+inline bool dsl_fork_early()  { const char* e = get("OCT_PHMM_DSL_FORK_EARLY"); return !e || atoi(e) != 0; }                                 // device-sized step with two DP launches: the score-only DP starts beside the traceback DP (default) or after it, beside the walk (0)
+inline uint32_t walk_rows_threads() { const char* e = get("OCT_PHMM_WALK_ROWS_THREADS"); const int v = e ? atoi(e) : 0; return v == 64 || v == 128 || v == 256 ? (uint32_t)v : 64u; }
+inline int  walk_stage()      { const char* e = get("OCT_PHMM_WALK_STAGE"); return !e ? -1 : atoi(e); }                             // -1 by launch size; 0 lockstep walker out of registers, 1 lockstep out of LDS-staged tiles, 2 one walk per 16-lane row (k_walk_rows; k_walk_long at bands 128 / 256 for 1 and 2)
 inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
 inline bool penalties_lane_kernel() { const char* e = get("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
 }
@@ -366,6 +373,30 @@ bool launch_dp(int band, bool tr, bool gen, bool fa, const DpParams& p, uint32_t
         default: return false;
     }
 }
+// the traceback list and the score-only list of one flavour in one launch (device-sized steps)
+template <int B, bool GEN, bool FA>
+bool launch_dp_pair_inst(const DpParams& pt, const DpParams& ps, uint32_t n_blocks_t, uint32_t n_blocks_s, size_t lds, rt::Stream s)
+{
+    if (lds > 64 * 1024 && !rt::allow_lds((k_dp_pair<B, GEN, FA>), lds)) return false;
+    OCT_LAUNCH((k_dp_pair<B, GEN, FA>), n_blocks_t + n_blocks_s, kBlockWaves * 64, lds, s, pt, ps, n_blocks_t);
+    return rt::launch_ok();
+}
+template <int B>
+bool launch_dp_pair_band(bool gen, bool fa, const DpParams& pt, const DpParams& ps, uint32_t nt, uint32_t ns, size_t lds, rt::Stream s)
+{
+    if (gen) return fa ? launch_dp_pair_inst<B, true, true>(pt, ps, nt, ns, lds, s) : launch_dp_pair_inst<B, true, false>(pt, ps, nt, ns, lds, s);
+    return fa ? launch_dp_pair_inst<B, false, true>(pt, ps, nt, ns, lds, s) : launch_dp_pair_inst<B, false, false>(pt, ps, nt, ns, lds, s);
+}
+bool launch_dp_pair(int band, bool gen, bool fa, const DpParams& pt, const DpParams& ps, uint32_t nt, uint32_t ns, size_t lds, rt::Stream s)
+{
+    switch (band) {
+        case 8:  return launch_dp_pair_band<8>(gen, fa, pt, ps, nt, ns, lds, s);
+        case 16: return launch_dp_pair_band<16>(gen, fa, pt, ps, nt, ns, lds, s);
+        case 32: return launch_dp_pair_band<32>(gen, fa, pt, ps, nt, ns, lds, s);
+        case 64: return launch_dp_pair_band<64>(gen, fa, pt, ps, nt, ns, lds, s);
+        default: return false;
+    }
+}
 template <int B, bool TR>
 bool launch_dp32_inst(const DpParams& p, uint32_t n_blocks, size_t lds, rt::Stream s)
 {
@@ -384,13 +415,14 @@ bool launch_dp32(int band, bool tr, const DpParams& p, uint32_t n_blocks, size_t
     }
 }
 template <int B, int TPR, int C>
-bool launch_walk_inst(const WalkParams& w, rt::Stream s, bool stage)
+bool launch_walk_inst(const WalkParams& w, rt::Stream s, int stage)     // stage: 0 lockstep walker out of registers, 1 lockstep out of LDS-staged tiles, 2 one walk per 16-lane row
 {
     const uint32_t blocks = (w.n_tasks + 255) / 256;
     const size_t lds = 256 * kWalkEvents * sizeof(uint32_t);
     if constexpr (C == 1) {
         const size_t stage_lds = walk_stage_lds_bytes(B, TPR);
-        if (stage && stage_lds <= rt::kMaxLdsBytes) {          // region-sized launch: one wave per workgroup, the tiles staged in LDS
+        if (stage == 2) { const uint32_t th = tune::walk_rows_threads(); OCT_LAUNCH((k_walk_rows<B, TPR>), (w.n_tasks + th / 16 - 1) / (th / 16), th, walk_rows_lds_bytes(B, th), s, w); }   // region-sized launch: four walks per wave, runs of matches in one move
+        else if (stage && stage_lds <= rt::kMaxLdsBytes) {          // one wave per workgroup, the tiles staged in LDS
             if (stage_lds > 64 * 1024 && !rt::allow_lds((k_walk<B, TPR, C, true>), stage_lds)) return false;
             OCT_LAUNCH((k_walk<B, TPR, C, true>), (w.n_tasks + 63) / 64, 64, stage_lds, s, w);
         } else OCT_LAUNCH((k_walk<B, TPR, C, false>), blocks, 256, lds, s, w);
@@ -403,7 +435,7 @@ bool launch_walk_inst(const WalkParams& w, rt::Stream s, bool stage)
     if (w.pair_key != nullptr) OCT_LAUNCH((k_walk_cigar<B, TPR, C>), blocks, 256, 0, s, w);       // align mode: the pairs' winning tasks write their CIGARs
     return rt::launch_ok();
 }
-bool launch_walk(int band, bool one_per_row, const WalkParams& w, rt::Stream s, bool stage)
+bool launch_walk(int band, bool one_per_row, const WalkParams& w, rt::Stream s, int stage)
 {
     switch (band) {
         case 8:   return one_per_row ? launch_walk_inst<8, 1, 1>(w, s, stage) : launch_walk_inst<8, 2, 1>(w, s, stage);
@@ -474,10 +506,12 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 // Run one kind's task list through the DP kernel (+ walk for traceback kinds), chunked so the traceback scratch fits.
 // `ref` (device-sized launch): `tasks` is the array that holds all six lists, `n_tasks` the host's bound for one list; the kernels take the list itself
 // from the totals in device memory.
+constexpr uint64_t kDslMergeMaxPairs = 12000;          // device-sized step: up to here the traceback and the score-only list of a flavour share one launch (k_dp_pair)
 constexpr uint32_t kDslMaxBlocks = 1024;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
 int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
                 int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false,
-                TaskListRef ref = TaskListRef {nullptr, nullptr, 0, nullptr}, const rt::Event* after_first_dp = nullptr)
+                TaskListRef ref = TaskListRef {nullptr, nullptr, 0, nullptr}, const rt::Event* after_first_dp = nullptr,
+                int paired_score_list = -1, uint32_t paired_score_bound = 0)     // device-sized traceback launch: the score-only list of the same flavour rides along (k_dp_pair)
 {
     if (!n_tasks) return OCT_PHMM_OK;
     const bool dsl = ref.totals != nullptr;
@@ -525,6 +559,12 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         if (h->timing) { RT(h->get_event(&e0)); RT(h->get_event(&e1)); RT(rt::event_record(e0, st)); }
         // (a device-sized launch does not know its task count: region-sized, so the spread-out form)
         const bool one_wave = tune::mw_planes() >= 0 ? tune::mw_planes() != 0 : (!dsl && p.n_tasks >= 640);
+        if (paired_score_list >= 0 && g0 == 0) {
+            DpParams ps = p;                                   // same tables (same flavour), the score-only list of the same task array, no traceback scratch
+            ps.ref.list = (uint32_t)paired_score_list; ps.tasks = tasks; ps.n_tasks = paired_score_bound / G * G; ps.bp = nullptr; ps.ends = nullptr; ps.late = 0;
+            const uint32_t n_blocks_s = std::min((ps.n_tasks / G + ps.groups_per_block - 1) / ps.groups_per_block, kDslMaxBlocks);
+            if (!launch_dp_pair(B, gen, b->fast_adds, p, ps, n_blocks, n_blocks_s, lds, st)) return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
+        } else
         if (!(b->multi_wave ? launch_dp_mw(B, one_wave, tr, gen, p, st) : b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
                         : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
@@ -552,7 +592,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
                 w.err_flags = b->d_err_flags; w.cig_ops = b->d_aln_ops; w.cig_n = b->d_aln_n; w.cig_mpos = b->d_aln_mpos; w.cig_cap = b->cig_cap;
             }
             // region-sized launches (a few hundred waves at most) stage their tiles in LDS; big ones hide the line fetches behind other waves
-            const bool stage = tune::walk_stage() >= 0 ? tune::walk_stage() != 0 : (dsl || (size_t)p.n_tasks <= 64 * 1024);
+            const int stage = tune::walk_stage() >= 0 ? tune::walk_stage() : ((dsl || (size_t)p.n_tasks <= 64 * 1024) ? 2 : 0);
             if (!launch_walk(B, h->wide || b->stream, w, st, stage)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
         }
     }
@@ -803,7 +843,8 @@ extern "C" void oct_phmm_destroy(oct_phmm_handle* h)
     for (int i = 1; i < oct_phmm_handle::kMaxSlices; ++i) rt::stream_destroy(h->slice_stream(i));
     for (auto& kv : h->pool.live) rt::dev_free(kv.first);
     h->pool.live.clear(); h->pool.trim();
-    rt::host_pinned_free(h->stage);
+    rt::host_pinned_free(h->stage); rt::host_pinned_free(h->out_stage);
+    for (void* p : h->stat_stage_free) rt::host_pinned_free(p);
     if (h->probe_ready) { rt::stream_sync(h->probe_stream); rt::stream_destroy(h->probe_stream); rt::dev_free(h->d_probe); rt::host_pinned_free(h->h_probe); }
     for (rt::Event e : h->ev_pool) rt::event_destroy(e);
     rt::event_destroy(h->ev_ready);
@@ -826,8 +867,9 @@ extern "C" int oct_phmm_set_timing(oct_phmm_handle* h, int enabled)
 extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
 {
     if (!b) return;
-    if (h) { rt::set_device(h->cfg.device_id); for (int i = 0; i < oct_phmm_handle::kMaxSlices; ++i) rt::stream_sync(h->slice_stream(i)); }
+    if (h && !b->synced) { rt::set_device(h->cfg.device_id); for (int i = 0; i < oct_phmm_handle::kMaxSlices; ++i) rt::stream_sync(h->slice_stream(i)); }   // (a waited batch has nothing in flight)
     if (!h) h = b->owner;
+    if (b->stat_stage) h->stat_stage_free.push_back(b->stat_stage);
     for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
     for (void* p : b->allocs) h->pool.release(p);
     for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_ends); h->pool.release(sl.d_keys); h->put_event(sl.done); if (b->dedup) h->put_event(sl.matched); }
@@ -1450,33 +1492,46 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             TaskListRef ref {sl.d_totals, sl.cnt_late ? sl.d_totals_late : nullptr, 0, d.dsl_overflow};
             OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
                        (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, ref, G); RT(rt::launch_ok());
-            // Region-sized and latency-bound: the score-only DP runs on a second stream beside the traceback WALK (a few hundred waves that mostly wait
-            // for LDS and memory), not beside the traceback DP (both are VALU-bound and would only share the issue slots): it starts when the first
-            // traceback DP launch is over.
+            // Region-sized and latency-bound: the score-only DP runs on a second stream beside the traceback DP (a region's two lists together are about one
+            // wave per SIMD; OCT_PHMM_DSL_FORK_EARLY=0: beside the traceback WALK instead, as round 2's lockstep walker wanted it).
             rt::Stream aux = h->slice_stream(1);
             auto flavour_live = [&](int list) { const bool gen = list == kScoreGen || list == kTraceGen || list == 5; return (b->dsl_flavours & (gen ? 2 : 1)) != 0; };
-            bool forked = false;
-            if (b->stream) { RT(rt::event_record(b->ev_fork, s)); forked = true; }     // (long reads: see the host-sized path)
+            // ... unless both fit ONE launch (k_dp_pair: packed int16 lanes, LDS-resident kernels): the score-only list of a flavour rides with that flavour's first
+            // traceback launch, no second stream, no events.
+            // Measured on one box, three interleaved repetitions each (profiles/r03_step7_dp_launch_forms_ab.log): one 300 x 24 region per call 0.242 ms merged, 0.250 forked
+            // early, 0.280 forked after the traceback DP; 16 callers on the region server (3.5 - 5 regions per device batch) 11.6 k / 13.7 k / 12.3 k regions/s - in the
+            // merged launch the score-only workgroups hold the traceback form's LDS and registers, which costs occupancy once a batch fills the chip. So: merged up
+            // to kDslMergeMaxPairs pairs, two launches side by side beyond.
+            const int want_merge = tune::dsl_merge_dp();
+            const bool merge = (want_merge >= 0 ? want_merge != 0 : np <= kDslMergeMaxPairs) && !h->wide && !b->stream && !b->multi_wave && !b->align_mode;
+            bool forked = false, score_done[2] = {false, false};
+            if (!merge && (b->stream || tune::dsl_fork_early())) { RT(rt::event_record(b->ev_fork, s)); forked = true; }     // (long reads: see the host-sized path)
             for (int list : {4, 5, (int)kTraceFast, (int)kTraceGen}) {
                 if (list >= 4 && !sl.cnt_late) continue;
                 if (!flavour_live(list)) continue;
                 ref.list = list;
+                const int fl = (list == kTraceGen || list == 5) ? 1 : 0;
+                const bool ride = merge && !score_done[fl];
                 const int rc = run_dp_kind(h, b, 0, list == 4 ? kTraceFast : list == 5 ? kTraceGen : list, sl.d_tasks, b->dsl_trace_cap, sl.d_ends, h->cfg.nuc_prior, nullptr, status,
-                                           nullptr, list >= 4, ref, forked ? nullptr : &b->ev_fork);
+                                           nullptr, list >= 4, ref, (merge || forked) ? nullptr : &b->ev_fork, ride ? (fl ? (int)kScoreGen : (int)kScoreFast) : -1, b->dsl_list_bound);
                 if (rc != OCT_PHMM_OK) return rc;
-                forked = true;
+                forked = true; if (ride) score_done[fl] = true;
             }
-            if (!forked) RT(rt::event_record(b->ev_fork, s));
-            RT(rt::stream_wait_event(aux, b->ev_fork));
-            for (int list : {(int)kScoreFast, (int)kScoreGen}) {
-                if (!flavour_live(list)) continue;
-                ref.list = list;
-                const int rc = run_dp_kind(h, b, 0, list, sl.d_tasks, b->dsl_list_bound, sl.d_ends, h->cfg.nuc_prior, nullptr, status, &aux, false, ref);
-                if (rc != OCT_PHMM_OK) return rc;
+            if (!(merge && score_done[0] == ((b->dsl_flavours & 1) != 0) && score_done[1] == ((b->dsl_flavours & 2) != 0))) {
+                if (!forked || merge) RT(rt::event_record(b->ev_fork, s));
+                RT(rt::stream_wait_event(aux, b->ev_fork));
+                for (int list : {(int)kScoreFast, (int)kScoreGen}) {
+                    if (!flavour_live(list) || score_done[list == kScoreGen ? 1 : 0]) continue;
+                    ref.list = list;
+                    const int rc = run_dp_kind(h, b, 0, list, sl.d_tasks, b->dsl_list_bound, sl.d_ends, h->cfg.nuc_prior, nullptr, status, &aux, false, ref);
+                    if (rc != OCT_PHMM_OK) return rc;
+                }
+                RT(rt::event_record(b->ev_join, aux)); RT(rt::stream_wait_event(s, b->ev_join));
             }
-            RT(rt::event_record(b->ev_join, aux)); RT(rt::stream_wait_event(s, b->ev_join));
         }
         if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
+        if (b->early_out && sl.out1 > sl.out0)                   // one-shot call: the results land in the handle's pinned zone behind the epilogue, no second synchronisation
+            RT(rt::d2h((double*)h->out_stage + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
         RT(rt::event_record(sl.done, s));
         return OCT_PHMM_OK;
     };
@@ -1548,7 +1603,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     };
     auto deliver = [&](int i) -> int {                        // finished slice -> the caller's buffer (host copy overlaps the later slices' kernels)
         const oct_phmm_batch::Slice& sl = b->slices[i];
-        if (!b->early_out || sl.out1 <= sl.out0) return OCT_PHMM_OK;
+        if (!b->early_out || sl.out1 <= sl.out0 || S == 1) return OCT_PHMM_OK;   // (a one-slice batch: oct_phmm_populate copies after its one wait)
         RT(rt::event_sync(sl.done));
         const char* src = (const char*)((const double*)h->out_stage + sl.out0); char* dst = (char*)(b->early_out + sl.out0);
         host_parallel((size_t)(sl.out1 - sl.out0) * sizeof(double), (size_t)2 << 20, [&](size_t lo, size_t hi) { memcpy(dst + lo, src + lo, hi - lo); });
@@ -1569,9 +1624,11 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     if (rc != OCT_PHMM_OK) return rc;
     for (int i = std::max(0, S - 2); i < S; ++i) { rc = deliver(i); if (rc != OCT_PHMM_OK) return rc; }
     for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(s0, b->slices[i].done));
-    b->h_stat_stripes.assign((size_t)kStatSlots * kStatStride + 2, 0);  // counters + the inverted error key + the overflow flag, one copy
-    RT(rt::d2h(b->h_stat_stripes.data(), d.stats, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));
-    b->ran = true;
+    constexpr size_t kStatWords = (size_t)kStatSlots * kStatStride + 2;   // counters + the inverted error key + the overflow flag, one copy
+    b->h_stat_stripes.assign(kStatWords, 0);
+    if (!b->stat_stage) b->stat_stage = (unsigned long long*)h->get_stat_stage(kStatWords * sizeof(unsigned long long));
+    RT(rt::d2h(b->stat_stage ? b->stat_stage : b->h_stat_stripes.data(), d.stats, kStatWords * sizeof(unsigned long long), s0));
+    b->ran = true; b->synced = false;
     return ok(status);
 }
 
@@ -1580,13 +1637,16 @@ extern "C" int oct_phmm_batch_wait(oct_phmm_handle* h, oct_phmm_batch* b, oct_ph
     if (!h || !b || b->owner != h || !b->ran) return fail(status, OCT_PHMM_EINVAL, "batch was not run");
     RT(rt::set_device(h->cfg.device_id));
     RT(rt::stream_sync(h->stream));
+    if (b->stat_stage) memcpy(b->h_stat_stripes.data(), b->stat_stage, b->h_stat_stripes.size() * sizeof(unsigned long long));
     if (b->dsl && b->h_stat_stripes[(size_t)kStatSlots * kStatStride + 1]) {
         // a traceback list outgrew the scratch provisioned for the device-sized launches: every list read as empty. Once more, host-sized.
         b->dsl = false;
         const int rc = oct_phmm_batch_run(h, b, status);
         if (rc != OCT_PHMM_OK) return rc;
         RT(rt::stream_sync(h->stream));
+        if (b->stat_stage) memcpy(b->h_stat_stripes.data(), b->stat_stage, b->h_stat_stripes.size() * sizeof(unsigned long long));
     }
+    b->synced = true;                                           // (every slice stream joined the handle's before the counters were copied)
     for (int k = 0; k < 12; ++k) { b->h_stats[k] = 0; for (uint32_t sl = 0; sl < kStatSlots; ++sl) b->h_stats[k] += b->h_stat_stripes[(size_t)sl * kStatStride + k]; }
     b->h_err_key = ~b->h_stat_stripes[(size_t)kStatSlots * kStatStride];
     if (tune::map_stats()) {
@@ -1825,16 +1885,19 @@ extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads
     oct_phmm_batch* b = nullptr;
     int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, false, 0, true);
     bool early = false;
-    if (rc == OCT_PHMM_OK && b->slices.size() > 1 && out) {   // big batch: results stream back slice by slice through a pinned landing zone
-        const size_t bytes = (size_t)b->n_out * sizeof(double);
+    if (rc == OCT_PHMM_OK && out && b->n_out) {                // results come back through a pinned landing zone: slice by slice while a big batch computes, behind the
+        const size_t bytes = (size_t)b->n_out * sizeof(double);  // epilogue of a small one - one stream synchronisation per call, no staged copy into pageable memory
         if (h->out_stage_bytes < bytes) {
+            const size_t roomy = std::max(bytes + bytes / 2, (size_t)1 << 20);     // (a region thread's calls differ in size: no regrowth per call)
             rt::host_pinned_free(h->out_stage); h->out_stage = nullptr; h->out_stage_bytes = 0;
-            if (rt::host_pinned_malloc(&h->out_stage, bytes)) h->out_stage_bytes = bytes;
+            if (rt::host_pinned_malloc(&h->out_stage, roomy)) h->out_stage_bytes = roomy;
+            else if (rt::host_pinned_malloc(&h->out_stage, bytes)) h->out_stage_bytes = bytes;
         }
         if (h->out_stage_bytes >= bytes) { b->early_out = out; early = true; }
     }
     if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_run(h, b, status);
     if (rc == OCT_PHMM_OK) rc = early ? oct_phmm_batch_wait(h, b, status) : oct_phmm_batch_download(h, b, out, status);
+    if (rc == OCT_PHMM_OK && early && b->slices.size() == 1) memcpy(out, h->out_stage, (size_t)b->n_out * sizeof(double));
     oct_phmm_batch_free(h, b);
     return rc;
 }

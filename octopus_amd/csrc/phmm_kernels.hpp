@@ -973,7 +973,7 @@ OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* c
 
 // Region-sized batches: the scan of the per-pair counts and the per-haplotype bases in ONE single-workgroup launch instead of four (three scan
 // launches + k_hap_bases), for both count arrays at once (workgroup 0: cnt, workgroup 1: cnt_late). A call is a chain of dependent launches and each
-// link costs ~5 us however little it does. Tiles of 4096 items (four consecutive per thread: a wave reads 4 KB in one piece), the thread sums
+// link costs ~5 us however little it does. Tiles of 8192 items (eight consecutive per thread), the thread sums
 // scanned with shuffles inside a wave and through 16 LDS words across the waves: two workgroup barriers per tile.
 constexpr uint32_t kScanBasesMaxItems = 64 * 1024;
 OCT_DEVICE uint4 shfl4(uint4 v, uint32_t src) { return make_uint4(hw::shfl(v.x, (int)src), hw::shfl(v.y, (int)src), hw::shfl(v.z, (int)src), hw::shfl(v.w, (int)src)); }
@@ -1000,13 +1000,16 @@ OCT_KERNEL(k_scan_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, 
     uint4* cnt = hw::block_idx() ? cnt1 : cnt0; uint4* hap_base = hw::block_idx() ? hap_base1 : hap_base0; uint4* totals = hw::block_idx() ? totals1 : totals0;
     const uint32_t tid = hw::thread_idx();
     uint4 carry = make_uint4(0, 0, 0, 0);
-    for (uint32_t base = 0; base < n_scan; base += kHapBaseThreads * 4) {      // exclusive scan of cnt[0, n_scan), in place
-        const uint32_t i0 = base + tid * 4;
-        uint4 v[4], sum = make_uint4(0, 0, 0, 0);
-        for (uint32_t j = 0; j < 4; ++j) { v[j] = i0 + j < n_scan ? cnt[i0 + j] : make_uint4(0, 0, 0, 0); sum = add4(sum, v[j]); }
+    constexpr uint32_t PER = 8;                                 // items per thread and tile: a 300 x 24 region (7,201 items) is ONE tile, i.e. one round of loads, scan, stores
+    for (uint32_t base = 0; base < n_scan; base += kHapBaseThreads * PER) {    // exclusive scan of cnt[0, n_scan), in place
+        const uint32_t i0 = base + tid * PER;
+        uint4 v[PER], sum = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) { v[j] = i0 + j < n_scan ? cnt[i0 + j] : make_uint4(0, 0, 0, 0); sum = add4(sum, v[j]); }
         uint4 tile_total;
         uint4 run = add4(carry, block_scan_excl(sum, sh, &tile_total));
-        for (uint32_t j = 0; j < 4; ++j) if (i0 + j < n_scan) { cnt[i0 + j] = run; run = add4(run, v[j]); }
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) if (i0 + j < n_scan) { cnt[i0 + j] = run; run = add4(run, v[j]); }
         carry = add4(carry, tile_total);
     }
     hw::block_sync();                                           // the scanned counts are read across threads below
@@ -1134,8 +1137,9 @@ inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool t
 // traceback scratch: per task group, ceil(iterations / 16) tiles of 64 lanes x 16 iterations, each lane's 16 dwords contiguous
 OCT_HD constexpr uint32_t bp_tiles(uint32_t t_cap, uint32_t B) { return (t_cap + B + 15) / 16 + 1; }
 
+// (the body of k_dp: workgroup `blk` of `nblk` - a launch may hold the workgroups of two task lists, see k_dp_pair)
 template <int B, bool TRACE, bool GENERIC, bool FASTADD>
-OCT_KERNEL(k_dp)(DpParams p)
+OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t nblk)
 {
     constexpr uint32_t ROWS = 64 / B, G = 2 * ROWS;
     OCT_DYN_SMEM(smem);
@@ -1161,7 +1165,7 @@ OCT_KERNEL(k_dp)(DpParams p)
     auto sadd = [](uint32_t x, uint32_t y) -> uint32_t { if constexpr (FASTADD) return x + y; else return hw::pk_add(x, y); };
 
     // (a host-sized launch has one workgroup per run of groups_per_block groups; a device-sized one a grid from the host's bound, strided)
-    for (uint32_t g_begin = hw::block_idx() * p.groups_per_block; g_begin < n_groups; g_begin += hw::grid_dim() * p.groups_per_block) {
+    for (uint32_t g_begin = blk * p.groups_per_block; g_begin < n_groups; g_begin += nblk * p.groups_per_block) {
     const uint32_t g_end = g_begin + p.groups_per_block < n_groups ? g_begin + p.groups_per_block : n_groups;
     uint32_t seg = g_begin;
     while (seg < g_end) {
@@ -1395,6 +1399,19 @@ OCT_KERNEL(k_dp)(DpParams p)
         seg = seg_end;
     }
     }
+}
+
+template <int B, bool TRACE, bool GENERIC, bool FASTADD>
+OCT_KERNEL(k_dp)(DpParams p) { dp_groups<B, TRACE, GENERIC, FASTADD>(p, hw::block_idx(), hw::grid_dim()); }
+
+// Region-sized (device-sized) steps: the traceback list and the score-only list of one cost flavour in ONE launch - the first n_blocks_t workgroups take the
+// traceback form, the rest the score-only form. Both are a few hundred latency-bound waves: side by side they fill the chip's SIMDs once, one after the other
+// (or on two streams, with an event between them) they cost a launch gap and their sum.
+template <int B, bool GENERIC, bool FASTADD>
+OCT_KERNEL(k_dp_pair)(DpParams pt, DpParams ps, uint32_t n_blocks_t)
+{
+    if (hw::block_idx() < n_blocks_t) dp_groups<B, true, GENERIC, FASTADD>(pt, hw::block_idx(), n_blocks_t);
+    else dp_groups<B, false, GENERIC, FASTADD>(ps, hw::block_idx() - n_blocks_t, hw::grid_dim() - n_blocks_t);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2258,6 +2275,268 @@ OCT_MAX_THREADS(STAGE ? 64 : 256) OCT_KERNEL(k_walk)(WalkParams w)
         const uint32_t* P = w.pos + (size_t)t.pair * (uint32_t)w.max_pos; const uint32_t np = w.npos[t.pair];
         unsigned long long order = 0;                       // not in the mapped list: the original (or shifted original) position
         for (uint32_t j = 0; j < np; ++j) if (P[j] == p) { order = j + 1; break; }
+        const unsigned long long key = (unsigned long long)(uint32_t)pen << 32 | order << 8;
+        w.task_key[ti] = key;
+        hw::atomic_min_u64(w.pair_key + t.pair, key);
+        return;
+    }
+    hw::atomic_min_i32(w.pair_best + t.pair, pen);
+}
+
+// Region-sized launches (a few thousand walks of ~150 columns): the lockstep walker above puts them into ~100 waves that each pay ~32 step slots per tile for
+// 64 DIFFERENT walks. Here ONE WALK OWNS A 16-LANE ROW (four walks per wave, ~1,600 waves for a 300 x 24 region):
+//  * the row stages the whole band of its task row for the next K tiles in LDS (lane l copies the 64-byte lines of band lane l: one memory round trip per
+//    K x 16 iterations, and a change of band lane - an indel column - is just another LDS address);
+//  * a run of match columns walks straight down one band lane at one diagonal parity, i.e. along ONE staged line: its sixteen words are looked at by the
+//    row's sixteen lanes at once (a ballot over "this word's label is not match") and the run is taken in ONE move, flank bookkeeping included - the
+//    columns inside a flank are counted, and their "costs something" marks queued, by the lanes that hold them;
+//  * everything else - the columns around an indel, a junk alignment that zig-zags through the band - goes one column at a time in an inner loop without
+//    any cross-lane operation, until the next run starts.
+// Every cross-lane operation sits in wave-uniform control flow (rows that are done idle along). Same steps, same events, same result as k_walk.
+constexpr uint32_t kWalkRowEvents = 64;
+constexpr uint32_t kWalkRowLine = 20;                                      // words per staged line: 16 + pad (16-byte aligned; the 16 lanes of a row write their lines with b128 stores, two-way conflicts at most)
+constexpr uint32_t walk_rows_tiles(uint32_t B) { return B <= 16 ? 4 : (B == 32 ? 2 : 1); }
+constexpr uint32_t walk_rows_row_words(uint32_t B) { return kWalkRowEvents + walk_rows_tiles(B) * B * kWalkRowLine + 8; }   // (+ 8: the four rows of a wave start in different banks)
+inline size_t walk_rows_lds_bytes(uint32_t B, uint32_t threads) { return threads / 16 * walk_rows_row_words(B) * sizeof(uint32_t); }
+
+template <int B, int TPR>
+OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
+{
+    constexpr uint32_t ROWS = 64 / B, G = TPR * ROWS;
+    constexpr uint32_t K = walk_rows_tiles(B), LPL = B <= 16 ? 1 : B / 16, LS = kWalkRowLine;   // tiles staged at a time, band lines per lane and tile
+    static_assert(B <= 64, "one band row per task group row");
+    OCT_DYN_SMEM(smem);
+    const uint32_t lane = hw::thread_idx() & 63u, l16 = lane & 15u, rowbase = lane & 48u;
+    uint32_t* evbuf = (uint32_t*)smem + (hw::thread_idx() >> 4) * walk_rows_row_words(B);      // [kWalkRowEvents] queued in-flank events of this row's walk
+    uint32_t* rowt = evbuf + kWalkRowEvents;                                                    // [K tiles][B band lanes][LS] staged backpointer lines
+    const uint32_t ti = (hw::block_idx() * hw::block_dim() + hw::thread_idx()) >> 4;
+    const DevTask* tasks = w.tasks; uint32_t n_tasks = w.n_tasks;
+    if (w.ref.totals) {                                                   // device-sized launch: the grid is the host's bound, surplus waves leave here
+        uint32_t first; task_list_range(w.ref, first, n_tasks); tasks += first;
+        if ((ti & ~3u) >= n_tasks) return;
+    }
+    DevTask t; t.pair = kPadTask; t.read = 0; t.hap = 0; t.off = 0;
+    if (ti < n_tasks) t = tasks[ti];
+    const bool active = t.pair != kPadTask;
+    TraceEnd end; end.score = 0; end.sidx = -1;
+    if (active) end = w.ends[ti];
+    const uint32_t group = ti / G, slot = ti % G, row = slot / TPR, half = slot % TPR;
+    const uint32_t ro = w.roff[t.read]; const int32_t T = active ? (int32_t)(w.roff[t.read + 1] - ro) : 1;
+    const uint32_t ho = w.hoff[t.hap]; const int32_t Lh = (int32_t)(w.hoff[t.hap + 1] - ho);
+    const int32_t L = T + 2 * B - 1, off = (int32_t)t.off;
+    const bool seam = w.out_first_pos != nullptr;
+    int32_t lhs = 0, rhs = 0; bool want_flank = true;                     // flank sizes in window coordinates (pair_hmm.hpp:572-587)
+    if (seam) {
+        want_flank = w.seam_lhs != nullptr;
+        if (want_flank && active) { lhs = w.seam_lhs[ti]; rhs = w.seam_rhs[ti]; }
+    } else if (active) {
+        const uint32_t g = w.hap_region[t.hap];
+        lhs = (int32_t)w.reg_lhs[g];
+        if (lhs < off) lhs = 0; else { lhs -= off; if (lhs < 0) lhs = 0; }
+        rhs = (int32_t)w.reg_rhs[g];
+        if (off + L < Lh - rhs) rhs = 0; else { rhs += off + L; rhs -= Lh; if (rhs < 0) rhs = 0; }
+    }
+    const int32_t rhs_begin = L - rhs;
+    const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
+    const uint32_t* bpg = w.bp + ((size_t)group * w.k_cap * 64 + row * B) * 16;   // this task row's lines: tile kt, band lane b at (kt * 64 + b) * 16 words
+    const uint32_t hshift = 16 * half;
+
+    int32_t sidx = end.sidx, i = sidx / 2 - T, y = T, x = sidx - T;       // walker state (set_alignments :180-193), the same in all sixteen lanes of the row
+    int32_t flank = 0, msz = 0; uint32_t nev = 0, state = 0;
+    bool ok = active && sidx >= 0, fin = !ok;
+    if (ok) { const int64_t f0 = (int64_t)sidx * B + i; if (f0 < 0 || f0 >= n_flat) { ok = false; fin = true; } }   // :186-190
+
+    WalkPricing pricing;
+    {
+        const bool fwd = !w.rrev[t.read];
+        const size_t hb0 = (size_t)ho + (uint32_t)off;
+        pricing.rbases = w.rbases + ro; pricing.rquals = (const int8_t*)w.rquals + ro; pricing.hbases = w.hbases + hb0;
+        pricing.mask = (fwd ? w.maskF : w.maskR) + hb0; pricing.prior = (fwd ? w.priorF : w.priorR) + hb0;
+        pricing.go = w.go + hb0; pricing.ge = w.ge + hb0;
+    }
+    const int32_t stop_below_x = (w.early_stop && lhs == 0) ? rhs_begin : INT32_MIN;          // see k_walk
+    auto in_flank_at = [&](int32_t xx) { return want_flank && (xx < lhs || xx >= rhs_begin); };   // calculate_flank_score_helper :383-424
+    auto word_from_memory = [&](int64_t flat) -> uint32_t {                                     // any cell by flat index = diagonal * B + lane
+        const int32_t s = (int32_t)(flat / B), li = (int32_t)(flat % B);
+        if (s >= 2 * (T + B)) return 0;                                                         // last row of the reference's array is never written
+        const uint32_t k = (uint32_t)s >> 1;
+        return bpg[((size_t)(k >> 4) * 64 + (uint32_t)li) * 16 + (k & 15)];
+    };
+    if (ok) {                                                                                   // the first move only reads the end cell's own label (:191-192)
+        const uint32_t wv = word_from_memory((int64_t)sidx * B + i);
+        state = (wv >> (hshift + 6 * ((uint32_t)sidx & 1u))) & 3u;
+        sidx -= 2;
+    }
+    // one alignment column from the backpointer word of cell (sidx, i): k_walk's step()
+    auto step = [&](uint32_t wv) __attribute__((always_inline)) {
+        const uint32_t par = (uint32_t)sidx & 1u;
+        const uint32_t bits = (wv >> (hshift + 6 * par)) & 63u, mism = (wv >> (hshift + 15 - par)) & 1u;
+        const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;                 // :200
+        const bool isM = state == 0, isI = state == 1, isD = !isM && !isI;
+        i += isI ? (sidx & 1) : 0;                                                              // insert :205-209
+        sidx -= isM ? 2 : 1;                                                                    // match :201-204
+        i -= isD ? (sidx & 1) : 0;                                                              // delete :210-215
+        x -= isI ? 0 : 1; y -= isD ? 0 : 1;
+        const bool inf = in_flank_at(x);
+        msz += (inf && !isD) ? 1 : 0;
+        flank += (inf && isI) ? w.nuc_prior : 0;
+        if (inf && (!isM || mism)) {
+            const bool ext = isI ? (y != 0 && new_state == 1) : new_state == 3;                 // first alignment column has prev_state = match (:369)
+            const int32_t xi = x - 1 < 0 ? 0 : x - 1;                                           // x-1 == -1 is out of bounds in the reference (UB): clamp
+            const uint32_t e = (isM ? 0u : (ext ? 2u : 1u)) << 30 | (uint32_t)(isM ? y : 0) << 15 | (uint32_t)(isI ? xi : x);
+            if (nev < kWalkRowEvents) { if (l16 == 0) evbuf[nev] = e; ++nev; } else flank += walk_price_event(pricing, e);
+        }
+        state = new_state;
+        if (y <= 0 || x < stop_below_x) fin = true;                                             // :194 / early stop
+    };
+
+    const int32_t mid_lo = want_flank ? lhs : INT32_MIN, mid_hi = (want_flank || stop_below_x != INT32_MIN) ? rhs_begin : INT32_MAX;   // mid_lo < x < mid_hi: the next column lies outside both flanks
+    int32_t st_top = INT32_MIN / 2;                                       // the staged window: tiles st_top, st_top - 1, ... st_top - K + 1 (nothing yet)
+    for (;;) {
+        if (!fin && sidx < 0) { ok = false; fin = true; }                                       // ran off the first diagonal with target bases left (:195-199)
+        if (hw::ballot(!fin) == 0) break;
+        const int32_t k = sidx >> 1, kt = k >> 4, kk = k & 15;
+        const bool in_band = !fin && (uint32_t)i < (uint32_t)B;
+        // ---- stage the next K tiles of this task row (lane l: the lines of band lane l, l + 16, ...) ----
+        const bool need = in_band && (uint32_t)(st_top - kt) >= K;
+        if (hw::ballot(need) != 0) {
+            uint4 v[K * LPL][4];
+#pragma unroll
+            for (uint32_t a = 0; a < K; ++a)
+#pragma unroll
+                for (uint32_t q = 0; q < LPL; ++q) {
+                    const int32_t tile = kt - (int32_t)a; const uint32_t b = l16 + 16 * q;
+                    const bool in = need && tile >= 0 && b < (uint32_t)B;
+                    const uint4* src = (const uint4*)(bpg + ((size_t)(in ? tile : 0) * 64 + (in ? b : 0)) * 16);
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) v[a * LPL + q][j] = in ? src[j] : make_uint4(0, 0, 0, 0);
+                }
+            hw::wave_lds_fence();                                                               // the reads of the window before are done
+#pragma unroll
+            for (uint32_t a = 0; a < K; ++a)
+#pragma unroll
+                for (uint32_t q = 0; q < LPL; ++q) {
+                    const uint32_t b = l16 + 16 * q;
+                    if (need && b < (uint32_t)B) {
+                        uint4* dst = (uint4*)(rowt + (a * B + b) * LS);
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) dst[j] = v[a * LPL + q][j];
+                    }
+                }
+            if (need) st_top = kt;
+            hw::wave_lds_fence();
+        }
+        // ---- a run of match columns: words kk, kk - 1, ... of the walk's line, as far as their labels say "match" (the turn itself is a plain step) ----
+        const uint32_t par = (uint32_t)sidx & 1u;
+        const bool runs = in_band && state == 0;
+        const uint32_t* ln = rowt + ((uint32_t)(st_top - kt) * B + (uint32_t)i) * LS;           // (only read where in_band: then the window holds tile kt)
+        const uint32_t mine = runs ? ln[l16] : 0u;
+        const bool mine_in = runs && (int32_t)l16 <= kk;
+        const uint32_t turns = (uint32_t)(hw::ballot(mine_in && ((mine >> (hshift + 6 * par)) & 3u) != 0u) >> rowbase) & 0xffffu;
+        int32_t n = 0;
+        if (runs) {
+            n = turns ? kk - (31 - (int32_t)__builtin_clz(turns)) : kk + 1;
+            n = n < y - 1 ? n : y - 1;                                                          // (the step that consumes the last read base is a plain step)
+            n = n < x ? n : x;                                                                  // (and so is anything left of the window)
+            if (stop_below_x != INT32_MIN) { const int32_t room = x - stop_below_x; n = n < room ? n : room; }   // (and the step that ends an early-stopping walk)
+            n = n < 0 ? 0 : n;
+        }
+        const int32_t j = kk - (int32_t)l16;                                                    // this lane's column of the run: after it x - 1 - j, y - 1 - j
+        const bool col = mine_in && j < n, col_fl = col && in_flank_at(x - 1 - j);
+        const uint32_t fl_cols = (uint32_t)(hw::ballot(col_fl) >> rowbase) & 0xffffu;
+        const uint32_t ev_cols = (uint32_t)(hw::ballot(col_fl && ((mine >> (hshift + 15 - par)) & 1u)) >> rowbase) & 0xffffu;
+        if (n > 0 && nev + (uint32_t)__builtin_popcount(ev_cols) > kWalkRowEvents) n = 0;       // no room to queue them: one at a time (which prices on overflow)
+        if (n > 0) {
+            if ((ev_cols >> l16) & 1u)
+                evbuf[nev + (uint32_t)__builtin_popcount(ev_cols & ((1u << l16) - 1u))] = (uint32_t)(y - 1 - j) << 15 | (uint32_t)(x - 1 - j);   // (kind 0: a match column)
+            nev += (uint32_t)__builtin_popcount(ev_cols); msz += __builtin_popcount(fl_cols);
+            sidx -= 2 * n; x -= n; y -= n;
+        }
+        // ---- plain steps, this row on its own, until the next run starts, the staged window ends or the walk does. The loop holds only what nearly every
+        //      step needs (the word is in the window, the event - if any - fits the queue) and keeps its flags in one register word (separate bools become
+        //      scalar mask arithmetic around every exit); anything else leaves it for ONE general step below ----
+        uint32_t lf = (fin ? 2u : 0u) | (n == 0 ? 4u : 0u);                                     // bit 1: the walk is over; bit 2: no run taken, so at least one step (every pass moves)
+        // Between the flanks nothing is priced: a step is a pure move. This is where a junk alignment (a wrong
+        // candidate position: ~200 columns that zig-zag through the band) spends its time, at one or two waves per SIMD, i.e. at the full latency of every
+        // instruction of the chain word -> label -> next cell -> word: the loop holds nothing else.
+        for (;;) {
+            const uint32_t rel = (uint32_t)(st_top - (sidx >> 5));
+            if ((lf & 2u) || sidx < 0 || (uint32_t)i >= (uint32_t)B || rel >= K || x <= mid_lo || x >= mid_hi) break;
+            const uint32_t wv = rowt[(rel * B + (uint32_t)i) * LS + (((uint32_t)sidx >> 1) & 15u)];
+            const uint32_t par1 = (uint32_t)sidx & 1u, bits = (wv >> (hshift + 6 * par1)) & 63u;
+            if (!(lf & 4u) && state == 0 && (bits & 3u) == 0u) break;                           // a run of match columns starts here
+            const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;             // :200
+            const bool isM = state == 0, isI = state == 1, isD = !isM && !isI;
+            i += (isI ? (int32_t)par1 : 0) - (isD ? (int32_t)(par1 ^ 1u) : 0);                  // insert :205-209 / delete :210-215 (after its sidx -= 1 the parity has flipped)
+            sidx -= isM ? 2 : 1;                                                                // match :201-204
+            x -= isI ? 0 : 1; y -= isD ? 0 : 1;
+            state = new_state;
+            lf = (y <= 0 || x < stop_below_x) ? 2u : 0u;                                        // :194 / early stop (a walk that STARTS left of the right flank takes one step, as in k_walk)
+        }
+        for (;;) {
+            // the columns inside a flank (written with selects: every exit of a loop costs scalar mask bookkeeping at the same full latency)
+            const uint32_t rel = (uint32_t)(st_top - (sidx >> 5));
+            const bool can = !(lf & 2u) && sidx >= 0 && (uint32_t)i < (uint32_t)B && rel < K && (x <= mid_lo || x >= mid_hi);
+            const uint32_t wv = rowt[can ? (rel * B + (uint32_t)i) * LS + (((uint32_t)sidx >> 1) & 15u) : 0u];
+            const uint32_t par1 = (uint32_t)sidx & 1u;
+            const uint32_t bits = (wv >> (hshift + 6 * par1)) & 63u, mism = (wv >> (hshift + 15 - par1)) & 1u;
+            const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;             // :200
+            const bool isM = state == 0, isI = state == 1, isD = !isM && !isI;
+            const int32_t ni = i + (isI ? (int32_t)par1 : 0) - (isD ? (int32_t)(par1 ^ 1u) : 0);   // insert :205-209 / delete :210-215 (after its sidx -= 1 the parity has flipped)
+            const int32_t nsidx = sidx - (isM ? 2 : 1);                                         // match :201-204
+            const int32_t nx = x - (isI ? 0 : 1), ny = y - (isD ? 0 : 1);
+            const bool inf = in_flank_at(nx), ev = inf && (!isM || mism);
+            const bool run_here = !(lf & 4u) && isM && (bits & 3u) == 0u;                       // a run of match columns starts here
+            if (!can || run_here || (ev && nev >= kWalkRowEvents)) break;                       // (no room in the queue: the general step below prices the event)
+            const bool ext = isI ? (ny != 0 && new_state == 1) : new_state == 3;                // first alignment column has prev_state = match (:369)
+            const int32_t xi = nx - 1 < 0 ? 0 : nx - 1;                                         // x-1 == -1 is out of bounds in the reference (UB): clamp
+            evbuf[ev ? nev : walk_rows_row_words(B) - 1u] =                                             // (all sixteen lanes store the same word; no event: a scratch word behind the queue)
+                (isM ? 0u : (ext ? 2u : 1u)) << 30 | (uint32_t)(isM ? ny : 0) << 15 | (uint32_t)(isI ? xi : nx);
+            nev += ev ? 1u : 0u;
+            msz += (inf && !isD) ? 1 : 0;
+            flank += (inf && isI) ? w.nuc_prior : 0;
+            i = ni; sidx = nsidx; x = nx; y = ny; state = new_state;
+            lf = (ny <= 0 || nx < stop_below_x) ? 2u : 0u;                                      // :194 / early stop
+        }
+        fin = (lf & 2u) != 0;
+        if (!fin && sidx >= 0 && ((uint32_t)i >= (uint32_t)B || nev >= kWalkRowEvents)) {        // the general step: outside the band (the flat-index rules), or an event to price at once
+            uint32_t wv = 0; bool go = true;
+            if (i < 0) { ok = false; fin = true; go = false; }                                  // :195-199
+            else if (i >= B) {                                                                  // the reference indexes its array flat: lane overflow reads the next diagonal
+                const int64_t f = (int64_t)sidx * B + i;
+                if (f >= n_flat) { ok = false; fin = true; go = false; } else wv = word_from_memory(f);
+            } else {
+                const uint32_t rel = (uint32_t)(st_top - (sidx >> 5));
+                if (rel >= K) go = false;                                                       // (the next window first)
+                else wv = rowt[(rel * B + (uint32_t)i) * LS + (((uint32_t)sidx >> 1) & 15u)];
+            }
+            if (go) step(wv);
+        }
+    }
+    const int32_t first_pos = ok ? x : -1;
+    hw::wave_lds_fence();
+    int32_t part = 0;                                                                           // the queued events, priced by the row's lanes together
+    if (ok) for (uint32_t e = l16; e < nev; e += 16) part += walk_price_event(pricing, evbuf[e]);
+    for (int m = 1; m < 16; m <<= 1) part += (int32_t)hw::shfl_xor((uint32_t)part, m);
+    flank += part;
+    if (l16 != 0 || !active) return;
+    if (seam) {
+        w.out_first_pos[ti] = first_pos;
+        if (want_flank) { w.out_flank[ti] = ok ? flank : 0; w.out_mask_size[ti] = ok ? msz : 0; }
+        return;
+    }
+    if (!ok) {
+        if (w.pair_key) { w.task_key[ti] = ~0ull; hw::atomic_or_u32(w.err_flags, 1u); }       // simd_align throws HMMOverflow (:811-813)
+        return;                                             // populate: lowest(), contributes nothing to the max (pair_hmm.hpp:750-752)
+    }
+    if (T - msz < 2) flank = 0;                             // :757-759 / :664-665
+    const int32_t score = end.score;
+    const int32_t pen = flank <= score ? score - flank : flank + score;   // :760-764 / :666-670
+    if (w.pair_key) {                                       // align mode: compete for the pair under the reference's tie rules
+        const uint32_t p = t.off + (uint32_t)B;
+        const uint32_t* P = w.pos + (size_t)t.pair * (uint32_t)w.max_pos; const uint32_t np = w.npos[t.pair];
+        unsigned long long order = 0;
+        for (uint32_t jj = 0; jj < np; ++jj) if (P[jj] == p) { order = jj + 1; break; }
         const unsigned long long key = (unsigned long long)(uint32_t)pen << 32 | order << 8;
         w.task_key[ti] = key;
         hw::atomic_min_u64(w.pair_key + t.pair, key);

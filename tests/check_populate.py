@@ -576,7 +576,7 @@ def check_launch_modes(backend, tol=0.0):
     must give the same bytes, and both must equal the oracle: packed int16, int32 lanes, the streaming kernels, generic bytes, several regions
     with templates, and the late traceback start."""
     import os
-    keep = {k: os.environ.get(k) for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_LATE_MIN_PAIRS", "OCT_PHMM_DSL_TRACE_PER_PAIR")}
+    keep = {k: os.environ.get(k) for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_LATE_MIN_PAIRS", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP")}
     rng = np.random.default_rng(4711)
     n = repeated = 0
     try:
@@ -596,9 +596,11 @@ def check_launch_modes(backend, tol=0.0):
         for B, kw, late, batch in cases:
             os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = "0" if late else "1000000000000"
             outs = []
-            for mode in ("default", "host", "budget", "overflow"):
-                for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR"):
+            for mode in ("default", "host", "budget", "overflow", "two_launches"):
+                for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP"):
                     os.environ.pop(k, None)
+                if mode == "two_launches":                          # traceback and score-only DP as two launches on two streams instead of one k_dp_pair launch
+                    os.environ["OCT_PHMM_DSL_MERGE_DP"] = "0"
                 if mode == "host":
                     os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"
                 if mode == "budget":
@@ -607,7 +609,7 @@ def check_launch_modes(backend, tol=0.0):
                     os.environ["OCT_PHMM_DSL_TRACE_PER_PAIR"] = "-1"
                 eng = make_engine(backend, max_indel_error=B, **kw)
                 rb = eng.upload(batch)
-                assert rb.device_sized() == (mode in ("default", "overflow")), (mode, B)
+                assert rb.device_sized() == (mode in ("default", "overflow", "two_launches")), (mode, B)
                 rb.run(); outs.append(rb.download().copy())
                 if mode == "overflow":
                     repeated += 0 if rb.device_sized() else 1
@@ -618,7 +620,7 @@ def check_launch_modes(backend, tol=0.0):
                 assert np.array_equal(one_shot, outs[-1])
                 eng.close()
             assert all(np.array_equal(outs[0], o) for o in outs[1:])
-            for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR"):
+            for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP"):
                 os.environ.pop(k, None)
             compare(backend, batch, tol, max_indel_error=B, **kw)
             n += 1

@@ -249,9 +249,10 @@ def test_gpu_device_sized_and_host_sized_launches_agree(monkeypatch):
 
 
 def test_gpu_staged_and_unstaged_walk_agree(monkeypatch):
-    """Region-sized traceback launches walk out of LDS-staged tiles; big launches keep one line per lane in registers. Both on small inputs."""
+    """Region-sized traceback launches give every walk a 16-lane row (2); big launches walk 64 tasks in lockstep with one line per lane in registers (0);
+    the lockstep walker out of LDS-staged tiles (1) is the A/B form. All three on small inputs."""
     import check_fuzz
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         monkeypatch.setenv("OCT_PHMM_WALK_STAGE", mode)
         cp.check_basic("gpu", TOL)
         cp.check_templates_and_regions("gpu", TOL)

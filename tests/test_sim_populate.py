@@ -1,4 +1,5 @@
 """CPU suite: the whole populate() pipeline (host API + every kernel) on the wave simulator vs the oracle, bit for bit."""
+import pytest
 import check_populate as cp
 
 
@@ -115,9 +116,11 @@ def test_sim_populate_host_sized_launches(monkeypatch):
     cp.check_ragged_and_edges("sim")
 
 
-def test_sim_populate_unstaged_walk(monkeypatch):
-    """Small traceback launches stage their tiles in LDS (k_walk<..., STAGE>); the line-per-lane walker that big launches use, on the same checks."""
-    monkeypatch.setenv("OCT_PHMM_WALK_STAGE", "0")
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_sim_populate_lockstep_walkers(mode, monkeypatch):
+    """Small traceback launches give every walk a 16-lane row (k_walk_rows); the lockstep walker - one line per lane in registers (0: what big launches use) or
+    tiles staged in LDS (1) - on the same checks."""
+    monkeypatch.setenv("OCT_PHMM_WALK_STAGE", mode)
     cp.check_basic("sim")
     cp.check_templates_and_regions("sim")
     cp.check_late_traceback_start("sim")
