@@ -163,7 +163,7 @@ struct oct_phmm_batch {
 //   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS, OCT_PHMM_UPLOAD_PROFILE
 //   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
 //                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED,
-//                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES, OCT_PHMM_DSL_FORK_EARLY, OCT_PHMM_DSL_MERGE_DP, OCT_PHMM_SERVER_WORKERS
+//                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES, OCT_PHMM_DSL_FORK_EARLY, OCT_PHMM_DSL_MERGE_DP, OCT_PHMM_HOST_MAPPED, OCT_PHMM_SERVER_WORKERS
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
 //                OCT_PHMM_DSL_TRACE_PER_PAIR, OCT_PHMM_TEST_FAIL_BP_ALLOCS (the first traceback-scratch allocations "fail")
@@ -204,6 +204,7 @@ inline int  device_sized()    { const char* e = get("OCT_PHMM_DEVICE_SIZED"); re
 inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
 inline bool multi_wave()      { const char* e = get("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
 inline int  mw_planes()       { const char* e = get("OCT_PHMM_MW_PLANES"); return !e ? -1 : atoi(e); }                              // k_dp_mw: -1 by task count, 0 one plane per wave (B / 64 waves per task), 1 all planes in one wave
+inline bool host_mapped()     { const char* e = get("OCT_PHMM_HOST_MAPPED"); return !e || atoi(e) != 0; }                                    // region-sized one-shot calls: inputs read and results written through mapped pinned host memory by kernels (0: DMA copies)
 inline int  dsl_merge_dp()    { const char* e = get("OCT_PHMM_DSL_MERGE_DP"); return !e ? -1 : atoi(e); }                                         // device-sized step: traceback and score-only list of a flavour in one launch (k_dp_pair): -1 by batch size, 0 never (two launches on two streams), 1 always
 inline bool dsl_fork_early()  { const char* e = get("OCT_PHMM_DSL_FORK_EARLY"); return !e || atoi(e) != 0; }                                 // device-sized step with two DP launches: the score-only DP starts beside the traceback DP (default) or after it, beside the walk (0)
 inline uint32_t walk_rows_threads() { const char* e = get("OCT_PHMM_WALK_ROWS_THREADS"); const int v = e ? atoi(e) : 0; return v == 64 || v == 128 || v == 256 ? (uint32_t)v : 64u; }
@@ -266,6 +267,8 @@ static size_t stage_max()
     return (size_t)64 << 20;
 }
 
+constexpr size_t kHostMappedCopyMax = (size_t)1 << 20;     // inputs up to here go up through k_copy_from_host, results of up to kHostMappedOutMax values come back through the epilogue's own stores
+constexpr uint64_t kHostMappedOutMax = 65536;
 bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
 {
     std::stable_partition(items.begin(), items.end(), [](const Item& it) { return it.src != nullptr; });   // inputs first, contiguous
@@ -297,6 +300,11 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
                 if (z > data_end) { const size_t p0 = std::max(a, data_end); memset((char*)h->stage + p0, 0, z - p0); }
             }
         });
+        if (in_bytes <= kHostMappedCopyMax && tune::host_mapped()) {                                // region-sized: a copy kernel reads the pinned image itself
+            const uint32_t n16 = (uint32_t)((in_bytes + 15) / 16);
+            OCT_LAUNCH(k_copy_from_host, (n16 + 255) / 256, 256, 0, s, (uint4*)base, (const uint4*)h->stage, n16);
+            return rt::launch_ok();
+        }
         return rt::h2d(base, h->stage, in_bytes, s);
     }
     if (tune::pageable_h2d()) {                 // A/B switch: straight from the caller's (pageable) arrays
@@ -1380,6 +1388,14 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         if (!ensure_bp(h, 0, (size_t)b->dsl_trace_cap / G * per_group)) b->dsl = false;
     }
     d.dsl_trace_cap = b->dsl ? b->dsl_trace_cap : 0;
+    constexpr size_t kStatWords = (size_t)kStatSlots * kStatStride + 2;   // counters + the inverted error key + the overflow flag, one copy
+    b->h_stat_stripes.assign(kStatWords, 0);
+    if (!b->stat_stage) b->stat_stage = (unsigned long long*)h->get_stat_stage(kStatWords * sizeof(unsigned long long));
+    // A one-shot region-sized call (oct_phmm_populate set early_out; one slice): no copy behind the last kernel. The epilogue stores the results into the pinned
+    // landing zone itself (mapped into the device) and leaves the sums of the counter stripes beside them; the host waits once.
+    const bool mapped_out = b->early_out && S == 1 && !b->align_mode && b->n_out <= kHostMappedOutMax && b->stat_stage && tune::host_mapped();
+    const uint32_t mapped_stripes = tune::map_stats() ? kStatSlots : (uint32_t)std::min<uint64_t>(kStatSlots, (b->n_pairs + 255) / 256);   // (k_classify's workgroups own the counters; the mapper's only with OCT_PHMM_MAP_STATS)
+    if (mapped_out) memset(b->stat_stage, 0, kStatWords * sizeof(unsigned long long));
     if (!b->stats_clear) RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
     b->stats_clear = false;
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
@@ -1529,8 +1545,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 RT(rt::event_record(b->ev_join, aux)); RT(rt::stream_wait_event(s, b->ev_join));
             }
         }
-        if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
-        if (b->early_out && sl.out1 > sl.out0)                   // one-shot call: the results land in the handle's pinned zone behind the epilogue, no second synchronisation
+        if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, mapped_out ? (double*)h->out_stage : b->d_out, sl.out0, sl.out1,
+                                            mapped_out ? b->stat_stage : nullptr, mapped_stripes); RT(rt::launch_ok()); }
+        if (b->early_out && !mapped_out && sl.out1 > sl.out0)    // one-shot call: the results land in the handle's pinned zone behind the epilogue, no second synchronisation
             RT(rt::d2h((double*)h->out_stage + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
         RT(rt::event_record(sl.done, s));
         return OCT_PHMM_OK;
@@ -1595,8 +1612,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             if (np) { OCT_LAUNCH(k_epilogue_align, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, b->d_aln_lik, b->d_aln_mpos, b->d_aln_n, b->d_aln_ops, b->cig_cap); RT(rt::launch_ok()); }
         } else if (sl.out1 > sl.out0) {
             if (b->dedup && sl.resumes) for (int j = 0; j < i; ++j) RT(rt::stream_wait_event(s, b->slices[j].done));   // pairs of a resumed region may share results of earlier slices
-            OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, b->d_out, sl.out0, sl.out1); RT(rt::launch_ok()); }
-        if (b->early_out && sl.out1 > sl.out0)
+            OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, mapped_out ? (double*)h->out_stage : b->d_out, sl.out0, sl.out1,
+                       mapped_out ? b->stat_stage : nullptr, mapped_stripes); RT(rt::launch_ok()); }
+        if (b->early_out && !mapped_out && sl.out1 > sl.out0)
             RT(rt::d2h((double*)h->out_stage + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
         RT(rt::event_record(sl.done, s));
         return OCT_PHMM_OK;
@@ -1624,10 +1642,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     if (rc != OCT_PHMM_OK) return rc;
     for (int i = std::max(0, S - 2); i < S; ++i) { rc = deliver(i); if (rc != OCT_PHMM_OK) return rc; }
     for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(s0, b->slices[i].done));
-    constexpr size_t kStatWords = (size_t)kStatSlots * kStatStride + 2;   // counters + the inverted error key + the overflow flag, one copy
-    b->h_stat_stripes.assign(kStatWords, 0);
-    if (!b->stat_stage) b->stat_stage = (unsigned long long*)h->get_stat_stage(kStatWords * sizeof(unsigned long long));
-    RT(rt::d2h(b->stat_stage ? b->stat_stage : b->h_stat_stripes.data(), d.stats, kStatWords * sizeof(unsigned long long), s0));
+    if (!mapped_out) RT(rt::d2h(b->stat_stage ? b->stat_stage : b->h_stat_stripes.data(), d.stats, kStatWords * sizeof(unsigned long long), s0));   // (else: the epilogue left the sums there)
     b->ran = true; b->synced = false;
     return ok(status);
 }

@@ -1036,6 +1036,14 @@ OCT_KERNEL(k_scan_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, 
 
 struct TaskArrays { DevTask* t[kNumKinds]; };
 
+// A region-sized call's inputs, from the handle's pinned staging buffer (mapped into the device) to their device block: a kernel starts sooner than a DMA copy
+// (~5 us against ~12 us before the first byte moves), and ~100 KB over the host link are a few microseconds either way.
+OCT_KERNEL(k_copy_from_host)(uint4* dst, const uint4* src, uint32_t n16)
+{
+    const uint32_t i = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (i < n16) dst[i] = src[i];
+}
+
 // Device-sized launches: first task and length of one of the six task lists, from k_hap_bases' totals in device memory (uniform: scalar loads)
 OCT_DEVICE void task_list_range(const TaskListRef& ref, uint32_t& first, uint32_t& n)
 {
@@ -2770,8 +2778,17 @@ OCT_KERNEL(k_walk_cigar)(WalkParams w)
 // ------------------------------------------------------------------------------------------------------------------
 // epilogue: penalty -> ln likelihood, mapping-quality mixture, template sum
 // ------------------------------------------------------------------------------------------------------------------
-OCT_KERNEL(k_epilogue)(DevBatch b, double* out, uint64_t out0, uint64_t out1)
+// `out` may be the caller-side landing zone itself (pinned host memory, mapped into the device: a one-shot region call has no copy behind its last kernel); then
+// host_stats is the run's counter block in pinned memory as well: the first workgroup leaves the sums of the first n_stripes counter stripes in stripe 0, plus
+// the error key and the overflow flag where the full copy would have put them.
+OCT_KERNEL(k_epilogue)(DevBatch b, double* out, uint64_t out0, uint64_t out1, unsigned long long* host_stats, uint32_t n_stripes)
 {
+    if (host_stats && hw::block_idx() == 0 && hw::thread_idx() < kStatStride) {
+        unsigned long long sum = 0;
+        for (uint32_t sl = 0; sl < n_stripes; ++sl) sum += b.stats[(size_t)sl * kStatStride + hw::thread_idx()];
+        host_stats[hw::thread_idx()] = sum;
+        if (hw::thread_idx() == 0) { host_stats[(size_t)kStatSlots * kStatStride] = *b.err_key; host_stats[(size_t)kStatSlots * kStatStride + 1] = *b.dsl_overflow; }
+    }
     const uint64_t o = out0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
     const uint64_t o_wave = wave_first_index(out0);
     if (o >= out1) return;
