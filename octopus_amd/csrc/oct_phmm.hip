@@ -514,6 +514,7 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 // Run one kind's task list through the DP kernel (+ walk for traceback kinds), chunked so the traceback scratch fits.
 // `ref` (device-sized launch): `tasks` is the array that holds all six lists, `n_tasks` the host's bound for one list; the kernels take the list itself
 // from the totals in device memory.
+constexpr uint64_t kWalkRowsMaxPairs = 49152;          // traceback walks of batches up to here: one walk per 16-lane row (k_walk_rows)
 constexpr uint64_t kDslMergeMaxPairs = 12000;          // device-sized step: up to here the traceback and the score-only list of a flavour share one launch (k_dp_pair)
 constexpr uint32_t kDslMaxBlocks = 1024;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
 int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
@@ -600,7 +601,10 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
                 w.err_flags = b->d_err_flags; w.cig_ops = b->d_aln_ops; w.cig_n = b->d_aln_n; w.cig_mpos = b->d_aln_mpos; w.cig_cap = b->cig_cap;
             }
             // region-sized launches (a few hundred waves at most) stage their tiles in LDS; big ones hide the line fetches behind other waves
-            const int stage = tune::walk_stage() >= 0 ? tune::walk_stage() : ((dsl || (size_t)p.n_tasks <= 64 * 1024) ? 2 : 0);
+            // ... and a few regions' worth of walks (up to kWalkRowsMaxPairs pairs) get a 16-lane row each: measured per 300 x 24 call 20 against 60 us, and a 1k x 64 batch
+            // 0.52 against 0.46 ms (profiles/r03_step7_small_batch_walkers_ab.log) - from there on the lockstep walker's 64 walks per wave win again
+            const bool small = dsl || (size_t)p.n_tasks <= 64 * 1024;
+            const int stage = tune::walk_stage() >= 0 ? tune::walk_stage() : (small ? (b->n_pairs <= kWalkRowsMaxPairs ? 2 : 1) : 0);
             if (!launch_walk(B, h->wide || b->stream, w, st, stage)) return fail(status, OCT_PHMM_EHIP, "walk kernel launch");
         }
     }
