@@ -16,3 +16,15 @@ def test_patched_reference_class_equals_the_unpatched_one_through_its_own_access
     assert oracle.have_patched_array("sim")
     import check_integration_patch as ci
     assert ci.check("sim") > 2000
+
+
+def test_patched_read_assigner_seam_equals_the_reference_functions():
+    """The second seam: read_assigner.cpp:145-287 compiled as it is and with its last function replaced by ONE oct_phmm_populate call
+    (oracle/integration/read_assigner_on_device.inc), on the simulator's build of the C ABI. See tests/check_assigner_patch.py."""
+    if not oracle.have_ref_array():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    build_sim()
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "all", "patched"], check=True, stdout=subprocess.DEVNULL)
+    import check_assigner_patch as ca
+    assert ca.have("ref") and ca.have("patched_sim")
+    assert ca.check("sim") > 150
