@@ -3,7 +3,9 @@ haplotype of the genotype, k-mer table, model.reset, model.evaluate read by read
 compiled between stand-in types in oracle/ref_assigner_bridge.cpp) against the same functions with the last one replaced by
 oracle/integration/read_assigner_on_device.inc (expand -> reset -> pack -> ONE oct_phmm_populate with the device's k-mer mapper). Both sides run the
 reference's real repeat-based error models on the expanded haplotypes; reads and templates, ploidies 2 - 4, haplotypes with indels against the reference
-(so that the expansion's indel factor is not zero), the reference's serial and thread-pool branches, and reads so far outside the haplotypes that both give up the same way."""
+(so that the expansion's indel factor is not zero), and reads so far outside the haplotypes that both give up the same way. The reference runs its SERIAL branch
+here: its thread-pool branch (:260-270) hands ONE mutable lambda - and with it one HaplotypeLikelihoodModel - to all pool threads (utils/parallel_transform.hpp:116-118
+captures `op` by reference), which reset() and evaluate() it concurrently: a data race that crashes or changes results under load (reproduced here with 8 threads)."""
 import ctypes as C
 import json
 from pathlib import Path
@@ -96,7 +98,7 @@ def likelihoods(which, sc, band, n_threads=1, mapq_cap=None):
 
 
 GOLDEN = ROOT / "tests" / "golden" / "assigner_seam_golden.json"
-SCENARIOS = ((8, 2, 24, 60, 170, False, 1, False), (16, 3, 30, 100, 240, True, 4, True), (16, 2, 20, 150, 300, False, 4, False), (32, 4, 16, 120, 330, True, 1, False))
+SCENARIOS = ((8, 2, 24, 60, 170, False, 1, False), (16, 3, 30, 100, 240, True, 1, True), (16, 2, 20, 150, 300, False, 1, False), (32, 4, 16, 120, 330, True, 1, False))   # (threads: 1 = the reference's serial branch, see above)
 
 
 def check(backend, tol=0.0, golden=False):
