@@ -267,8 +267,8 @@ static size_t stage_max()
     return (size_t)64 << 20;
 }
 
-constexpr size_t kHostMappedCopyMax = (size_t)1 << 20;     // inputs up to here go up through k_copy_from_host, results of up to kHostMappedOutMax values come back through the epilogue's own stores
-constexpr uint64_t kHostMappedOutMax = 65536;
+constexpr size_t kHostMappedCopyMax = (size_t)1 << 20;     // inputs up to here go up through k_copy_from_host, results of up to kHostMappedOutMax values (one region's) come back through the epilogue's own stores
+constexpr uint64_t kHostMappedOutMax = 12288;             // (the epilogue's stores over the host link: 4 us for one region's 58 KB, 30 us for four regions', 82 for eight - a DMA copy wins from two regions on)
 bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
 {
     std::stable_partition(items.begin(), items.end(), [](const Item& it) { return it.src != nullptr; });   // inputs first, contiguous
@@ -514,6 +514,9 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 // Run one kind's task list through the DP kernel (+ walk for traceback kinds), chunked so the traceback scratch fits.
 // `ref` (device-sized launch): `tasks` is the array that holds all six lists, `n_tasks` the host's bound for one list; the kernels take the list itself
 // from the totals in device memory.
+// One workgroup scans ~10 us per tile of 8,192 pairs (41 us at four regions, 82 at eight: profiles/r03_step7_multi_region_timelines.txt); the four launches of the tiled scan
+// cost ~20 us whatever the size
+constexpr uint32_t kScanBasesOneLaunchMax = 2 * 8192;
 constexpr uint64_t kWalkRowsMaxPairs = 49152;          // traceback walks of batches up to here: one walk per 16-lane row (k_walk_rows)
 constexpr uint64_t kDslMergeMaxPairs = 12000;          // device-sized step: up to here the traceback and the score-only list of a flavour share one launch (k_dp_pair)
 constexpr uint32_t kDslMaxBlocks = 1024;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
@@ -1464,7 +1467,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         }
         if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one
         const uint64_t n_scan = np + 1;
-        if (b->dsl && n_scan <= kScanBasesMaxItems) {         // region-sized: scans and per-haplotype bases of both count arrays in one launch
+        if (b->dsl && n_scan <= kScanBasesOneLaunchMax) {     // region-sized: scans and per-haplotype bases of both count arrays in one launch
             OCT_LAUNCH(k_scan_bases, sl.cnt_late ? 2 : 1, kHapBaseThreads, 16 * sizeof(uint4), s, d, sl.hap0, sl.hap1, sl.cnt, sl.cnt_late, sl.pair0, (uint32_t)n_scan,
                        b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G); RT(rt::launch_ok());
             return OCT_PHMM_OK;
