@@ -224,14 +224,14 @@ def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12, 
 
 def region_call_legs():
     """The reference's calling pattern (one populate per active region from each region-task thread, caller.cpp:1159-1196) through the C ABI, without an
-    interpreter in the way: tools/region_calls_bench (built by __graft_entry__.build()) makes 1,000 regions of 300 reads x 24 haplotypes and issues
+    interpreter in the way: tools/region_calls_bench (built by __graft_entry__.build()) makes 3,000 regions of 300 reads x 24 haplotypes and issues
     one call per region (i) from one thread on one handle, (ii) from 16 threads through the region server; the server's answers are compared with plain calls."""
     import subprocess
     exe = ROOT / "tools" / "region_calls_bench"
     if not exe.exists():
         return {"region_calls": {"error": "tools/region_calls_bench is not built (python -c 'import __graft_entry__ as g; g.build()')"}}
     try:
-        r = subprocess.run([str(exe), "1000", "300", "24", "1", "16"], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([str(exe), "3000", "300", "24", "1", "16"], capture_output=True, text=True, timeout=300)
     except Exception as e:      # noqa: BLE001
         return {"region_calls": {"error": repr(e)}}
     rows = []
@@ -244,7 +244,7 @@ def region_call_legs():
     check = next((x for x in rows if x.get("mode") == "server vs plain calls"), {})
     one, srv16, srv1, h16 = pick("handle per thread", 1), pick("server", 16), pick("server", 1), pick("handle per thread", 16)
     legs = {"region_call_ms": one.get("ms_per_call"), "region_server_regions_per_s": srv16.get("regions_per_s"),
-            "region_calls": {"regions": "1,000 synthetic active regions of 300 reads x 24 haplotypes (150 bp x 300 bp, flank 40/40), one oct_phmm call per region from host buffers",
+            "region_calls": {"regions": "3,000 synthetic active regions of 300 reads x 24 haplotypes (150 bp x 300 bp, flank 40/40), one oct_phmm call per region from host buffers",
                              "one_thread_one_handle": one, "server_1_caller": srv1, "server_16_callers": srv16, "handle_per_thread_16": h16,
                              "server_answers_equal_plain_calls": check, "rc": r.returncode}}
     return legs
