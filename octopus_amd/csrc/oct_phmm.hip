@@ -176,14 +176,16 @@ namespace tune {
 // The profiling switches (stderr reports, HIP-event timing, roctx ranges) are read from the environment directly: they change no result and no code path.
 inline std::mutex& switch_mu() { static std::mutex m; return m; }
 inline std::map<std::string, std::string>& switch_table() { static std::map<std::string, std::string> t; return t; }
+inline std::atomic<bool>& switch_table_used() { static std::atomic<bool> u {false}; return u; }
 inline const char* get(const char* name)
 {
+    static const bool env_ok = getenv("OCT_PHMM_ENV_SWITCHES") != nullptr;
+    if (!env_ok && !switch_table_used().load(std::memory_order_acquire)) return nullptr;     // production: no table, no environment - a call asks ~30 times, from every region thread
     {
         std::lock_guard<std::mutex> lk(switch_mu());
         auto it = switch_table().find(name);
         if (it != switch_table().end()) return it->second.c_str();          // (entries are only ever replaced between runs: tests and tools are single-threaded there)
     }
-    static const bool env_ok = getenv("OCT_PHMM_ENV_SWITCHES") != nullptr;
     return env_ok ? getenv(name) : nullptr;
 }
 inline bool prof_flag(const char* name) { return getenv(name) != nullptr; }
@@ -241,7 +243,8 @@ int band_for(int max_indel_error)   // simd_pair_hmm_wrapper.hpp:219-241
 // Run f(lo, hi) over [0, n) on a few host threads (memory-bound passes over a big batch's arrays); small n stays on the caller's thread.
 template <class F> void host_parallel(size_t n, size_t grain, F&& f)
 {
-    unsigned T = std::thread::hardware_concurrency(); T = T > 4 ? 4 : (T ? T : 1);
+    static const unsigned kCores = std::thread::hardware_concurrency();     // (asked once: glibc reads /sys for it, ~15 us per call - five calls were a third of a region call's host time)
+    unsigned T = kCores > 4 ? 4 : (kCores ? kCores : 1);
     if (n / grain < T) T = (unsigned)(n / grain);
     if (T <= 1) { f((size_t)0, n); return; }
     std::vector<std::thread> th; th.reserve(T - 1);
@@ -669,7 +672,8 @@ void host_penalty_vectors_one(const oct_phmm_error_model& m, const uint8_t* s, u
 
 void host_penalty_vectors(const oct_phmm_error_model& m, uint32_t n_haps, const uint8_t* bases, const uint32_t* off, const uint8_t* sub, PenaltyOut out)
 {
-    unsigned T = std::thread::hardware_concurrency(); T = T ? std::min(T, 16u) : 1;
+    static const unsigned kCores = std::thread::hardware_concurrency();     // (asked once, see host_parallel)
+    unsigned T = kCores ? std::min(kCores, 16u) : 1;
     const uint32_t n_bases = n_haps ? off[n_haps] : 0;
     if (n_bases < 2000 || n_haps < 4) T = 1;                           // a thread start costs more than a few short haplotypes
     T = std::min<unsigned>(T, std::max<uint32_t>(1, n_haps / 2));
@@ -1753,6 +1757,7 @@ extern "C" int oct_phmm_test_set(const char* name, const char* value)
 {
     if (!name || strncmp(name, "OCT_PHMM_", 9) != 0) return OCT_PHMM_EINVAL;
     std::lock_guard<std::mutex> lk(tune::switch_mu());
+    tune::switch_table_used().store(true, std::memory_order_release);
     if (value) tune::switch_table()[name] = value; else tune::switch_table().erase(name);
     return OCT_PHMM_OK;
 }
