@@ -166,7 +166,7 @@ struct oct_phmm_batch {
 //                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES, OCT_PHMM_DSL_FORK_EARLY, OCT_PHMM_DSL_MERGE_DP, OCT_PHMM_HOST_MAPPED, OCT_PHMM_SERVER_WORKERS
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
-//                OCT_PHMM_DSL_TRACE_PER_PAIR, OCT_PHMM_TEST_FAIL_BP_ALLOCS (the first traceback-scratch allocations "fail")
+//                OCT_PHMM_DSL_TRACE_PER_PAIR, OCT_PHMM_TEST_FAIL_BP_ALLOCS (the first traceback-scratch allocations "fail"), OCT_PHMM_SCAN_ONE_LAUNCH_MAX
 // ---------------------------------------------------------------------------------------------------------------
 namespace tune {
 // Switches reach the library in two ways, neither by accident:
@@ -1471,7 +1471,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         }
         if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one
         const uint64_t n_scan = np + 1;
-        if (b->dsl && n_scan <= kScanBasesOneLaunchMax) {     // region-sized: scans and per-haplotype bases of both count arrays in one launch
+        long long one_launch_max = kScanBasesOneLaunchMax; tune::number("OCT_PHMM_SCAN_ONE_LAUNCH_MAX", &one_launch_max);      // (test hook: 0 = the tiled scan for every device-sized batch)
+        if (b->dsl && (long long)n_scan <= one_launch_max) {  // region-sized: scans and per-haplotype bases of both count arrays in one launch
             OCT_LAUNCH(k_scan_bases, sl.cnt_late ? 2 : 1, kHapBaseThreads, 16 * sizeof(uint4), s, d, sl.hap0, sl.hap1, sl.cnt, sl.cnt_late, sl.pair0, (uint32_t)n_scan,
                        b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G); RT(rt::launch_ok());
             return OCT_PHMM_OK;

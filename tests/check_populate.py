@@ -579,7 +579,8 @@ def check_launch_modes(backend, tol=0.0):
     must give the same bytes, and both must equal the oracle: packed int16, int32 lanes, the streaming kernels, generic bytes, several regions
     with templates, and the late traceback start."""
     import os
-    keep = {k: os.environ.get(k) for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_LATE_MIN_PAIRS", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP")}
+    SW = ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP", "OCT_PHMM_SCAN_ONE_LAUNCH_MAX", "OCT_PHMM_HOST_MAPPED")
+    keep = {k: os.environ.get(k) for k in SW + ("OCT_PHMM_LATE_MIN_PAIRS",)}
     rng = np.random.default_rng(4711)
     n = repeated = 0
     try:
@@ -600,10 +601,12 @@ def check_launch_modes(backend, tol=0.0):
             os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = "0" if late else "1000000000000"
             outs = []
             for mode in ("default", "host", "budget", "overflow", "two_launches"):
-                for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP"):
+                for k in SW:
                     os.environ.pop(k, None)
-                if mode == "two_launches":                          # traceback and score-only DP as two launches on two streams instead of one k_dp_pair launch
-                    os.environ["OCT_PHMM_DSL_MERGE_DP"] = "0"
+                if mode == "two_launches":                          # what batches of several regions take: traceback and score-only DP as two launches on two streams instead of one
+                    os.environ["OCT_PHMM_DSL_MERGE_DP"] = "0"       # k_dp_pair launch, the tiled scan instead of the one-workgroup one, DMA copies instead of mapped pinned memory
+                    os.environ["OCT_PHMM_SCAN_ONE_LAUNCH_MAX"] = "0"
+                    os.environ["OCT_PHMM_HOST_MAPPED"] = "0"
                 if mode == "host":
                     os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"
                 if mode == "budget":
@@ -623,7 +626,7 @@ def check_launch_modes(backend, tol=0.0):
                 assert np.array_equal(one_shot, outs[-1])
                 eng.close()
             assert all(np.array_equal(outs[0], o) for o in outs[1:])
-            for k in ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP"):
+            for k in SW:
                 os.environ.pop(k, None)
             compare(backend, batch, tol, max_indel_error=B, **kw)
             n += 1
