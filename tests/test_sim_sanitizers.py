@@ -26,6 +26,7 @@ import check_server
 check_server.check_server("sim", n_threads=3, per_thread=5)
 cp.check_empty_batches("sim")
 cp.check_shared_pairs("sim")                       # canonical windows, matcher, verifier, tables across slices
+cp.check_launch_modes("sim")                       # device- and host-sized launches, forced scratch overflow, the multi-region forms (two DP launches, tiled scan, DMA copies)
 import check_error_model as ce
 ce.check_device_kernels_on_the_corpus("sim", 40)   # both penalty-vector kernels
 print("SANITIZED-OK")
