@@ -540,6 +540,8 @@ def check_shared_pairs(backend, tol=0.0):
         for slices in ("1", "3"):
             os.environ["OCT_PHMM_SLICES"] = slices
             for positions in ("device", "given"):
+                if backend == "sim" and slices == "3" and positions == "given":
+                    continue                                        # (the simulator's budget: three slices with the device's own positions only)
                 bt = batch if positions == "device" else given
                 res = {}
                 for mode in ("0", "1"):
@@ -597,10 +599,13 @@ def check_launch_modes(backend, tol=0.0):
                 for g in regs:
                     g["reads"][rng.integers(0, g["reads"].shape[0], 3), rng.integers(0, T, 3)] = ord("N")
             cases.append((B, kw, late, synth.batch_from_regions(regs)))
-        for B, kw, late, batch in cases:
+        for case_no, (B, kw, late, batch) in enumerate(cases):
             os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = "0" if late else "1000000000000"
             outs = []
-            for mode in ("default", "host", "budget", "overflow", "two_launches"):
+            modes = ("default", "host", "budget", "overflow", "two_launches")
+            if backend == "sim" and case_no >= 3:                   # (every lane is a coroutine there: the chunked and the multi-region forms on the first three shapes only)
+                modes = ("default", "host", "overflow")
+            for mode in modes:
                 for k in SW:
                     os.environ.pop(k, None)
                 if mode == "two_launches":                          # what batches of several regions take: traceback and score-only DP as two launches on two streams instead of one

@@ -100,7 +100,7 @@ def test_sim_leading_slice_without_pairs_still_hashes_the_reads():
 
 
 def test_sim_pairs_with_equal_candidates_share_one_result():
-    assert len(cp.check_shared_pairs("sim")) == 4
+    assert len(cp.check_shared_pairs("sim")) == 3       # (one slice with given and with device positions, three slices with device positions)
 
 
 def test_sim_device_sized_and_host_sized_launches_agree():
@@ -123,7 +123,8 @@ def test_sim_populate_lockstep_walkers(mode, monkeypatch):
     monkeypatch.setenv("OCT_PHMM_WALK_STAGE", mode)
     cp.check_basic("sim")
     cp.check_templates_and_regions("sim")
-    cp.check_late_traceback_start("sim")
+    if mode == "0":
+        cp.check_late_traceback_start("sim")        # (early-stopping walks are the register walker's: what launches of > 64 k walks take)
 
 
 def test_sim_scratch_allocation_failures_fall_back_and_leave_no_error():
