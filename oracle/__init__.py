@@ -25,10 +25,15 @@ ISA = {"sse2": 0, "avx2": 1, "avx512": 2, "native": -1}
 
 
 def build(quiet: bool = True) -> None:
-    """make liboracle.so (always), _ref/libref_phmm.so + libref_array*.so and the INTEGRATION-patched class against whichever builds of
-    the C ABI exist (only where /root/reference is present)."""
-    for target in ("all", "patched"):
-        subprocess.run(["make", "-C", str(_DIR), "-j4", target], check=True, stdout=subprocess.DEVNULL if quiet else None)
+    """make liboracle.so (always), _ref/libref_phmm.so + libref_array*.so and the INTEGRATION-patched seams against whichever builds of
+    the C ABI exist (only where /root/reference is present). Raises when make fails OR when a library this invocation is responsible for
+    (`make expected`) is not there afterwards: a build that reports success without its libraries would turn parity tests into skips."""
+    make = ["make", "-C", str(_DIR), "--no-print-directory"]
+    subprocess.run(make + ["-j4", "all", "patched"], check=True, stdout=subprocess.DEVNULL if quiet else None)
+    expected = subprocess.run(make + ["expected"], check=True, capture_output=True, text=True).stdout.split()
+    missing = [name for name in expected if not (_DIR / name).exists()]
+    if missing:
+        raise RuntimeError(f"oracle.build(): make succeeded but {missing} are missing")
 
 
 def lib() -> C.CDLL:
@@ -68,7 +73,7 @@ def have_ref_array(isa: str = "sse2") -> bool:
 
 
 _ARRAY_LIBS = {"sse2": "libref_array.so", "avx2": "libref_array_avx2.so",
-               # the reference's class with INTEGRATION.md's patch applied (oracle/apply_integration_patch.py), on the simulator / GPU build of the C ABI
+               # the reference's class with INTEGRATION.md's patch applied (oracle/make_patched_tree.py), on the simulator / GPU build of the C ABI
                "patched_sim": "libref_array_patched_sim.so", "patched_gpu": "libref_array_patched_gpu.so"}
 
 

@@ -181,7 +181,7 @@ extern "C" double ref_array_time_populate(const ref_array_args* a, int reps)
 
 
 // Every read-back method of the class after one populate(), for tests/test_integration_patch.py (the same bridge is compiled against the
-// unpatched reference class and against the class with INTEGRATION.md's patch applied, oracle/apply_integration_patch.py):
+// unpatched reference class and against the class with INTEGRATION.md's patch applied, oracle/make_patched_tree.py):
 //   sec[0] operator()(sample, Haplotype)            sec[1] extract_sample(sample).at(haplotype)
 //   sec[2] prime(sample) + operator[](Haplotype)    sec[3] merge_samples(all) + operator[](IndexedHaplotype)
 //   sec[4] merge_samples({first, last sample}) + operator[](Haplotype)   (rows of those two samples only, row-major per haplotype)

@@ -31,3 +31,10 @@ def make_engine(backend: str, **cfg_kw) -> engine.Engine:
         return engine.Engine(cfg, lib_path=build_sim())
     assert backend == "gpu"
     return engine.Engine(cfg)
+
+
+def require_reference_build(present: bool, what: str) -> None:
+    """GPU tests that compare with the REFERENCE's compiled code (oracle/_ref, prebuilt where /root/reference exists and shipped with the
+    tree) FAIL when that library is missing: a box fed from a tree whose oracle build broke must not turn its parity tests into skips."""
+    assert present, (f"{what} is missing on this box: build it where /root/reference exists "
+                     "(python -c 'import __graft_entry__ as g; g.build()') and ship it with the tree")

@@ -13,11 +13,11 @@ def need_ref(test):
     """These are the tests that carry full-size parity: on the GPU box the reference build (oracle/_ref, shipped with the snapshot) must be there - a box
     without it FAILS them instead of quietly skipping the three most important checks."""
     import functools
+    from backends import require_reference_build
 
     @functools.wraps(test)
     def run(*a, **kw):
-        assert oracle.have_ref_array(), ("oracle/_ref/libref_array.so is missing on this box: build it where /root/reference exists "
-                                         "(python -c 'import __graft_entry__ as g; g.build()') and ship it with the tree")
+        require_reference_build(oracle.have_ref_array(), "oracle/_ref/libref_array.so")
         return test(*a, **kw)
     return run
 

@@ -9,7 +9,7 @@ import check_host_mirror
 import check_l1
 import check_populate as cp
 import oracle
-from backends import make_engine
+from backends import make_engine, require_reference_build
 from octopus_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
@@ -290,8 +290,7 @@ def test_gpu_chunked_traceback_launches():
 
 def test_gpu_matrix_equals_the_reference_array_populate():
     """Device output against the reference's own HaplotypeLikelihoodArray::populate (prebuilt oracle/_ref/libref_array.so travels with the snapshot)."""
-    if not oracle.have_ref_array():
-        pytest.skip("oracle/_ref/libref_array.so not built")
+    require_reference_build(oracle.have_ref_array(), "oracle/_ref/libref_array.so")
     assert cp.check_against_reference_array("gpu", TOL) > 400
 
 
@@ -305,8 +304,7 @@ def test_gpu_empty_batches():
 
 def test_gpu_matrix_equals_the_reference_composed_piece_by_piece():
     """The reference's own error models, k-mer mapper and likelihood model (oracle/_ref) produce the matrix; the GPU must reproduce it."""
-    if not oracle.have_ref():
-        pytest.skip("reference build absent")
+    require_reference_build(oracle.have_ref(), "oracle/_ref/libref_phmm.so")
     from test_oracle_l3 import check_populate_composed_from_the_reference_pieces
     check_populate_composed_from_the_reference_pieces("gpu", TOL)
 
@@ -340,8 +338,7 @@ def test_gpu_leading_slice_without_pairs_still_hashes_the_reads():
 
 def test_gpu_patched_reference_class_equals_the_unpatched_one():
     """INTEGRATION.md's patch compiled into the reference's own class, linked against liboct_phmm.so (prebuilt oracle/_ref/libref_array_patched_gpu.so)."""
-    if not (oracle.have_ref_array() and oracle.have_patched_array("gpu")):
-        pytest.skip("oracle/_ref patched build absent")
+    require_reference_build(oracle.have_ref_array() and oracle.have_patched_array("gpu"), "oracle/_ref/libref_array_patched_gpu.so")
     import check_integration_patch as ci
     assert ci.check("gpu", TOL) > 2000
 
@@ -350,8 +347,7 @@ def test_gpu_patched_read_assigner_seam_equals_the_reference_functions():
     """INTEGRATION.md's second seam (read_assigner.cpp:145-287) with its last function replaced by one oct_phmm_populate call, linked against
     liboct_phmm.so (prebuilt oracle/_ref/libref_assigner_patched_gpu.so), against the reference's own functions' committed output."""
     import check_assigner_patch as ca
-    if not ca.have("patched_gpu"):
-        pytest.skip("oracle/_ref assigner build absent")
+    require_reference_build(ca.have("patched_gpu"), "oracle/_ref/libref_assigner_patched_gpu.so")
     # against the matrices the reference's functions gave where tests/golden/make_assigner_seam_golden.py ran (the CPU suite compares the two libraries directly)
     assert ca.check("gpu", TOL, golden=True) > 150
 
@@ -363,8 +359,7 @@ def test_gpu_pairs_with_equal_candidates_share_one_result():
 
 def test_gpu_populate_generates_the_penalty_vectors_on_host_threads_and_on_the_device():
     """SURVEY 8f-3 in the product: NULL vectors + oct_phmm_set_error_model; both generation paths equal the reference's error-model classes."""
-    if not oracle.have_ref():
-        pytest.skip("reference build absent")
+    require_reference_build(oracle.have_ref(), "oracle/_ref/libref_phmm.so")
     import check_error_model as ce
     assert ce.check_populate_generates_the_vectors("gpu", TOL) > 0
 
