@@ -307,10 +307,10 @@ def main():
     else:
         lib_path = None
         eng = engine.Engine(cfg)                  # fails loudly if liboct_phmm.so / a gfx950 device is missing
-    stream = args.workload == "stream"
+    stream = args.workload in ("stream", "stream-hq")
     if stream:        # configs[3]: ONE stream of independent active regions, region i -> rank i mod N, one flat batch per rank per step
         regions = synth.region_stream_shard(seed=42, n_regions=args.regions, rank=rank, world=world, B=B, positions="none", cap=args.stream_cap,
-                                            workers=max(1, min(8, (os.cpu_count() or 1) // max(world, 1))))
+                                            workers=max(1, min(8, (os.cpu_count() or 1) // max(world, 1))), hq=args.workload == "stream-hq")
     else:             # candidate positions come from the device k-mer mapper
         regions = [synth.config_region(args.workload, seed=42 + rank, B=B, positions="none")]
     batch = synth.batch_from_regions(regions)
@@ -407,7 +407,7 @@ def main():
         dp_s_per_step = ((tr_ms + sc_ms + kind_ms["score_generic"][0] + kind_ms["trace_generic"][0]) / 1e3) / 3
         traffic = None
         pmc_file, pmc, pmc_current = latest_pmc_summary()
-        if pmc is not None and args.workload == "100kx128" and B == 16:
+        if pmc is not None and args.workload == "100kx128" and B == 16 and not os.environ.get("OCT_BENCH_NO_PMC_SUMMARY"):
             pm = pmc.get(f"octphmm::k_dp<{B}, true, false, true>", {})
             ps = pmc.get(f"octphmm::k_dp<{B}, false, false, true>", {})
             if "hbm_read_bytes_corrected" in pm and "hbm_write_bytes" in pm:

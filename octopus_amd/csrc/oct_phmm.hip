@@ -199,6 +199,7 @@ inline bool pageable_h2d()    { return flag("OCT_PHMM_PAGEABLE_H2D"); }       //
 inline bool map_count_only()  { return flag("OCT_PHMM_MAP_COUNT_ONLY"); }     // k-mer mapper without the exact shortcut
 inline bool lane_mapper()     { return flag("OCT_PHMM_LANE_MAPPER"); }        // the (slower) lane-per-pair mapper
 inline bool big_mapper()      { return flag("OCT_PHMM_BIG_MAPPER"); }         // test hook: the long-haplotype mapper on short haplotypes
+inline bool map_mismatches()  { const char* e = get("OCT_PHMM_MAP_MISMATCHES"); return !e || atoi(e) != 0; }   // 0: k_classify compares the bases of every candidate itself (A/B, tests)
 inline int  penalties_where() { const char* e = get("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' || e[0] == 'l' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
 inline int  dedup()           { const char* e = get("OCT_PHMM_DEDUP"); return !e ? -1 : atoi(e); }                                  // -1 by shape, 0 never, 1 wherever it is possible
 inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_HASH_BITS", &n) && n >= 1 && n < 32 ? (1u << n) - 1u : 0xffffffffu; }   // test hook: collisions
@@ -1109,7 +1110,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     pk.upload(reg_lhs.data(), reg_lhs.size(), &d.reg_lhs);
     pk.upload(reg_rhs.data(), reg_rhs.size(), &d.reg_rhs);
     pk.dalloc(&d.pos, (size_t)b->n_pairs * S + 1); pk.dalloc(&d.npos, (size_t)b->n_pairs + 1);
-    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr; d.hhash = nullptr; d.map_count_only = 0; d.map_stats = 0;
+    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr; d.hhash = nullptr; d.map_count_only = 0; d.map_stats = 0; d.pair_mm = nullptr;
     if (!positions) {
         if (b->map_big) pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1);      // the u16 table of k_kmer_map_big only
         pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
@@ -1125,6 +1126,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             else if (kmer_map_lanes_lds_bytes(b->lh_cap, 64) <= rt::kMaxLdsBytes) b->map_lanes = 64;
         }
         if (b->map_lanes) b->map_reads_per_block = (uint32_t)b->map_lanes;
+        if (b->map_lanes && tune::map_mismatches()) pk.dalloc(&d.pair_mm, (size_t)b->n_pairs + 2);   // k_kmer_map_lanes tells k_classify what it saw along the mapped position
         std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, read chunk of its region)
         for (uint32_t hp = 0; hp < H->n_haps; ++hp) {
             const uint32_t g = hap_region[hp];

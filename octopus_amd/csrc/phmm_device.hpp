@@ -57,6 +57,10 @@ struct DevBatch {
     const uint32_t* reg_row0; const uint32_t* reg_read0; const uint32_t* reg_lhs; const uint32_t* reg_rhs;
     // candidate mapping positions per pair: pos[e * max_pos + j], j < npos[e] (host-provided or written by k_kmer_map)
     uint32_t* pos; uint8_t* npos;
+    // what k_kmer_map learnt about the base mismatches between the read and the haplotype along a pair's ONE mapped position pos[e * max_pos] (it compares the
+    // two 6-mer hash sequences there anyway; a hash is two bits per base): state << 14 | i1, state 0 = nothing known, 1 = no mismatch, 2 = exactly one, at read
+    // position i1, 3 = two or more. Holds for pure-ACGT reads on pure-ACGT haplotypes (k_classify checks); null when another mapper or the caller made the positions.
+    uint16_t* pair_mm;
     // 6-mer tables per haplotype (k_kmer_tables): bin_start[h * 4097 + hash], bin_idx[hoff[h] + slot]
     uint32_t* bin32;                                  // bin32[h * 4096 + hash] = start | occupancy << 16 (k_kmer_map_lanes); null when unused
     uint16_t* hhash;                                  // hhash[hoff[h] + p]: 6-mer hash of haplotype h at p (k_kmer_tables); k_kmer_map's exact-count shortcut

@@ -551,14 +551,12 @@ OCT_DEVICE uint32_t first_mismatch(const uint8_t* a, const uint8_t* b, uint32_t 
 OCT_DEVICE bool bytes_equal(const uint8_t* a, const uint8_t* b, uint32_t n) { return first_mismatch(a, b, 0, n) == n; }
 
 // hmm::detail::try_naive_evaluate, pair_hmm.hpp:278-319. Returns true when handled; *pen = phred penalty.
-OCT_DEVICE bool try_naive(const uint8_t* truth, uint32_t Lh, const uint8_t* target, uint32_t T, const uint8_t* quals, uint32_t pos,
-                          const int8_t* go, const int8_t* ge, const uint8_t* mask, const int8_t* prior,
-                          uint32_t lhs, uint32_t rhs, int32_t* pen)
+// try_naive_one: its second half, for a read with exactly ONE mismatch against the haplotype at `pos`, at read position i1 (:290-318).
+OCT_DEVICE bool try_naive_one(const uint8_t* truth, uint32_t Lh, const uint8_t* target, uint32_t T, const uint8_t* quals, uint32_t pos, uint32_t i1,
+                              const int8_t* go, const int8_t* ge, const uint8_t* mask, const int8_t* prior,
+                              uint32_t lhs, uint32_t rhs, int32_t* pen)
 {
     const uint8_t* tr = truth + pos;
-    const uint32_t i1 = first_mismatch(target, tr, 0, T);
-    if (i1 == T) { *pen = 0; return true; }
-    if (first_mismatch(target, tr, i1 + 1, T) != T) return false;
     const uint64_t idx = (uint64_t)i1 + pos;
     if (idx < (uint64_t)lhs || idx >= ((uint64_t)Lh - (uint64_t)rhs)) { *pen = 0; return true; }   // is_in_flank :206-214
     uint32_t mp = quals[i1];
@@ -569,6 +567,16 @@ OCT_DEVICE bool try_naive(const uint8_t* truth, uint32_t Lh, const uint8_t* targ
     if (bytes_equal(target + i1, tr + i1 + 1, T - i1)) { *pen = gop; return true; }                // :309
     if ((int32_t)mp <= gop + (int32_t)ge[idx]) { *pen = (int32_t)mp; return true; }                // :313
     return false;
+}
+OCT_DEVICE bool try_naive(const uint8_t* truth, uint32_t Lh, const uint8_t* target, uint32_t T, const uint8_t* quals, uint32_t pos,
+                          const int8_t* go, const int8_t* ge, const uint8_t* mask, const int8_t* prior,
+                          uint32_t lhs, uint32_t rhs, int32_t* pen)
+{
+    const uint8_t* tr = truth + pos;
+    const uint32_t i1 = first_mismatch(target, tr, 0, T);
+    if (i1 == T) { *pen = 0; return true; }
+    if (first_mismatch(target, tr, i1 + 1, T) != T) return false;
+    return try_naive_one(truth, Lh, target, T, quals, pos, i1, go, ge, mask, prior, lhs, rhs, pen);
 }
 
 OCT_DEVICE bool pos_in_range(uint64_t p, uint32_t T, uint32_t Lh, uint32_t B)   // num_out_of_range_bases(...) == 0, model.cpp:187-207
@@ -640,23 +648,30 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
         const int8_t* go = b.go + ho; const int8_t* ge = b.ge + ho;
         const uint64_t orig = (uint64_t)(b.rbegin[r] - b.hbegin[h]);                               // begin_distance, model.cpp:220
         const uint32_t* P = b.pos + e * (uint64_t)b.max_pos; const uint32_t npos = b.npos[e];
+        const bool clean = b.racgt[r] && b.hclean[h];                                               // pure ACGT on both sides: equal 6-mer hashes <=> equal bases
+        // the mapper's account of the base mismatches along the pair's one mapped position (DevBatch::pair_mm): slot 0 then needs no pass over the bases
+        const uint32_t mm = b.pair_mm && clean && npos == 1 ? (uint32_t)b.pair_mm[e] : 0u, mm_state = mm >> 14, mm_i1 = mm & 0x3fffu;
         int32_t best = kNoScore; uint32_t cls = 0, n_score = 0, n_trace = 0, n_late = 0, extra = 0;
         bool orig_mapped = false, any = false;
         unsigned long long key = ~0ull;
         uint64_t dedup_acc = 0;                                                                     // k_dedup_match: hash over the DP tasks, in slot order
         auto visit = [&](uint32_t slot, uint32_t p) {
             ++st_cand;
+            const uint32_t known = slot == 0 ? mm_state : 0u;
             if (b.align_mode) {                                                                     // hmm::align, pair_hmm.hpp:861-872
-                bool same = true;                                                                   // try_naive_align :321-341
-                for (uint32_t tt = 0; tt < T; ++tt) if (target[tt] != truth[p + tt]) { same = false; break; }
+                bool same = known ? known == 1 : true;                                              // try_naive_align :321-341
+                if (!known) for (uint32_t tt = 0; tt < T; ++tt) if (target[tt] != truth[p + tt]) { same = false; break; }
                 const unsigned long long order = slot == (uint32_t)b.max_pos ? 0ull : (unsigned long long)slot + 1;
                 if (same) { ++st_fast; const unsigned long long k = order << 8 | 1ull; if (k < key) key = k; return; }
                 st_cells += 2ull * B * (T + B);                                                     // simd_align always tracebacks (:806-810)
                 cls |= 2u << (2 * slot); ++n_trace; ++st_trace;
                 return;
             }
-            int32_t pen;
-            if (try_naive(truth, Lh, target, T, quals, p, go, ge, mask, prior, lhs, rhs, &pen)) { ++st_fast; if (pen < best) best = pen; return; }
+            int32_t pen = 0;
+            const bool handled = known == 1 ? true : known == 3 ? false
+                               : known == 2 ? try_naive_one(truth, Lh, target, T, quals, p, mm_i1, go, ge, mask, prior, lhs, rhs, &pen)
+                               : try_naive(truth, Lh, target, T, quals, p, go, ge, mask, prior, lhs, rhs, &pen);
+            if (handled) { ++st_fast; if (pen < best) best = pen; return; }
             const uint32_t off = p > B ? p - B : 0;                                                 // pair_hmm.hpp:735
             if ((uint64_t)off + T + 2 * B - 1 > Lh) return;                                         // :736-738 -> lowest()
             const bool adjusted = (uint64_t)p < (uint64_t)lhs + B || (uint64_t)p + T + B > (uint64_t)Lh - (uint64_t)rhs;   // :123-137
@@ -683,7 +698,7 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
         b.pair_best[e] = best; b.pair_cls[e] = cls; b.pair_extra[e] = extra;
         if (b.canon) { b.pair_hash[e] = cls ? pair_hash_final(dedup_acc, cls, best, Lh, b.dedup_hash_mask) : 0u; b.pair_fast[e] = best; }
         if (b.align_mode) b.pair_key[e] = key;
-        const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
+        const bool generic = b.wide || !clean;
         cnt[e - pair0] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
         if (e + 1 == pair1) cnt[pair1 - pair0] = make_uint4(0, 0, 0, 0);                               // the scan's extra entry (totals land here)
         if (cnt_late) { cnt_late[e - pair0] = generic ? make_uint4(0, n_late, 0, 0) : make_uint4(n_late, 0, 0, 0); if (e + 1 == pair1) cnt_late[pair1 - pair0] = make_uint4(0, 0, 0, 0); }
@@ -2403,7 +2418,7 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
     for (;;) {
         if (!fin && sidx < 0) { ok = false; fin = true; }                                       // ran off the first diagonal with target bases left (:195-199)
         if (hw::ballot(!fin) == 0) break;
-        const int32_t k = sidx >> 1, kt = k >> 4, kk = k & 15;
+        const int32_t k = sidx >> 1, kt = k >> 4, kk = k & 15, sidx_at_pass_start = sidx;
         const bool in_band = !fin && (uint32_t)i < (uint32_t)B;
         // ---- stage the next K tiles of this task row (lane l: the lines of band lane l, l + 16, ...) ----
         const bool need = in_band && (uint32_t)(st_top - kt) >= K;
@@ -2466,25 +2481,38 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
         uint32_t lf = (fin ? 2u : 0u) | (n == 0 ? 4u : 0u);                                     // bit 1: the walk is over; bit 2: no run taken, so at least one step (every pass moves)
         // Between the flanks nothing is priced: a step is a pure move. This is where a junk alignment (a wrong
         // candidate position: ~200 columns that zig-zag through the band) spends its time, at one or two waves per SIMD, i.e. at the full latency of every
-        // instruction of the chain word -> label -> next cell -> word: the loop holds nothing else.
-        for (;;) {
-            const uint32_t rel = (uint32_t)(st_top - (sidx >> 5));
-            if ((lf & 2u) || sidx < 0 || (uint32_t)i >= (uint32_t)B || rel >= K || x <= mid_lo || x >= mid_hi) break;
-            const uint32_t wv = rowt[(rel * B + (uint32_t)i) * LS + (((uint32_t)sidx >> 1) & 15u)];
-            const uint32_t par1 = (uint32_t)sidx & 1u, bits = (wv >> (hshift + 6 * par1)) & 63u;
-            if (!(lf & 4u) && state == 0 && (bits & 3u) == 0u) break;                           // a run of match columns starts here
-            const uint32_t new_state = (bits >> (state == 3 ? 4 : 2 * state)) & 3u;             // :200
-            const bool isM = state == 0, isI = state == 1, isD = !isM && !isI;
-            i += (isI ? (int32_t)par1 : 0) - (isD ? (int32_t)(par1 ^ 1u) : 0);                  // insert :205-209 / delete :210-215 (after its sidx -= 1 the parity has flipped)
-            sidx -= isM ? 2 : 1;                                                                // match :201-204
-            x -= isI ? 0 : 1; y -= isD ? 0 : 1;
-            state = new_state;
-            lf = (y <= 0 || x < stop_below_x) ? 2u : 0u;                                        // :194 / early stop (a walk that STARTS left of the right flank takes one step, as in k_walk)
+        // instruction of the chain word -> label -> next cell -> word: the loop holds nothing else, keeps the walker's state as the shift that picks its
+        // label (0 match, 2 insert, 4 delete), folds its range tests into unsigned compares and has ONE exit. (Walks that stop early - no left flank -
+        // never get here: the loop below takes all their steps.)
+        if (!(lf & 2u) && stop_below_x == INT32_MIN) {
+            const int32_t lo_tile = st_top - (int32_t)K + 1 < 0 ? 0 : st_top - (int32_t)K + 1;
+            const int32_t sidx_lo = lo_tile * 32; const uint32_t sidx_span = (uint32_t)((st_top + 1) * 32 - sidx_lo);       // the window's diagonals (and none below zero)
+            const uint32_t x_span = mid_hi > mid_lo ? (uint32_t)mid_hi - (uint32_t)mid_lo - 1u : 0u;                          // mid_lo < x < mid_hi (none where the flanks meet or overlap)
+            uint32_t ssh = state == 3 ? 4u : 2u * state, first = (lf & 4u);                                                  // first: the pass's forced step
+            for (;;) {
+                // (bitwise on 0 / 1 words: `&&` would become nested branches around the load)
+                const uint32_t in = ((uint32_t)(sidx - sidx_lo) < sidx_span ? 1u : 0u) & ((uint32_t)i < (uint32_t)B ? 1u : 0u)
+                                  & (((uint32_t)x - (uint32_t)mid_lo - 1u) < x_span ? 1u : 0u) & (y > 0 ? 1u : 0u);
+                const uint32_t rel = (uint32_t)(st_top - (sidx >> 5));
+                const uint32_t cell = rel * B + (uint32_t)i;                                       // (LS = 20 = 16 + 4: two shift-adds instead of a 64-bit multiply-add)
+                static_assert(LS == 20, "staged line stride");
+                const uint32_t wv = rowt[((cell << 4) + (cell << 2) + (((uint32_t)sidx >> 1) & 15u)) & (0u - in)];
+                const uint32_t par1 = (uint32_t)sidx & 1u, bits = (wv >> (hshift + 6 * par1)) & 63u;
+                if ((in ^ 1u) | ((ssh | (bits & 3u) | first) == 0u ? 1u : 0u)) break;               // the window / the band / the flank-free stretch / the read ends, or a run of match columns starts here
+                const uint32_t ns = (bits >> ssh) & 3u;                                         // :200
+                const uint32_t isM = ssh == 0u ? 1u : 0u, isI = ssh == 2u ? 1u : 0u, isD = ssh == 4u ? 1u : 0u;
+                i += (int32_t)(isI & par1) - (int32_t)(isD & (par1 ^ 1u));                      // insert :205-209 / delete :210-215 (after its sidx -= 1 the parity has flipped)
+                sidx -= 1 + (int32_t)isM;                                                       // match :201-204
+                x -= (int32_t)(isI ^ 1u); y -= (int32_t)(isD ^ 1u);
+                ssh = ns == 3u ? 4u : 2u * ns; first = 0u;
+            }
+            state = ssh == 4u ? 3u : ssh >> 1;
+            lf = (y <= 0 ? 2u : 0u) | first;
         }
         for (;;) {
             // the columns inside a flank (written with selects: every exit of a loop costs scalar mask bookkeeping at the same full latency)
             const uint32_t rel = (uint32_t)(st_top - (sidx >> 5));
-            const bool can = !(lf & 2u) && sidx >= 0 && (uint32_t)i < (uint32_t)B && rel < K && (x <= mid_lo || x >= mid_hi);
+            const bool can = !(lf & 2u) && sidx >= 0 && (uint32_t)i < (uint32_t)B && rel < K && (x <= mid_lo || x >= mid_hi || stop_below_x != INT32_MIN);   // (an early-stopping walk takes all its steps here)
             const uint32_t wv = rowt[can ? (rel * B + (uint32_t)i) * LS + (((uint32_t)sidx >> 1) & 15u) : 0u];
             const uint32_t par1 = (uint32_t)sidx & 1u;
             const uint32_t bits = (wv >> (hshift + 6 * par1)) & 63u, mism = (wv >> (hshift + 15 - par1)) & 1u;
@@ -2507,7 +2535,9 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
             lf = (ny <= 0 || nx < stop_below_x) ? 2u : 0u;                                      // :194 / early stop
         }
         fin = (lf & 2u) != 0;
-        if (!fin && sidx >= 0 && ((uint32_t)i >= (uint32_t)B || nev >= kWalkRowEvents)) {        // the general step: outside the band (the flat-index rules), or an event to price at once
+        // the general step: outside the band (the flat-index rules), an event to price at once - or a pass that has not moved the walk (whatever the loops' entry
+        // conditions left out: every pass takes at least one column, so the kernel ends)
+        if (!fin && sidx >= 0 && ((uint32_t)i >= (uint32_t)B || nev >= kWalkRowEvents || sidx == sidx_at_pass_start)) {
             uint32_t wv = 0; bool go = true;
             if (i < 0) { ok = false; fin = true; go = false; }                                  // :195-199
             else if (i >= B) {                                                                  // the reference indexes its array flat: lane overflow reads the next diagonal

@@ -73,16 +73,73 @@ def make_haplotypes(rng: np.random.Generator, H: int, Lh: int, n_homopolymers: i
     return haps, maps
 
 
-def make_reads(rng: np.random.Generator, haps, maps, R: int, T: int, B: int, min_diffs: int = 0, q_values=None, indels_per_read: int = 0):
-    """R reads of length T sampled from uniformly chosen haplotypes, Illumina-like qualities and errors."""
+def make_tree_haplotypes(rng: np.random.Generator, H: int, Lh: int, n_homopolymers: int = 3):
+    """Haplotypes the way a caller's haplotype generator makes them: ceil(log2 H) candidate variant sites on one base sequence (80 % SNVs, 10 % deletions,
+    10 % insertions of 1-10 bases) and H distinct combinations of their alleles, the all-reference combination first. Two haplotypes differ only at the sites
+    a read overlaps, so reads meet haplotypes that equal their own over the read's span - the pairs try_naive_evaluate answers."""
+    base = BASES[rng.integers(0, 4, Lh)].copy()
+    for _ in range(n_homopolymers):
+        n = int(rng.integers(8, 16))
+        a = int(rng.integers(20, Lh - 20 - n))
+        base[a:a + n] = BASES[rng.integers(0, 4)]
+    n_sites = int(np.ceil(np.log2(H))) if H > 1 else 0
+    sites = np.sort(rng.choice(np.arange(60, Lh - 60, 12), size=n_sites, replace=False)) if n_sites else np.zeros(0, np.int64)   # >= 12 bases apart
+    alleles = []
+    for p in sites:
+        kind = rng.random()
+        if kind < 0.8:
+            alleles.append(("snv", int(BASES[(int(np.searchsorted(BASES, base[p])) + int(rng.integers(1, 4))) % 4])))
+        elif kind < 0.9:
+            alleles.append(("del", int(rng.integers(1, 11))))
+        else:
+            alleles.append(("ins", BASES[rng.integers(0, 4, int(rng.integers(1, 11)))]))
+    patterns = np.arange(H) if H == (1 << n_sites) else np.concatenate([[0], 1 + np.sort(rng.choice((1 << n_sites) - 1, size=H - 1, replace=False))])
+    haps, maps = [], []
+    for pat in patterns:
+        seq, cmap, prev, shift = [], np.arange(Lh + 1), 0, 0
+        for k, p in enumerate(sites):
+            if not (int(pat) >> k) & 1:
+                continue
+            p = int(p)
+            seq.append(base[prev:p])
+            kind, val = alleles[k]
+            if kind == "snv":
+                seq.append(np.array([val], np.uint8)); prev = p + 1
+            elif kind == "del":
+                prev = p + val
+                cmap[p + 1:] = np.maximum(cmap[p + 1:] - val, cmap[p])
+            else:
+                seq.append(val); prev = p
+                cmap[p:] += len(val)
+        seq.append(base[prev:])
+        arr = np.concatenate(seq).astype(np.uint8)
+        if len(arr) < Lh:     # padded back to Lh
+            arr = np.concatenate([arr, BASES[rng.integers(0, 4, Lh - len(arr))]])
+        haps.append(arr[:Lh])
+        maps.append(np.minimum(cmap, Lh))
+    return haps, maps
+
+
+# Base-quality profiles: (values, probabilities, quality lost over the last 30 cycles).
+#   "stress"  SURVEY.md 8d: 2 % of the bases at Q2 and 8 % at Q12 plant ~3 mismatches in every read - nearly every candidate reaches the DP (the GCUPS stress)
+#   "hq"      a current Illumina run: 88 % Q37, 8 % Q30, ~92 % of all bases >= Q30 after the tail decay, ~0.35 mismatches per read - most
+#             candidates against the read's own haplotype are answered by try_naive_evaluate (pair_hmm.hpp:278-319), the regime real reads live in
+Q_PROFILES = {"stress": ([37, 25, 12, 2], [0.7, 0.2, 0.08, 0.02], 20),
+              "hq": ([37, 30, 25, 12, 2], [0.88, 0.08, 0.025, 0.012, 0.003], 8)}
+
+
+def make_reads(rng: np.random.Generator, haps, maps, R: int, T: int, B: int, min_diffs: int = 0, q_values=None, indels_per_read: int = 0,
+               q_profile: str = "stress", ploidy: int = 0):
+    """R reads of length T sampled from uniformly chosen haplotypes (ploidy > 0: from that many of them, the sample's genotype), Illumina-like qualities and errors."""
     H, Lh = len(haps), len(haps[0])
-    src = rng.integers(0, H, R)
+    src = rng.integers(0, H, R) if not ploidy else rng.choice(H, size=min(ploidy, H), replace=False)[rng.integers(0, min(ploidy, H), R)]
     start = rng.integers(B, Lh - T - B + 1, R)              # start in BASE coordinates = the read's reference begin
+    q_vals, q_p, q_decay = Q_PROFILES[q_profile]
     if q_values is None:
-        quals = rng.choice(np.array([37, 25, 12, 2], dtype=np.uint8), size=(R, T), p=[0.7, 0.2, 0.08, 0.02])
+        quals = rng.choice(np.array(q_vals, dtype=np.uint8), size=(R, T), p=q_p)
     else:
         quals = rng.integers(q_values[0], q_values[1] + 1, size=(R, T)).astype(np.uint8)
-    decay = np.concatenate([np.zeros(T - min(30, T)), np.linspace(0, 20, min(30, T))]).astype(np.int64)
+    decay = np.concatenate([np.zeros(T - min(30, T)), np.linspace(0, q_decay, min(30, T))]).astype(np.int64)
     quals = np.clip(quals.astype(np.int64) - decay[None, :], 2, 64).astype(np.uint8)
     first = np.minimum(np.stack(maps)[src, start], Lh - T)
     reads = np.stack(haps)[src[:, None], first[:, None] + np.arange(T)[None, :]]
@@ -110,11 +167,14 @@ def make_reads(rng: np.random.Generator, haps, maps, R: int, T: int, B: int, min
 
 
 def make_region(rng: np.random.Generator, R: int, H: int, T: int = 150, Lh: int = 300, B: int = 16,
-                flank=(40, 40), min_diffs: int = 0, positions: str = "true", q_values=None, indels_per_read: int = 0):
+                flank=(40, 40), min_diffs: int = 0, positions: str = "true", q_values=None, indels_per_read: int = 0, q_profile: str = "stress",
+                hap_model: str = "edits"):
     """Arrays of one populate() call. positions: 'true' = each read's start mapped through the haplotype's edits
-    (a stand-in for the k-mer mapper's output), 'none' = leave mapping to the library."""
-    haps, maps = make_haplotypes(rng, H, Lh)
-    reads, quals, begin, reverse, mapq, _ = make_reads(rng, haps, maps, R, T, B, min_diffs, q_values, indels_per_read)
+    (a stand-in for the k-mer mapper's output), 'none' = leave mapping to the library. hap_model: 'edits' = every haplotype its own 1-3 random edits
+    (SURVEY.md 8d), 'tree' = allele combinations of a few candidate sites with reads from a diploid genotype (make_tree_haplotypes)."""
+    haps, maps = make_haplotypes(rng, H, Lh) if hap_model == "edits" else make_tree_haplotypes(rng, H, Lh)
+    reads, quals, begin, reverse, mapq, _ = make_reads(rng, haps, maps, R, T, B, min_diffs, q_values, indels_per_read, q_profile,
+                                                       ploidy=2 if hap_model == "tree" else 0)
     pos = None
     if positions == "true":
         pos = np.stack([np.minimum(m[begin], Lh - T) for m in maps]).astype(np.uint32)     # [H, R]
@@ -169,6 +229,14 @@ def config_region(name: str, seed: int = 42, B: int = 16, positions: str = "true
         return make_region(rng, 1000, 64, B=B, positions=positions)
     if name == "100kx128":
         return make_region(rng, 100_000, 128, B=B, positions=positions)
+    if name == "100kx128-hq":      # the same haplotypes (the generator draws them first), reads of a realistic Illumina quality profile
+        return make_region(rng, 100_000, 128, B=B, positions=positions, q_profile="hq")
+    if name == "10kx64-hq":
+        return make_region(rng, 10_000, 64, B=B, positions=positions, q_profile="hq")
+    if name == "100kx128-tree":    # a caller's haplotypes (all combinations of seven candidate alleles), diploid sample, hq reads
+        return make_region(rng, 100_000, 128, B=B, positions=positions, q_profile="hq", hap_model="tree")
+    if name == "10kx16-tree":
+        return make_region(rng, 10_000, 16, B=B, positions=positions, q_profile="hq", hap_model="tree")
     if name == "100kx128-nofast":
         return make_region(rng, 100_000, 128, B=B, min_diffs=2, positions=positions)
     if name == "10kx64":
@@ -210,7 +278,7 @@ def region_stream(seed: int, n_regions: int, B: int = 16, positions: str = "true
     return out
 
 
-def stream_region(seed: int, i: int, B: int = 16, positions: str = "true", cap=None) -> dict:
+def stream_region(seed: int, i: int, B: int = 16, positions: str = "true", cap=None, hq: bool = False) -> dict:
     """Region i of the fixed active-region stream `seed`: same shape distribution as region_stream, but every region has its own
     generator state, so any rank can produce exactly its share of ONE stream without generating the rest."""
     rng = np.random.default_rng([seed, i])
@@ -219,21 +287,25 @@ def stream_region(seed: int, i: int, B: int = 16, positions: str = "true", cap=N
     Lh = 300 + int(rng.integers(0, 201))
     if cap is not None:          # (max reads, max haplotypes): toy sizes for the simulator-backed tests
         R, H = min(R, cap[0]), min(H, cap[1])
+    if hq:                       # the same shapes with a caller's haplotypes (allele combinations, diploid sample) and a current Illumina quality profile
+        return make_region(rng, R, max(H, 1), Lh=Lh, B=B, positions=positions, q_profile="hq", hap_model="tree")
     return make_region(rng, R, max(H, 1), Lh=Lh, B=B, positions=positions)
 
 
 def _stream_regions(args):
-    seed, idx, B, positions, cap = args
-    return [stream_region(seed, i, B=B, positions=positions, cap=cap) for i in idx]
+    seed, idx, B, positions, cap = args[:5]
+    hq = bool(args[5]) if len(args) > 5 else False
+    return [stream_region(seed, i, B=B, positions=positions, cap=cap, hq=hq) for i in idx]
 
 
-def region_stream_shard(seed: int, n_regions: int, rank: int = 0, world: int = 1, B: int = 16, positions: str = "true", cap=None, workers: int = 1) -> List[dict]:
+def region_stream_shard(seed: int, n_regions: int, rank: int = 0, world: int = 1, B: int = 16, positions: str = "true", cap=None, workers: int = 1,
+                        hq: bool = False) -> List[dict]:
     """BASELINE.json configs[3]: the regions i = rank (mod world) of a stream of n_regions regions (round-robin over the GPUs, no exchange).
     A big shard (the 50,000-region stream of bench.py at N > 1) is generated by `workers` spawned processes: every region has its own generator state,
     so the result does not depend on who makes it."""
     idx = list(range(rank, n_regions, world))
     if workers <= 1 or len(idx) < 4000:
-        return _stream_regions((seed, idx, B, positions, cap))
+        return _stream_regions((seed, idx, B, positions, cap, hq))
     # plain child interpreters (no multiprocessing: its spawn mode re-imports the parent's __main__, and the parent may hold a HIP context that must not be forked)
     import pickle
     import subprocess
@@ -245,14 +317,21 @@ def region_stream_shard(seed: int, n_regions: int, rank: int = 0, world: int = 1
     procs = [subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE) for _ in chunks]
     import threading
     parts = [None] * len(chunks)
+    errors = [None] * len(chunks)
 
     def talk(k):
-        out, _ = procs[k].communicate(pickle.dumps((seed, chunks[k], B, positions, cap), protocol=4))
-        if procs[k].returncode != 0:
-            raise RuntimeError("region generator child failed")
-        parts[k] = pickle.loads(out)
+        try:
+            out, _ = procs[k].communicate(pickle.dumps((seed, chunks[k], B, positions, cap, hq), protocol=4))
+            if procs[k].returncode != 0:
+                raise RuntimeError(f"region generator child {k} exited with {procs[k].returncode}")
+            parts[k] = pickle.loads(out)
+        except BaseException as e:      # noqa: BLE001 - re-raised in the caller's thread below: a thread's exception is otherwise lost with the thread
+            errors[k] = e
     ths = [threading.Thread(target=talk, args=(k,)) for k in range(len(chunks))]
     [t.start() for t in ths]; [t.join() for t in ths]
+    for k, e in enumerate(errors):
+        if e is not None or parts[k] is None:
+            raise RuntimeError(f"region_stream_shard: generator child {k} of {len(chunks)} failed") from e
     by_index = {}
     for c, regs in zip(chunks, parts):
         by_index.update(zip(c, regs))

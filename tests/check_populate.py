@@ -643,3 +643,50 @@ def check_launch_modes(backend, tol=0.0):
                 os.environ[k] = v
     assert repeated >= 4, repeated
     return n
+
+
+def check_mapper_mismatch_account(backend, tol=0.0):
+    """k_kmer_map hands k_classify the base mismatches it saw along a pair's one mapped position (DevBatch::pair_mm: none / exactly one at i1 / two or more), so
+    that try_naive_evaluate (pair_hmm.hpp:278-319) needs no pass over the bases. Regions of allele-combination haplotypes and high-quality reads (most candidates
+    are exact or one mismatch away), plus crafted reads for the branches behind the single mismatch: a substitution inside a homopolymer the read ends in (the
+    shifted-suffix tests :305 / :309 with a gap-open penalty below the base quality), a mismatch in the read's first / last six bases (k-mers at the edges), in the
+    flank, reads and haplotypes with an N (hash equality is then no base equality: the account must be ignored). Every variant against the oracle (values, counters,
+    the mapper's positions) and with the account switched off."""
+    import os
+    out = []
+    for seed, B, T, Lh in ((3, 8, 60, 170), (4, 16, 75, 220), (5, 8, 61, 180), (6, 8, 197, 460), (7, 8, 203, 470)):    # (197: the last three-round read length; 203: four rounds)
+        rng = np.random.default_rng(seed)
+        g = synth.make_region(rng, 40, 6, T=T, Lh=Lh, B=B, flank=(25, 20), positions="none", q_profile="hq", hap_model="tree")
+        haps, reads, quals, begin = g["haps"], g["reads"], g["quals"], g["begin"]
+        hp = haps[0]
+        run = int(rng.integers(T + B - 6, Lh - T - B + 1))        # every crafted read below stays in range
+        for h in haps:
+            h[run:run + 10] = ord("A")                              # a homopolymer every haplotype shares (open penalty 21 < Q37)
+        quals[:] = np.maximum(quals, 30)
+        k = 0
+
+        def put(start, edit, pos_in_read, base=None):
+            nonlocal k
+            row = hp[start:start + T].copy()
+            if edit:
+                row[pos_in_read] = base if base is not None else synth.BASES[(int(np.searchsorted(synth.BASES, row[pos_in_read])) + 1) % 4]
+            reads[k] = row; begin[k] = start; quals[k] = 37; k += 1
+        put(run + 6 - T, True, T - 4, ord("C"))                     # ends inside the homopolymer, substitution inside it: the suffix equals the haplotype shifted by one
+        put(run + 8 - T, True, T - 5, ord("G"))
+        put(run - 3, True, 4, ord("T"))                             # starts just before it: substitution in the first k-mer only
+        for i in (0, 1, 5, 6, T - 1, T - 6, T - 7, T // 2):         # one mismatch at the edges of the k-mer cover
+            put(B + 3, True, i)
+        put(B, False, 0); put(Lh - T - B, False, 0)                 # exact, at both ends of the range
+        put(B + 1, True, 2); reads[k - 1][T - 3] = ord("N")         # a read with an N: its hashes lie
+        row = hp[B + 5:B + 5 + T].copy(); row[[7, 30]] = [ord("N"), synth.BASES[(int(np.searchsorted(synth.BASES, row[30])) + 2) % 4]]; reads[k] = row; begin[k] = B + 5; k += 1
+        haps[-1][B + 9] = ord("N")                                   # a haplotype with an N (code 0 like A)
+        batch = synth.batch_from_regions([g])
+        on = compare(backend, batch, tol, max_indel_error=B)
+        os.environ["OCT_PHMM_MAP_MISMATCHES"] = "0"
+        try:
+            off = compare(backend, batch, tol, max_indel_error=B)
+        finally:
+            del os.environ["OCT_PHMM_MAP_MISMATCHES"]
+        assert on == off and on["n_fast_path"] > 30, (on, off)
+        out.append(on)
+    return out

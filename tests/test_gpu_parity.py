@@ -374,3 +374,8 @@ def test_gpu_device_penalty_vectors_on_the_corpus_and_on_many_haplotypes():
 def test_gpu_align_and_server_generate_the_penalty_vectors():
     import check_error_model as ce
     assert ce.check_align_and_server_generate_the_vectors("gpu", TOL) >= 5
+
+
+def test_gpu_mapper_mismatch_account_feeds_the_fast_path():
+    """k_kmer_map's account of the base mismatches along the mapped position (pair_mm) against the oracle and against the run without it."""
+    assert len(cp.check_mapper_mismatch_account("gpu", TOL)) == 5

@@ -129,3 +129,8 @@ def test_sim_populate_lockstep_walkers(mode, monkeypatch):
 
 def test_sim_scratch_allocation_failures_fall_back_and_leave_no_error():
     cp.check_scratch_allocation_failures("sim")
+
+
+def test_sim_mapper_mismatch_account_feeds_the_fast_path():
+    stats = cp.check_mapper_mismatch_account("sim")
+    assert len(stats) == 5
