@@ -182,71 +182,121 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12, in_flight: int = 2):
+def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12, in_flight: int = 2, pipelined: bool = True):
     """What a caller gets who hands over HOST buffers: (i) one oct_phmm_populate of the many-region batch, PCIe both ways; (ii) the same batch
     over and over from `in_flight` host threads with a handle each - while one handle's batch computes, the others' next batches are validated, packed,
-    copied up and their results stream back - the sustained rate over n_batches consecutive batches. Every result is compared with the resident run's
-    matrix (which is verified against the reference's own populate on a sample of regions)."""
+    copied up and their results stream back - the sustained rate over n_batches consecutive batches. Arrays and `out` live in page-locked memory
+    (oct_phmm_host_alloc: the DMA engines read and write the caller's buffers themselves); the `_pageable` figures are the same calls on plain numpy arrays,
+    which the library stages through its own pinned buffers. Every result is compared with the resident run's matrix (which is verified against the
+    reference's own populate on a sample of regions)."""
     import threading
     from octopus_amd import engine
-    out = np.empty(batch.out_size())
-    eng.populate(batch, out=out)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        eng.populate(batch, out=out)
-    one = (time.perf_counter() - t0) / 3
-    same = bool(np.array_equal(out, resident))
-    res = {"e2e_ms_from_host": one * 1e3, "e2e_regions_per_s": n_regions / one}
-    for k in sorted({in_flight, 3}):
-        engs = [eng] + [engine.Engine(cfg) for _ in range(k - 1)]
-        outs = [out] + [np.empty(batch.out_size()) for _ in range(k - 1)]
-        for e, o in zip(engs[1:], outs[1:]):
-            e.populate(batch, out=o)                        # warm the other handles' pools
-        done = [0] * k
+    pool = engine.PinnedPool()
+    res = {}
+    same = True
+    try:
+        locked = pool.batch(batch)
+        for tag, bt, mk in (("", locked, lambda: pool.empty(batch.out_size(), np.float64)), ("_pageable", batch, lambda: np.empty(batch.out_size()))):
+            out = mk()
+            eng.populate(bt, out=out)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                eng.populate(bt, out=out)
+            one = (time.perf_counter() - t0) / 3
+            same = same and bool(np.array_equal(out, resident))
+            res.update({f"e2e_ms_from_host{tag}": one * 1e3, f"e2e_regions_per_s{tag}": n_regions / one})
+            if not pipelined:
+                continue
+            for k in sorted({in_flight, 3}) if not tag else [in_flight]:
+                engs = [eng] + [engine.Engine(cfg) for _ in range(k - 1)]
+                outs = [out] + [mk() for _ in range(k - 1)]
+                errors = []
+                for e, o in zip(engs[1:], outs[1:]):
+                    e.populate(bt, out=o)                        # warm the other handles' pools
+                done = [0] * k
 
-        def work(t):
-            for _ in range(n_batches // k):
-                engs[t].populate(batch, out=outs[t]); done[t] += 1
-        ths = [threading.Thread(target=work, args=(t,)) for t in range(k)]
-        t0 = time.perf_counter()
-        [t.start() for t in ths]; [t.join() for t in ths]
-        dt = time.perf_counter() - t0
-        same = same and all(bool(np.array_equal(o, resident)) for o in outs)
-        for e in engs[1:]:
-            e.close()
-        n = sum(done)
-        tag = "e2e_pipelined" if k == in_flight else f"e2e_pipelined_{k}_in_flight"
-        res.update({f"{tag}_regions_per_s": n * n_regions / dt, f"{tag}_ms_per_batch": dt / n * 1e3, f"{tag}_batches": n})
-    res["e2e_pipelined_how"] = f"{in_flight} host threads, one handle each, oct_phmm_populate from host buffers back to back ({in_flight} batches in flight)"
+                def work(t):
+                    try:
+                        for _ in range(n_batches // k):
+                            engs[t].populate(bt, out=outs[t]); done[t] += 1
+                    except Exception as e:      # noqa: BLE001 - reported below: a thread's exception is otherwise lost and the rate silently wrong
+                        errors.append(repr(e))
+                ths = [threading.Thread(target=work, args=(t,)) for t in range(k)]
+                t0 = time.perf_counter()
+                [t.start() for t in ths]; [t.join() for t in ths]
+                dt = time.perf_counter() - t0
+                same = same and all(bool(np.array_equal(o, resident)) for o in outs)
+                for e in engs[1:]:
+                    e.close()
+                n = sum(done)
+                name = ("e2e_pipelined" if k == in_flight else f"e2e_pipelined_{k}_in_flight") + tag
+                res.update({f"{name}_regions_per_s": n * n_regions / dt, f"{name}_ms_per_batch": dt / max(n, 1) * 1e3, f"{name}_batches": n})
+                if errors:
+                    res[f"{name}_errors"] = errors
+    finally:
+        pool.close()
+    res["e2e_pipelined_how"] = (f"{in_flight} host threads, one handle each, oct_phmm_populate from page-locked host buffers back to back ({in_flight} batches in flight); "
+                                "_pageable: the same from plain (pageable) arrays")
     res["e2e_results_equal_resident_run"] = same
     return res
 
 
-def region_call_legs():
+def region_call_legs(stream_regions=None, stream_resident=None, B: int = 16):
     """The reference's calling pattern (one populate per active region from each region-task thread, caller.cpp:1159-1196) through the C ABI, without an
-    interpreter in the way: tools/region_calls_bench (built by __graft_entry__.build()) makes 3,000 regions of 300 reads x 24 haplotypes and issues
-    one call per region (i) from one thread on one handle, (ii) from 16 threads through the region server; the server's answers are compared with plain calls."""
+    interpreter in the way: tools/region_calls_bench (built by __graft_entry__.build()) issues one call per region (i) from one thread on one handle, (ii) from
+    N threads through the region server - on 3,000 regions of 300 reads x 24 haplotypes of its own generator (continuity with round 3; answers compared with
+    plain calls), and on the configs[3] stream's own regions (the very regions the `stream` leg runs as one flat batch): every answer of the
+    server compared with the resident run's matrix, and a 5 % sample of the regions with the reference's own populate."""
     import subprocess
+    import tempfile
+    from octopus_amd import synth
     exe = ROOT / "tools" / "region_calls_bench"
     if not exe.exists():
         return {"region_calls": {"error": "tools/region_calls_bench is not built (python -c 'import __graft_entry__ as g; g.build()')"}}
+
+    def run(args):
+        r = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=420)
+        rows = []
+        for line in r.stdout.splitlines():
+            try:
+                rows.append(json.loads(line))
+            except ValueError:
+                pass
+        return r.returncode, rows
+    pick = lambda rows, mode, th: next((x for x in rows if x.get("mode") == mode and x.get("threads") == th), {})
     try:
-        r = subprocess.run([str(exe), "3000", "300", "24", "1", "16"], capture_output=True, text=True, timeout=300)
+        rc, rows = run(["3000", "300", "24", "1", "16"])
     except Exception as e:      # noqa: BLE001
         return {"region_calls": {"error": repr(e)}}
-    rows = []
-    for line in r.stdout.splitlines():
-        try:
-            rows.append(json.loads(line))
-        except ValueError:
-            pass
-    pick = lambda mode, th: next((x for x in rows if x.get("mode") == mode and x.get("threads") == th), {})
     check = next((x for x in rows if x.get("mode") == "server vs plain calls"), {})
-    one, srv16, srv1, h16 = pick("handle per thread", 1), pick("server", 16), pick("server", 1), pick("handle per thread", 16)
+    one, srv16, srv1, h16 = pick(rows, "handle per thread", 1), pick(rows, "server", 16), pick(rows, "server", 1), pick(rows, "handle per thread", 16)
     legs = {"region_call_ms": one.get("ms_per_call"), "region_server_regions_per_s": srv16.get("regions_per_s"),
             "region_calls": {"regions": "3,000 synthetic active regions of 300 reads x 24 haplotypes (150 bp x 300 bp, flank 40/40), one oct_phmm call per region from host buffers",
                              "one_thread_one_handle": one, "server_1_caller": srv1, "server_16_callers": srv16, "handle_per_thread_16": h16,
-                             "server_answers_equal_plain_calls": check, "rc": r.returncode}}
+                             "server_answers_equal_plain_calls": check, "rc": rc}}
+    if stream_regions is not None:
+        callers = [1, 16, 32, 64, 128]
+        with tempfile.TemporaryDirectory() as tmp:
+            synth.write_regions_file(os.path.join(tmp, "regions.bin"), stream_regions)
+            try:
+                rc, rows = run(["--file", os.path.join(tmp, "regions.bin"), "--out", os.path.join(tmp, "out.bin")] + [str(c) for c in callers])
+                got = np.fromfile(os.path.join(tmp, "out.bin"), dtype=np.float64)
+            except Exception as e:      # noqa: BLE001
+                legs["region_calls"]["stream_regions_error"] = repr(e)
+                return legs
+        st = {"regions": f"the {len(stream_regions)} regions of the configs[3] stream (SURVEY 8d config 4: R ~ lognormal(300, 0.8) in [20, 5000], H ~ min(200, geometric(24)), Lh 300-500), "
+                         "one oct_phmm call per region from host buffers", "rc": rc,
+              "one_thread_one_handle": pick(rows, "handle per thread", 1),
+              "server_answers_equal_plain_calls": next((x for x in rows if x.get("mode") == "server vs plain calls"), {})}
+        for c in callers:
+            st[f"server_{c}_callers"] = pick(rows, "server", c)
+        if stream_resident is not None:
+            st["answers_equal_the_flat_batch_run"] = bool(got.shape == stream_resident.shape and np.array_equal(got, stream_resident))
+        if got.size == sum(g["reads"].shape[0] * len(g["haps"]) for g in stream_regions):
+            v = verify_against_reference(got, stream_regions, B, frac=0.05, seed=2)
+            st.update({"verified_rows": v["verified_rows"], "verified_max_abs_diff": v["verified_max_abs_diff"], "verified_against": v["verified_against"]})
+        legs["region_calls"]["stream_regions"] = st
+        legs["region_calls_stream_regions_per_s_64_callers"] = st.get("server_64_callers", {}).get("regions_per_s")
     return legs
 
 
@@ -425,6 +475,7 @@ def main():
             "metric": "pair-HMM band cell-updates/s", "value": cells / per_step / 1e9, "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": per_step * 1e3,
             "higher_is_better": True, "scaling": "strong" if stream else "weak", "vs_baseline": None, "dtype": "int16",
+            "workload": args.workload, "regions": args.regions if stream else 1,
             "data": "synthetic" if not sim else "synthetic, SIMULATOR BACKEND (test hook, not a measurement)",
             "config": {"workload": (f"{args.workload}: Illumina-like 150 bp reads x 300 bp haplotypes per region, band {B}, "
                                     f"int16 lanes, flank 40/40, device k-mer mapping, one region per GPU") if not stream else
@@ -463,6 +514,7 @@ def main():
                                           "issue_weighted_frac prices every instruction at its measured cost = the share of DP kernel time the instruction "
                                           "stream itself accounts for (the rest: staging latency, reductions, tile flushes, tails)"}},
         }
+        stream_regs_for_calls, stream_resident_for_calls = None, None
         if world == 1 and extras and not sim:
             # PCIe-inclusive: one oct_phmm_populate of the same batch from host buffers (H2D, table build, run, results streamed back)
             outbuf = np.empty(batch.out_size())
@@ -487,6 +539,62 @@ def main():
                                  "gcups_reference_work": ss["band_cells"] / dt / 1e9, "pairs_shared": ss.get("n_pairs_shared", 0),
                                  "loglik_per_s": ss["n_pairs"] / dt, "verified_rows": sv["verified_rows"], "verified_max_abs_diff": sv["verified_max_abs_diff"]}
                 out["stream"].update(stream_from_host(eng, cfg, sbatch, resident, len(sregs)))
+                stream_regs_for_calls, stream_resident_for_calls = sregs, resident
+                # The regime real reads live in (round-3 verdict): a current Illumina quality profile (~92 % of the bases >= Q30, ~0.35 mismatches per read) on
+                # (i) the very haplotypes of the headline batch, (ii) the configs[3] stream with a caller's haplotypes (allele combinations of a few candidate
+                # sites, diploid sample): the share of candidates try_naive_evaluate answers grows and the mapper + classifier become a larger part of the step.
+                def leg(regs, steps, frac):
+                    bt = synth.batch_from_regions(regs)
+                    rb2 = eng.upload(bt)
+                    dt2 = timed_resident(rb2, steps)
+                    s2 = rb2.stats()
+                    v2 = verify_against_reference(rb2.download(), regs, B, frac=frac)
+                    rb2.free()
+                    return {"ms": dt2 * 1e3, "loglik_per_s": s2["n_pairs"] / dt2, "gcups": (s2["band_cells"] - s2.get("band_cells_shared", 0)) / dt2 / 1e9,
+                            "gcups_reference_work": s2["band_cells"] / dt2 / 1e9, "n_pairs": s2["n_pairs"], "n_candidates": s2["n_candidates"], "n_fast_path": s2["n_fast_path"],
+                            "fast_path_share_of_candidates": s2["n_fast_path"] / max(s2["n_candidates"], 1), "dp_tasks": s2["n_dp_score_only"] + s2["n_dp_traceback"],
+                            "pairs_shared": s2.get("n_pairs_shared", 0), "verified_rows": v2["verified_rows"], "verified_max_abs_diff": v2["verified_max_abs_diff"]}
+                out["hq"] = dict(leg([synth.config_region("100kx128-hq", seed=42, B=B, positions="none")], 5, 0.05),
+                                 workload="100kx128-hq: the headline batch's haplotypes, reads of a current Illumina quality profile (synth.Q_PROFILES['hq'])")
+                out["stream_hq"] = dict(leg(synth.region_stream_shard(seed=42, n_regions=args.regions, B=B, positions="none", hq=True), 5, 0.05),
+                                        workload=f"stream-hq: the {args.regions}-region stream's shapes with allele-combination haplotypes (synth.make_tree_haplotypes), diploid samples, hq reads",
+                                        regions=args.regions)
+                out["stream_hq"]["regions_per_s"] = args.regions / (out["stream_hq"]["ms"] / 1e3)
+                # One rank's share of the 8-GPU split (configs[3] at N = 8: region i of the 50,000-region stream -> GPU i mod 8), timed on this one GPU: no
+                # scaling curve can be measured here, but T(6,250 regions) against T(50,000) / 8 extrapolated from the 2,000-region figure says whether fixed
+                # costs would flatten the strong-scaling line, and it runs the N > 1 default's batch size on hardware.
+                def hbm_free():
+                    import ctypes
+                    try:
+                        hip = ctypes.CDLL("libamdhip64.so")
+                        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+                        return int(free.value) if hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0 else None
+                    except OSError:
+                        return None
+                t1 = time.perf_counter()
+                shard = synth.region_stream_shard(seed=42, n_regions=50000, rank=0, world=8, B=B, positions="none", workers=max(1, min(8, os.cpu_count() or 1)))
+                t_gen = time.perf_counter() - t1
+                shbatch = synth.batch_from_regions(shard)
+                free0 = hbm_free()
+                t1 = time.perf_counter()
+                shb = eng.upload(shbatch)
+                t_up = time.perf_counter() - t1
+                free1 = hbm_free()
+                dt = timed_resident(shb, 3)
+                shs = shb.stats()
+                shres = shb.download().copy()
+                shv = verify_against_reference(shres, shard, B, frac=0.01)
+                shb.free()
+                sh_e2e = stream_from_host(eng, cfg, shbatch, shres, len(shard), pipelined=False)
+                out["stream_shard_1_of_8"] = {"regions": len(shard), "of_stream": 50000, "ms": dt * 1e3, "regions_per_s": len(shard) / dt, "pairs": shs["n_pairs"],
+                                              "gcups": (shs["band_cells"] - shs.get("band_cells_shared", 0)) / dt / 1e9, "loglik_per_s": shs["n_pairs"] / dt,
+                                              "generate_s": t_gen, "upload_ms": t_up * 1e3, "hbm_bytes_resident": (free0 - free1) if free0 and free1 else None,
+                                              "regions_per_s_of_the_2000_region_stream": out["stream"]["regions_per_s"],
+                                              "e2e_ms_from_host": sh_e2e.get("e2e_ms_from_host"), "e2e_regions_per_s": sh_e2e.get("e2e_regions_per_s"), "e2e_ms_from_host_pageable": sh_e2e.get("e2e_ms_from_host_pageable"),
+                                              "e2e_results_equal_resident_run": sh_e2e.get("e2e_results_equal_resident_run"),
+                                              "verified_rows": shv["verified_rows"], "verified_max_abs_diff": shv["verified_max_abs_diff"],
+                                              "note": "rank 0's share of `bench.py --gpus 8` (the driver's SCALE run) on one GPU; N > 1 itself stays unmeasured"}
+                del shres, shbatch, shard
                 # configs[4]: 64 x 10 kb reads, 8 x 20 kb haplotypes, band 256, int32 lanes (streaming DP kernels, traceback in HBM)
                 lcfg = abi.Config.default(max_indel_error=256, use_int_scores=1, device_id=local_rank)
                 leng = engine.Engine(lcfg)
@@ -498,7 +606,7 @@ def main():
                 out["long_read"] = {"ms": dt * 1e3, "gcups": ls["band_cells"] / dt / 1e9, "dtype": "int32", "band": 256,
                                     "workload": "long64x8: 64 x 10 kb reads x 8 x 20 kb haplotypes (BASELINE configs[4])", "dp_tasks": ls["n_dp_score_only"] + ls["n_dp_traceback"]}
         if world == 1 and extras and not sim:
-            out.update(region_call_legs())
+            out.update(region_call_legs(stream_regs_for_calls, stream_resident_for_calls, B))
         if world == 1 and not args.no_small_batch:
             small = eng.upload(synth.config_batch("1kx64", seed=42, B=B, positions="none"))
             for _ in range(3):

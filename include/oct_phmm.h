@@ -164,6 +164,15 @@ void oct_phmm_destroy(oct_phmm_handle* h);
 int  oct_phmm_band_size(const oct_phmm_handle* h);
 const char* oct_phmm_strerror(int code);
 
+/* ---- page-locked host memory for big batches ------------------------------------------------------- */
+/* The input arrays and `out` may live anywhere. Where a caller that hands over HUNDREDS of megabytes per call (many regions in one batch) keeps them in
+ * page-locked memory, the library skips its staging copies: inputs go to the device straight from the caller's arrays and results land in `out` itself
+ * (the DMA engines move ~50 GB/s; a staged copy through host threads ~15). Any page-locked memory the HIP runtime knows will do (hipHostMalloc,
+ * hipHostRegister); these two calls provide it without a HIP dependency in the caller. Detected per array, per call, for batches above 8 MB only -
+ * region-sized calls (caller.cpp:1159-1196) never pay for the question. NULL on failure. */
+void* oct_phmm_host_alloc(size_t bytes);
+void  oct_phmm_host_free(void* p);
+
 /* ---- the hot path ----------------------------------------------------------------------------- */
 /* HaplotypeLikelihoodArray::populate: out[out_offset(hap) + row - first row of the region] =
  * ln p(row | haplotype); for one region that is an H x n_rows row-major matrix, haplotype-major, i.e.

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <list>
 #include <map>
 #include <mutex>
 #include <string>
@@ -38,20 +39,25 @@ struct DevPool {
     std::unordered_map<void*, size_t> live;
     size_t cached = 0;
     static constexpr size_t kCacheCap = (size_t)16 << 30;
-    static size_t size_class(size_t n)                  // powers of two up to 1 MB, then eight classes per octave: few distinct sizes, so blocks get reused
+    // Powers of two up to 1 GB (a thread's region calls differ in size by orders of magnitude - 20 to 5,000 reads, 1 to 200 haplotypes: with finer classes most
+    // calls of a run's first thousands met a size nobody had freed yet and paid a hipMalloc, which synchronises the device), eight classes per octave beyond
+    // (resident many-gigabyte batches are not rounded up by half of themselves).
+    static size_t size_class(size_t n)
     {
-        if (n < 512) return 512;
-        size_t c = 512; while (c < n && c < ((size_t)1 << 20)) c <<= 1;
+        if (n < 4096) return 4096;
+        size_t c = 4096; while (c < n && c < ((size_t)1 << 30)) c <<= 1;
         if (c >= n) return c;
-        size_t p2 = (size_t)1 << 20; while ((p2 << 1) <= n) p2 <<= 1;      // largest power of two <= n
+        size_t p2 = (size_t)1 << 30; while ((p2 << 1) <= n) p2 <<= 1;      // largest power of two <= n
         const size_t step = p2 >> 3;
         return (n + step - 1) / step * step;
     }
     bool alloc(void** p, size_t n)
     {
         const size_t c = size_class(n);
-        auto it = free_blocks.lower_bound(c);             // the smallest cached block that fits, if it is not wastefully large
-        if (it != free_blocks.end() && it->first <= c + c / 2) { *p = it->second; const size_t got = it->first; free_blocks.erase(it); cached -= got; live[*p] = got; return true; }
+        auto it = free_blocks.lower_bound(c);             // the smallest cached block that fits, if it is not wastefully large (small blocks: up to 8x, nobody misses those bytes)
+        if (it != free_blocks.end() && (it->first <= c + c / 2 || it->first <= std::min<size_t>(8 * c, (size_t)64 << 20))) {
+            *p = it->second; const size_t got = it->first; free_blocks.erase(it); cached -= got; live[*p] = got; return true;
+        }
         if (!rt::dev_malloc(p, c)) {
             rt::clear_error();
             trim();                                     // give cached blocks back and retry once
@@ -105,6 +111,7 @@ struct oct_phmm_handle {
 };
 
 struct oct_phmm_batch {
+    double* out_landing = nullptr;   // oct_phmm_populate with a page-locked `out`: results are copied there by the DMA engine, no landing zone of the handle's in between
     DevBatch d {};
     std::vector<void*> allocs;
     // host-side shape + small copies needed for error reporting
@@ -184,7 +191,7 @@ inline const char* get(const char* name)
     {
         std::lock_guard<std::mutex> lk(switch_mu());
         auto it = switch_table().find(name);
-        if (it != switch_table().end()) return it->second.c_str();          // (entries are only ever replaced between runs: tests and tools are single-threaded there)
+        if (it != switch_table().end()) return it->second.c_str();          // (stays valid: oct_phmm_test_set retires replaced strings instead of freeing them)
     }
     return env_ok ? getenv(name) : nullptr;
 }
@@ -195,9 +202,10 @@ inline bool timing()          { return prof_flag("OCT_PHMM_TIMING"); }          
 inline bool server_profile()  { return prof_flag("OCT_PHMM_SERVER_PROFILE"); }     // region server: where the workers' time goes, printed at destroy
 inline bool map_stats()       { return prof_flag("OCT_PHMM_MAP_STATS"); }          // k-mer mapper: pairs decided by the shortcut / counted, printed per run
 inline bool exact_adds()      { return flag("OCT_PHMM_EXACT_ADDS"); }         // keep v_pk_add_u16 even where the host bound allows v_add_u32
+inline bool pinned_direct()   { const char* e = get("OCT_PHMM_PINNED_DIRECT"); return !e || atoi(e) != 0; }   // 0: page-locked caller arrays are staged like pageable ones (A/B)
+inline size_t pinned_min_bytes(size_t dflt) { long long kb; return number("OCT_PHMM_PINNED_MIN_KB", &kb) && kb >= 0 ? (size_t)kb << 10 : dflt; }   // test hook: arrays / results from this size on are asked whether they are page-locked
 inline bool pageable_h2d()    { return flag("OCT_PHMM_PAGEABLE_H2D"); }       // big batches: copy from the caller's arrays instead of the pinned staging halves
 inline bool map_count_only()  { return flag("OCT_PHMM_MAP_COUNT_ONLY"); }     // k-mer mapper without the exact shortcut
-inline bool lane_mapper()     { return flag("OCT_PHMM_LANE_MAPPER"); }        // the (slower) lane-per-pair mapper
 inline bool big_mapper()      { return flag("OCT_PHMM_BIG_MAPPER"); }         // test hook: the long-haplotype mapper on short haplotypes
 inline bool map_mismatches()  { const char* e = get("OCT_PHMM_MAP_MISMATCHES"); return !e || atoi(e) != 0; }   // 0: k_classify compares the bases of every candidate itself (A/B, tests)
 inline int  penalties_where() { const char* e = get("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' || e[0] == 'l' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
@@ -311,6 +319,45 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
         }
         return rt::h2d(base, h->stage, in_bytes, s);
     }
+    size_t n_in = 0; while (n_in < items.size() && items[n_in].src) ++n_in;
+    {   // Big batch with arrays in page-locked caller memory (oct_phmm_host_alloc, hipHostMalloc, hipHostRegister): the DMA engine reads those arrays themselves; the
+        // others (the library's own small tables, pageable caller arrays) go through the staging halves one by one
+        std::vector<char> direct(n_in, 0); bool any = false;
+        if (tune::pinned_direct()) for (size_t i = 0; i < n_in; ++i) if (items[i].bytes >= tune::pinned_min_bytes((size_t)1 << 20) && rt::host_is_pinned(items[i].src)) { direct[i] = 1; any = true; }
+        if (any) {
+            if (h->stage_bytes < kStageMax) {
+                rt::host_pinned_free(h->stage); h->stage = nullptr; h->stage_bytes = 0;
+                if (!rt::host_pinned_malloc(&h->stage, kStageMax)) return false;
+                h->stage_bytes = kStageMax;
+            }
+            const size_t half = (kStageMax / 2) & ~(size_t)255;
+            rt::Event ev[2] {}; bool used[2] = {false, false};
+            if (!h->get_event(&ev[0]) || !h->get_event(&ev[1])) return false;
+            bool ok = true; int k = 0;
+            for (size_t i = 0; i < n_in && ok; ++i) {
+                const Item& it = items[i];
+                const size_t slot = aligned(it.bytes);
+                if (direct[i]) {
+                    ok = rt::dev_memset((char*)base + it.off + it.bytes, 0, slot - it.bytes, s) && rt::h2d((char*)base + it.off, it.src, it.bytes, s);   // (kernels read up to 16 bytes past an array)
+                    continue;
+                }
+                for (size_t pos = 0; pos < slot && ok; pos += half, k ^= 1) {
+                    const size_t len = slot - pos < half ? slot - pos : half;
+                    char* buf = (char*)h->stage + (size_t)k * half;
+                    if (used[k]) ok = rt::event_sync(ev[k]);
+                    host_parallel(len, (size_t)4 << 20, [&](size_t lo, size_t hi) {
+                        const size_t a = pos + lo, z = pos + hi;                  // bytes [a, z) of the slot: payload, then zero padding
+                        if (a < it.bytes) memcpy(buf + lo, (const char*)it.src + a, (z < it.bytes ? z : it.bytes) - a);
+                        if (z > it.bytes) { const size_t p0 = a > it.bytes ? a : it.bytes; memset(buf + (p0 - pos), 0, z - p0); }
+                    });
+                    ok = ok && rt::h2d((char*)base + it.off + pos, buf, len, s) && rt::event_record(ev[k], s);
+                    used[k] = true;
+                }
+            }
+            for (int i = 0; i < 2; ++i) { if (used[i]) ok = rt::event_sync(ev[i]) && ok; h->put_event(ev[i]); }
+            return ok;
+        }
+    }
     if (tune::pageable_h2d()) {                 // A/B switch: straight from the caller's (pageable) arrays
         for (auto& it : items) {
             if (!it.src) break;
@@ -326,7 +373,6 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
         if (!rt::host_pinned_malloc(&h->stage, kStageMax)) return false;
         h->stage_bytes = kStageMax;
     }
-    size_t n_in = 0; while (n_in < items.size() && items[n_in].src) ++n_in;
     const size_t half = (kStageMax / 2) & ~(size_t)255;
     rt::Event ev[2] {}; bool used[2] = {false, false};
     if (!h->get_event(&ev[0]) || !h->get_event(&ev[1])) return false;
@@ -501,7 +547,11 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 {
     if (h->bp_bytes[slice] >= bytes) return true;
     // grow by half at least (below 4 GB): a region thread's calls differ in size, and every regrowth is a hipFree + hipMalloc that stalls the device
-    const size_t old = h->bp_bytes[slice], roomy = old < ((size_t)4 << 30) ? std::max(bytes, old + old / 2) : bytes;
+    // (doubling: three workers of a region server each met their biggest batch late in a run of 8,000 calls, and every regrowth of a multi-gigabyte block took
+    // 0.1 - 1 s of hipMalloc: profiles/r04_step3_server_api_trace.txt); never beyond the handle's budget
+    const size_t old = h->bp_bytes[slice];
+    size_t roomy = old < ((size_t)4 << 30) ? std::max(bytes, 2 * old) : bytes;
+    if (roomy > h->bp_budget) roomy = std::max(bytes, h->bp_budget);
     rt::dev_free(h->bp[slice]); h->bp[slice] = nullptr; h->bp_bytes[slice] = 0;
     void* p = nullptr; size_t got = roomy;
     if (h->fail_bp_allocs > 0) { --h->fail_bp_allocs; return false; }      // test hook (OCT_PHMM_TEST_FAIL_BP_ALLOCS): the device "has no room": the caller halves its chunk
@@ -521,6 +571,8 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 // One workgroup scans ~10 us per tile of 8,192 pairs (41 us at four regions, 82 at eight: profiles/r03_step7_multi_region_timelines.txt); the four launches of the tiled scan
 // cost ~20 us whatever the size
 constexpr uint32_t kScanBasesOneLaunchMax = 2 * 8192;
+constexpr size_t   kPinnedOutMinBytes = (size_t)8 << 20;  // results from here on: is the caller's `out` page-locked? (the question costs microseconds: not asked for region-sized calls)
+constexpr uint64_t kLaneMapMinPairs = 200000;          // k-mer mapper: one lane per pair from here on (k_kmer_map_lanes), one wave per pair below
 constexpr uint64_t kWalkRowsMaxPairs = 49152;          // traceback walks of batches up to here: one walk per 16-lane row (k_walk_rows)
 constexpr uint64_t kDslMergeMaxPairs = 12000;          // device-sized step: up to here the traceback and the score-only list of a flavour share one launch (k_dp_pair)
 constexpr uint32_t kDslMaxBlocks = 1024;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
@@ -1110,23 +1162,30 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     pk.upload(reg_lhs.data(), reg_lhs.size(), &d.reg_lhs);
     pk.upload(reg_rhs.data(), reg_rhs.size(), &d.reg_rhs);
     pk.dalloc(&d.pos, (size_t)b->n_pairs * S + 1); pk.dalloc(&d.npos, (size_t)b->n_pairs + 1);
-    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr; d.hhash = nullptr; d.map_count_only = 0; d.map_stats = 0; d.pair_mm = nullptr;
+    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr; d.hhash = nullptr; d.map_count_only = 0; d.map_stats = 0; d.pair_mm = nullptr; d.rhash_rows = nullptr; d.rhash_stride = 0;
     if (!positions) {
         if (b->map_big) pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1);      // the u16 table of k_kmer_map_big only
         pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
-        pk.dalloc(&d.rhash, (size_t)n_read_bases + 1); pk.dalloc(&d.hhash, (size_t)n_hap_bases + 1);
+        pk.dalloc(&d.hhash, (size_t)n_hap_bases + 1);
         d.map_count_only = tune::map_count_only(); d.map_stats = tune::map_stats();
         b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 256;      // the haplotype's tables are staged once per workgroup: big batches amortise them over more reads
         pk.dalloc(&d.bin32, (size_t)H->n_haps * kKmerBins + 4);
         { long long n; if (tune::number("OCT_PHMM_MAP_READS_PER_BLOCK", &n) && n >= 4 && n <= 4096) b->map_reads_per_block = (uint32_t)n; }
-        // lane-per-pair mapper: byte counters need every read's k-mer count to stay below 256, and bins + LANES counter rows must fit LDS
-        if (!b->map_big && b->t_cap <= 255 + kKmer - 1 && tune::lane_mapper()) {     // A/B switch: measured 3.8x SLOWER than the wave mapper
-            const int lanes = b->n_pairs < 500000 ? 64 : 256;                 // region-sized calls: more, smaller workgroups (latency)
-            if (kmer_map_lanes_lds_bytes(b->lh_cap, (uint32_t)lanes) <= rt::kMaxLdsBytes) b->map_lanes = lanes;
-            else if (kmer_map_lanes_lds_bytes(b->lh_cap, 64) <= rt::kMaxLdsBytes) b->map_lanes = 64;
+        // lane-per-pair mapper (k_kmer_map_lanes: 256 reads of one haplotype per workgroup, the exact shortcut per lane): batches big enough to fill the chip with
+        // 256-pair workgroups; region-sized calls keep one wave per pair (more, shorter waves). OCT_PHMM_LANE_MAPPER=0 / 1 forces one or the other.
+        {
+            long long want = -1; tune::number("OCT_PHMM_LANE_MAPPER", &want);
+            const uint32_t nq_cap = b->t_cap >= kKmer ? b->t_cap - kKmer + 1 : 0;
+            const bool can = !b->map_big && nq_cap >= 1 && nq_cap <= kLaneMapMaxKmers && kmer_map_lds_bytes(b->lh_cap) <= rt::kMaxLdsBytes;
+            if (can && (want >= 0 ? want != 0 : b->n_pairs >= kLaneMapMinPairs)) b->map_lanes = (int)kLaneMapThreads;
         }
-        if (b->map_lanes) b->map_reads_per_block = (uint32_t)b->map_lanes;
-        if (b->map_lanes && tune::map_mismatches()) pk.dalloc(&d.pair_mm, (size_t)b->n_pairs + 2);   // k_kmer_map_lanes tells k_classify what it saw along the mapped position
+        if (!b->map_lanes) pk.dalloc(&d.rhash, (size_t)n_read_bases + 1);        // (the lane mapper reads rhash_rows instead)
+        if (b->map_lanes) {
+            b->map_reads_per_block = (uint32_t)b->map_lanes;
+            d.rhash_stride = rhash_row_stride(b->t_cap);
+            pk.dalloc(&d.rhash_rows, (size_t)R->n_reads * d.rhash_stride + 64);
+            if (tune::map_mismatches()) pk.dalloc(&d.pair_mm, (size_t)b->n_pairs + 2);   // k_kmer_map_lanes tells k_classify what it saw along the mapped position
+        }
         std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, read chunk of its region)
         for (uint32_t hp = 0; hp < H->n_haps; ++hp) {
             const uint32_t g = hap_region[hp];
@@ -1368,8 +1427,9 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         if (n_hap_bases) {
             OCT_LAUNCH(k_window_insert, (n_hap_bases + 255) / 256, 256, 0, s, d, (const uint64_t*)h->d_pwinv, (const uint64_t*)d_prefix, n_hap_bases,
                        d_wkey, d_tkeys, d_tvals, (uint32_t)(tsize - 1)); RT(rt::launch_ok());
-            OCT_LAUNCH(k_window_resolve, (n_hap_bases + 255) / 256, 256, 0, s, d, n_hap_bases, (const unsigned long long*)d_wkey,
+            OCT_LAUNCH(k_window_candidate, (n_hap_bases + 255) / 256, 256, 0, s, d, n_hap_bases, (const unsigned long long*)d_wkey,
                        (const unsigned long long*)d_tkeys, (const uint32_t*)d_tvals, (uint32_t)(tsize - 1)); RT(rt::launch_ok());
+            OCT_LAUNCH(k_window_confirm, (H->n_haps + 3) / 4, 256, 0, s, d); RT(rt::launch_ok());                                          // one wave per haplotype
         }
     }
     // The copies above read this call's host-side staging (pinned buffer, position vectors): a caller of the split API may upload the next batch
@@ -1406,7 +1466,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     if (!b->stat_stage) b->stat_stage = (unsigned long long*)h->get_stat_stage(kStatWords * sizeof(unsigned long long));
     // A one-shot region-sized call (oct_phmm_populate set early_out; one slice): no copy behind the last kernel. The epilogue stores the results into the pinned
     // landing zone itself (mapped into the device) and leaves the sums of the counter stripes beside them; the host waits once.
-    const bool mapped_out = b->early_out && S == 1 && !b->align_mode && b->n_out <= kHostMappedOutMax && b->stat_stage && tune::host_mapped();
+    const bool mapped_out = b->early_out && !b->out_landing && S == 1 && !b->align_mode && b->n_out <= kHostMappedOutMax && b->stat_stage && tune::host_mapped();
     const uint32_t mapped_stripes = tune::map_stats() ? kStatSlots : (uint32_t)std::min<uint64_t>(kStatSlots, (b->n_pairs + 255) / 256);   // (k_classify's workgroups own the counters; the mapper's only with OCT_PHMM_MAP_STATS)
     if (mapped_out) memset(b->stat_stage, 0, kStatWords * sizeof(unsigned long long));
     if (!b->stats_clear) RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
@@ -1440,14 +1500,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_big, lds));
                 OCT_LAUNCH(k_kmer_map_big, (uint32_t)np, 256, lds, s, d, sl.pair0); RT(rt::launch_ok());
             } else if (sl.blk1 > sl.blk0 && b->map_lanes) {
-                const size_t lds = kmer_map_lanes_lds_bytes(b->lh_cap, (uint32_t)b->map_lanes);
-                if (b->map_lanes == 256) {
-                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_lanes<256>, lds));
-                    OCT_LAUNCH(k_kmer_map_lanes<256>, sl.blk1 - sl.blk0, 256, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0, (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap);
-                } else {
-                    if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_lanes<64>, lds));
-                    OCT_LAUNCH(k_kmer_map_lanes<64>, sl.blk1 - sl.blk0, 64, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0, (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap);
-                }
+                const size_t lds = kmer_map_lds_bytes(b->lh_cap);
+                if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_lanes, lds));
+                OCT_LAUNCH(k_kmer_map_lanes, sl.blk1 - sl.blk0, kLaneMapThreads, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0, (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap);
                 RT(rt::launch_ok());
             } else if (sl.blk1 > sl.blk0) {
                 const size_t lds = kmer_map_lds_bytes(b->lh_cap);
@@ -1562,7 +1617,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         if (sl.out1 > sl.out0) { OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, mapped_out ? (double*)h->out_stage : b->d_out, sl.out0, sl.out1,
                                             mapped_out ? b->stat_stage : nullptr, mapped_stripes); RT(rt::launch_ok()); }
         if (b->early_out && !mapped_out && sl.out1 > sl.out0)    // one-shot call: the results land in the handle's pinned zone behind the epilogue, no second synchronisation
-            RT(rt::d2h((double*)h->out_stage + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
+            RT(rt::d2h((b->out_landing ? b->out_landing : (double*)h->out_stage) + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
         RT(rt::event_record(sl.done, s));
         return OCT_PHMM_OK;
     };
@@ -1629,13 +1684,13 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             OCT_LAUNCH(k_epilogue, (uint32_t)((sl.out1 - sl.out0 + 255) / 256), 256, 0, s, d, mapped_out ? (double*)h->out_stage : b->d_out, sl.out0, sl.out1,
                        mapped_out ? b->stat_stage : nullptr, mapped_stripes); RT(rt::launch_ok()); }
         if (b->early_out && !mapped_out && sl.out1 > sl.out0)
-            RT(rt::d2h((double*)h->out_stage + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
+            RT(rt::d2h((b->out_landing ? b->out_landing : (double*)h->out_stage) + sl.out0, b->d_out + sl.out0, (size_t)(sl.out1 - sl.out0) * sizeof(double), s));
         RT(rt::event_record(sl.done, s));
         return OCT_PHMM_OK;
     };
     auto deliver = [&](int i) -> int {                        // finished slice -> the caller's buffer (host copy overlaps the later slices' kernels)
         const oct_phmm_batch::Slice& sl = b->slices[i];
-        if (!b->early_out || sl.out1 <= sl.out0 || S == 1) return OCT_PHMM_OK;   // (a one-slice batch: oct_phmm_populate copies after its one wait)
+        if (!b->early_out || sl.out1 <= sl.out0 || S == 1 || b->out_landing) return OCT_PHMM_OK;   // (a one-slice batch: oct_phmm_populate copies after its one wait; a page-locked `out`: the DMA wrote it)
         RT(rt::event_sync(sl.done));
         const char* src = (const char*)((const double*)h->out_stage + sl.out0); char* dst = (char*)(b->early_out + sl.out0);
         host_parallel((size_t)(sl.out1 - sl.out0) * sizeof(double), (size_t)2 << 20, [&](size_t lo, size_t hi) { memcpy(dst + lo, src + lo, hi - lo); });
@@ -1761,7 +1816,12 @@ extern "C" int oct_phmm_test_set(const char* name, const char* value)
     if (!name || strncmp(name, "OCT_PHMM_", 9) != 0) return OCT_PHMM_EINVAL;
     std::lock_guard<std::mutex> lk(tune::switch_mu());
     tune::switch_table_used().store(true, std::memory_order_release);
-    if (value) tune::switch_table()[name] = value; else tune::switch_table().erase(name);
+    // tune::get hands out pointers into the table's strings and its callers read them after the lock is gone (atoll on another thread's upload): a value that is
+    // replaced or removed moves to a list that is never freed instead of dying under a reader (a few bytes per oct_phmm_test_set call, tests and tools only)
+    static std::list<std::string> retired;
+    auto it = tune::switch_table().find(name);
+    if (it != tune::switch_table().end()) { retired.push_back(std::move(it->second)); tune::switch_table().erase(it); }
+    if (value) tune::switch_table().emplace(name, value);
     return OCT_PHMM_OK;
 }
 
@@ -1908,6 +1968,9 @@ extern "C" int oct_phmm_batch_genotype_likelihoods(oct_phmm_handle* h, oct_phmm_
     return ok(status);
 }
 
+extern "C" void* oct_phmm_host_alloc(size_t bytes) { void* p = nullptr; return rt::host_pinned_malloc(&p, bytes) ? p : nullptr; }
+extern "C" void oct_phmm_host_free(void* p) { rt::host_pinned_free(p); }
+
 extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
                                  const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                                  const oct_phmm_positions* positions, double* out, oct_phmm_status* status)
@@ -1917,17 +1980,18 @@ extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads
     bool early = false;
     if (rc == OCT_PHMM_OK && out && b->n_out) {                // results come back through a pinned landing zone: slice by slice while a big batch computes, behind the
         const size_t bytes = (size_t)b->n_out * sizeof(double);  // epilogue of a small one - one stream synchronisation per call, no staged copy into pageable memory
-        if (h->out_stage_bytes < bytes) {
+        if (bytes >= tune::pinned_min_bytes(kPinnedOutMinBytes) && tune::pinned_direct() && rt::host_is_pinned(out)) { b->early_out = out; b->out_landing = out; early = true; }   // the caller's own page-locked buffer IS the landing zone
+        else if (h->out_stage_bytes < bytes) {
             const size_t roomy = std::max(bytes + bytes / 2, (size_t)1 << 20);     // (a region thread's calls differ in size: no regrowth per call)
             rt::host_pinned_free(h->out_stage); h->out_stage = nullptr; h->out_stage_bytes = 0;
             if (rt::host_pinned_malloc(&h->out_stage, roomy)) h->out_stage_bytes = roomy;
             else if (rt::host_pinned_malloc(&h->out_stage, bytes)) h->out_stage_bytes = bytes;
         }
-        if (h->out_stage_bytes >= bytes) { b->early_out = out; early = true; }
+        if (!early && h->out_stage_bytes >= bytes) { b->early_out = out; early = true; }
     }
     if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_run(h, b, status);
     if (rc == OCT_PHMM_OK) rc = early ? oct_phmm_batch_wait(h, b, status) : oct_phmm_batch_download(h, b, out, status);
-    if (rc == OCT_PHMM_OK && early && b->slices.size() == 1) memcpy(out, h->out_stage, (size_t)b->n_out * sizeof(double));
+    if (rc == OCT_PHMM_OK && early && b->slices.size() == 1 && !b->out_landing) memcpy(out, h->out_stage, (size_t)b->n_out * sizeof(double));
     oct_phmm_batch_free(h, b);
     return rc;
 }
@@ -1944,7 +2008,8 @@ struct oct_phmm_server {
 #if defined(OCTPHMM_SIM)
     static constexpr int kWorkers = 1;                   // the CPU wave simulator is single-threaded
 #else
-    static constexpr int kWorkers = 2;                   // two device queues: while one worker's batch computes, the other gathers and uploads the calls that arrived since
+    static constexpr int kWorkers = 3;                   // device queues per GPU: while one worker's batch computes, the others gather and upload the calls that arrived since
+                                                         // (configs[3] regions, 16 / 64 / 128 callers: 2 workers 13.6 / 12.7 / 15.5 k regions/s, 3: 13.9 / 17.0 / 16.8, 4: 13.5 / 16.7 / 18.4, 6: 9.6 / 16.6 / 16.8 - profiles/r04_step3_server_sweep.log)
 #endif
     std::vector<oct_phmm_handle*> hs;                    // kWorkers handles per device, device-major
     uint32_t max_regions = 256;
@@ -1954,6 +2019,10 @@ struct oct_phmm_server {
     std::vector<std::thread> workers;                    // one per handle; all of them drain the one queue, so an idle device takes the next calls
     uint64_t n_calls = 0, n_batches = 0;
     std::vector<uint64_t> n_calls_by_device;
+    int busy_workers = 0;                                // workers between taking calls and answering them (under mu)
+    static constexpr int kLingerSteps = 6;
+    int linger_us = [] { long long v; return tune::number("OCT_PHMM_SERVER_LINGER_US", &v) && v >= 0 && v <= 10000 ? (int)v : 0; }();    // 0 (default): take what is there. Measured: 25 us x 6 steps doubles the regions per device batch (13 -> 22 at 128 callers) and LOSES 5 - 20 % throughput
+                                                         // (profiles/r04_step3_server_sweep.log): a bigger device batch is not cheaper per region, the step is a chain of ~25 small launches either way
     std::atomic<bool> has_model {false};                 // oct_phmm_server_set_error_model: calls may leave their penalty vectors NULL
     // the model travels to the handles through their own worker threads (under mu): a handle is only ever touched by its worker
     oct_phmm_error_model pending_model {}; bool pending_has_model = false; uint64_t model_version = 0; std::vector<uint64_t> worker_version;
@@ -2048,7 +2117,18 @@ struct oct_phmm_server {
                     oct_phmm_set_error_model(h, pending_has_model ? &pending_model : nullptr);
                     worker_version[(size_t)w] = model_version;
                 }
+                // Bounded linger: when another worker's batch is on the device, the calls that woke this worker are mostly the first of a burst (the callers of
+                // the batch that just finished come back one after the other) - a device batch of 3 regions costs nearly what one of 30 does, so wait while
+                // calls keep arriving, at most kLingerSteps x kLingerUs. With the device idle nothing waits.
+                if (linger_us > 0 && busy_workers > 0 && queue.size() < max_regions) {
+                    for (int step = 0; step < kLingerSteps && !stop; ++step) {
+                        const size_t before = queue.size();
+                        cv_work.wait_for(lk, std::chrono::microseconds(linger_us), [&] { return stop || queue.size() >= max_regions; });
+                        if (queue.size() == before || busy_workers == 0) break;
+                    }
+                }
                 while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
+                ++busy_workers;
             }
             std::vector<Request*> batchable, single;
             for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : batchable).push_back(q);
@@ -2079,6 +2159,7 @@ struct oct_phmm_server {
                 std::lock_guard<std::mutex> lk(mu);
                 n_calls += take.size(); n_batches += (batchable.empty() ? 0 : 1) + (batchable_gen.empty() ? 0 : 1) + single.size();
                 n_calls_by_device[(size_t)device_of[(size_t)w]] += take.size();
+                --busy_workers;
                 for (Request* q : take) { q->done = true; q->cv.notify_one(); }     // under the lock: the request lives on its caller's stack
             }
         }
@@ -2102,6 +2183,12 @@ extern "C" int oct_phmm_server_create_multi(const oct_phmm_config* cfg, const in
             oct_phmm_handle* h = nullptr;
             const int rc = oct_phmm_create(&c, &h);
             if (rc != OCT_PHMM_OK) { for (auto* k : s->hs) oct_phmm_destroy(k); delete s; return rc; }
+            // A worker's traceback scratch: capped (a device batch that needs more runs its traceback lists in chunks) and reserved now - a multi-gigabyte
+            // hipMalloc in the middle of a run stalled every caller for up to a second, once per worker and growth step
+            { long long gb = 4; tune::number("OCT_PHMM_SERVER_BP_BUDGET_GB", &gb); if (gb >= 1) h->bp_budget = std::min<size_t>(h->bp_budget, (size_t)gb << 30); }
+#if !defined(OCTPHMM_SIM)
+            (void)ensure_bp(h, 0, std::min<size_t>(h->bp_budget, (size_t)1 << 30));
+#endif
             s->hs.push_back(h); s->device_of.push_back((int)dv);
         }
     }

@@ -62,10 +62,11 @@ struct DevBatch {
     // position i1, 3 = two or more. Holds for pure-ACGT reads on pure-ACGT haplotypes (k_classify checks); null when another mapper or the caller made the positions.
     uint16_t* pair_mm;
     // 6-mer tables per haplotype (k_kmer_tables): bin_start[h * 4097 + hash], bin_idx[hoff[h] + slot]
-    uint32_t* bin32;                                  // bin32[h * 4096 + hash] = start | occupancy << 16 (k_kmer_map_lanes); null when unused
+    uint32_t* bin32;                                  // bin32[h * 4096 + hash] = start | occupancy << 16 (k_kmer_map, k_kmer_map_lanes); null when unused
     uint16_t* hhash;                                  // hhash[hoff[h] + p]: 6-mer hash of haplotype h at p (k_kmer_tables); k_kmer_map's exact-count shortcut
     int map_count_only;                               // test / A-B switch: every pair takes the counting path
     int map_stats;                                    // OCT_PHMM_MAP_STATS: count the pairs the shortcut decides (diagnostics)
+    uint16_t* rhash_rows; uint32_t rhash_stride;     // k_kmer_map_lanes: the same hashes as rhash in one 16-byte aligned row per read, 4096 behind a read's last k-mer; null when unused
     uint16_t* bin_start; uint16_t* bin_idx; uint16_t* rhash;   // rhash[roff[r] + q]: 6-mer hash of read r at q (written by the trailing workgroups of k_kmer_tables)
     // per pair
     uint64_t  n_pairs;

@@ -140,7 +140,14 @@ OCT_DEVICE void read_hash_wave(const DevBatch& b, uint32_t r, uint32_t lane)   /
 {
     if (r >= b.n_reads) return;
     const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro;
-    for (uint32_t q = lane; q + kKmer <= T; q += 64) b.rhash[ro + q] = (uint16_t)kmer_hash6(b.rbases + ro + q);
+    // k_kmer_map_lanes reads a read's hashes eight at a time, one lane per read: a row per read, 16-byte aligned, the entries behind the last k-mer = 4096
+    // ("no k-mer": occupancy 0, equals no haplotype hash), so that its loop needs neither bounds tests nor unaligned loads. The other mappers read rhash.
+    if (!b.rhash_rows) { for (uint32_t q = lane; q + kKmer <= T; q += 64) b.rhash[ro + q] = (uint16_t)kmer_hash6(b.rbases + ro + q); }
+    else {
+        const uint32_t nq = T >= kKmer ? T - kKmer + 1 : 0;
+        uint16_t* row = b.rhash_rows + (size_t)r * b.rhash_stride;
+        for (uint32_t q = lane; q < b.rhash_stride; q += 64) row[q] = q < nq ? (uint16_t)kmer_hash6(b.rbases + ro + q) : (uint16_t)kKmerBins;
+    }
 }
 
 // The workgroups past `n_hap_blocks` (one slice only) compute the read hashes of the whole batch in the same launch, four reads each.
@@ -198,6 +205,68 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks)
 // one diagonal (the normal case: the read's true offset) is merged into a single add.
 constexpr uint32_t kMapPad = 256;          // sentinel entries behind the haplotype's hash sequence: q + d never needs a bounds test (q <= 255, d < nk)
 inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + (2 * ((lh_cap + 1) & ~1u) + kMapPad) * 2 + kKmerBins + 4 + kBlockWaves * (lh_cap + 64) * 4; }
+
+// map_query_to_target's vote (:128-144) and its output (:145-157) for ONE (haplotype, read) pair by a whole wave: the path of the pairs the exact shortcuts of
+// k_kmer_map / k_kmer_map_lanes cannot decide. `rh` = the read's hashes, `counts` = the wave's nk + 64 diagonal counters in LDS (zero on entry and on return).
+OCT_DEVICE void kmer_count_votes_wave(const DevBatch& b, uint64_t e, const uint16_t* rh, uint32_t nq, uint32_t nk, const uint16_t* bins, const uint16_t* idx,
+                                      uint32_t* counts, uint32_t lane, uint32_t max_pos)
+{
+        uint32_t hq_next = lane < nq ? rh[lane] : 0;                        // software pipeline: next batch's hashes are in flight
+        for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            const bool valid = q < nq;
+            const uint32_t hq = hq_next;
+            if (q0 + 64 < nq) hq_next = q + 64 < nq ? rh[q + 64] : 0;
+            const uint32_t b0 = bins[hq], n = valid ? (uint32_t)bins[hq + 1] - b0 : 0;
+            for (uint32_t j = 0; hw::ballot(j < n) != 0; ++j) {
+                const uint32_t ti = j < n ? idx[b0 + j] : 0;
+                const bool vote = j < n && ti >= q;                    // :130
+                const uint32_t d = ti - q;                             // mapping_begin :131
+                const uint64_t voters = hw::ballot(vote);
+                if (voters == 0) continue;
+                const uint32_t src = (uint32_t)__builtin_ctzll(voters);
+                const uint32_t d0 = hw::readlane(d, src);
+                if (hw::ballot(vote && d != d0) == 0) {                // every vote on one diagonal: one add
+                    if (lane == src) hw::atomic_add_lds_u32(&counts[d0], (uint32_t)__builtin_popcountll(voters));
+                } else if (vote) {
+                    hw::atomic_add_lds_u32(&counts[d], 1u);            // ++mapping_counts[mapping_begin], :132
+                }
+            }
+        }
+        hw::wave_lds_fence();
+        // max_hit_count, then the ascending positions that reach it, at most max_pos of them (:145-157). The first 8 chunks of the
+        // counters are read once into registers (and cleared: reset_mapping_counts :115-118) and reused by the output pass.
+        uint32_t cr[8];
+        uint32_t mx = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t d = (uint32_t)q * 64 + lane;
+            cr[q] = d < nk ? counts[d] : 0;
+            if (d < nk) counts[d] = 0;
+            mx = cr[q] > mx ? cr[q] : mx;
+        }
+        for (uint32_t d = 512 + lane; d < nk; d += 64) { const uint32_t c = counts[d]; mx = c > mx ? c : mx; }
+        mx = hw::wave_max_u32(mx);
+        uint32_t n_out = 0;
+        auto emit = [&](uint32_t d, uint32_t c) {
+            const bool is = mx > 0 && d < nk && c == mx;
+            const uint64_t mask = hw::ballot(is);
+            const uint32_t rank = n_out + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (is && rank < max_pos) b.pos[e * (uint64_t)max_pos + rank] = d;
+            n_out += (uint32_t)__builtin_popcountll(mask);
+        };
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { if ((uint32_t)q * 64 < nk) emit((uint32_t)q * 64 + lane, cr[q]); }
+        for (uint32_t d0 = 512; d0 < nk; d0 += 64) {
+            const uint32_t d = d0 + lane;
+            const uint32_t c = d < nk ? counts[d] : 0;
+            if (d < nk) counts[d] = 0;
+            emit(d, c);
+        }
+        if (n_out > max_pos) n_out = max_pos;
+        if (lane == 0) b.npos[e] = (uint8_t)n_out;
+        hw::wave_lds_fence();
+}
 
 template <int ROUNDS>      // 64-lane rounds that hold the k-mers of the batch's longest read (3 for 150-base reads, at most 4 for the shortcut)
 OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap, uint32_t reads_per_block)
@@ -343,149 +412,165 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
             }
         }
         if (b.map_stats && lane == 0) hw::atomic_add_u64(b.stats + (size_t)(hw::block_idx() % kStatSlots) * kStatStride + (decided ? 6 : 7), 1ull);   // OCT_PHMM_MAP_STATS: pairs decided by the shortcut / counted
-        if (!decided) {
-        uint32_t hq_next = lane < nq ? b.rhash[ro + lane] : 0;             // software pipeline: next batch's hashes are in flight
-        for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
-            const uint32_t q = q0 + lane;
-            const bool valid = q < nq;
-            const uint32_t hq = hq_next;
-            if (q0 + 64 < nq) hq_next = q + 64 < nq ? b.rhash[ro + q + 64] : 0;
-            const uint32_t b0 = bins[hq], n = valid ? (uint32_t)bins[hq + 1] - b0 : 0;
-            for (uint32_t j = 0; hw::ballot(j < n) != 0; ++j) {
-                const uint32_t ti = j < n ? idx[b0 + j] : 0;
-                const bool vote = j < n && ti >= q;                    // :130
-                const uint32_t d = ti - q;                             // mapping_begin :131
-                const uint64_t voters = hw::ballot(vote);
-                if (voters == 0) continue;
-                const uint32_t src = (uint32_t)__builtin_ctzll(voters);
-                const uint32_t d0 = hw::readlane(d, src);
-                if (hw::ballot(vote && d != d0) == 0) {                // every vote on one diagonal: one add
-                    if (lane == src) hw::atomic_add_lds_u32(&counts[d0], (uint32_t)__builtin_popcountll(voters));
-                } else if (vote) {
-                    hw::atomic_add_lds_u32(&counts[d], 1u);            // ++mapping_counts[mapping_begin], :132
-                }
-            }
-        }
-        hw::wave_lds_fence();
-        // max_hit_count, then the ascending positions that reach it, at most max_pos of them (:145-157). The first 8 chunks of the
-        // counters are read once into registers (and cleared: reset_mapping_counts :115-118) and reused by the output pass.
-        uint32_t cr[8];
-        uint32_t mx = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const uint32_t d = (uint32_t)q * 64 + lane;
-            cr[q] = d < nk ? counts[d] : 0;
-            if (d < nk) counts[d] = 0;
-            mx = cr[q] > mx ? cr[q] : mx;
-        }
-        for (uint32_t d = 512 + lane; d < nk; d += 64) { const uint32_t c = counts[d]; mx = c > mx ? c : mx; }
-        mx = hw::wave_max_u32(mx);
-        uint32_t n_out = 0;
-        auto emit = [&](uint32_t d, uint32_t c) {
-            const bool is = mx > 0 && d < nk && c == mx;
-            const uint64_t mask = hw::ballot(is);
-            const uint32_t rank = n_out + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (is && rank < max_pos) b.pos[e * (uint64_t)max_pos + rank] = d;
-            n_out += (uint32_t)__builtin_popcountll(mask);
-        };
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { if ((uint32_t)q * 64 < nk) emit((uint32_t)q * 64 + lane, cr[q]); }
-        for (uint32_t d0 = 512; d0 < nk; d0 += 64) {
-            const uint32_t d = d0 + lane;
-            const uint32_t c = d < nk ? counts[d] : 0;
-            if (d < nk) counts[d] = 0;
-            emit(d, c);
-        }
-        if (n_out > max_pos) n_out = max_pos;
-        if (lane == 0) b.npos[e] = (uint8_t)n_out;
-        hw::wave_lds_fence();
-        }
+        if (!decided) kmer_count_votes_wave(b, e, b.rhash + ro, nq, nk, bins, idx, counts, lane, max_pos);
         ro = ro_n; nq = nq_n; ro_n = ro_nn; nq_n = nq_nn;
 #pragma unroll
         for (int k = 0; k < ROUNDS; ++k) hq4[k] = hq4_n[k];
     }
 }
 
-// The same mapping with ONE LANE per (haplotype, read) pair: a workgroup of LANES lanes takes LANES reads of one haplotype. The haplotype's
-// bins (start | occupancy << 16, one LDS read per k-mer) and bin entries sit in LDS once; every lane owns a row of BYTE counters (a
-// diagonal is voted at most once per read k-mer, so its count is at most T - 5 <= 255: the host checks the batch's longest read), needs
-// no atomics, no ballots and no scalar control flow, keeps the run of consecutive votes for one diagonal in registers (a read that
-// matches its haplotype votes one diagonal ~T times: one counter update), and tracks the maximum and how many diagonals hold it as it
-// goes, so the usual case - one winning diagonal - ends without a sweep over the counters.
-// (k_kmer_map above issues ~670 instructions per pair around wave-wide ballots and LDS atomics and waits half of its time; this form
-// issues a few dozen. Same votes, same output: tests/check_populate.py::assert_device_positions.)
-OCT_HD uint32_t kmer_lanes_stride(uint32_t lh_cap) { return ((lh_cap + 3) & ~3u) + 4; }      // bytes per lane; the odd dword count staggers the lanes' banks
-inline uint32_t kmer_map_lanes_lds_bytes(uint32_t lh_cap, uint32_t lanes) { return kKmerBins * 4 + ((lh_cap + 1) & ~1u) * 2 + lanes * kmer_lanes_stride(lh_cap); }
+// The same mapping with ONE LANE per (haplotype, read) pair for big batches: a workgroup of 256 lanes takes 256 reads of one haplotype (tables in LDS as above).
+// A lane runs the exact shortcut of k_kmer_map on its own: candidates = the diagonals named by the first k-mer of the read's first eight and by the last of its
+// last eight that occur in the haplotype (first entry of their bins); one pass over the read's hashes counts, per lane and in registers, the votes of both
+// (positions where the two hash sequences agree), the k-mers with a bin entry on neither (the bound for any other diagonal's votes) and - a 6-mer hash being two
+// bits per base - the BASE mismatches along the first candidate, which is what try_naive_evaluate asks next (DevBatch::pair_mm, read by k_classify). No
+// counters, no ballots, no reductions: ~40 wave-instructions per pair instead of the ~270 (120 vector + 150 scalar) of the wave-per-pair form, whose bound is the CU's one scalar ALU.
+// The pairs a lane cannot decide (a few percent: both probes miss, repeats, near-even indel splits) are counted afterwards by the whole wave, one after the
+// other (kmer_count_votes_wave). Same votes, same output: tests/check_populate.py::assert_device_positions.
+constexpr uint32_t kLaneMapThreads = 256;
+// entries per row of DevBatch::rhash_rows: the kernel's loop takes three 16-byte chunks (24 k-mers) per trip and has the next trip's first chunk in flight
+OCT_HD uint32_t rhash_row_stride(uint32_t t_cap) { const uint32_t nq = t_cap >= kKmer ? t_cap - kKmer + 1 : 0; return 8u * (3u * (((nq + 7) / 8 + 2) / 3) + 1u); }
+constexpr uint32_t kLaneMapMaxKmers = 232;       // lane form up to here: q < 240 in the last trip, so q + d stays inside the kMapPad sentinels behind the haplotype's hashes
 
-template <int LANES>
 OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap)
 {
     OCT_DYN_SMEM(smem);
-    uint32_t* bins = (uint32_t*)smem;                                  // [4096] start | occupancy << 16
-    uint16_t* idx = (uint16_t*)(bins + kKmerBins);                     // [lh_cap rounded to even] haplotype positions, bin by bin
-    const uint32_t stride = kmer_lanes_stride(lh_cap);
-    uint8_t* counters = (uint8_t*)(idx + ((lh_cap + 1) & ~1u));        // [LANES][stride]
-    const uint32_t tid = hw::thread_idx();
-    const uint32_t h = blk_hap[hw::block_idx()], r = blk_read0[hw::block_idx()] + tid;
+    uint16_t* bins = (uint16_t*)smem;                                  // [4097]
+    uint16_t* idx = bins + kKmerBins + 2;                              // [lh_cap rounded to even]
+    uint16_t* hh = idx + ((lh_cap + 1) & ~1u);                         // [lh_cap rounded to even + kMapPad] the haplotype's hash at every position, then 0xffff
+    uint8_t* occ = (uint8_t*)(hh + ((lh_cap + 1) & ~1u) + kMapPad);    // [4096 + 1] bin occupancy capped at 255; entry 4096 = 0
+    uint32_t* counts_all = (uint32_t*)(occ + kKmerBins + 4);           // [waves][lh_cap + 64] (the counting path of undecided pairs)
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63;
+    const uint32_t wave = hw::readfirstlane(tid >> 6);
+    const uint32_t h = blk_hap[hw::block_idx()], r_first = blk_read0[hw::block_idx()];
     const uint32_t g = b.hap_region[h];
     const uint32_t reg_r0 = b.reg_read0[g], reg_r1 = b.reg_read0[g + 1];
     const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;
-    for (uint32_t i = tid; i < kKmerBins; i += LANES) bins[i] = b.bin32[(size_t)h * kKmerBins + i];
-    for (uint32_t i = tid; i < nk; i += LANES) idx[i] = b.bin_idx[ho + i];
-    uint8_t* cnt = counters + tid * stride;
-    for (uint32_t d = 0; d < stride; d += 4) *(uint32_t*)(cnt + d) = 0;
+    {
+        const uint4* src = (const uint4*)(b.bin32 + (size_t)h * kKmerBins);
+        for (uint32_t i = tid; i < kKmerBins / 4; i += kLaneMapThreads) {
+            const uint4 v = src[i];
+            const uint32_t c0 = v.x >> 16, c1 = v.y >> 16, c2 = v.z >> 16, c3 = v.w >> 16;
+            *(uint2*)(bins + 4 * i) = make_uint2((v.x & 0xffffu) | v.y << 16, (v.z & 0xffffu) | v.w << 16);
+            *(uint32_t*)(occ + 4 * i) = (c0 < 255 ? c0 : 255u) | (c1 < 255 ? c1 : 255u) << 8 | (c2 < 255 ? c2 : 255u) << 16 | (c3 < 255 ? c3 : 255u) << 24;
+        }
+        if (tid == 0) { bins[kKmerBins] = (uint16_t)nk; *(uint32_t*)(occ + kKmerBins) = 0; }
+    }
+    for (uint32_t i = tid; i < nk; i += kLaneMapThreads) { idx[i] = b.bin_idx[ho + i]; hh[i] = b.hhash[ho + i]; }
+    for (uint32_t i = nk + tid; i < ((lh_cap + 1) & ~1u) + kMapPad; i += kLaneMapThreads) hh[i] = 0xffffu;   // no read hash equals it
+    uint32_t* counts = counts_all + wave * (lh_cap + 64);
+    for (uint32_t d = lane; d < nk + 64; d += 64) counts[d] = 0;
     hw::block_sync();
-    if (r >= reg_r1) return;
-    const uint64_t e = b.hap_pair_off[h] + (r - reg_r0);
-    const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;      // compute_kmer_hashes :57-69
-    const uint32_t max_pos = (uint32_t)b.max_pos;
-    uint32_t mx = 0, n_best = 0, d_best = 0;                            // max_hit_count, the number of diagonals that hold it, one of them
-    uint32_t d_run = 0, run = 0;                                        // consecutive votes for one diagonal, not yet in its counter
-    auto flush = [&]() {
-        if (!run) return;
-        const uint32_t c = (uint32_t)cnt[d_run] + run;
-        cnt[d_run] = (uint8_t)c;
-        if (c > mx) { mx = c; n_best = 1; d_best = d_run; }
-        else if (c == mx) ++n_best;
-    };
-    auto vote = [&](uint32_t ti, uint32_t q) {
-        if (ti < q) return;                                             // :130
-        const uint32_t d = ti - q;                                      // mapping_begin :131
-        if (run && d == d_run) { ++run; return; }
-        flush();
-        d_run = d; run = 1;
-    };
-    // Eight k-mers per trip: one 16-byte load of the read's hashes (the next trip's is in flight), eight independent bin reads, eight
-    // independent first-entry reads, then the votes in order; a bin with more than one entry (a k-mer that repeats in the haplotype)
-    // walks its remaining entries in a loop that is almost never entered.
-    const uint8_t* rh = (const uint8_t*)(b.rhash + ro);
-    uint4 hnext = make_uint4(0, 0, 0, 0);
-    if (nq) __builtin_memcpy(&hnext, rh, 16);
-    for (uint32_t q0 = 0; q0 < nq; q0 += 8) {
-        const uint4 hv = hnext;
-        if (q0 + 8 < nq) __builtin_memcpy(&hnext, rh + 2 * (q0 + 8), 16);
-        const uint32_t hw4[4] = {hv.x, hv.y, hv.z, hv.w};
-        uint32_t ent[8], ti0[8];
+    const uint32_t max_pos = (uint32_t)b.max_pos, none = 0xffffffffu;
+    const uint32_t r = r_first + tid;
+    const bool live = r < reg_r1;
+    const uint64_t e = b.hap_pair_off[h] + (uint64_t)((live ? r : reg_r0) - reg_r0);
+    uint32_t nq = 0;
+    if (live) { const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro; nq = T >= kKmer ? T - kKmer + 1 : 0; }
+    const bool eligible = live && nq > 0 && nq <= kLaneMapMaxKmers && !b.map_count_only;
+    const uint4* row = (const uint4*)(b.rhash_rows + (size_t)(live ? r : reg_r0) * b.rhash_stride);
+    auto hash_of = [](const uint4& v, int j) -> uint32_t { const uint32_t w = j < 2 ? v.x : j < 4 ? v.y : j < 6 ? v.z : v.w; return (j & 1) ? w >> 16 : w & 0xffffu; };
+    // Three probes - the read's first, its middle and its last k-mer that occur exactly ONCE in the haplotype (a k-mer of a homopolymer or repeat names the
+    // diagonal of its first copy, mostly the wrong one), each naming the diagonal of its bin's one entry - give the two candidates. A diagonal can only beat the bound below with more than half of the read's k-mers on it, and such a stretch of the read holds the middle
+    // k-mer: dA = the middle probe's diagonal (a read whose two ends lie across two indels from each other is decided by it), dB = the first probe's where that
+    // differs, else the last one's (a read split by one indel: both of its diagonals, as k_kmer_map's first attempt takes them). Eight k-mers per step (one
+    // 16-byte load), until every lane of the wave has found its own: mostly one step per probe (a read's tail is where its errors sit).
+    uint32_t dA = none, dB = none;
+    {
+        const uint32_t nq_e = eligible ? nq : 0u;
+        auto scan_up = [&](uint32_t c0, uint32_t& q_found, uint32_t& h_found) {                   // the first k-mer from chunk c0 on that occurs in the haplotype
+            for (uint32_t c = c0; hw::ballot(q_found == none && c * 8 < nq_e) != 0; ++c) {
+                const uint4 v = row[c];
+                uint32_t qj = none, hj = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ent[k] = bins[(hw4[k >> 1] >> (16 * (k & 1))) & 0xfffu];
+                for (int j = 7; j >= 0; --j) { const uint32_t hq = hash_of(v, j); if (occ[hq] == 1) { qj = c * 8 + (uint32_t)j; hj = hq; } }   // (behind the read: 4096, occupancy 0)
+                if (q_found == none && qj != none) { q_found = qj; h_found = hj; }
+            }
+        };
+        uint32_t qf = none, hqf = 0, qm = none, hqm = 0, ql = none, hql = 0;
+        scan_up(0, qf, hqf);
+        scan_up((nq_e >> 1) >> 3, qm, hqm);
+        const uint32_t c_last = hw::wave_max_u32(nq_e ? (nq_e - 1) >> 3 : 0u);
+        for (uint32_t c = c_last + 1; c-- > 0 && hw::ballot(ql == none && c * 8 < nq_e) != 0; ) {
+            const uint4 v = row[c];
+            uint32_t qj = none, hj = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ti0[k] = idx[ent[k] & 0xffffu];     // in bounds even for an empty bin (its start is at most nk)
+            for (int j = 0; j < 8; ++j) { const uint32_t hq = hash_of(v, j); if (occ[hq] == 1) { qj = c * 8 + (uint32_t)j; hj = hq; } }
+            if (ql == none && qj != none) { ql = qj; hql = hj; }
+        }
+        uint32_t dF = none, dM = none, dL = none;
+        if (qf != none) { const uint32_t t = idx[bins[hqf]]; if (t >= qf) dF = t - qf; }
+        if (qm != none) { const uint32_t t = idx[bins[hqm]]; if (t >= qm) dM = t - qm; }
+        if (ql != none) { const uint32_t t = idx[bins[hql]]; if (t >= ql) dL = t - ql; }
+        dA = dM != none ? dM : dF != none ? dF : dL;
+        dB = (dF != none && dF != dA) ? dF : dL;
+        if (dB == dA) dB = none;
+        if (!eligible) { dA = none; dB = none; }
+    }
+    // one pass over the hashes. A diagonal that is "none" points at the sentinels behind the haplotype's hashes (0xffff: never a vote).
+    const uint16_t* hA = hh + (dA != none ? dA : nk);
+    const uint16_t* hB = hh + (dB != none ? dB : nk);
+    uint32_t cntA = 0, cntB = 0, others = 0, mm = 0, mm_pos = 0;
+    const uint32_t nq_wave = hw::wave_max_u32(eligible && dA != none ? nq : 0u);          // (lanes with fewer k-mers read sentinels)
+    uint4 hv = row[0];
+    for (uint32_t c = 0; c * 8 < nq_wave; c += 3) {                                       // 24 k-mers per trip: q % 6 is then a compile-time constant
+        uint4 chunk[3];
+        chunk[0] = hv; chunk[1] = row[c + 1]; chunk[2] = row[c + 2];                      // (reads of up to kLaneMapMaxKmers k-mers: the row's slack covers c + 3)
+        hv = row[c + 3];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t q = q0 + (uint32_t)k, n = q < nq ? ent[k] >> 16 : 0u;
-            if (n) vote(ti0[k], q);
-            for (uint32_t j = 1; j < n; ++j) vote(idx[(ent[k] & 0xffffu) + j], q);
+        for (int jj = 0; jj < 24; ++jj) {
+            const uint32_t q = c * 8 + (uint32_t)jj;
+            const uint32_t hq = hash_of(chunk[jj >> 3], jj & 7);
+            const uint32_t a = hA[q], bb = hB[q], n = occ[hq];
+            const uint32_t onA = a == hq ? 1u : 0u, onB = bb == hq ? 1u : 0u;
+            cntA += onA; cntB += onB;
+            others += n > onA + onB ? 1u : 0u;
+            if (jj % 6 == 0) {                                                            // six fresh bases: bit 2j + 1 of t = base j of this k-mer differs
+                const uint32_t x = a ^ hq;
+                uint32_t t = hw_lshl_or(x, 1, x) & 0xaaau;
+                t = q + 1 < nq ? t : 0u;                                                  // (the read's LAST k-mer is taken below, whatever its q)
+                mm += (uint32_t)__builtin_popcount(t);
+                mm_pos = t ? q + ((uint32_t)__builtin_ctz(t) >> 1) : mm_pos;
+            }
         }
     }
-    flush();
-    // the ascending positions that reach the maximum, at most max_pos of them (:145-157)
-    uint32_t n_out = 0;
-    if (mx > 0 && n_best == 1) {
-        if (max_pos) { b.pos[e * (uint64_t)max_pos] = d_best; n_out = 1; }
-    } else if (mx > 0) {
-        for (uint32_t d = 0; d < nk && n_out < max_pos; ++d) if (cnt[d] == mx) b.pos[e * (uint64_t)max_pos + n_out++] = d;
+    bool decided = false;
+    uint32_t w0 = none, w1 = none, mm_word = 0;
+    if (eligible && dA != none) {
+        {   // the bases only the read's last k-mer covers (all six when nq - 1 is a multiple of six)
+            const uint32_t tailq = nq - 1, tr = tailq % 6u, tailmask = tr ? (0xaaau & ~((1u << (2u * (6u - tr))) - 1u)) : 0xaaau;
+            const uint32_t hq = (uint32_t)((const uint16_t*)row)[tailq];
+            const uint32_t x = (uint32_t)hA[tailq] ^ hq, t = hw_lshl_or(x, 1, x) & tailmask;
+            mm += (uint32_t)__builtin_popcount(t);
+            mm_pos = t ? tailq + ((uint32_t)__builtin_ctz(t) >> 1) : mm_pos;
+        }
+        const uint32_t best = cntA > cntB ? cntA : cntB;
+        if (best != 0 && best > others) {
+            decided = true;
+            if (cntA == cntB) { w0 = dA < dB ? dA : dB; w1 = dA < dB ? dB : dA; }       // only possible with two diagonals
+            else { w0 = cntA > cntB ? dA : dB; }
+            if (w1 == none && w0 == dA) mm_word = mm == 0 ? 1u << 14 : mm == 1 ? (2u << 14 | mm_pos) : 3u << 14;
+            uint32_t n_w = 0;
+            if (max_pos >= 1) { b.pos[e * (uint64_t)max_pos] = w0; n_w = 1; }
+            if (w1 != none && max_pos >= 2) { b.pos[e * (uint64_t)max_pos + 1] = w1; n_w = 2; }
+            b.npos[e] = (uint8_t)n_w;
+        }
     }
-    b.npos[e] = (uint8_t)n_out;
+    if (live && b.pair_mm) b.pair_mm[e] = (uint16_t)mm_word;
+    // the undecided pairs of this wave, one after the other, by the whole wave
+    uint64_t todo = hw::ballot(live && !decided);
+    const uint64_t all = hw::ballot(live);
+    if (b.map_stats && lane == 0) {
+        unsigned long long* st = b.stats + (size_t)(hw::block_idx() % kStatSlots) * kStatStride;
+        hw::atomic_add_u64(st + 6, (unsigned long long)__builtin_popcountll(all & ~todo)); hw::atomic_add_u64(st + 7, (unsigned long long)__builtin_popcountll(todo));
+    }
+    while (todo) {
+        const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t r_u = hw::readlane(r, src), nq_u = hw::readlane(nq, src);
+        const uint64_t e_u = b.hap_pair_off[h] + (uint64_t)(r_u - reg_r0);
+        kmer_count_votes_wave(b, e_u, b.rhash_rows + (size_t)r_u * b.rhash_stride, nq_u, nk, bins, idx, counts, lane, max_pos);
+    }
 }
 
 // Long haplotypes (bins + per-wave counters no longer fit LDS beside each other): one workgroup per (haplotype, read) pair, the
@@ -783,8 +868,16 @@ OCT_DEVICE bool window_bytes_equal(const DevBatch& b, uint32_t a, uint32_t c, ui
         && bytes_equal((const uint8_t*)b.priorR + a, (const uint8_t*)b.priorR + c, n);
 }
 
-// canon[x] = the table's window for x's key if its bytes (and region, and length) are those of x, else x itself
-OCT_KERNEL(k_window_resolve)(DevBatch b, uint32_t n_bases, const unsigned long long* wkey, const unsigned long long* tkeys, const uint32_t* tvals, uint32_t tmask)
+// canon[x] = the table's window for x's key if its bytes (and region, and length) are those of x, else x itself. Two steps:
+//   k_window_candidate  one thread per window: canon[x] = the table's window `first` when region and length agree (the CANDIDATE), else x
+//   k_window_confirm    one wave per haplotype, its windows in order: consecutive windows share all but one position and, between two haplotypes that are a few
+//                       edits apart, consecutive windows name consecutive candidates - so a window whose candidate continues its predecessor's (first == the
+//                       predecessor's first + 1) is confirmed by ITS LAST POSITION alone once the predecessor is; only the head of such a run compares whole
+//                       windows (7 arrays x window_len bytes - what every window did before: 25 GB of compares per upload of the 2,000-region stream,
+//                       2.5 ms; now the runs' heads and 14 bytes per window).
+// Still every byte of a shared window has been compared with its canonical twin's: hashes only propose.
+OCT_DEVICE uint32_t window_len_at(const DevBatch& b, uint32_t off, uint32_t Lh) { return (off + b.window_len < Lh ? off + b.window_len : Lh) - off; }
+OCT_KERNEL(k_window_candidate)(DevBatch b, uint32_t n_bases, const unsigned long long* wkey, const unsigned long long* tkeys, const uint32_t* tvals, uint32_t tmask)
 {
     const uint32_t x = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (x >= n_bases) return;
@@ -792,14 +885,53 @@ OCT_KERNEL(k_window_resolve)(DevBatch b, uint32_t n_bases, const unsigned long l
     uint32_t slot = (uint32_t)(key >> 20) & tmask;
     while (tkeys[slot] != key) slot = (slot + 1) & tmask;
     const uint32_t first = tvals[slot];
-    uint32_t canon = x;
+    uint32_t cand = x;
     if (first != x) {
-        const uint32_t h = upper_bound_idx(b.hoff, b.n_haps + 1, x), ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, off = x - ho;
-        const uint32_t h2 = upper_bound_idx(b.hoff, b.n_haps + 1, first), ho2 = b.hoff[h2], Lh2 = b.hoff[h2 + 1] - ho2, off2 = first - ho2;
-        const uint32_t n = (off + b.window_len < Lh ? off + b.window_len : Lh) - off, n2 = (off2 + b.window_len < Lh2 ? off2 + b.window_len : Lh2) - off2;
-        if (n == n2 && b.hap_region[h] == b.hap_region[h2] && window_bytes_equal(b, x, first, n)) canon = first;
+        const uint32_t x_wave = hw::readfirstlane(hw::block_idx() * hw::block_dim() + (hw::thread_idx() & ~63u));
+        const uint32_t h = upper_bound_near(b.hoff, b.n_haps + 1, x_wave, x), ho = b.hoff[h], Lh = b.hoff[h + 1] - ho;
+        const uint32_t h2 = upper_bound_idx(b.hoff, b.n_haps + 1, first), ho2 = b.hoff[h2], Lh2 = b.hoff[h2 + 1] - ho2;
+        if (window_len_at(b, x - ho, Lh) == window_len_at(b, first - ho2, Lh2) && b.hap_region[h] == b.hap_region[h2]) cand = first;
     }
-    b.canon[x] = canon;
+    b.canon[x] = cand;
+}
+OCT_DEVICE bool window_position_equal(const DevBatch& b, uint32_t a, uint32_t c)       // the seven arrays at a and at c
+{
+    return b.hbases[a] == b.hbases[c] && b.go[a] == b.go[c] && b.ge[a] == b.ge[c] && b.maskF[a] == b.maskF[c] && b.priorF[a] == b.priorF[c]
+        && b.maskR[a] == b.maskR[c] && b.priorR[a] == b.priorR[c];
+}
+OCT_KERNEL(k_window_confirm)(DevBatch b)
+{
+    const uint32_t lane = hw::thread_idx() & 63u;
+    const uint32_t h = hw::block_idx() * (hw::block_dim() / 64) + hw::readfirstlane(hw::thread_idx() >> 6);
+    if (h >= b.n_haps) return;                                  // (whole waves)
+    const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho;
+    uint32_t prev_cand = 0xffffffffu;                           // candidate of the window before this round's first, and whether it was confirmed
+    bool prev_ok = false;
+    for (uint32_t o0 = 0; o0 < Lh; o0 += 64) {
+        const uint32_t off = o0 + lane, x = ho + off;
+        const bool in = off < Lh;
+        const uint32_t cand = in ? b.canon[x] : 0xffffffffu;
+        uint32_t before = hw::shfl(cand, (int)(lane ? lane - 1 : 0));
+        if (lane == 0) before = prev_cand;
+        const bool self = !in || cand == x;                                             // its own canonical form (or no window): nothing to confirm
+        const bool cont = !self && off > 0 && before != x - 1 && cand == before + 1;    // continues the run of its predecessor (which is not its own canonical form)
+        const uint32_t n = in ? window_len_at(b, off, Lh) : 0;
+        // own evidence: a continuing window checks its last position (one cut by the haplotype's end adds none: it lies inside its predecessor); the head of a
+        // run compares its whole window
+        bool own = true;
+        if (cont) { if (n == b.window_len) own = window_position_equal(b, x + n - 1, cand + n - 1); }
+        else if (!self) own = window_bytes_equal(b, x, cand, n);
+        // confirmed = nothing failed from the head of the run up to here; a run that came in from the round before carries that round's verdict
+        const uint64_t bad = hw::ballot(!self && !own), starts = hw::ballot(!cont);
+        const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        const uint64_t s_here = starts & upto;
+        const uint32_t start = s_here ? 63u - (uint32_t)__builtin_clzll(s_here) : 0u;
+        const uint64_t range = upto & ~((1ull << start) - 1ull);
+        bool ok = (bad & range) == 0 && (s_here != 0 || prev_ok);
+        if (cont && own && !ok) ok = window_bytes_equal(b, x, cand, n);                 // the run broke before this window (a colliding key upstream): on its own, then
+        if (!self) b.canon[x] = ok ? cand : x;
+        prev_cand = hw::shfl(cand, 63); prev_ok = hw::shfl((uint32_t)(!self && ok ? 1u : 0u), 63) != 0;
+    }
 }
 
 // Match: one lane per read, 64 consecutive reads per wave (the pair arrays of a haplotype are read-major: coalesced), the haplotypes of the

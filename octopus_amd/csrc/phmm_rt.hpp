@@ -36,6 +36,13 @@ inline void dev_free(void* p) { if (p) (void)hipFree(p); }
 inline bool mem_info(size_t* free_b, size_t* total_b) { OCT_RT_CHECK(hipMemGetInfo(free_b, total_b)); return true; }
 inline bool host_pinned_malloc(void** p, size_t n) { OCT_RT_CHECK(hipHostMalloc(p, n ? n : 16, hipHostMallocDefault)); return true; }
 inline void host_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+// does the runtime know this host address as page-locked memory (hipHostMalloc / hipHostRegister)? Then the DMA engines read and write it directly.
+inline bool host_is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // (an address the runtime has never seen: an error, and a sticky one)
+    return a.type == hipMemoryTypeHost;
+}
 inline bool h2d(void* d, const void* h, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); return true; }
 inline bool d2h(void* h, const void* d, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); return true; }
 inline bool dev_memset(void* d, int v, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemsetAsync(d, v, n, s)); return true; }

@@ -139,6 +139,45 @@ def default_error_model(lib_path: Optional[Path] = None) -> abi.ErrorModel:
     return m
 
 
+class PinnedPool:
+    """Page-locked host memory from the library (oct_phmm_host_alloc) as numpy arrays: inputs and `out` of big batches that live here go to and from the
+    device without the library's staging copies. Freed by close()."""
+
+    def __init__(self, lib_path: Optional[Path] = None):
+        self.lib = load(lib_path)
+        self.lib.oct_phmm_host_alloc.restype = C.c_void_p
+        self.lib.oct_phmm_host_alloc.argtypes = [C.c_size_t]
+        self.lib.oct_phmm_host_free.argtypes = [C.c_void_p]
+        self.blocks = []
+
+    def empty(self, n: int, dtype) -> np.ndarray:
+        nbytes = max(int(n) * np.dtype(dtype).itemsize, 16)
+        ptr = self.lib.oct_phmm_host_alloc(nbytes)
+        if not ptr:
+            raise MemoryError(f"oct_phmm_host_alloc({nbytes})")
+        self.blocks.append(ptr)
+        return np.frombuffer((C.c_char * nbytes).from_address(ptr), dtype=dtype, count=int(n))
+
+    def copy(self, a: np.ndarray) -> np.ndarray:
+        out = self.empty(a.size, a.dtype)
+        out[:] = np.ascontiguousarray(a).reshape(-1)
+        return out.reshape(a.shape)
+
+    def batch(self, batch: "abi.Batch") -> "abi.Batch":
+        """The same batch with every array in page-locked memory."""
+        import copy as _copy
+        b = _copy.copy(batch)
+        for k, v in vars(batch).items():
+            if isinstance(v, np.ndarray):
+                setattr(b, k, self.copy(v))
+        return b
+
+    def close(self):
+        for ptr in self.blocks:
+            self.lib.oct_phmm_host_free(ptr)
+        self.blocks = []
+
+
 def test_set(name: str, value: Optional[str], lib_path: Optional[Path] = None) -> None:
     """oct_phmm_test_set: a test / A-B switch by its OCT_PHMM_* name (None removes it); read when a handle is created or a batch is uploaded."""
     code = load(lib_path).oct_phmm_test_set(name.encode(), None if value is None else str(value).encode())

@@ -191,8 +191,13 @@ def batch_from_regions(regions: List[dict]) -> abi.Batch:
     total = 0
     for g in regions:
         R, T = g["reads"].shape
-        rb.append(g["reads"].reshape(-1)); rq.append(g["quals"].reshape(-1))
-        ro.extend((ro[-1] + T * (np.arange(R) + 1)).tolist())
+        if g.get("read_len") is not None:          # reads of different lengths: row r holds read_len[r] bases, the rest of the row is padding
+            keep = np.arange(T)[None, :] < np.asarray(g["read_len"])[:, None]
+            rb.append(g["reads"][keep]); rq.append(g["quals"][keep])
+            ro.extend((ro[-1] + np.cumsum(g["read_len"])).tolist())
+        else:
+            rb.append(g["reads"].reshape(-1)); rq.append(g["quals"].reshape(-1))
+            ro.extend((ro[-1] + T * (np.arange(R) + 1)).tolist())
         mq.append(g["mapq"]); rv.append(g["reverse"]); beg.append(g["begin"])
         for h in g["haps"]:
             a, b, c, d, e, f = _penalties(h)
@@ -244,6 +249,13 @@ def config_region(name: str, seed: int = 42, B: int = 16, positions: str = "true
     if name == "long64x8":      # BASELINE.json configs[4]: 10 kb reads x 20 kb haplotypes, band 256 (int32 lanes), PacBio-like Q 8-15, indel-rich
         return make_region(rng, 64, 8, T=10_000, Lh=20_000, B=256, flank=(400, 400), positions=positions,
                            q_values=(8, 15), indels_per_read=40)
+    if name == "long512x8":     # eight times configs[4]'s reads: enough tasks to put several waves on every SIMD (a throughput figure, not a latency one)
+        return make_region(rng, 512, 8, T=10_000, Lh=20_000, B=256, flank=(400, 400), positions=positions, q_values=(8, 15), indels_per_read=40)
+    if name == "ccs256x12":     # long reads the way the reference configures them (resources/configs/PacBioCCS.config: max-indel-errors=16; int32 lanes for long reads,
+        # option_collation.cpp:1687-1693): 256 HiFi-like reads of 10-14 kb (Q20-40, a dozen indel errors each) against 12 haplotypes of 16 kb, band 16
+        g = make_region(rng, 256, 12, T=14_000, Lh=16_000, B=B, flank=(300, 300), positions=positions, q_values=(20, 40), indels_per_read=12)
+        g["read_len"] = rng.integers(10_000, 14_001, 256).astype(np.int64)
+        return g
     if name == "tiny":
         return make_region(rng, 40, 6, B=B, positions=positions)
     raise KeyError(name)
@@ -258,7 +270,7 @@ def subset_reads(region: dict, idx) -> dict:
     other reads of the call, so the rows of the sub-region equal the corresponding rows of the full one."""
     idx = np.asarray(idx)
     sub = dict(region)
-    for k in ("reads", "quals", "begin", "reverse", "mapq"):
+    for k in ("reads", "quals", "begin", "reverse", "mapq") + (("read_len",) if region.get("read_len") is not None else ()):
         sub[k] = region[k][idx]
     if region["pos"] is not None:
         sub["pos"] = region["pos"][:, idx]
@@ -336,3 +348,24 @@ def region_stream_shard(seed: int, n_regions: int, rank: int = 0, world: int = 1
     for c, regs in zip(chunks, parts):
         by_index.update(zip(c, regs))
     return [by_index[i] for i in idx]
+
+
+def write_regions_file(path, regions: List[dict]) -> None:
+    """The regions as tools/region_calls_bench reads them (`--file`): one self-contained record per region, so that a C++ caller can issue one oct_phmm call per
+    region without an interpreter in the way. "OCTR", u32 n; per region u32 {R, H, has_flank, lhs, rhs}, u64 {read bases, haplotype bases}, then read offsets
+    u32[R + 1], bases, qualities, mapq u8[R], reverse u8[R], ref_begin i64[R], haplotype offsets u32[H + 1], bases, ref_begin i64[H], and the six penalty vectors."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"OCTR" + struct.pack("<I", len(regions)))
+        for g in regions:
+            R, T = g["reads"].shape
+            H = len(g["haps"])
+            flank = g["flank"]
+            hb = np.concatenate(g["haps"]).astype(np.uint8)
+            ho = np.concatenate([[0], np.cumsum([len(h) for h in g["haps"]])]).astype(np.uint32)
+            pen = [np.concatenate(x) for x in zip(*[_penalties(h) for h in g["haps"]])]        # go, ge, mask_f, prior_f, mask_r, prior_r
+            f.write(struct.pack("<5I2Q", R, H, 1 if flank is not None else 0, flank[0] if flank else 0, flank[1] if flank else 0, R * T, len(hb)))
+            for a in ((T * np.arange(R + 1)).astype(np.uint32), g["reads"].astype(np.uint8).reshape(-1), g["quals"].astype(np.uint8).reshape(-1), g["mapq"].astype(np.uint8),
+                      g["reverse"].astype(np.uint8), g["begin"].astype(np.int64), ho, hb, np.zeros(H, np.int64), pen[0].astype(np.int8), pen[1].astype(np.int8),
+                      pen[2].astype(np.uint8), pen[3].astype(np.int8), pen[4].astype(np.uint8), pen[5].astype(np.int8)):
+                f.write(np.ascontiguousarray(a).tobytes())

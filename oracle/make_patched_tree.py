@@ -13,7 +13,12 @@ Second seam, src/core/tools/read_assigner.cpp:145-287
                                                cut out of a copy of the file as they are
   read_assigner_seam_patched.inc               the same helpers, with the LAST function (:251-287) replaced by
                                                #include "oracle/integration/read_assigner_on_device.inc" (expand -> reset -> pack -> ONE oct_phmm_populate)
-Both seams:
+Third seam, src/core/tools/read_realigner.cpp:83-155:
+  read_realigner_seam_ref.inc                  the reference's own compute_read_hashes, the two realign(read, haplotype, ...) helpers and
+                                               realign(reads, haplotype, model, log_likelihoods, workers), cut out of a copy of the file as they are
+  read_realigner_seam_patched.inc              the same helpers, with the LAST function (:114-155) replaced by
+                                               #include "oracle/integration/read_realigner_on_device.inc" (reset -> pack -> ONE oct_phmm_align -> AlignedRead::realign)
+All seams:
   core/models/haplotype_likelihood_model.hpp   src/core/models/haplotype_likelihood_model.hpp + one `friend` line per seam (FRIENDS below): the seams hand the six
                                                penalty vectors reset() prepares to the device
 
@@ -39,6 +44,8 @@ FRIENDS = [
      "friend class HaplotypeLikelihoodArray;   // INTEGRATION patch: populate() hands the six penalty vectors to the device"),
     ("namespace { struct ReadAssignerDevice; }",   # the struct lives in read_assigner.cpp's unnamed namespace
      "friend struct octopus::ReadAssignerDevice;   // INTEGRATION patch, second seam: read_assigner.cpp hands the six penalty vectors to the device"),
+    ("namespace { struct ReadRealignerDevice; }",   # ... and this one in read_realigner.cpp's
+     "friend struct octopus::ReadRealignerDevice;   // INTEGRATION patch, third seam: read_realigner.cpp hands the six penalty vectors to the device"),
 ]
 
 
@@ -79,6 +86,17 @@ assert first < last0 < last1
 asg_inc = (HERE / "integration" / "read_assigner_on_device.inc").resolve()
 (out / "read_assigner_seam_patched.inc").write_text(asg[first:last0] + '#include "' + str(asg_inc) + '"\n')
 
+# ---- third seam: src/core/tools/read_realigner.cpp:83-155
+rea = (ref / "src" / "core" / "tools" / "read_realigner.cpp").read_text()
+r_first = rea.index("auto compute_read_hashes(const std::vector<AlignedRead>& reads")
+r_sig = ("void realign(std::vector<AlignedRead>& reads, const Haplotype& haplotype,\n             HaplotypeLikelihoodModel model,\n"
+         "             boost::optional<std::vector<HaplotypeLikelihoodModel::LogProbability>&> log_likelihoods,")
+r_last0, r_last1 = function_span(rea, r_sig, r_first)
+assert r_first < r_last0 < r_last1
+(out / "read_realigner_seam_ref.inc").write_text(rea[r_first:r_last1] + "\n")
+rea_inc = (HERE / "integration" / "read_realigner_on_device.inc").resolve()
+(out / "read_realigner_seam_patched.inc").write_text(rea[r_first:r_last0] + '#include "' + str(rea_inc) + '"\n')
+
 # ---- the model's header, with every seam's friend line
 hpp = (src / "haplotype_likelihood_model.hpp").read_text()
 m = re.search(r"class HaplotypeLikelihoodModel\s*\{\s*public:", hpp)
@@ -91,4 +109,5 @@ for _, line in FRIENDS:
 
 stamp.write_text("written by oracle/make_patched_tree.py\n")
 print(f"patched copies in {out}: populate() bodies {a1 - a0} + {b1 - b0} characters -> {inc.name}; "
-      f"read_assigner.cpp seam {last1 - first} characters, of which the last function's {last1 - last0} -> {asg_inc.name}")
+      f"read_assigner.cpp seam {last1 - first} characters, of which the last function's {last1 - last0} -> {asg_inc.name}; "
+      f"read_realigner.cpp seam {r_last1 - r_first} characters, of which the last function's {r_last1 - r_last0} -> {rea_inc.name}")

@@ -17,6 +17,14 @@ public:
     const BaseQualityVector& base_qualities() const noexcept { return base_qualities_; }
     MappingQuality mapping_quality() const noexcept { return mapping_quality_; }
     bool is_marked_reverse_mapped() const noexcept { return reverse_; }
+    // the realignment seam (core/tools/read_realigner.cpp:97-104): where the read lies now and how (one word per operation: length << 8 | the flag's character)
+    std::int64_t realigned_end_ = 0; std::vector<std::uint32_t> realigned_cigar_;
+    template <typename Region, typename Cigar> void realign(const Region& region, Cigar cigar)
+    {
+        begin_ = static_cast<std::int64_t>(region.begin); realigned_end_ = static_cast<std::int64_t>(region.end);
+        realigned_cigar_.clear();
+        for (const auto& op : cigar) realigned_cigar_.push_back(static_cast<std::uint32_t>(op.size()) << 8 | static_cast<unsigned char>(op.flag()));
+    }
     std::string name() const { return {}; }                                        // debug printers of haplotype_likelihood_array.hpp only
     std::string cigar() const { return {}; }
 };

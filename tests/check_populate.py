@@ -646,7 +646,7 @@ def check_launch_modes(backend, tol=0.0):
 
 
 def check_mapper_mismatch_account(backend, tol=0.0):
-    """k_kmer_map hands k_classify the base mismatches it saw along a pair's one mapped position (DevBatch::pair_mm: none / exactly one at i1 / two or more), so
+    """k_kmer_map_lanes hands k_classify the base mismatches it saw along a pair's one mapped position (DevBatch::pair_mm: none / exactly one at i1 / two or more), so
     that try_naive_evaluate (pair_hmm.hpp:278-319) needs no pass over the bases. Regions of allele-combination haplotypes and high-quality reads (most candidates
     are exact or one mismatch away), plus crafted reads for the branches behind the single mismatch: a substitution inside a homopolymer the read ends in (the
     shifted-suffix tests :305 / :309 with a gap-open penalty below the base quality), a mismatch in the read's first / last six bases (k-mers at the edges), in the
@@ -681,12 +681,57 @@ def check_mapper_mismatch_account(backend, tol=0.0):
         row = hp[B + 5:B + 5 + T].copy(); row[[7, 30]] = [ord("N"), synth.BASES[(int(np.searchsorted(synth.BASES, row[30])) + 2) % 4]]; reads[k] = row; begin[k] = B + 5; k += 1
         haps[-1][B + 9] = ord("N")                                   # a haplotype with an N (code 0 like A)
         batch = synth.batch_from_regions([g])
-        on = compare(backend, batch, tol, max_indel_error=B)
-        os.environ["OCT_PHMM_MAP_MISMATCHES"] = "0"
+        os.environ["OCT_PHMM_LANE_MAPPER"] = "1"                      # the mapper of big batches (one lane per pair): the one that keeps the account
         try:
+            on = compare(backend, batch, tol, max_indel_error=B)
+            os.environ["OCT_PHMM_MAP_MISMATCHES"] = "0"
             off = compare(backend, batch, tol, max_indel_error=B)
         finally:
-            del os.environ["OCT_PHMM_MAP_MISMATCHES"]
-        assert on == off and on["n_fast_path"] > 30, (on, off)
+            os.environ.pop("OCT_PHMM_MAP_MISMATCHES", None); del os.environ["OCT_PHMM_LANE_MAPPER"]
+        wave = compare(backend, batch, tol, max_indel_error=B)         # one wave per pair (what a batch of this size takes by default)
+        assert on == off == wave and on["n_fast_path"] > 30, (on, off, wave)
         out.append(on)
     return out
+
+
+def check_page_locked_caller_buffers(backend, tol=0.0):
+    """Big batches whose arrays and `out` live in page-locked memory (oct_phmm_host_alloc) skip the library's staging copies: inputs are copied by the DMA engine
+    from the caller's arrays (the library's own small tables still go through the staging halves), results land in `out` itself, slice by slice. Forced on a
+    small multi-region batch (OCT_PHMM_STAGE_MAX_KB=2: the streaming upload; OCT_PHMM_PINNED_MIN_KB=0: every array is asked), one slice and three, against the
+    oracle and against the same call from pageable arrays; then with only SOME arrays page-locked."""
+    import os
+    from octopus_amd import engine
+    from backends import build_sim
+    lib_path = build_sim() if backend == "sim" else None
+    regions = [small_region(31 + k, R=10 + 3 * k, H=3 + k, T=40 + 5 * k, Lh=130 + 10 * k)[0] for k in range(3)]
+    batch = synth.batch_from_regions(regions)
+    cfg = abi.Config.default(max_indel_error=8)
+    want, wst, _ = oracle.populate(cfg, batch, n_threads=2)
+    assert wst.code == abi.OK
+    pool = engine.PinnedPool(lib_path)
+    old = {k: os.environ.get(k) for k in ("OCT_PHMM_STAGE_MAX_KB", "OCT_PHMM_PINNED_MIN_KB", "OCT_PHMM_SLICES")}
+    n = 0
+    try:
+        os.environ["OCT_PHMM_STAGE_MAX_KB"] = "2"; os.environ["OCT_PHMM_PINNED_MIN_KB"] = "0"
+        locked = pool.batch(batch)
+        some = pool.batch(batch); some.read_quals = batch.read_quals.copy(); some.gap_open = batch.gap_open.copy(); some.hap_offsets = batch.hap_offsets.copy()
+        for slices in ("1", "3"):
+            os.environ["OCT_PHMM_SLICES"] = slices
+            eng = make_engine(backend, max_indel_error=8)
+            for bt, out in ((locked, pool.empty(batch.out_size(), np.float64)), (some, pool.empty(batch.out_size(), np.float64)), (locked, np.empty(batch.out_size())),
+                            (batch, pool.empty(batch.out_size(), np.float64)), (batch, np.empty(batch.out_size()))):
+                out[:] = np.nan
+                got, st = eng.populate(bt, out=out)
+                assert st.code == abi.OK
+                bad = np.flatnonzero(~(np.abs(got - want) <= tol)) if tol else np.flatnonzero(got != want)
+                assert bad.size == 0, (slices, bad[:5])
+                n += 1
+            eng.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        pool.close()
+    return n

@@ -3,6 +3,8 @@
 #pragma once
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include "hipsim.hpp"
 
 namespace octphmm { namespace rt {
@@ -20,8 +22,19 @@ inline bool stream_sync(Stream) { return true; }
 inline bool dev_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); if (*p) memset(*p, 0xCD, n ? n : 16); return *p != nullptr; }
 inline void dev_free(void* p) { free(p); }
 inline bool mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)288 << 30; return true; }
-inline bool host_pinned_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); return *p != nullptr; }
-inline void host_pinned_free(void* p) { free(p); }
+// "pinned" allocations are remembered, so that the library's fast paths for page-locked caller buffers run in the CPU suite too
+inline std::mutex& pinned_mu() { static std::mutex m; return m; }
+inline std::map<const char*, size_t>& pinned_blocks() { static std::map<const char*, size_t> b; return b; }
+inline bool host_pinned_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); if (*p) { std::lock_guard<std::mutex> g(pinned_mu()); pinned_blocks()[(const char*)*p] = n ? n : 16; } return *p != nullptr; }
+inline void host_pinned_free(void* p) { if (p) { std::lock_guard<std::mutex> g(pinned_mu()); pinned_blocks().erase((const char*)p); } free(p); }
+inline bool host_is_pinned(const void* p)
+{
+    std::lock_guard<std::mutex> g(pinned_mu());
+    auto it = pinned_blocks().upper_bound((const char*)p);
+    if (it == pinned_blocks().begin()) return false;
+    --it;
+    return (const char*)p < it->first + it->second;
+}
 inline bool h2d(void* d, const void* h, size_t n, Stream) { if (n) memcpy(d, h, n); return true; }
 inline bool d2h(void* h, const void* d, size_t n, Stream) { if (n) memcpy(h, d, n); return true; }
 inline bool dev_memset(void* d, int v, size_t n, Stream) { if (n) memset(d, v, n); return true; }

@@ -15,7 +15,7 @@ from octopus_amd import engine
 REF = Path("/root/reference/src/core/models/pairhmm")
 ALL_LIBS = ["liboracle.so", "_ref/libref_phmm.so", "_ref/libref_array.so", "_ref/libref_array_avx2.so", "_ref/libref_assigner.so",
             "_ref/libref_array_patched_sim.so", "_ref/libref_assigner_patched_sim.so", "_ref/libref_array_patched_gpu.so",
-            "_ref/libref_assigner_patched_gpu.so"]
+            "_ref/libref_assigner_patched_gpu.so", "_ref/libref_realigner.so", "_ref/libref_realigner_patched_sim.so", "_ref/libref_realigner_patched_gpu.so"]
 
 
 def run_build(tree: Path) -> subprocess.CompletedProcess:
@@ -40,7 +40,8 @@ def test_oracle_builds_from_a_clean_checkout_and_fails_loudly(tmp_path):
     assert not missing, missing
     # the model header carries every seam's friend line whatever the order the seams were built in
     hpp = (tmp_path / "oracle" / "_ref" / "patched" / "core" / "models" / "haplotype_likelihood_model.hpp").read_text()
-    assert hpp.count("friend ") >= 2 and "friend class HaplotypeLikelihoodArray;" in hpp and "friend struct octopus::ReadAssignerDevice;" in hpp
+    assert hpp.count("friend ") >= 3 and "friend class HaplotypeLikelihoodArray;" in hpp and "friend struct octopus::ReadAssignerDevice;" in hpp
+    assert "friend struct octopus::ReadRealignerDevice;" in hpp
 
     # one statement less in a seam's patch: the build must RAISE (last round it reported success and left no patched libraries)
     inc = tmp_path / "oracle" / "integration" / "read_assigner_on_device.inc"

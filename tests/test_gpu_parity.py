@@ -379,3 +379,28 @@ def test_gpu_align_and_server_generate_the_penalty_vectors():
 def test_gpu_mapper_mismatch_account_feeds_the_fast_path():
     """k_kmer_map's account of the base mismatches along the mapped position (pair_mm) against the oracle and against the run without it."""
     assert len(cp.check_mapper_mismatch_account("gpu", TOL)) == 5
+
+
+def test_gpu_lane_per_pair_mapper(monkeypatch):
+    """k_kmer_map_lanes forced on small batches (the full-size tests run it by default): positions pair by pair against the oracle's mapper, populate checks."""
+    monkeypatch.setenv("OCT_PHMM_LANE_MAPPER", "1")
+    cp.check_device_kmer_mapper("gpu", TOL)
+    assert cp.check_kmer_mapper_positions("gpu") >= 200
+    cp.check_basic("gpu", TOL)
+    cp.check_generic_bytes("gpu", TOL)
+    cp.check_templates_and_regions("gpu", TOL)
+    cp.check_ragged_and_edges("gpu", TOL)
+    monkeypatch.setenv("OCT_PHMM_MAP_COUNT_ONLY", "1")
+    cp.check_device_kmer_mapper("gpu", TOL)
+
+
+def test_gpu_page_locked_caller_buffers_skip_the_staging_copies():
+    assert cp.check_page_locked_caller_buffers("gpu", TOL) == 10
+
+
+def test_gpu_patched_read_realigner_seam_equals_the_reference_functions():
+    """INTEGRATION.md's third seam (read_realigner.cpp:83-155) with its last function replaced by one oct_phmm_align call, linked against liboct_phmm.so
+    (prebuilt oracle/_ref/libref_realigner_patched_gpu.so), against the reference's own functions' committed output: region, CIGAR, log-likelihood per read."""
+    import check_realigner_patch as cr
+    require_reference_build(cr.have("patched_gpu"), "oracle/_ref/libref_realigner_patched_gpu.so")
+    assert cr.check("gpu", TOL, golden=True) == 69

@@ -28,3 +28,17 @@ def test_patched_read_assigner_seam_equals_the_reference_functions():
     import check_assigner_patch as ca
     assert ca.have("ref") and ca.have("patched_sim")
     assert ca.check("sim") > 150
+
+
+def test_patched_read_realigner_seam_equals_the_reference_functions():
+    """The third seam: read_realigner.cpp:83-155 compiled as it is and with its last function replaced by ONE oct_phmm_align call
+    (oracle/integration/read_realigner_on_device.inc), on the simulator's build of the C ABI: new region, CIGAR and log-likelihood of every read.
+    See tests/check_realigner_patch.py."""
+    if not oracle.have_ref_array():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    build_sim()
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "all", "patched"], check=True, stdout=subprocess.DEVNULL)
+    import check_realigner_patch as cr
+    assert cr.have("ref") and cr.have("patched_sim")
+    assert cr.check("sim") == 69
+    assert cr.check("sim", golden=True) == 69        # (the committed goldens the GPU box compares with are the reference's answers of today)

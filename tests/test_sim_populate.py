@@ -134,3 +134,23 @@ def test_sim_scratch_allocation_failures_fall_back_and_leave_no_error():
 def test_sim_mapper_mismatch_account_feeds_the_fast_path():
     stats = cp.check_mapper_mismatch_account("sim")
     assert len(stats) == 5
+
+
+def test_sim_lane_per_pair_mapper(monkeypatch):
+    """Big batches map with one lane per (haplotype, read) pair (k_kmer_map_lanes: the exact shortcut per lane, the undecided pairs counted by the whole wave);
+    forced on the small batches of the mapper and populate checks."""
+    monkeypatch.setenv("OCT_PHMM_LANE_MAPPER", "1")
+    cp.check_device_kmer_mapper("sim")
+    assert cp.check_kmer_mapper_positions("sim") >= 200
+    cp.check_basic("sim")
+    cp.check_generic_bytes("sim")
+    cp.check_templates_and_regions("sim")
+    cp.check_ragged_and_edges("sim")
+    monkeypatch.setenv("OCT_PHMM_SLICES", "3")
+    cp.check_device_kmer_mapper("sim")
+    monkeypatch.setenv("OCT_PHMM_MAP_COUNT_ONLY", "1")              # every pair through the lane kernel's counting path
+    cp.check_device_kmer_mapper("sim")
+
+
+def test_sim_page_locked_caller_buffers_skip_the_staging_copies():
+    assert cp.check_page_locked_caller_buffers("sim") == 10

@@ -25,18 +25,29 @@ for _ in range(3):
     t0 = time.perf_counter(); r2 = eng.upload(batch); t1 = time.perf_counter(); r2.run(); r2.wait(); t2 = time.perf_counter(); r2.download(); t3 = time.perf_counter(); r2.free()
     t["upload"].append(t1 - t0); t["run"].append(t2 - t1); t["download"].append(t3 - t2)
 res["split_ms"] = {k: min(v) * 1e3 for k, v in t.items()}
-for k in ks:
+pool = engine.PinnedPool()
+locked = pool.batch(batch)
+for tag, bt, mk in (("", locked, lambda: pool.empty(batch.out_size(), np.float64)), ("_pageable", batch, lambda: np.empty(batch.out_size()))):
+  t = {"upload": [], "run": [], "download": []}
+  o1 = mk()
+  for _ in range(3):
+    t0 = time.perf_counter(); r2 = eng.upload(bt); t1 = time.perf_counter(); r2.run(); r2.wait(); t2 = time.perf_counter(); r2.free()
+    t["upload"].append(t1 - t0); t["run"].append(t2 - t1)
+  for _ in range(3):
+    t0 = time.perf_counter(); eng.populate(bt, out=o1); t["download"].append(time.perf_counter() - t0)
+  res["split_ms" + tag] = {"upload": min(t["upload"]) * 1e3, "run": min(t["run"]) * 1e3, "one_populate_call": min(t["download"]) * 1e3}
+  for k in ks:
     engs = [eng] + [engine.Engine(cfg) for _ in range(k - 1)]
-    outs = [np.empty(batch.out_size()) for _ in range(k)]
+    outs = [mk() for _ in range(k)]
     for e, o in zip(engs, outs):
-        e.populate(batch, out=o)
+        e.populate(bt, out=o)
     n_each = max(2, 12 // k)
     def work(i):
         for _ in range(n_each):
-            engs[i].populate(batch, out=outs[i])
+            engs[i].populate(bt, out=outs[i])
     ths = [threading.Thread(target=work, args=(i,)) for i in range(k)]
     t0 = time.perf_counter(); [x.start() for x in ths]; [x.join() for x in ths]; dt = time.perf_counter() - t0
-    res[f"in_flight_{k}"] = {"ms_per_batch": dt / (k * n_each) * 1e3, "regions_per_s": 2000 * k * n_each / dt, "equal": all(np.array_equal(o, resident) for o in outs)}
+    res[f"in_flight_{k}{tag}"] = {"ms_per_batch": dt / (k * n_each) * 1e3, "regions_per_s": 2000 * k * n_each / dt, "x_resident": (min(ts) * k * n_each) / dt, "equal": all(np.array_equal(o, resident) for o in outs)}
     for e in engs[1:]:
         e.close()
 print(json.dumps(res))
