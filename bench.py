@@ -72,16 +72,17 @@ def latest_pmc_summary():
 # ------------------------------------------------------------------------------------------------------------------
 # checker + CPU baseline: the only places that touch oracle/ (never inside a timed GPU region)
 # ------------------------------------------------------------------------------------------------------------------
-def verify_against_reference(got: np.ndarray, regions, B: int, frac: float = 0.05, seed: int = 1):
+def verify_against_reference(got: np.ndarray, regions, B: int, frac: float = 0.05, seed: int = 1, cfg=None):
     """Compare the matrix the timed loop left on the device with the reference's OWN HaplotypeLikelihoodArray::populate
     (oracle/_ref/libref_array*.so; the oracle restatement where that build is absent) on a sample of rows: for a one-region batch
     a random `frac` of its reads against all haplotypes, for a multi-region batch every 1/frac-th region in full. A (read, haplotype)
     result does not depend on the other reads of its call, so the sub-call reproduces the sampled rows exactly."""
     import oracle
     from octopus_amd import abi, synth
-    cfg = abi.Config.default(max_indel_error=B)
+    cfg = cfg if cfg is not None else abi.Config.default(max_indel_error=B)
     cores = oracle.host_cores()
     use_ref = oracle.have_ref_array()
+    n_rows = lambda g: g["reads"].shape[0] if g.get("row_off") is None else len(g["row_off"]) - 1       # likelihood rows: reads, or templates of linked reads
     isa = "avx2" if use_ref and oracle.have_ref_array("avx2") else "sse2"
 
     def reference(batch):
@@ -104,11 +105,11 @@ def verify_against_reference(got: np.ndarray, regions, B: int, frac: float = 0.0
     else:
         step = max(1, int(round(1 / frac)))
         first = int(rng.integers(0, min(step, len(regions))))
-        off = np.concatenate([[0], np.cumsum([g["reads"].shape[0] * len(g["haps"]) for g in regions])])
+        off = np.concatenate([[0], np.cumsum([n_rows(g) * len(g["haps"]) for g in regions])])
         for i in range(first, len(regions), step):
             want = reference(synth.batch_from_regions([regions[i]]))
             worst = max(worst, float(np.max(np.abs(got[off[i]:off[i + 1]] - want), initial=0.0)))
-            rows += regions[i]["reads"].shape[0]
+            rows += n_rows(regions[i])
     return {"verified_rows": rows, "verified_max_abs_diff": worst,
             "verified_against": (f"the reference's own HaplotypeLikelihoodArray::populate ({isa.upper()} kernels, {cores} host threads)" if use_ref
                                  else "CPU oracle restatement (no reference build on this box)")}
@@ -605,6 +606,48 @@ def main():
                 lb.free(); leng.close()
                 out["long_read"] = {"ms": dt * 1e3, "gcups": ls["band_cells"] / dt / 1e9, "dtype": "int32", "band": 256,
                                     "workload": "long64x8: 64 x 10 kb reads x 8 x 20 kb haplotypes (BASELINE configs[4])", "dp_tasks": ls["n_dp_score_only"] + ls["n_dp_traceback"]}
+                # the same shape at throughput size (8 x the reads: several waves per SIMD instead of less than one)
+                leng = engine.Engine(lcfg)
+                lregs = [synth.config_region("long512x8", seed=42, B=256, positions="none")]
+                lb = leng.upload(synth.batch_from_regions(lregs))
+                dt = timed_resident(lb, 2)
+                ls = lb.stats()
+                lgot = lb.download().copy()
+                lb.free(); leng.close()
+                lv = verify_against_reference(lgot, lregs, 256, frac=0.03, cfg=lcfg)
+                n_tasks_l = ls["n_dp_score_only"] + ls["n_dp_traceback"]
+                out["long512x8"] = {"ms": dt * 1e3, "gcups": ls["band_cells"] / dt / 1e9, "dtype": "int32", "band": 256, "dp_tasks": n_tasks_l,
+                                    "waves_per_simd_one_wave_per_task": n_tasks_l / 1024.0, "verified_rows": lv["verified_rows"], "verified_max_abs_diff": lv["verified_max_abs_diff"],
+                                    "workload": "long512x8: 512 x 10 kb reads x 8 x 20 kb haplotypes, band 256, int32 lanes"}
+                # Long reads the way the reference's own PacBio configuration hands them to the likelihood model (resources/configs/PacBioCCS.config: max-read-length=500,
+                # split-long-reads, read-linkage=LINKED, max-indel-errors=16): 500-base linked chunks, one likelihood row per long read (template), band 16, int16 lanes
+                cregs = synth.linked_stream(42, 1000, B=16)
+                ccfg = abi.Config.default(max_indel_error=16, device_id=local_rank)
+                ceng = engine.Engine(ccfg)
+                cb = ceng.upload(synth.batch_from_regions(cregs))
+                dt = timed_resident(cb, 3)
+                cs = cb.stats()
+                cgot = cb.download().copy()
+                cb.free(); ceng.close()
+                cv = verify_against_reference(cgot, cregs, 16, frac=0.05, cfg=ccfg)
+                out["ccs_linked"] = {"ms": dt * 1e3, "gcups": (cs["band_cells"] - cs.get("band_cells_shared", 0)) / dt / 1e9, "gcups_reference_work": cs["band_cells"] / dt / 1e9,
+                                     "regions": len(cregs), "regions_per_s": len(cregs) / dt, "loglik_per_s": cgot.size / dt, "chunk_pairs_per_s": cs["n_pairs"] / dt,
+                                     "dtype": "int16", "band": 16, "dp_tasks": cs["n_dp_score_only"] + cs["n_dp_traceback"], "verified_rows": cv["verified_rows"],
+                                     "verified_max_abs_diff": cv["verified_max_abs_diff"],
+                                     "workload": "ccs-linked: 1,000 regions of ~45 long reads cut into 500-base linked chunks (PacBioCCS.config), haplotypes of 1.4-1.8 kb, band 16"}
+                # ... and unsplit (what --split-long-reads=false, or the realigner's model of option_collation.cpp:1687-1713, would ask): 10-14 kb reads at band 16, int32 lanes
+                kcfg = abi.Config.default(max_indel_error=16, use_int_scores=1, use_mapping_quality=0, device_id=local_rank)
+                keng = engine.Engine(kcfg)
+                kregs = [synth.config_region("ccs256x12", seed=42, B=16, positions="none")]
+                kb = keng.upload(synth.batch_from_regions(kregs))
+                dt = timed_resident(kb, 3)
+                ks = kb.stats()
+                kgot = kb.download().copy()
+                kb.free(); keng.close()
+                kv = verify_against_reference(kgot, kregs, 16, frac=0.1, cfg=kcfg)
+                out["ccs256x12"] = {"ms": dt * 1e3, "gcups": ks["band_cells"] / dt / 1e9, "dtype": "int32", "band": 16, "dp_tasks": ks["n_dp_score_only"] + ks["n_dp_traceback"],
+                                    "verified_rows": kv["verified_rows"], "verified_max_abs_diff": kv["verified_max_abs_diff"],
+                                    "workload": "ccs256x12: 256 unsplit HiFi-like reads of 10-14 kb x 12 haplotypes of 16 kb, band 16, int32 lanes, no mapping-quality floor"}
         if world == 1 and extras and not sim:
             out.update(region_call_legs(stream_regs_for_calls, stream_resident_for_calls, B))
         if world == 1 and not args.no_small_batch:

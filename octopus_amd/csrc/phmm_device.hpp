@@ -125,6 +125,7 @@ struct DpParams {
     uint32_t  lh_cap;                                 // longest haplotype in the batch
     uint32_t  nuc4;                                   // packed {nuc_prior << 2, nuc_prior << 2}
     uint32_t  groups_per_block;
+    uint32_t  rec_chunk;                              // k_dp / k_dp_pair: iterations' worth of read records a wave keeps in LDS at a time (a multiple of 4); 0 = the whole reads
     // late traceback start (tasks whose window touches only the RIGHT inactive flank): the traceback words are needed, and written, only for the
     // last iterations; everything before runs the score-only recurrence. 0 = off.
     int late; const uint32_t* hap_region; const uint32_t* reg_rhs;

@@ -203,7 +203,7 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks)
 // map_query_to_target (:120-159): one wave per (haplotype, read) pair; the workgroup keeps the haplotype's bins in LDS and its
 // four waves stride over a chunk of the region's reads. Votes go to per-wave LDS counters; a 64-lane batch whose votes all fall on
 // one diagonal (the normal case: the read's true offset) is merged into a single add.
-constexpr uint32_t kMapPad = 256;          // sentinel entries behind the haplotype's hash sequence: q + d never needs a bounds test (q <= 255, d < nk)
+constexpr uint32_t kMapPad = 520;          // sentinel entries behind the haplotype's hash sequence: q + d never needs a bounds test (q < 512 in k_kmer_map_lanes, q <= 255 in k_kmer_map; d < nk)
 inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2 + 2 + (2 * ((lh_cap + 1) & ~1u) + kMapPad) * 2 + kKmerBins + 4 + kBlockWaves * (lh_cap + 64) * 4; }
 
 // map_query_to_target's vote (:128-144) and its output (:145-157) for ONE (haplotype, read) pair by a whole wave: the path of the pairs the exact shortcuts of
@@ -430,7 +430,7 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
 constexpr uint32_t kLaneMapThreads = 256;
 // entries per row of DevBatch::rhash_rows: the kernel's loop takes three 16-byte chunks (24 k-mers) per trip and has the next trip's first chunk in flight
 OCT_HD uint32_t rhash_row_stride(uint32_t t_cap) { const uint32_t nq = t_cap >= kKmer ? t_cap - kKmer + 1 : 0; return 8u * (3u * (((nq + 7) / 8 + 2) / 3) + 1u); }
-constexpr uint32_t kLaneMapMaxKmers = 232;       // lane form up to here: q < 240 in the last trip, so q + d stays inside the kMapPad sentinels behind the haplotype's hashes
+constexpr uint32_t kLaneMapMaxKmers = 496;       // lane form up to here (500-base chunks of long reads: 495 k-mers): q < 504 in the last trip, so q + d stays inside the kMapPad sentinels
 
 OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap)
 {
@@ -1284,10 +1284,14 @@ template <bool V> struct BoolC { static constexpr bool value = V; };
 // LDS footprint of one DP workgroup (bytes) — must match the carve-up in k_dp.
 OCT_HD constexpr uint32_t dp_rec_n(uint32_t t_cap, uint32_t B) { return (t_cap + 2 * B + 12) & ~3u; }
 constexpr uint32_t kTileStride = 66;   // dwords per row of the 16 x 64 backpointer transpose tile (66: conflict-free both ways)
-inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool trace)
+// rec_chunk (k_dp / k_dp_pair only): 0 = a wave stages its reads' records whole (index j = read position j - B, T + 2B + 12 entries per row); n = it stages n iterations'
+// worth at a time (n + 2B + 12 entries) and restages every n iterations. 500-base reads (the chunks the reference's PacBio configuration cuts long reads into)
+// against 1.8 kb haplotypes would otherwise take 115 KB of LDS per workgroup = one wave per SIMD.
+OCT_HD constexpr uint32_t dp_rec_rows_n(uint32_t t_cap, uint32_t B, uint32_t rec_chunk) { return rec_chunk ? dp_rec_n(rec_chunk, B) : dp_rec_n(t_cap, B); }
+inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool trace, uint32_t rec_chunk = 0)
 {
     const uint32_t rows = 64 / B;
-    return 2 * ((lh_cap + 8 + 1) & ~1u) * 8 + kBlockWaves * rows * dp_rec_n(t_cap, B) * 8 + (trace ? kBlockWaves * 16 * kTileStride * 4 : 0);
+    return 2 * ((lh_cap + 8 + 1) & ~1u) * 8 + kBlockWaves * rows * dp_rec_rows_n(t_cap, B, rec_chunk) * 8 + (trace ? kBlockWaves * 16 * kTileStride * 4 : 0);
 }
 // traceback scratch: per task group, ceil(iterations / 16) tiles of 64 lanes x 16 iterations, each lane's 16 dwords contiguous
 OCT_HD constexpr uint32_t bp_tiles(uint32_t t_cap, uint32_t B) { return (t_cap + B + 15) / 16 + 1; }
@@ -1300,10 +1304,10 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
     OCT_DYN_SMEM(smem);
     const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = hw::readfirstlane(tid >> 6);   // uniform, and known to be: group index and tile addresses live in SGPRs
     const uint32_t row = lane / B, li = lane % B;
-    const uint32_t lh_n = (p.lh_cap + 8 + 1) & ~1u, rec_n = dp_rec_n(p.t_cap, B);
+    const uint32_t lh_n = (p.lh_cap + 8 + 1) & ~1u, rec_n = dp_rec_rows_n(p.t_cap, B, p.rec_chunk);
     uint2* tabF = (uint2*)smem;                      // [lh_n] forward-strand table of the current haplotype
     uint2* tabR = tabF + lh_n;                       // [lh_n] reverse-strand table
-    uint2* recs = tabR + lh_n;                       // [kBlockWaves][ROWS][rec_n] read-side records
+    uint2* recs = tabR + lh_n;                       // [kBlockWaves][ROWS][rec_n] read-side records (of the whole reads, or of p.rec_chunk iterations at a time)
     uint32_t* tiles = (uint32_t*)(recs + kBlockWaves * ROWS * rec_n);   // [kBlockWaves][16][kTileStride] backpointer transpose tiles (TRACE)
     uint2* rec_row = recs + (wave * ROWS + row) * rec_n;
     uint32_t* tile = tiles + wave * 16 * kTileStride;
@@ -1349,12 +1353,17 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
             Tmax = hw::readfirstlane(Tmax); Tmin = hw::readfirstlane(Tmin);          // wave-uniform loop bounds (SGPRs)
             const uint32_t K4 = (Tmax + B + 3) & ~3u;                                 // iterations, run in quads
 
-            // ---- stage the read-side records of this row: index j holds read position t = j - B; 4 positions per lane per trip ----
+            // ---- stage the read-side records of this row: entry j holds read position t = k_base + j - B; 4 positions per lane per trip. With p.rec_chunk the row
+            // holds the entries of the next rec_chunk iterations only (iteration k reads entries k - k_base + B - li and one beyond) and is restaged at every chunk border ----
+            const uint32_t n_entries_all = K4 + B + 1;
+            auto stage = [&](const uint32_t k_base) {
+            const uint32_t n_need = p.rec_chunk && k_base + p.rec_chunk + B + 2 < n_entries_all ? p.rec_chunk + B + 2 : n_entries_all - k_base;
+            hw::wave_lds_fence();                                                            // (a restage: every lane has read what it needed of the old entries)
             if constexpr (!GENERIC) {
                 // fast cost: the two reads' precomputed rows (read_record_thread), interleaved into {selA, selB + 4, qA, qB}
-                const uint4* rowA = (const uint4*)(p.rrec + (size_t)tA.read * p.rrec_stride);
-                const uint4* rowB = (const uint4*)(p.rrec + (size_t)tB.read * p.rrec_stride);
-                for (uint32_t j0 = 4 * li; j0 < K4 + B + 1; j0 += 4 * B) {
+                const uint4* rowA = (const uint4*)(p.rrec + (size_t)tA.read * p.rrec_stride) + (k_base >> 2);
+                const uint4* rowB = (const uint4*)(p.rrec + (size_t)tB.read * p.rrec_stride) + (k_base >> 2);
+                for (uint32_t j0 = 4 * li; j0 < n_need; j0 += 4 * B) {
                     const uint4 a = rowA[j0 >> 2], c = rowB[j0 >> 2];
                     rec_row[j0 + 0] = make_uint2(hw::perm(c.x, a.x, 0x05040100u) | 0x00040000u, hw::perm(c.x, a.x, 0x07060302u));
                     rec_row[j0 + 1] = make_uint2(hw::perm(c.y, a.y, 0x05040100u) | 0x00040000u, hw::perm(c.y, a.y, 0x07060302u));
@@ -1362,8 +1371,8 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                     rec_row[j0 + 3] = make_uint2(hw::perm(c.w, a.w, 0x05040100u) | 0x00040000u, hw::perm(c.w, a.w, 0x07060302u));
                 }
             } else
-            for (uint32_t j0 = 4 * li; j0 < K4 + B + 1; j0 += 4 * B) {
-                const int32_t t0 = (int32_t)j0 - B;
+            for (uint32_t j0 = 4 * li; j0 < n_need; j0 += 4 * B) {
+                const int32_t t0 = (int32_t)(k_base + j0) - B;
                 auto load4 = [&](const uint8_t* base, uint32_t T) -> uint32_t {
                     if (t0 >= 0 && (uint32_t)t0 + 4 <= T) { uint32_t v; __builtin_memcpy(&v, base + t0, 4); return v; }
                     uint32_t v = 0;
@@ -1391,10 +1400,12 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                 }
             }
             hw::wave_lds_fence();
+            };
+            stage(0);
 
             const uint2* pA = (p.rrev[tA.read] ? tabR : tabF) + tA.off + li;
             const uint2* pB = (p.rrev[tB.read] ? tabR : tabF) + tB.off + li;
-            const uint2* rp = rec_row + (B - li);
+            const uint2* rp = rec_row + (B - li);                      // rp[k] = the record of iteration k; rebased when the row is restaged (p.rec_chunk)
             const uint32_t kendA = TA + li, kendB = TB + li;          // the iteration whose M cells are this lane's end cells (t == T)
             uint4* bpg = TRACE ? (uint4*)(p.bp + (size_t)g * p.k_cap * 1024) : nullptr;   // this group's tiles (k_cap tiles of 4 KB)
 
@@ -1498,6 +1509,15 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
 
             const uint32_t kB = (Tmin & ~3u) > (uint32_t)B ? (Tmin & ~3u) : (uint32_t)B;   // no end cell before the shortest read is consumed
             uint32_t k = 0;
+            // quads up to iteration k_end; with p.rec_chunk the row is restaged (and rp rebased) whenever k reaches the end of what it holds
+            uint32_t k_restage = p.rec_chunk ? p.rec_chunk : 0xffffffffu;
+            auto run_to = [&](const uint32_t k_end, auto init_c, auto cap_c, auto tr_c) {
+                while (k < k_end) {
+                    if (k == k_restage) { stage(k); rp = rec_row + (B - li) - k; k_restage += p.rec_chunk; }
+                    const uint32_t stop = k_end < k_restage ? k_end : k_restage;
+                    for (; k < stop; k += 4) quad(k, init_c, cap_c, tr_c);
+                }
+            };
             if constexpr (TRACE) {
                 // Late traceback start (p.late): every task of this launch needs its walk only inside the RIGHT inactive flank, i.e. only the
                 // traceback words of the last iterations. Until k_sw the wave runs the score-only recurrence (no label extraction, no tile
@@ -1518,16 +1538,14 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                     ks = hw::readfirstlane(ks);
                     k_sw = (ks < Tmin ? ks : Tmin) & ~15u;
                 }
-                for (; k < (uint32_t)B && k < k_sw; k += 4) quad(k, BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
-                for (; k < k_sw; k += 4) quad(k, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
+                run_to(k_sw < (uint32_t)B ? k_sw : (uint32_t)B, BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
+                run_to(k_sw, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
                 if (k_sw) { I1 |= 0x00010001u; D1 |= 0x00030003u; I2 |= 0x00010001u; D2 |= 0x00030003u; y1 = hw::pk_min_u(M1, I1); }
             }
-            if (Tmin >= (uint32_t)B) {                                                                   // no read of the wave ends inside the rolling initialisation: no end cells to capture yet
-                for (; k < (uint32_t)B; k += 4) quad(k, BoolC<true>{}, BoolC<false>{}, BoolC<true>{});
-            }
-            for (; k < (uint32_t)B; k += 4) quad(k, BoolC<true>{}, BoolC<true>{}, BoolC<true>{});         // rolling initialisation lasts B iterations
-            for (; k < kB; k += 4) quad(k, BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
-            for (; k < K4; k += 4) quad(k, BoolC<false>{}, BoolC<true>{}, BoolC<true>{});
+            if (Tmin >= (uint32_t)B) run_to((uint32_t)B, BoolC<true>{}, BoolC<false>{}, BoolC<true>{});   // no read of the wave ends inside the rolling initialisation: no end cells to capture yet
+            run_to((uint32_t)B, BoolC<true>{}, BoolC<true>{}, BoolC<true>{});                              // rolling initialisation lasts B iterations
+            run_to(kB, BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
+            run_to(K4, BoolC<false>{}, BoolC<true>{}, BoolC<true>{});
             if constexpr (TRACE) { if (K4 & 15) flush_tile(K4 >> 4); }
 
             // ---- first minimum over the row's end cells, per packed task (:285-291,309-315,323) ----

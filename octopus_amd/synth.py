@@ -181,6 +181,54 @@ def make_region(rng: np.random.Generator, R: int, H: int, T: int = 150, Lh: int 
     return dict(haps=haps, reads=reads, quals=quals, begin=begin, reverse=reverse, mapq=mapq, flank=flank, pos=pos)
 
 
+def make_linked_region(rng: np.random.Generator, n_long_reads: int, H: int, Lh: int = 1600, chunk: int = 500, B: int = 16, flank=(100, 100), positions: str = "none") -> dict:
+    """An active region the way the reference's own long-read configuration presents it to the likelihood model (resources/configs/PacBioCCS.config:
+    max-read-length=500, split-long-reads=true, read-linkage=LINKED, max-indel-errors=16, max-assembly-region-size=1000): every long read that crosses the region is
+    cut into 500-base chunks, the chunks inside the region are LINKED reads of one template (one likelihood row = the sum over its chunks,
+    haplotype_likelihood_model.cpp:306-320), haplotypes are allele combinations over ~1.6 kb. HiFi-like qualities (Q20-40), substitutions at the quality's rate,
+    half of the chunks with a 1-2 base indel error, diploid sample."""
+    haps, maps = make_tree_haplotypes(rng, H, Lh)
+    hs, ms = np.stack(haps), np.stack(maps)
+    genotype = rng.choice(H, size=min(2, H), replace=False)
+    reads, quals, begin, rows = [], [], [], [0]
+    for _ in range(n_long_reads):
+        src = int(genotype[rng.integers(0, len(genotype))])
+        s0 = B + int(rng.integers(0, chunk))
+        while s0 + chunk + B <= Lh:
+            first = int(min(ms[src, s0], Lh - chunk))
+            row = hs[src, first:first + chunk + 4].copy()
+            if rng.random() < 0.5:
+                p = int(rng.integers(10, chunk - 10)); n = int(rng.integers(1, 3))
+                row = np.concatenate([row[:p], BASES[rng.integers(0, 4, n)], row[p:]]) if rng.random() < 0.5 else np.concatenate([row[:p], row[p + n:]])
+            row = row[:chunk].copy()
+            if len(row) < chunk:
+                row = np.concatenate([row, BASES[rng.integers(0, 4, chunk - len(row))]])
+            q = rng.integers(20, 41, chunk).astype(np.uint8)
+            err = rng.random(chunk) < np.power(10.0, -q.astype(np.float64) / 10.0)
+            row[err] = BASES[rng.integers(0, 4, int(err.sum()))]
+            reads.append(row); quals.append(q); begin.append(s0)
+            s0 += chunk
+        if len(reads) > rows[-1]:
+            rows.append(len(reads))
+    R = len(reads)
+    g = dict(haps=haps, reads=np.stack(reads), quals=np.stack(quals), begin=np.asarray(begin, np.int64), reverse=(rng.random(R) < 0.5).astype(np.uint8),
+             mapq=np.full(R, 60, np.uint8), flank=flank, pos=None, row_off=np.asarray(rows, np.int64))
+    if positions == "true":
+        g["pos"] = np.stack([np.minimum(m[g["begin"]], Lh - chunk) for m in maps]).astype(np.uint32)
+    return g
+
+
+def linked_stream(seed: int, n_regions: int, B: int = 16) -> List[dict]:
+    """`ccs-linked`: a stream of such regions, 30-60 x coverage (long reads per region ~ lognormal around 45), haplotypes ~ min(400, geometric(mean 24)) (max-haplotypes=400)."""
+    out = []
+    for i in range(n_regions):
+        rng = np.random.default_rng([seed, 7, i])
+        n = int(np.clip(rng.lognormal(np.log(45), 0.4), 8, 200))
+        H = int(min(400, rng.geometric(1 / 24.0)))
+        out.append(make_linked_region(rng, n, max(H, 1), Lh=1400 + int(rng.integers(0, 401)), B=B))
+    return out
+
+
 def batch_from_regions(regions: List[dict]) -> abi.Batch:
     """Concatenate regions into one flat C-ABI batch (region tables + flank states + CSR positions)."""
     rb, rq, ro, mq, rv, beg = [], [], [0], [], [], []
@@ -188,6 +236,8 @@ def batch_from_regions(regions: List[dict]) -> abi.Batch:
     reg_rows, reg_haps, flank = [0], [0], []
     pos_off, pos_val = [np.zeros(1, np.uint64)], []
     have_pos = all(g["pos"] is not None for g in regions)
+    any_rows = any(g.get("row_off") is not None for g in regions)
+    row_off, n_reads_so_far = [0], 0
     total = 0
     for g in regions:
         R, T = g["reads"].shape
@@ -202,7 +252,14 @@ def batch_from_regions(regions: List[dict]) -> abi.Batch:
         for h in g["haps"]:
             a, b, c, d, e, f = _penalties(h)
             hb.append(h); ho.append(ho[-1] + len(h)); go.append(a); ge.append(b); mf.append(c); pf.append(d); mr.append(e); pr.append(f)
-        reg_rows.append(reg_rows[-1] + R); reg_haps.append(reg_haps[-1] + len(g["haps"]))
+        if any_rows:                               # rows = templates of consecutive reads (g["row_off"], region-relative) or single reads
+            ro_g = np.asarray(g["row_off"] if g.get("row_off") is not None else np.arange(R + 1), np.int64)
+            row_off.extend((n_reads_so_far + ro_g[1:]).tolist())
+            reg_rows.append(reg_rows[-1] + len(ro_g) - 1)
+        else:
+            reg_rows.append(reg_rows[-1] + R)
+        n_reads_so_far += R
+        reg_haps.append(reg_haps[-1] + len(g["haps"]))
         flank.append(g["flank"] if g["flank"] is not None else (0, 0))
         if have_pos:
             n = len(g["haps"]) * R
@@ -211,7 +268,7 @@ def batch_from_regions(regions: List[dict]) -> abi.Batch:
             total += n
     b = abi.Batch(
         read_bases=np.concatenate(rb), read_quals=np.concatenate(rq), read_offsets=np.asarray(ro, np.uint32),
-        mapq=np.concatenate(mq), reverse=np.concatenate(rv), read_ref_begin=np.concatenate(beg), row_offsets=None,
+        mapq=np.concatenate(mq), reverse=np.concatenate(rv), read_ref_begin=np.concatenate(beg), row_offsets=np.asarray(row_off, np.uint32) if any_rows else None,
         hap_bases=np.concatenate(hb), hap_offsets=np.asarray(ho, np.uint32), hap_ref_begin=np.zeros(len(hb), np.int64),
         gap_open=np.concatenate(go), gap_extend=np.concatenate(ge), snv_mask_fwd=np.concatenate(mf),
         snv_prior_fwd=np.concatenate(pf), snv_mask_rev=np.concatenate(mr), snv_prior_rev=np.concatenate(pr))
@@ -251,9 +308,10 @@ def config_region(name: str, seed: int = 42, B: int = 16, positions: str = "true
                            q_values=(8, 15), indels_per_read=40)
     if name == "long512x8":     # eight times configs[4]'s reads: enough tasks to put several waves on every SIMD (a throughput figure, not a latency one)
         return make_region(rng, 512, 8, T=10_000, Lh=20_000, B=256, flank=(400, 400), positions=positions, q_values=(8, 15), indels_per_read=40)
-    if name == "ccs256x12":     # long reads the way the reference configures them (resources/configs/PacBioCCS.config: max-indel-errors=16; int32 lanes for long reads,
-        # option_collation.cpp:1687-1693): 256 HiFi-like reads of 10-14 kb (Q20-40, a dozen indel errors each) against 12 haplotypes of 16 kb, band 16
-        g = make_region(rng, 256, 12, T=14_000, Lh=16_000, B=B, flank=(300, 300), positions=positions, q_values=(20, 40), indels_per_read=12)
+    if name == "ccs256x12":     # UNSPLIT long reads at the PacBio configuration's band (max-indel-errors=16) with the int32 lanes the realigner's model takes for long reads
+        # (option_collation.cpp:1687-1693): 256 HiFi-like reads of 10-14 kb (Q20-40, six indel errors each) against 12 haplotypes of 16 kb. The CALLING path of that
+        # configuration never sees this shape - it cuts reads into 500-base linked chunks (linked_stream below) - the realignment path does.
+        g = make_region(rng, 256, 12, T=14_000, Lh=16_000, B=B, flank=(300, 300), positions=positions, q_values=(20, 40), indels_per_read=6)
         g["read_len"] = rng.integers(10_000, 14_001, 256).astype(np.int64)
         return g
     if name == "tiny":

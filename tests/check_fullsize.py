@@ -94,3 +94,20 @@ def check_long_reads(backend, region=None, B=256, max_cigar_ops=4096):
     finally:
         oracle.set_l1_backend("oracle")
     return dict(stats=stats, n=got.size, n_alignments=len(res["cigar_strings"]))
+
+
+def check_linked_stream(backend, n_regions=200, B=16, seed=42):
+    """`bench.py`'s ccs_linked leg at a fifth of its size: long reads cut into 500-base linked chunks (PacBioCCS.config), every region against the reference's own
+    populate (TemplateMap overload: a row = the sum over a template's reads)."""
+    regs = synth.linked_stream(seed, n_regions, B=B)
+    batch = synth.batch_from_regions(regs)
+    cfg = abi.Config.default(max_indel_error=B)
+    eng = make_engine(backend, max_indel_error=B)
+    rb = eng.upload(batch); rb.run(); got = rb.download().copy(); stats = rb.stats(); rb.free(); eng.close()
+    off, worst = 0, 0.0
+    for g in regs:
+        want = _ref_populate(cfg, synth.batch_from_regions([g]), oracle.host_cores())
+        worst = max(worst, float(np.max(np.abs(got[off:off + want.size] - want), initial=0.0)))
+        off += want.size
+    assert off == got.size and worst <= TOL, worst
+    return dict(stats=stats, regions=len(regs), n=got.size)

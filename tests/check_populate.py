@@ -735,3 +735,20 @@ def check_page_locked_caller_buffers(backend, tol=0.0):
                 os.environ[k] = v
         pool.close()
     return n
+
+
+def check_linked_chunks(backend, tol=0.0):
+    """Long reads as the reference's PacBioCCS configuration presents them (synth.make_linked_region): linked chunks of one long read form one template (one row, the
+    sum over its chunks), several regions with different haplotype lengths in one batch, device k-mer mapping; and ragged reads (synth `read_len`)."""
+    out = []
+    for seed, (n, H, Lh, chunk, B) in enumerate(((4, 3, 520, 150, 8), (5, 4, 640, 200, 16))):
+        rng = np.random.default_rng(500 + seed)
+        regs = [synth.make_linked_region(rng, n, H, Lh=Lh + 40 * k, chunk=chunk, B=B, flank=(30, 30)) for k in range(2)]
+        batch = synth.batch_from_regions(regs)
+        assert batch.row_offsets is not None and batch.n_rows < batch.n_reads
+        out.append(compare(backend, batch, tol, max_indel_error=B))
+    rng = np.random.default_rng(77)
+    g = synth.make_region(rng, 12, 3, T=90, Lh=260, B=8, flank=(20, 20), positions="none")
+    g["read_len"] = rng.integers(40, 91, 12)
+    out.append(compare(backend, synth.batch_from_regions([g]), tol, max_indel_error=8))
+    return out

@@ -22,13 +22,14 @@ SEQS = ["hiseq_2000", "hiseq_2500", "hiseq_4000", "xten", "novaseq", "bgiseq_500
 
 
 @pytest.fixture(scope="module")
-def tables():
+def tables(tmp_path_factory):
     if Path("/root/reference/src/core/models/error/error_model_factory.cpp").exists():
-        before = FIX.read_text()
-        hdr = ROOT / "octopus_amd" / "csrc" / "phmm_error_model_tables.hpp"
-        hdr_before = hdr.read_text()
-        subprocess.run([sys.executable, str(ROOT / "tools" / "make_error_model_tables.py")], check=True, capture_output=True)
-        assert FIX.read_text() == before and hdr.read_text() == hdr_before, "committed tables are not what the reference's factory holds"
+        # re-derived into a scratch directory and compared: the source tree is never written by a test run (read-only checkouts, pytest-xdist)
+        out = tmp_path_factory.mktemp("error_model_tables")
+        subprocess.run([sys.executable, str(ROOT / "tools" / "make_error_model_tables.py"), f"--out-dir={out}"], check=True, capture_output=True)
+        hdr = Path("octopus_amd") / "csrc" / "phmm_error_model_tables.hpp"
+        assert (out / "tests" / "golden" / "error_model_tables.json").read_text() == FIX.read_text() and (out / hdr).read_text() == (ROOT / hdr).read_text(), \
+            "committed tables are not what the reference's factory holds (python tools/make_error_model_tables.py regenerates them)"
     return json.loads(FIX.read_text())
 
 

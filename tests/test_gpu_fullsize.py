@@ -45,3 +45,10 @@ def test_gpu_long_read_config_full_size_populate_and_align():
     r = cf.check_long_reads("gpu")
     assert r["n"] == 512 and r["n_alignments"] == 512 and r["stats"]["band_cells"] > 4_000_000_000
     assert r["stats"]["n_dp_traceback"] > 0 and r["stats"]["n_dp_score_only"] > 0
+
+
+@need_ref
+def test_gpu_linked_chunk_stream_equals_the_reference_region_by_region():
+    """The reference's own long-read configuration (PacBioCCS.config: 500-base linked chunks, band 16): 200 regions, templates of 2-3 chunks."""
+    r = cf.check_linked_stream("gpu", n_regions=200)
+    assert r["regions"] == 200 and r["stats"]["n_pairs"] > 300_000 and r["stats"]["n_dp_traceback"] > 0

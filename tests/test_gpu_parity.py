@@ -404,3 +404,17 @@ def test_gpu_patched_read_realigner_seam_equals_the_reference_functions():
     import check_realigner_patch as cr
     require_reference_build(cr.have("patched_gpu"), "oracle/_ref/libref_realigner_patched_gpu.so")
     assert cr.check("gpu", TOL, golden=True) == 69
+
+
+def test_gpu_linked_chunks_of_long_reads_and_ragged_reads():
+    assert len(cp.check_linked_chunks("gpu", TOL)) == 3
+
+
+@pytest.mark.parametrize("chunk", ["16", "40"])
+def test_gpu_read_records_staged_in_chunks(chunk, monkeypatch):
+    monkeypatch.setenv("OCT_PHMM_REC_CHUNK", chunk)
+    cp.check_basic("gpu", TOL)
+    cp.check_generic_bytes("gpu", TOL)
+    cp.check_ragged_and_edges("gpu", TOL)
+    cp.check_late_traceback_start("gpu", TOL)
+    cp.check_device_kmer_mapper("gpu", TOL)

@@ -154,3 +154,21 @@ def test_sim_lane_per_pair_mapper(monkeypatch):
 
 def test_sim_page_locked_caller_buffers_skip_the_staging_copies():
     assert cp.check_page_locked_caller_buffers("sim") == 10
+
+
+def test_sim_linked_chunks_of_long_reads_and_ragged_reads():
+    stats = cp.check_linked_chunks("sim")
+    assert len(stats) == 3 and all(s["n_dp_score_only"] + s["n_dp_traceback"] > 0 for s in stats)
+
+
+@pytest.mark.parametrize("chunk", ["16", "40"])
+def test_sim_read_records_staged_in_chunks(chunk, monkeypatch):
+    """The packed int16 DP kernels keep a chunk of iterations' read records in LDS and restage at its borders where whole reads would leave one wave per SIMD
+    (500-base reads); forced on the small reads of the populate checks (borders inside the rolling initialisation, the capture phase, the late traceback start)."""
+    monkeypatch.setenv("OCT_PHMM_REC_CHUNK", chunk)
+    cp.check_basic("sim")
+    cp.check_generic_bytes("sim")
+    cp.check_ragged_and_edges("sim")
+    if chunk == "16":
+        cp.check_late_traceback_start("sim")
+        cp.check_templates_and_regions("sim")
