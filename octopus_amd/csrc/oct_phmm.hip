@@ -543,17 +543,20 @@ bool launch_dp_mw(int band, bool one_wave, bool tr, bool gen, const DpParams& p,
     return false;
 }
 
-// Read records of the packed int16 kernels: whole reads in LDS while a workgroup then still fits twice on a CU (150-base reads: 46 KB with traceback tiles), else
-// the largest chunk of iterations (a multiple of 32, at least 64) with which it does - 500-base chunks of long reads against 1.8 kb haplotypes: 115 KB -> 75 KB, one
-// wave per SIMD -> two. OCT_PHMM_REC_CHUNK=n forces a chunk (test hook: restaging on small reads; 0 = never).
-uint32_t dp_rec_chunk(uint32_t t_cap, uint32_t lh_cap, uint32_t B)
+// Read records of the packed int16 kernels: whole reads in LDS while three workgroups then fit on a CU (150-base reads: 47 KB with traceback tiles, 30 KB without), else
+// the largest chunk of iterations (a multiple of 32, at least 64) with which three do, else two - 500-base chunks of long reads against 1.8 kb haplotypes: 115 KB -> 75 KB
+// with traceback (one wave per SIMD -> two), 98 -> 51 KB without (-> three). OCT_PHMM_REC_CHUNK=n forces a chunk (test hook: restaging on small reads; 0 = never).
+uint32_t dp_rec_chunk(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool trace)
 {
     long long v;
     if (tune::number("OCT_PHMM_REC_CHUNK", &v)) return v > 0 ? (uint32_t)((v + 3) & ~3ll) : 0u;
-    constexpr size_t kTwoPerCu = rt::kMaxLdsBytes / 2 - 1024;
-    if (dp_lds_bytes(t_cap, lh_cap, B, true) <= kTwoPerCu || t_cap <= 128) return 0;
-    for (uint32_t c = (t_cap / 32) * 32; c >= 64; c -= 32) if (c < t_cap && dp_lds_bytes(t_cap, lh_cap, B, true, c) <= kTwoPerCu) return c;
-    return dp_lds_bytes(t_cap, lh_cap, B, true) <= rt::kMaxLdsBytes ? 0u : 64u;      // (no chunk gives two per CU: whole reads if they fit at all)
+    if (t_cap <= 128) return 0;
+    for (size_t per_cu : {(size_t)3, (size_t)2}) {
+        const size_t budget = rt::kMaxLdsBytes / per_cu - 1024;
+        if (dp_lds_bytes(t_cap, lh_cap, B, trace) <= budget) return 0;
+        for (uint32_t c = ((t_cap - 1) / 32) * 32; c >= 64; c -= 32) if (dp_lds_bytes(t_cap, lh_cap, B, trace, c) <= budget) return c;
+    }
+    return dp_lds_bytes(t_cap, lh_cap, B, trace) <= rt::kMaxLdsBytes ? 0u : 64u;      // (no chunk gives two per CU: whole reads if they fit at all)
 }
 
 bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
@@ -601,7 +604,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     const uint32_t C = (uint32_t)h->lanes_c;
     const uint32_t G = b->stream ? (B < 64 ? 64u / (uint32_t)B : 1u) : (h->wide ? 1 : 2) * (64 / B);
     const bool tr = kind == kTraceFast || kind == kTraceGen, gen = kind == kScoreGen || kind == kTraceGen;
-    const uint32_t rec_chunk = (b->stream || h->wide) ? 0u : dp_rec_chunk(b->t_cap, b->lh_cap, (uint32_t)B);
+    const uint32_t rec_chunk = (b->stream || h->wide) ? 0u : dp_rec_chunk(b->t_cap, b->lh_cap, (uint32_t)B, tr);
     const size_t lds = b->stream ? 0 : dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr, rec_chunk);
     if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
     DpParams p {};
@@ -1073,7 +1076,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     for (uint32_t r = 0; r < R->n_reads; ++r) b->t_cap = std::max(b->t_cap, R->offsets[r + 1] - R->offsets[r]);
     for (uint32_t hp = 0; hp < H->n_haps; ++hp) b->lh_cap = std::max(b->lh_cap, H->offsets[hp + 1] - H->offsets[hp]);
     {
-        const bool fits = h->band <= 64 && dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)h->band, true, h->wide ? 0u : dp_rec_chunk(b->t_cap, b->lh_cap, (uint32_t)h->band)) <= rt::kMaxLdsBytes;
+        const bool fits = h->band <= 64 && dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)h->band, true, h->wide ? 0u : dp_rec_chunk(b->t_cap, b->lh_cap, (uint32_t)h->band, true)) <= rt::kMaxLdsBytes;
         b->stream = h->band > 64 || !fits;      // long reads at any band stream their operands (PacBioCCS.config: max-indel-errors=16 with 10-20 kb reads)
         b->multi_wave = h->band >= 128 && h->wide && tune::multi_wave();
         if (b->t_cap + 2 * (uint32_t)h->band >= 32768) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long (walk events hold 15-bit coordinates)");
