@@ -298,6 +298,10 @@ typedef struct oct_phmm_error_model {
     int32_t use_snv_model;                     /* 0: no SNV model (PacBio sequencers, error_model_factory.cpp:480-483): masks = the haplotype itself, priors = 100 (model.cpp:69-73) */
 } oct_phmm_error_model;
 void oct_phmm_error_model_default(oct_phmm_error_model* model);
+/* NOT covered: the reference's CustomRepeatBasedIndelErrorModel (core/models/error/custom_repeat_based_indel_error_model.cpp), which `--sequence-error-model <file>` builds from
+ * a model FILE of motif -> penalty rows (error_model_factory.cpp:572-590) - its look-ups are keyed by motif strings (std::unordered_map, with an iteration-order-dependent default),
+ * not by this struct's period tables. A caller that runs such a model passes the six vectors itself (the reference's own reset() computes them once per haplotype:
+ * haplotype_likelihood_model.cpp:60-78, exactly what INTEGRATION.md's populate patch hands over), which every entry point accepts. */
 /* Every parameter set the reference's factory holds (error_model_factory.cpp:220-517), by the names --sequence-error-model takes (option_parser.cpp:571-573;
  * matched like the reference's operator>>: case-insensitive, "PCR-free" also as "PCRF"):
  *   library preparation  PCR, PCR-free, 10X, MDA;  sequencer  HiSeq-2000, HiSeq-2500, HiSeq-4000, X10, NovaSeq, BGISEQ-500, PacBio, PacBioCCS.

@@ -38,7 +38,7 @@ struct DevPool {
     std::multimap<size_t, void*> free_blocks;
     std::unordered_map<void*, size_t> live;
     size_t cached = 0;
-    static constexpr size_t kCacheCap = (size_t)16 << 30;
+    static constexpr size_t kCacheCap = (size_t)64 << 30;       // (288 GB of HBM: a handle that streams 6,250-region batches - 20 GB resident each - paid a 20 GB hipMalloc + hipFree, 0.4 s, per call with the cap at 16 GB)
     // Powers of two up to 1 GB (a thread's region calls differ in size by orders of magnitude - 20 to 5,000 reads, 1 to 200 haplotypes: with finer classes most
     // calls of a run's first thousands met a size nobody had freed yet and paid a hipMalloc, which synchronises the device), eight classes per octave beyond
     // (resident many-gigabyte batches are not rounded up by half of themselves).

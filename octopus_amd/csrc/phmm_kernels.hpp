@@ -505,6 +505,8 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
         dA = dM != none ? dM : dF != none ? dF : dL;
         dB = (dF != none && dF != dA) ? dF : dL;
         if (dB == dA) dB = none;
+        // (a third stream for the last probe where all three disagree - a read across two indels - decided 3.3 % more of the headline batch's pairs and cost the
+        // pass 25 % more LDS gathers: k_kmer_map_lanes 2.29 -> 2.51 ms per launch, stream-hq 3.28 -> 3.84. Measured, not kept: those pairs are counted by the wave below.)
         if (!eligible) { dA = none; dB = none; }
     }
     // one pass over the hashes. A diagonal that is "none" points at the sentinels behind the haplotype's hashes (0xffff: never a vote).
@@ -1097,8 +1099,13 @@ OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* c
         const uint4 a = cnt[b.hap_pair_off[h] - pair0], z = cnt[b.hap_pair_off[h + 1] - pair0];
         return make_uint4(up(z.x - a.x), up(z.y - a.y), up(z.z - a.z), up(z.w - a.w));
     };
+    // (a thread's haplotypes four at a time: eight independent loads in flight instead of a chain of dependent ones - 49 k haplotypes on 1,024 threads were 0.36 ms of latency)
     uint4 sum = make_uint4(0, 0, 0, 0);
-    for (uint32_t h = lo; h < hi; ++h) sum = add4(sum, padded(h));
+    for (uint32_t h = lo; h < hi; h += 4) {
+        uint4 v[4];
+        for (uint32_t u = 0; u < 4; ++u) v[u] = h + u < hi ? padded(h + u) : make_uint4(0, 0, 0, 0);
+        for (uint32_t u = 0; u < 4; ++u) sum = add4(sum, v[u]);
+    }
     sh[tid] = sum;
     hw::block_sync();
     for (uint32_t d = 1; d < kHapBaseThreads; d <<= 1) {
@@ -1109,7 +1116,11 @@ OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* c
         hw::block_sync();
     }
     uint4 run = tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0);
-    for (uint32_t h = lo; h < hi; ++h) { hap_base[h] = run; run = add4(run, padded(h)); }
+    for (uint32_t h = lo; h < hi; h += 4) {
+        uint4 v[4];
+        for (uint32_t u = 0; u < 4; ++u) v[u] = h + u < hi ? padded(h + u) : make_uint4(0, 0, 0, 0);
+        for (uint32_t u = 0; u < 4; ++u) if (h + u < hi) { hap_base[h + u] = run; run = add4(run, v[u]); }
+    }
     if (tid == kHapBaseThreads - 1) {
         const uint4 all = sh[tid];
         *totals = all;
