@@ -136,6 +136,7 @@ struct oct_phmm_batch {
     double* d_out = nullptr;
     uint32_t n_tasks[kNumKinds] = {0, 0, 0, 0};
     unsigned long long h_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> h_tab_base, h_tab_mask;                     // canonical windows: first slot and mask of every region's hash table (upload)
     bool dedup = false, dedup_tables = false; std::vector<DedupSeg> h_segs; DedupSeg* d_segs = nullptr;   // exact de-duplication of pairs (phmm_kernels.hpp)
     std::vector<unsigned long long> h_stat_stripes;
     unsigned long long* stat_stage = nullptr;                   // pinned landing block of the counters' copy (the handle's; pageable destinations cost a staged copy per call)
@@ -1429,10 +1430,24 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             RT(rt::h2d(h->d_pw, pw.data(), n * 8, s)); RT(rt::h2d(h->d_pwinv, pwinv.data(), n * 8, s)); RT(rt::stream_sync(s));
             h->pw_n = n;
         }
-        uint32_t tbits = 10; while (((size_t)1 << tbits) < (size_t)n_hap_bases * 2) ++tbits;
-        const size_t tsize = (size_t)1 << tbits;
+        // one table per region (phmm_kernels.hpp, k_window_insert): a power of two of slots >= 1.25 x the region's windows, one behind the other
+        std::vector<uint32_t> tab_base(G + 1, 0), tab_mask(G + 1, 0);
+        size_t tsize = 0;
+        for (uint32_t g = 0; g < G; ++g) {
+            const size_t w = (size_t)H->offsets[g_hap[g + 1]] - H->offsets[g_hap[g]];
+            size_t n = 16; while (n < w + w / 4) n <<= 1;
+            tab_base[g] = (uint32_t)tsize; tab_mask[g] = (uint32_t)(n - 1); tsize += n;
+        }
+        if (tsize >= 0xffffffffull) { b->dedup = false; d.canon = nullptr; }       // (more than 2^32 table slots: no sharing for this batch)
+        tab_base[G] = (uint32_t)tsize;
+      if (b->dedup) {
+        b->h_tab_base = std::move(tab_base); b->h_tab_mask = std::move(tab_mask);           // (the copies below read them: they live as long as the batch)
+        const size_t n_wblk = ((size_t)n_hap_bases + 255) / 256;
+        b->h_tab_base.reserve((size_t)G + 1 + n_wblk);                                      // behind the bases: the haplotype of every 256-window workgroup's first window
+        for (size_t blk = 0, hp = 0; blk < n_wblk; ++blk) { while (hp + 1 < H->n_haps && H->offsets[hp + 1] <= blk * 256) ++hp; b->h_tab_base.push_back((uint32_t)hp); }
+        const size_t n_tab = ((size_t)G + 2 + n_wblk) & ~(size_t)1;
         const size_t n_prefix = ((size_t)n_hap_bases + H->n_haps + 2) & ~(size_t)1, n_wkey = ((size_t)n_hap_bases + 2) & ~(size_t)1;
-        const size_t need = (n_prefix + n_wkey + tsize) * 8 + tsize * 4;
+        const size_t need = (n_prefix + n_wkey + tsize) * 8 + tsize * 4 + 2 * n_tab * 4 + 64;
         if (h->dedup_scratch_bytes < need) {
             RT(rt::stream_sync(s));
             h->pool.release(h->dedup_scratch); h->dedup_scratch = nullptr; h->dedup_scratch_bytes = 0;
@@ -1440,15 +1455,21 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         }
         uint64_t* d_prefix = (uint64_t*)h->dedup_scratch; unsigned long long* d_wkey = (unsigned long long*)(d_prefix + n_prefix);
         unsigned long long* d_tkeys = d_wkey + n_wkey; uint32_t* d_tvals = (uint32_t*)(d_tkeys + tsize);
+        uint32_t* d_tab_base = d_tvals + ((tsize + 1) & ~(size_t)1); uint32_t* d_tab_mask = d_tab_base + n_tab;
+        RT(rt::h2d(d_tab_base, b->h_tab_base.data(), b->h_tab_base.size() * 4, s)); RT(rt::h2d(d_tab_mask, b->h_tab_mask.data(), ((size_t)G + 1) * 4, s));
+        const uint32_t* d_blk_hap_w = d_tab_base + G + 1;
         RT(rt::dev_memset(d_tkeys, 0, tsize * 8, s)); RT(rt::dev_memset(d_tvals, 0xff, tsize * 4, s));
         OCT_LAUNCH(k_window_prefix, (H->n_haps + 3) / 4, 256, 0, s, d, (const uint64_t*)h->d_pw, d_prefix); RT(rt::launch_ok());   // one wave per haplotype
         if (n_hap_bases) {
-            OCT_LAUNCH(k_window_insert, (n_hap_bases + 255) / 256, 256, 0, s, d, (const uint64_t*)h->d_pwinv, (const uint64_t*)d_prefix, n_hap_bases,
-                       d_wkey, d_tkeys, d_tvals, (uint32_t)(tsize - 1)); RT(rt::launch_ok());
+            for (int phase = 0; phase < 2; ++phase) {                       // every region's first haplotype, then the rest (k_window_insert)
+                OCT_LAUNCH(k_window_insert, (n_hap_bases + 255) / 256, 256, 0, s, d, (const uint64_t*)h->d_pwinv, (const uint64_t*)d_prefix, n_hap_bases,
+                           d_wkey, d_tkeys, d_tvals, (const uint32_t*)d_tab_base, (const uint32_t*)d_tab_mask, d_blk_hap_w, phase); RT(rt::launch_ok());
+            }
             OCT_LAUNCH(k_window_candidate, (n_hap_bases + 255) / 256, 256, 0, s, d, n_hap_bases, (const unsigned long long*)d_wkey,
-                       (const unsigned long long*)d_tkeys, (const uint32_t*)d_tvals, (uint32_t)(tsize - 1)); RT(rt::launch_ok());
+                       (const unsigned long long*)d_tkeys, (const uint32_t*)d_tvals, (const uint32_t*)d_tab_base, (const uint32_t*)d_tab_mask, d_blk_hap_w); RT(rt::launch_ok());
             OCT_LAUNCH(k_window_confirm, (H->n_haps + 3) / 4, 256, 0, s, d); RT(rt::launch_ok());                                          // one wave per haplotype
         }
+      }
     }
     // The copies above read this call's host-side staging (pinned buffer, position vectors): a caller of the split API may upload the next batch
     // right away, so they must have landed. A one-shot call (populate, align) runs on the same stream at once and does not return before its

@@ -116,6 +116,9 @@ OCT_DEVICE unsigned long long atomic_cas_u64(unsigned long long* p, unsigned lon
 // 64-bit mailboxes in LDS between the waves of a workgroup (k_dp_mw): value and tag travel in ONE store / ONE load, re-read until the tag is right
 OCT_DEVICE void lds_store_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 OCT_DEVICE unsigned long long lds_load_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// loads that see what other CUs' atomics have written (device scope: past this CU's L1, which is not coherent), for look-before-you-swap in hash tables
+OCT_DEVICE unsigned long long load_device_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+OCT_DEVICE uint32_t load_device_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 OCT_DEVICE void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 OCT_DEVICE uint32_t thread_idx() { return threadIdx.x; }
 OCT_DEVICE uint32_t block_idx() { return blockIdx.x; }

@@ -845,20 +845,35 @@ OCT_KERNEL(k_window_prefix)(DevBatch b, const uint64_t* pw, uint64_t* prefix)
 }
 
 // key of every window (never 0) and, per key, the smallest window index: open addressing, keys claimed with compare-and-swap
+// (round 4: the table is one small table PER REGION - tab_base[g], tab_mask[g]: a power of two of slots around 1.25-2.5 x the region's windows - because a region's windows only
+// ever meet each other: the threads of a wave work on one region's few hundred KB of slots, which stay in L2, instead of scattering atomics over one 800 MB table)
 OCT_KERNEL(k_window_insert)(DevBatch b, const uint64_t* pwinv, const uint64_t* prefix, uint32_t n_bases, unsigned long long* wkey,
-                            unsigned long long* tkeys, uint32_t* tvals, uint32_t tmask)
+                            unsigned long long* tkeys, uint32_t* tvals, const uint32_t* tab_base, const uint32_t* tab_mask, const uint32_t* blk_hap, int phase)
 {
     const uint32_t x = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (x >= n_bases) return;
-    const uint32_t h = upper_bound_idx(b.hoff, b.n_haps + 1, x), ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, off = x - ho;
+    // blk_hap[workgroup] = the haplotype of the workgroup's first window (host-made): a binary search per wave over 49 k haplotype offsets was 16 dependent scalar loads, and under
+    // the load of 300 k waves those were most of the kernel
+    uint32_t h = blk_hap[hw::block_idx()];
+    while (h + 1 < b.n_haps && b.hoff[h + 1] <= x) ++h;
+    // Two launches: phase 0 = the windows of every region's FIRST haplotype, phase 1 = all the others. A region's haplotypes are on the chip at the same time, so in one
+    // launch its ~20 copies of a window all found the slot empty and all swapped (30 M atomics for 19.6 M windows: the L2's atomic unit was the bound); after phase 0 most
+    // windows of phase 1 find their key with a plain look and touch nothing.
+    if (((h == 0 || b.hap_region[h - 1] != b.hap_region[h]) ? 0 : 1) != phase) return;
+    const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, off = x - ho;
     const uint32_t end = off + b.window_len < Lh ? off + b.window_len : Lh;
     const uint64_t* pre = prefix + (size_t)ho + h;
     const uint64_t sum = (pre[end] - pre[off]) * pwinv[off];                 // the window's polynomial, independent of where it starts
     const unsigned long long key = (mix64(sum ^ mix64((uint64_t)(end - off) << 32 | b.hap_region[h])) & ((uint64_t)b.dedup_hash_mask << 32 | b.dedup_hash_mask)) | 1ull;
     wkey[x] = key;
+    const uint32_t g = b.hap_region[h], base = tab_base[g], tmask = tab_mask[g];
+    // A key is met by as many windows as haplotypes share it (5-20 in a region of a few edits apart): one compare-and-swap and one atomic minimum per window were 39 M atomics on
+    // ~3 M addresses, and the L2's atomic unit was the kernel's bound. A plain look first: a slot that already shows the key needs no swap, a value already below x no minimum (values
+    // only fall; a stale look costs an atomic that changes nothing).
     for (uint32_t slot = (uint32_t)(key >> 20) & tmask; ; slot = (slot + 1) & tmask) {
-        const unsigned long long prev = hw::atomic_cas_u64(tkeys + slot, 0ull, key);
-        if (prev == 0ull || prev == key) { hw::atomic_min_u32(tvals + slot, x); break; }
+        unsigned long long seen = hw::load_device_u64(tkeys + base + slot);
+        if (seen == 0ull) seen = hw::atomic_cas_u64(tkeys + base + slot, 0ull, key);
+        if (seen == 0ull || seen == key) { if (hw::load_device_u32(tvals + base + slot) > x) hw::atomic_min_u32(tvals + base + slot, x); break; }
     }
 }
 
@@ -879,18 +894,21 @@ OCT_DEVICE bool window_bytes_equal(const DevBatch& b, uint32_t a, uint32_t c, ui
 //                       2.5 ms; now the runs' heads and 14 bytes per window).
 // Still every byte of a shared window has been compared with its canonical twin's: hashes only propose.
 OCT_DEVICE uint32_t window_len_at(const DevBatch& b, uint32_t off, uint32_t Lh) { return (off + b.window_len < Lh ? off + b.window_len : Lh) - off; }
-OCT_KERNEL(k_window_candidate)(DevBatch b, uint32_t n_bases, const unsigned long long* wkey, const unsigned long long* tkeys, const uint32_t* tvals, uint32_t tmask)
+OCT_KERNEL(k_window_candidate)(DevBatch b, uint32_t n_bases, const unsigned long long* wkey, const unsigned long long* tkeys, const uint32_t* tvals,
+                               const uint32_t* tab_base, const uint32_t* tab_mask, const uint32_t* blk_hap)
 {
     const uint32_t x = hw::block_idx() * hw::block_dim() + hw::thread_idx();
     if (x >= n_bases) return;
     const unsigned long long key = wkey[x];
+    uint32_t h = blk_hap[hw::block_idx()];
+    while (h + 1 < b.n_haps && b.hoff[h + 1] <= x) ++h;
+    const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho;
+    const uint32_t g = b.hap_region[h], base = tab_base[g], tmask = tab_mask[g];
     uint32_t slot = (uint32_t)(key >> 20) & tmask;
-    while (tkeys[slot] != key) slot = (slot + 1) & tmask;
-    const uint32_t first = tvals[slot];
+    while (tkeys[base + slot] != key) slot = (slot + 1) & tmask;
+    const uint32_t first = tvals[base + slot];
     uint32_t cand = x;
     if (first != x) {
-        const uint32_t x_wave = hw::readfirstlane(hw::block_idx() * hw::block_dim() + (hw::thread_idx() & ~63u));
-        const uint32_t h = upper_bound_near(b.hoff, b.n_haps + 1, x_wave, x), ho = b.hoff[h], Lh = b.hoff[h + 1] - ho;
         const uint32_t h2 = upper_bound_idx(b.hoff, b.n_haps + 1, first), ho2 = b.hoff[h2], Lh2 = b.hoff[h2 + 1] - ho2;
         if (window_len_at(b, x - ho, Lh) == window_len_at(b, first - ho2, Lh2) && b.hap_region[h] == b.hap_region[h2]) cand = first;
     }

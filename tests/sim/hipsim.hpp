@@ -209,6 +209,8 @@ inline uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p;
 inline unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long expected, unsigned long long v) { const auto o = *p; if (o == expected) *p = v; return o; }
 inline void lds_store_u64(unsigned long long* p, unsigned long long v) { *(volatile unsigned long long*)p = v; }
 inline unsigned long long lds_load_u64(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
+inline unsigned long long load_device_u64(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
+inline uint32_t load_device_u32(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 inline void spin_pause() { hipsim::yield_to_sched(hipsim::kRun); }      // a lane that waits for another wave's mailbox: let the other lanes run
 inline uint32_t thread_idx() { return hipsim::S().cur; }
 inline uint32_t block_idx() { return hipsim::S().bid; }

@@ -29,6 +29,15 @@ cp.check_shared_pairs("sim")                       # canonical windows, matcher,
 cp.check_launch_modes("sim")                       # device- and host-sized launches, forced scratch overflow, the multi-region forms (two DP launches, tiled scan, DMA copies)
 import check_error_model as ce
 ce.check_device_kernels_on_the_corpus("sim", 40)   # both penalty-vector kernels
+import os
+os.environ["OCT_PHMM_LANE_MAPPER"] = "1"           # round 4: one lane per pair (probes, the pass over the hash rows, the wave's counting of undecided pairs), the mismatch account
+cp.check_device_kmer_mapper("sim"); cp.check_ragged_and_edges("sim"); cp.check_mapper_mismatch_account("sim")
+os.environ.pop("OCT_PHMM_LANE_MAPPER", None)
+os.environ["OCT_PHMM_REC_CHUNK"] = "16"            # read records restaged every 16 iterations (the row pointer is rebased below the row's start)
+cp.check_basic("sim"); cp.check_generic_bytes("sim"); cp.check_late_traceback_start("sim")
+os.environ.pop("OCT_PHMM_REC_CHUNK", None)
+cp.check_linked_chunks("sim")                      # templates of linked chunks, ragged reads
+cp.check_page_locked_caller_buffers("sim")         # page-locked arrays / out: the direct upload path, results landing in the caller's buffer
 print("SANITIZED-OK")
 """
 
