@@ -1023,21 +1023,35 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     if (R->row_offsets && (!monotone(R->row_offsets, n_rows) || R->row_offsets[0] != 0 || R->row_offsets[n_rows] != R->n_reads))
         return fail(status, OCT_PHMM_EINVAL, "row_offsets must partition the reads");
     const uint32_t n_read_bases = R->offsets[R->n_reads], n_hap_bases = H->offsets[H->n_haps];
-    {   // branch-free reductions (these loops run over every base of the batch and must vectorise)
-        std::atomic<uint32_t> qor {0}, por {0};
-        host_parallel(n_read_bases, (size_t)8 << 20, [&](size_t lo, size_t hi) {
-            uint32_t v = 0;
-            for (size_t i = lo; i < hi; ++i) v |= R->qualities[i];
-            qor.fetch_or(v);
+    // The contract's range checks and the bounds the FASTADD decision below needs, in ONE pass over the read qualities and one over the penalty vectors. These loops are
+    // the first touch of every byte of the batch - memory-bound on a core (a 64-region device batch of the region server: 12.5 MB, 1.4 ms of a 2.2 ms upload when each
+    // check was its own single-threaded pass) - so a batch from ~2 MB on is cut over up to four threads. Inner loops are branch-free and vectorise.
+    uint32_t q_or = 0, pen_or = 0, gomax = 0, gemax = 0, t_min = 0xffffffffu; uint64_t sum_q_max = 0; bool any_empty = false;
+    {
+        std::mutex mx;
+        const size_t read_grain = std::max<size_t>(1, (size_t)R->n_reads / std::max<size_t>(1, (size_t)n_read_bases >> 20));      // reads per ~1 MB of qualities
+        host_parallel(R->n_reads, read_grain, [&](size_t r0, size_t r1) {
+            uint32_t v = 0, shortest = 0xffffffffu; uint64_t best = 0;
+            for (size_t r = r0; r < r1; ++r) {
+                const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
+                uint32_t sq = 0, o = 0;                           // reads are < 32,768 bases of quality <= 127
+                for (uint32_t i = 0; i < n; ++i) { sq += q[i]; o |= q[i]; }
+                v |= o; best = std::max<uint64_t>(best, sq); shortest = std::min(shortest, n);
+            }
+            std::lock_guard<std::mutex> lk(mx); q_or |= v; sum_q_max = std::max(sum_q_max, best); t_min = std::min(t_min, shortest);
         });
-        if (qor.load() & 0x80u) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
-        if (!gen_device) host_parallel(n_hap_bases, (size_t)4 << 20, [&](size_t lo, size_t hi) {       // (device-made vectors come out of validated tables)
-            uint32_t v = 0;
-            for (size_t i = lo; i < hi; ++i)
-                v |= (uint32_t)(uint8_t)H->gap_open[i] | (uint8_t)H->gap_extend[i] | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
-            por.fetch_or(v);
+        any_empty = R->n_reads && t_min == 0;
+        if (q_or & 0x80u) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
+        if (!gen_device) host_parallel(n_hap_bases, (size_t)1 << 18, [&](size_t lo, size_t hi) {       // (device-made vectors come out of validated tables)
+            uint32_t v = 0, a = 0, e = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                const uint32_t go = (uint8_t)H->gap_open[i], ge = (uint8_t)H->gap_extend[i];
+                v |= go | ge | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
+                a = std::max(a, go); e = std::max(e, ge);           // (as bytes: with no sign bit anywhere - checked below - these are the values)
+            }
+            std::lock_guard<std::mutex> lk(mx); pen_or |= v; gomax = std::max(gomax, a); gemax = std::max(gemax, e);
         });
-        if (por.load() & 0x80u) return fail(status, OCT_PHMM_EINVAL, "negative penalty");
+        if (pen_or & 0x80u) return fail(status, OCT_PHMM_EINVAL, "negative penalty");
     }
 
     // regions
@@ -1087,29 +1101,13 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         // path along its diagonal plus one gap opening, every not-yet-initialised ("infinite") cell by infinity_ plus the deletion chain's
         // growth (the 0x7FF tolerance the reference itself relies on, simd_pair_hmm.hpp:55). If neither can, a 32-bit add of two packed
         // halves never carries between them and k_dp uses v_add_u32 (FASTADD); otherwise it keeps v_pk_add_u16. Results are identical.
-        std::mutex mx; uint64_t sum_q_max = 0; uint32_t gomax = 0, gemax = 0, t_min = 0xffffffffu;
-        host_parallel(R->n_reads, (size_t)50000, [&](size_t r0, size_t r1) {
-            uint64_t best = 0; uint32_t shortest = 0xffffffffu;
-            for (size_t r = r0; r < r1; ++r) {
-                uint32_t sq = 0;                               // reads are < 32,768 bases of quality <= 127
-                const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
-                for (uint32_t i = 0; i < n; ++i) sq += q[i];
-                best = std::max<uint64_t>(best, sq); shortest = std::min(shortest, n);
-            }
-            std::lock_guard<std::mutex> lk(mx); sum_q_max = std::max(sum_q_max, best); t_min = std::min(t_min, shortest);
-        });
         if (gen_device) {                                   // the vectors do not exist yet: bound them by the model's tables
             const oct_phmm_error_model& m = h->model;
             for (int i = 0; i < OCT_PHMM_INDEL_TABLE; ++i) {
                 gomax = std::max<uint32_t>(gomax, std::max(std::max(m.at_homopolymer_open[i], m.cg_homopolymer_open[i]), std::max(m.dinucleotide_open[i], m.trinucleotide_open[i])));
                 gemax = std::max<uint32_t>(gemax, std::max(m.homopolymer_extend[i], std::max(m.dinucleotide_extend[i], m.trinucleotide_extend[i])));
             }
-        } else
-        host_parallel(n_hap_bases, (size_t)4 << 20, [&](size_t lo, size_t hi) {
-            uint32_t a = 0, e = 0;
-            for (size_t i = lo; i < hi; ++i) { a = std::max<uint32_t>(a, (uint32_t)H->gap_open[i]); e = std::max<uint32_t>(e, (uint32_t)H->gap_extend[i]); }
-            std::lock_guard<std::mutex> lk(mx); gomax = std::max(gomax, a); gemax = std::max(gemax, e);
-        });
+        }
         const uint64_t B64 = (uint64_t)h->band, nuc = (uint64_t)std::max(0, h->cfg.nuc_prior);
         // A read shorter than its wave's longest keeps iterating (padding quality 64) after its end cells were captured: its rows past the end
         // grow by at most one insertion step (gap extend + nuc_prior) per iteration. An uninitialised lane runs its insertion chain
@@ -1119,7 +1117,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         const uint64_t garbage = 4 * (2 * B64 * (gemax + nuc) + 64 + gomax + gemax + nuc) + 64;
         b->fast_adds = finite < 0xF800u && garbage < 0x7FFu && h->cfg.nuc_prior >= 0 && !tune::exact_adds();
     }
-    for (uint32_t r = 0; r < R->n_reads; ++r) if (R->offsets[r + 1] == R->offsets[r]) return fail(status, OCT_PHMM_EINVAL, "empty read");
+    if (any_empty) return fail(status, OCT_PHMM_EINVAL, "empty read");
     std::vector<uint32_t> h_pos; std::vector<uint8_t> h_npos;
     const uint32_t S = (uint32_t)h->cfg.max_mapping_positions;
     if (positions) {
@@ -1311,11 +1309,15 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         if (b->dsl && !gen_device && !d.wide) {
             // which of the two cost flavours can occur at all (k_hap_tables / read_flags_thread decide per read and haplotype): a clean region launches no generic kernels
             const uint8_t* rb = (const uint8_t*)R->bases; const uint8_t* hb = (const uint8_t*)H->bases;
-            uint32_t dirty = 0;                                  // branch-free: these loops run over every base of the call and must vectorise
+            std::atomic<uint32_t> dirty {0};                     // branch-free: these loops run over every base of the call and must vectorise (and take threads as the checks above do)
             auto not_acgt = [](uint8_t c) -> uint32_t { return ((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')) ? 0u : 1u; };
-            for (uint32_t i = 0; i < n_read_bases; ++i) dirty |= not_acgt(rb[i]);
-            for (uint32_t i = 0; i < n_hap_bases; ++i) dirty |= not_acgt(hb[i]) | (H->snv_mask_fwd[i] == '0' ? 1u : 0u) | (H->snv_mask_rev[i] == '0' ? 1u : 0u);
-            b->dsl_flavours = dirty ? 3 : 1;
+            host_parallel(n_read_bases, (size_t)1 << 20, [&](size_t lo, size_t hi) { uint32_t v = 0; for (size_t i = lo; i < hi; ++i) v |= not_acgt(rb[i]); dirty.fetch_or(v); });
+            host_parallel(n_hap_bases, (size_t)1 << 18, [&](size_t lo, size_t hi) {
+                uint32_t v = 0;
+                for (size_t i = lo; i < hi; ++i) v |= not_acgt(hb[i]) | (H->snv_mask_fwd[i] == '0' ? 1u : 0u) | (H->snv_mask_rev[i] == '0' ? 1u : 0u);
+                dirty.fetch_or(v);
+            });
+            b->dsl_flavours = dirty.load() ? 3 : 1;
         } else b->dsl_flavours = d.wide ? 2 : 3;            // bit 0: fast-cost lists may hold tasks, bit 1: generic lists may
     }
     if (b->dedup && !b->h_segs.empty()) pk.upload(b->h_segs.data(), b->h_segs.size(), (const DedupSeg**)&b->d_segs);

@@ -988,16 +988,25 @@ OCT_KERNEL(k_dedup_match)(DevBatch b, const DedupSeg* segs, uint32_t n_segs)
         const uint32_t n = b.dd_n[r];
         for (uint32_t j = 0; j < n; ++j) find_or_insert(b.dd_hash[(size_t)j * b.n_reads + r], b.dd_hap[(size_t)j * b.n_reads + r]);
     }
-    for (uint32_t h0 = sg.hap_lo; h0 < sg.hap_hi; h0 += 8) {    // eight haplotypes' hashes in flight at a time (a lone wave per SIMD hides no latency)
-        uint32_t keys[8];
+    // Eight haplotypes' hashes per round, the NEXT round's loads in flight while this round's keys go through the table (a lone wave per SIMD hides no latency: a region
+    // of 200 haplotypes is 25 dependent rounds, and on a device batch of 64 regions the launch waits for exactly that wave). Every haplotype of a region pairs with the
+    // region's reads, so haplotype h's pairs start at pair_base + (h - hap_first) * n_reads: no look-up of hap_pair_off in front of each load.
+    const uint64_t pair_base = b.hap_pair_off[sg.hap_first] + rl;
+    auto pair_at = [&](uint32_t hp) -> uint64_t { return pair_base + (uint64_t)(hp - sg.hap_first) * sg.n_reads; };
+    uint32_t keys[8], next[8];
 #pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) keys[u] = h0 + u < sg.hap_hi ? b.pair_hash[b.hap_pair_off[h0 + u] + rl] : 0u;
+    for (uint32_t u = 0; u < 8; ++u) keys[u] = sg.hap_lo + u < sg.hap_hi ? b.pair_hash[pair_at(sg.hap_lo + u)] : 0u;
+    for (uint32_t h0 = sg.hap_lo; h0 < sg.hap_hi; h0 += 8) {
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) next[u] = h0 + 8 + u < sg.hap_hi ? b.pair_hash[pair_at(h0 + 8 + u)] : 0u;
 #pragma unroll
         for (uint32_t u = 0; u < 8; ++u) {
             if (!keys[u]) continue;
             const uint32_t found = find_or_insert(keys[u], h0 + u);
-            if (found != kNoPair) b.pair_rep[b.hap_pair_off[h0 + u] + rl] = found;     // (the haplotype: k_dedup_verify turns it into the pair, or forgets it)
+            if (found != kNoPair) b.pair_rep[pair_at(h0 + u)] = found;                  // (the haplotype: k_dedup_verify turns it into the pair, or forgets it)
         }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) keys[u] = next[u];
     }
     if (sg.continues) {
         uint32_t n = 0;

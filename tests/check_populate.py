@@ -1,5 +1,6 @@
 """Backend-independent parity checks of the whole populate() path against the CPU oracle."""
 import numpy as np
+import pytest
 
 import oracle
 from backends import make_engine
@@ -752,3 +753,40 @@ def check_linked_chunks(backend, tol=0.0):
     g["read_len"] = rng.integers(40, 91, 12)
     out.append(compare(backend, synth.batch_from_regions([g]), tol, max_indel_error=8))
     return out
+
+
+def check_input_contract(backend):
+    """What an upload refuses (OCT_PHMM_EINVAL, nothing launched): a base quality above 127, a negative penalty, an empty read - in a region-sized batch and in one big
+    enough (3 MB of qualities, 1.2 M haplotype bases) for the checks to run on several host threads, with the offending byte in the first, a middle and the last chunk.
+    The same arrays untouched are accepted."""
+    import copy
+    rng = np.random.default_rng(77)
+    small = synth.batch_from_regions([synth.make_region(rng, 30, 3, B=16, positions="none")])
+    g = synth.make_region(rng, 20_000, 1, T=150, Lh=300, B=16, positions="none")
+    big = synth.batch_from_regions([g])
+    wide = synth.batch_from_regions([synth.make_region(rng, 2, 3_000, T=150, Lh=400, B=16, positions="none")])
+    eng = make_engine(backend, max_indel_error=16)
+    rb = eng.upload(small); rb.free()
+    for batch in (small, big, wide):
+        nq, nh = len(batch.read_quals), len(batch.gap_open)
+        for where in (0, nq // 2, nq - 1):
+            bad = copy.copy(batch); bad.read_quals = batch.read_quals.copy(); bad.read_quals[where] = 128
+            with pytest.raises(Exception) as e:
+                eng.upload(bad)
+            assert e.value.code == abi.EINVAL and "quality" in str(e.value), str(e.value)
+        for name in ("gap_open", "gap_extend", "snv_prior_fwd", "snv_prior_rev"):
+            for where in (0, nh // 2, nh - 1):
+                bad = copy.copy(batch); arr = getattr(batch, name).copy(); arr[where] = -1; setattr(bad, name, arr)
+                with pytest.raises(Exception) as e:
+                    eng.upload(bad)
+                assert e.value.code == abi.EINVAL and "penalty" in str(e.value), (name, where, str(e.value))
+        for r in (0, batch.n_reads // 2, batch.n_reads - 1):
+            bad = copy.copy(batch); off = batch.read_offsets.copy()
+            if r + 1 < batch.n_reads: off[r + 1] = off[r]            # read r empty (read r + 1 takes its bases)
+            else: off[r] = off[r + 1]
+            bad.read_offsets = off
+            with pytest.raises(Exception) as e:
+                eng.upload(bad)
+            assert e.value.code == abi.EINVAL, str(e.value)
+        rb = eng.upload(batch); rb.free()                            # the arrays themselves are fine
+    eng.close()

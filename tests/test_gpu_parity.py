@@ -394,6 +394,10 @@ def test_gpu_lane_per_pair_mapper(monkeypatch):
     cp.check_device_kmer_mapper("gpu", TOL)
 
 
+def test_gpu_upload_refuses_what_the_input_contract_excludes():
+    cp.check_input_contract("gpu")
+
+
 def test_gpu_page_locked_caller_buffers_skip_the_staging_copies():
     assert cp.check_page_locked_caller_buffers("gpu", TOL) == 10
 

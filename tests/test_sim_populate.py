@@ -172,3 +172,7 @@ def test_sim_read_records_staged_in_chunks(chunk, monkeypatch):
     if chunk == "16":
         cp.check_late_traceback_start("sim")
         cp.check_templates_and_regions("sim")
+
+
+def test_sim_upload_refuses_what_the_input_contract_excludes():
+    cp.check_input_contract("sim")

@@ -14,6 +14,7 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <sys/resource.h>
 #include <vector>
 #include "oct_phmm.h"
 
@@ -122,13 +123,16 @@ int main(int argc, char** argv)
             // pass 0 warms the handles' pools (file mode: one whole round - the regions differ in size by orders of magnitude); pass 1 is timed, `reps` rounds
             const int count = pass ? n_regions * reps : (from_file ? n_regions : std::min(n_regions, 4 * T));
             uint64_t c0 = 0, b0 = 0, c1 = 0, b1 = 0; oct_phmm_server_stats(srv, &c0, &b0);
+            auto cpu_s = [] { rusage u; getrusage(RUSAGE_SELF, &u); return (double)u.ru_utime.tv_sec + u.ru_utime.tv_usec * 1e-6 + (double)u.ru_stime.tv_sec + u.ru_stime.tv_usec * 1e-6; };
+            const double cpu0 = cpu_s();
             const auto t0 = std::chrono::steady_clock::now();
             std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t, count);
             for (auto& x : th) x.join();
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double cpu = cpu_s() - cpu0;                       // host cores the process kept busy (callers + workers + the runtime's threads)
             oct_phmm_server_stats(srv, &c1, &b1);
-            if (pass) printf("{\"mode\": \"server\", \"devices\": %d, \"threads\": %d, \"regions_per_s\": %.1f, \"M_loglik_per_s\": %.2f, \"regions_per_device_batch\": %.2f, \"failures\": %d}\n",
-                             (int)devs.size(), T, (double)count / dt, n_loglik * reps / dt / 1e6, (double)(c1 - c0) / (double)std::max<uint64_t>(1, b1 - b0), failures);
+            if (pass) printf("{\"mode\": \"server\", \"devices\": %d, \"threads\": %d, \"regions_per_s\": %.1f, \"M_loglik_per_s\": %.2f, \"regions_per_device_batch\": %.2f, \"host_cores_busy\": %.2f, \"failures\": %d}\n",
+                             (int)devs.size(), T, (double)count / dt, n_loglik * reps / dt / 1e6, (double)(c1 - c0) / (double)std::max<uint64_t>(1, b1 - b0), cpu / dt, failures);
         }
         if (T == threads.back()) {                                  // the server's answers against plain populate calls on a handle of our own, bit for bit
             oct_phmm_handle* hv = nullptr;
