@@ -183,10 +183,11 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 12, in_flight: int = 2, pipelined: bool = True):
+def stream_from_host(eng, cfg, batch, resident, n_regions, n_batches: int = 36, in_flight: int = 2, pipelined: bool = True):
     """What a caller gets who hands over HOST buffers: (i) one oct_phmm_populate of the many-region batch, PCIe both ways; (ii) the same batch
     over and over from `in_flight` host threads with a handle each - while one handle's batch computes, the others' next batches are validated, packed,
-    copied up and their results stream back - the sustained rate over n_batches consecutive batches. Arrays and `out` live in page-locked memory
+    copied up and their results stream back - the sustained rate over n_batches consecutive batches (36: the first upload and the last run of the pipeline, which
+    overlap with nothing, are 5 % of a 12-batch measurement and under 2 % of this one). Arrays and `out` live in page-locked memory
     (oct_phmm_host_alloc: the DMA engines read and write the caller's buffers themselves); the `_pageable` figures are the same calls on plain numpy arrays,
     which the library stages through its own pinned buffers. Every result is compared with the resident run's matrix (which is verified against the
     reference's own populate on a sample of regions)."""

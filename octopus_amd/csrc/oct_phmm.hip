@@ -590,6 +590,9 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 constexpr uint32_t kScanBasesOneLaunchMax = 2 * 8192;
 constexpr size_t   kPinnedOutMinBytes = (size_t)8 << 20;  // results from here on: is the caller's `out` page-locked? (the question costs microseconds: not asked for region-sized calls)
 constexpr uint64_t kLaneMapMinPairs = 200000;          // k-mer mapper: one lane per pair from here on (k_kmer_map_lanes), one wave per pair below
+constexpr uint64_t kDslMaxPairs = 100000;              // device-sized launches (no read-back inside the step, grids sized by the host's bound) up to here; beyond, the read-back costs less than the
+                                                       // bound's empty workgroups and the scan of every base for the cost flavours: first 6 / 8 / 12 / 16 / 64 regions of the configs[3] stream
+                                                       // (50 k / 70 k / 110 k / 150 k / 660 k pairs), one populate from host buffers: 0.54 / 0.60 / 1.04 / 1.31 / 4.14 ms device-sized, 0.57 / 0.57 / 0.97 / 1.21 / 3.56 host-sized
 constexpr uint64_t kWalkRowsMaxPairs = 49152;          // traceback walks of batches up to here: one walk per 16-lane row (k_walk_rows)
 constexpr uint64_t kDslMergeMaxPairs = 12000;          // device-sized step: up to here the traceback and the score-only list of a flavour share one launch (k_dp_pair)
 constexpr uint32_t kDslMaxBlocks = 1024;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
@@ -1023,37 +1026,6 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     if (R->row_offsets && (!monotone(R->row_offsets, n_rows) || R->row_offsets[0] != 0 || R->row_offsets[n_rows] != R->n_reads))
         return fail(status, OCT_PHMM_EINVAL, "row_offsets must partition the reads");
     const uint32_t n_read_bases = R->offsets[R->n_reads], n_hap_bases = H->offsets[H->n_haps];
-    // The contract's range checks and the bounds the FASTADD decision below needs, in ONE pass over the read qualities and one over the penalty vectors. These loops are
-    // the first touch of every byte of the batch - memory-bound on a core (a 64-region device batch of the region server: 12.5 MB, 1.4 ms of a 2.2 ms upload when each
-    // check was its own single-threaded pass) - so a batch from ~2 MB on is cut over up to four threads. Inner loops are branch-free and vectorise.
-    uint32_t q_or = 0, pen_or = 0, gomax = 0, gemax = 0, t_min = 0xffffffffu; uint64_t sum_q_max = 0; bool any_empty = false;
-    {
-        std::mutex mx;
-        const size_t read_grain = std::max<size_t>(1, (size_t)R->n_reads / std::max<size_t>(1, (size_t)n_read_bases >> 20));      // reads per ~1 MB of qualities
-        host_parallel(R->n_reads, read_grain, [&](size_t r0, size_t r1) {
-            uint32_t v = 0, shortest = 0xffffffffu; uint64_t best = 0;
-            for (size_t r = r0; r < r1; ++r) {
-                const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
-                uint32_t sq = 0, o = 0;                           // reads are < 32,768 bases of quality <= 127
-                for (uint32_t i = 0; i < n; ++i) { sq += q[i]; o |= q[i]; }
-                v |= o; best = std::max<uint64_t>(best, sq); shortest = std::min(shortest, n);
-            }
-            std::lock_guard<std::mutex> lk(mx); q_or |= v; sum_q_max = std::max(sum_q_max, best); t_min = std::min(t_min, shortest);
-        });
-        any_empty = R->n_reads && t_min == 0;
-        if (q_or & 0x80u) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
-        if (!gen_device) host_parallel(n_hap_bases, (size_t)1 << 18, [&](size_t lo, size_t hi) {       // (device-made vectors come out of validated tables)
-            uint32_t v = 0, a = 0, e = 0;
-            for (size_t i = lo; i < hi; ++i) {
-                const uint32_t go = (uint8_t)H->gap_open[i], ge = (uint8_t)H->gap_extend[i];
-                v |= go | ge | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
-                a = std::max(a, go); e = std::max(e, ge);           // (as bytes: with no sign bit anywhere - checked below - these are the values)
-            }
-            std::lock_guard<std::mutex> lk(mx); pen_or |= v; gomax = std::max(gomax, a); gemax = std::max(gemax, e);
-        });
-        if (pen_or & 0x80u) return fail(status, OCT_PHMM_EINVAL, "negative penalty");
-    }
-
     // regions
     uint32_t one_row[2] = {0, n_rows}, one_hap[2] = {0, H->n_haps};
     uint8_t one_hf = flank ? 1 : 0; oct_phmm_flank_state one_fl = flank ? *flank : oct_phmm_flank_state {0, 0};
@@ -1088,6 +1060,43 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     b->h_hap_region = hap_region; b->h_hap_out_off = hap_out_off; b->h_reg_hap0.assign(g_hap, g_hap + G + 1);
     b->n_out = hap_out_off[H->n_haps]; b->n_pairs = hap_pair_off[H->n_haps];
     if (b->n_pairs >= 0xffffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "more than 2^32-1 pairs in one batch");
+    // The contract's range checks and the bounds the FASTADD decision below needs, in ONE pass over the read qualities and one over the penalty vectors. These loops are
+    // the first touch of every byte of the batch - memory-bound on a core (a 64-region device batch of the region server: 12.5 MB, 1.4 ms of a 2.2 ms upload when each
+    // check was its own single-threaded pass) - so a batch from ~2 MB on is cut over up to four threads. Inner loops are branch-free and vectorise.
+    // A batch that may take device-sized launches also learns here whether every base is one of ACGT and every SNV mask byte set (a clean batch launches no generic kernels).
+    uint32_t q_or = 0, pen_or = 0, gomax = 0, gemax = 0, t_min = 0xffffffffu, dirty = 0; uint64_t sum_q_max = 0; bool any_empty = false;
+    const bool dsl_wanted = !align_mode && tune::device_sized() != 0 && (b->n_pairs <= kDslMaxPairs || tune::device_sized() > 0);
+    const bool want_dirty = dsl_wanted && !gen_device;
+    {
+        std::mutex mx;
+        auto not_acgt = [](uint8_t c) -> uint32_t { return ((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')) ? 0u : 1u; };
+        const size_t read_grain = std::max<size_t>(1, (size_t)R->n_reads / std::max<size_t>(1, (size_t)n_read_bases >> 20));      // reads per ~1 MB of qualities
+        host_parallel(R->n_reads, read_grain, [&](size_t r0, size_t r1) {
+            uint32_t v = 0, shortest = 0xffffffffu, dd = 0; uint64_t best = 0;
+            for (size_t r = r0; r < r1; ++r) {
+                const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
+                uint32_t sq = 0, o = 0;                           // reads are < 32,768 bases of quality <= 127
+                for (uint32_t i = 0; i < n; ++i) { sq += q[i]; o |= q[i]; }
+                v |= o; best = std::max<uint64_t>(best, sq); shortest = std::min(shortest, n);
+            }
+            if (want_dirty && r1 > r0) { const uint8_t* rb = (const uint8_t*)R->bases; for (size_t i = R->offsets[r0]; i < R->offsets[r1]; ++i) dd |= not_acgt(rb[i]); }
+            std::lock_guard<std::mutex> lk(mx); q_or |= v; dirty |= dd; sum_q_max = std::max(sum_q_max, best); t_min = std::min(t_min, shortest);
+        });
+        any_empty = R->n_reads && t_min == 0;
+        if (q_or & 0x80u) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
+        if (!gen_device) host_parallel(n_hap_bases, (size_t)1 << 18, [&](size_t lo, size_t hi) {       // (device-made vectors come out of validated tables)
+            uint32_t v = 0, a = 0, e = 0, dd = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                const uint32_t go = (uint8_t)H->gap_open[i], ge = (uint8_t)H->gap_extend[i];
+                v |= go | ge | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
+                a = std::max(a, go); e = std::max(e, ge);           // (as bytes: with no sign bit anywhere - checked below - these are the values)
+            }
+            if (want_dirty) { const uint8_t* hb = (const uint8_t*)H->bases; for (size_t i = lo; i < hi; ++i) dd |= not_acgt(hb[i]) | (H->snv_mask_fwd[i] == '0' ? 1u : 0u) | (H->snv_mask_rev[i] == '0' ? 1u : 0u); }
+            std::lock_guard<std::mutex> lk(mx); pen_or |= v; dirty |= dd; gomax = std::max(gomax, a); gemax = std::max(gemax, e);
+        });
+        if (pen_or & 0x80u) return fail(status, OCT_PHMM_EINVAL, "negative penalty");
+    }
+
     for (uint32_t r = 0; r < R->n_reads; ++r) b->t_cap = std::max(b->t_cap, R->offsets[r + 1] - R->offsets[r]);
     for (uint32_t hp = 0; hp < H->n_haps; ++hp) b->lh_cap = std::max(b->lh_cap, H->offsets[hp + 1] - H->offsets[hp]);
     {
@@ -1304,20 +1313,11 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         const uint64_t trace_cap = per_pair < 0 ? Gs : std::min<uint64_t>(list_bound, (b->n_pairs * (uint64_t)per_pair + pad + Gs - 1) / Gs * Gs + Gs);   // (negative: one task group, test hook)
         const uint64_t bp_bytes = trace_cap / Gs * ((uint64_t)bp_tiles(b->t_cap, Bw) * 4096u * (b->stream ? (uint64_t)h->lanes_c : 1u));
         const uint64_t cap = std::min<uint64_t>((uint64_t)8 << 30, h->bp_budget);
-        b->dsl = b->slices.size() == 1 && !align_mode && b->n_pairs > 0 && bp_bytes <= cap && list_bound < 0x7fffffffull && tune::device_sized() != 0;
+        b->dsl = b->slices.size() == 1 && dsl_wanted && b->n_pairs > 0 && bp_bytes <= cap && list_bound < 0x7fffffffull;
         b->dsl_list_bound = b->dsl ? (uint32_t)list_bound : 0; b->dsl_total_bound = b->dsl ? (size_t)total_bound : 0; b->dsl_trace_cap = b->dsl ? (uint32_t)trace_cap : 0;
-        if (b->dsl && !gen_device && !d.wide) {
+        if (b->dsl && want_dirty && !d.wide) {
             // which of the two cost flavours can occur at all (k_hap_tables / read_flags_thread decide per read and haplotype): a clean region launches no generic kernels
-            const uint8_t* rb = (const uint8_t*)R->bases; const uint8_t* hb = (const uint8_t*)H->bases;
-            std::atomic<uint32_t> dirty {0};                     // branch-free: these loops run over every base of the call and must vectorise (and take threads as the checks above do)
-            auto not_acgt = [](uint8_t c) -> uint32_t { return ((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')) ? 0u : 1u; };
-            host_parallel(n_read_bases, (size_t)1 << 20, [&](size_t lo, size_t hi) { uint32_t v = 0; for (size_t i = lo; i < hi; ++i) v |= not_acgt(rb[i]); dirty.fetch_or(v); });
-            host_parallel(n_hap_bases, (size_t)1 << 18, [&](size_t lo, size_t hi) {
-                uint32_t v = 0;
-                for (size_t i = lo; i < hi; ++i) v |= not_acgt(hb[i]) | (H->snv_mask_fwd[i] == '0' ? 1u : 0u) | (H->snv_mask_rev[i] == '0' ? 1u : 0u);
-                dirty.fetch_or(v);
-            });
-            b->dsl_flavours = dirty.load() ? 3 : 1;
+            b->dsl_flavours = dirty ? 3 : 1;
         } else b->dsl_flavours = d.wide ? 2 : 3;            // bit 0: fast-cost lists may hold tasks, bit 1: generic lists may
     }
     if (b->dedup && !b->h_segs.empty()) pk.upload(b->h_segs.data(), b->h_segs.size(), (const DedupSeg**)&b->d_segs);

@@ -24,7 +24,7 @@ for _ in range(15):
     c = time.perf_counter(); rb.download(); t["download"].append(time.perf_counter() - c)
     c = time.perf_counter(); rb.free(); t["free"].append(time.perf_counter() - c)
     c = time.perf_counter(); eng.populate(batch, out=out); t["populate"].append(time.perf_counter() - c)
-rb = eng.upload(batch); st = rb.stats(); ds = rb.device_sized(); rb.free()
+rb = eng.upload(batch); rb.run(); rb.wait(); st = rb.stats(); ds = rb.device_sized(); rb.free()
 time.sleep(0.05)
 eng.populate(batch, out=out)            # the last populate of the trace
 print(json.dumps({"regions": n, "reads": int(batch.n_reads), "haps": int(batch.n_haps), "device_sized": ds, "ms": {k: round(sorted(v)[len(v) // 2] * 1e3, 4) for k, v in t.items()}, "stats": st}))

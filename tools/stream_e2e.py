@@ -41,7 +41,7 @@ for tag, bt, mk in (("", locked, lambda: pool.empty(batch.out_size(), np.float64
     outs = [mk() for _ in range(k)]
     for e, o in zip(engs, outs):
         e.populate(bt, out=o)
-    n_each = max(2, 12 // k)
+    n_each = max(2, 36 // k)          # (the pipeline's fill and drain - one upload, one run that overlap with nothing - are under 2 % of 36 batches)
     def work(i):
         for _ in range(n_each):
             engs[i].populate(bt, out=outs[i])
