@@ -5,7 +5,7 @@ import sys; sys.path.insert(0, "/root/repo")
 from octopus_amd import synth
 synth.write_regions_file("/tmp/stream_regions.bin", synth.region_stream_shard(seed=42, n_regions=2000, B=16, positions="none"))
 PY
-(cd /tmp && OCT_BENCH_REPS=2 timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv -d /root/repo/$O/trace -o s -- /root/repo/tools/region_calls_bench --file /tmp/stream_regions.bin 64 > /root/repo/$O/trace.log 2> /root/repo/$O/trace.err)
+(cd /tmp && OCT_PHMM_SERVER_WORKERS=${WORKERS:-3} OCT_BENCH_REPS=2 timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv -d /root/repo/$O/trace -o s -- /root/repo/tools/region_calls_bench --file /tmp/stream_regions.bin ${CALLERS:-64} > /root/repo/$O/trace.log 2> /root/repo/$O/trace.err)
 python - <<'PY' > $O/cycles.txt
 import csv, glob, collections, statistics as st
 rows = []
