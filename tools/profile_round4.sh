@@ -29,5 +29,12 @@ done; done
 unset OCT_PHMM_LIB OCT_PHMM_SLICES
 timeout -k 5 300 python tools/stream_e2e.py 1 2 3 > $O/stream_e2e.json 2> $O/stream_e2e.err; echo "stream_e2e rc=$?" >> $O/rc.log
 timeout -k 5 200 python tools/long_read_legs.py > $O/long_legs.json 2> $O/long_legs.err; echo "long legs rc=$?" >> $O/rc.log
+# the long-read kernels' counters (k_dp_wide<16> on ccs256x12, k_dp_mw<256> on long512x8): instruction mix / waits, VALU busy cycles
+for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
+  D=long_pmc_$(echo $C | cut -d' ' -f1)
+  (cd /tmp && timeout -k 5 200 rocprofv3 --pmc $C --output-format csv -d /root/repo/$O/$D -o p -- python /root/repo/tools/long_read_legs.py ccs256x12 long512x8 > /root/repo/$O/$D.json 2> /root/repo/$O/$D.err); echo "$D rc=$?" >> $O/rc.log
+done
+(cd /tmp && timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/long_kstats -o s -- python /root/repo/tools/long_read_legs.py ccs256x12 long512x8 > /root/repo/$O/long_kstats.json 2> /root/repo/$O/long_kstats.err); echo "long kstats rc=$?" >> $O/rc.log
+find $O -name "*kernel_trace.csv" -size +1M -delete
 timeout -k 5 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/rc.log
 du -sh $O; cat $O/rc.log; tail -4 $O/pytest_gpu.log; cut -c1-300 $O/bench.json
