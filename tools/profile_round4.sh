@@ -19,6 +19,9 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT
   D=pmc_$(echo $C | cut -d' ' -f1)
   (cd /tmp && timeout -k 5 200 rocprofv3 --pmc $C --output-format csv -d /root/repo/$O/$D -o p -- python /root/repo/bench.py $P --steps 2 --warmup 1 > /root/repo/$O/$D.json 2> /root/repo/$O/$D.err); echo "$D rc=$?" >> $O/rc.log
 done
+# the counter summary bench.py's roofline block reads (profiles/r*_pmc_summary.json, stamped with the kernel sources' digest): written here so that the bench run below cites counters of these very kernels
+python tools/summarize_pmc.py $O/pmc_SQ_WAVES $O/pmc_SQ_ACTIVE_INST_VALU $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE --out $O/${SUMMARY:-r04_final_pmc_summary} --sha $(cat $O/kernel_source_sha) > $O/summarize.log 2>&1; echo "summarize rc=$?" >> $O/rc.log
+cp $O/${SUMMARY:-r04_final_pmc_summary}.json $O/${SUMMARY:-r04_final_pmc_summary}.md profiles/ 2>> $O/summarize.log
 # mapper + classifier wait split, before (round-3 kernels: tools/next_round/liboct_phmm_head.so) and after, on the headline batch and on stream-hq
 for W in 100kx128 stream-hq; do for V in before after; do
   if [ $V = before ]; then export OCT_PHMM_LIB=/root/repo/tools/next_round/liboct_phmm_head.so; else unset OCT_PHMM_LIB; fi
@@ -34,6 +37,7 @@ for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WA
   D=long_pmc_$(echo $C | cut -d' ' -f1)
   (cd /tmp && timeout -k 5 200 rocprofv3 --pmc $C --output-format csv -d /root/repo/$O/$D -o p -- python /root/repo/tools/long_read_legs.py ccs256x12 long512x8 > /root/repo/$O/$D.json 2> /root/repo/$O/$D.err); echo "$D rc=$?" >> $O/rc.log
 done
+python tools/summarize_pmc.py $O/long_pmc_SQ_WAVES $O/long_pmc_SQ_ACTIVE_INST_VALU --min-grid 1000 --out $O/r04_final_long_read_pmc --sha $(cat $O/kernel_source_sha) >> $O/summarize.log 2>&1
 (cd /tmp && timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$O/long_kstats -o s -- python /root/repo/tools/long_read_legs.py ccs256x12 long512x8 > /root/repo/$O/long_kstats.json 2> /root/repo/$O/long_kstats.err); echo "long kstats rc=$?" >> $O/rc.log
 find $O -name "*kernel_trace.csv" -size +1M -delete
 timeout -k 5 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/rc.log

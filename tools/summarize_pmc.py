@@ -67,8 +67,8 @@ git = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], c
 dirty = bool(subprocess.run(["git", "-C", str(ROOT), "status", "--porcelain", "--", "octopus_amd/csrc", "include"], capture_output=True, text=True).stdout.strip())
 out["_meta"] = {"kernel_source_sha": a.sha or engine.kernel_source_sha(), "git": git + ("+dirty" if dirty else ""), "passes": [str(p) for p in a.passes]}
 Path(a.out + ".json").write_text(json.dumps(out, indent=1) + "\n")
-cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
-        "SQ_WAIT_INST_ANY", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"]
+cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+        "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE", "launch_ns_under_pmc"]
 with open(a.out + ".md", "w") as f:
     f.write("| kernel | " + " | ".join(cols) + " |\n|---|" + "---|" * len(cols) + "\n")
     for k, d in sorted(out.items()):
