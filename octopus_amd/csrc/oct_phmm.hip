@@ -136,6 +136,7 @@ struct oct_phmm_batch {
     double* d_out = nullptr;
     uint32_t n_tasks[kNumKinds] = {0, 0, 0, 0};
     unsigned long long h_stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> h_win_blocks;                                   // canonical windows: (region, key class) of every k_window_region workgroup (upload)
     std::vector<uint32_t> h_tab_base, h_tab_mask;                     // canonical windows: first slot and mask of every region's hash table (upload)
     bool dedup = false, dedup_tables = false; std::vector<DedupSeg> h_segs; DedupSeg* d_segs = nullptr;   // exact de-duplication of pairs (phmm_kernels.hpp)
     std::vector<unsigned long long> h_stat_stripes;
@@ -208,6 +209,7 @@ inline size_t pinned_min_bytes(size_t dflt) { long long kb; return number("OCT_P
 inline bool pageable_h2d()    { return flag("OCT_PHMM_PAGEABLE_H2D"); }       // big batches: copy from the caller's arrays instead of the pinned staging halves
 inline bool map_count_only()  { return flag("OCT_PHMM_MAP_COUNT_ONLY"); }     // k-mer mapper without the exact shortcut
 inline bool big_mapper()      { return flag("OCT_PHMM_BIG_MAPPER"); }         // test hook: the long-haplotype mapper on short haplotypes
+inline bool window_lds()      { const char* e = get("OCT_PHMM_WINDOW_LDS"); return !e || atoi(e) != 0; }      // 0: canonical windows through per-region hash tables in global memory (k_window_insert x 2 + k_window_candidate) instead of k_window_region (A/B, tests)
 inline bool map_mismatches()  { const char* e = get("OCT_PHMM_MAP_MISMATCHES"); return !e || atoi(e) != 0; }   // 0: k_classify compares the bases of every candidate itself (A/B, tests)
 inline int  penalties_where() { const char* e = get("OCT_PHMM_PENALTIES"); return !e ? 0 : (e[0] == 'd' || e[0] == 'l' ? 2 : 1); }   // 0 by size, 1 host threads, 2 device
 inline int  dedup()           { const char* e = get("OCT_PHMM_DEDUP"); return !e ? -1 : atoi(e); }                                  // -1 by shape, 0 never, 1 wherever it is possible
@@ -1432,6 +1434,33 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             RT(rt::h2d(h->d_pw, pw.data(), n * 8, s)); RT(rt::h2d(h->d_pwinv, pwinv.data(), n * 8, s)); RT(rt::stream_sync(s));
             h->pw_n = n;
         }
+        if (tune::window_lds()) {
+            // keys, table and candidates of a region in ONE workgroup with the table in LDS (k_window_region), then the confirmation by runs
+            const size_t n_prefix = ((size_t)n_hap_bases + H->n_haps + 2) & ~(size_t)1;
+            b->h_win_blocks.clear();                                                             // one workgroup per (region, class of its keys)
+            for (uint32_t g = 0; g < G; ++g) {
+                const uint32_t np = window_passes((uint64_t)H->offsets[g_hap[g + 1]] - H->offsets[g_hap[g]]);
+                for (uint32_t p = 0; p < np; ++p) { b->h_win_blocks.push_back(g); b->h_win_blocks.push_back(p); }
+            }
+            const size_t n_wblk = b->h_win_blocks.size() / 2;
+            const size_t need = (n_prefix + n_wblk + 1) * 8 + ((size_t)G + 2) * 4 + 64;
+            if (h->dedup_scratch_bytes < need) {
+                RT(rt::stream_sync(s));
+                h->pool.release(h->dedup_scratch); h->dedup_scratch = nullptr; h->dedup_scratch_bytes = 0;
+                RT(h->pool.alloc(&h->dedup_scratch, need + need / 4)); h->dedup_scratch_bytes = need + need / 4;
+            }
+            uint64_t* d_prefix = (uint64_t*)h->dedup_scratch;
+            uint2* d_win_blocks = (uint2*)(d_prefix + n_prefix); uint32_t* d_reg_hap0 = (uint32_t*)(d_win_blocks + n_wblk + 1);
+            RT(rt::h2d(d_reg_hap0, b->h_reg_hap0.data(), ((size_t)G + 1) * 4, s));             // (both live as long as the batch)
+            if (n_wblk) RT(rt::h2d(d_win_blocks, b->h_win_blocks.data(), n_wblk * 8, s));
+            OCT_LAUNCH(k_window_prefix, (H->n_haps + 3) / 4, 256, 0, s, d, (const uint64_t*)h->d_pw, d_prefix); RT(rt::launch_ok());   // one wave per haplotype
+            if (n_hap_bases && n_wblk) {
+                const size_t lds = window_region_lds_bytes();
+                RT(rt::allow_lds(k_window_region, lds));
+                OCT_LAUNCH(k_window_region, (uint32_t)n_wblk, kWinThreads, lds, s, d, (const uint64_t*)h->d_pwinv, (const uint64_t*)d_prefix, (const uint32_t*)d_reg_hap0, (const uint2*)d_win_blocks); RT(rt::launch_ok());
+                OCT_LAUNCH(k_window_confirm, (H->n_haps + 3) / 4, 256, 0, s, d); RT(rt::launch_ok());                                  // one wave per haplotype
+            }
+        } else {
         // one table per region (phmm_kernels.hpp, k_window_insert): a power of two of slots >= 1.25 x the region's windows, one behind the other
         std::vector<uint32_t> tab_base(G + 1, 0), tab_mask(G + 1, 0);
         size_t tsize = 0;
@@ -1472,6 +1501,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
             OCT_LAUNCH(k_window_confirm, (H->n_haps + 3) / 4, 256, 0, s, d); RT(rt::launch_ok());                                          // one wave per haplotype
         }
       }
+        }
     }
     // The copies above read this call's host-side staging (pinned buffer, position vectors): a caller of the split API may upload the next batch
     // right away, so they must have landed. A one-shot call (populate, align) runs on the same stream at once and does not return before its

@@ -103,6 +103,8 @@ OCT_DEVICE uint32_t wave_sum_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 OCT_DEVICE uint32_t atomic_add_lds_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+OCT_DEVICE unsigned long long atomic_cas_lds_u64(unsigned long long* p, unsigned long long expected, unsigned long long v) { return atomicCAS(p, expected, v); }   // ds_cmpst_rtn_b64
+OCT_DEVICE void atomic_min_lds_u64(unsigned long long* p, unsigned long long v) { atomicMin(p, v); }                                                               // ds_min_u64
 OCT_DEVICE uint32_t atomic_max_lds_u32(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 OCT_DEVICE void block_sync() { __syncthreads(); }
 OCT_DEVICE int  atomic_min_i32(int32_t* p, int32_t v) { return atomicMin(p, v); }

@@ -914,6 +914,100 @@ OCT_KERNEL(k_window_candidate)(DevBatch b, uint32_t n_bases, const unsigned long
     }
     b.canon[x] = cand;
 }
+// Keys, table and candidates of a region with the table in LDS (round 4, step 7; replaces k_window_insert x 2 + k_window_candidate and their tables in global memory).
+// A region's windows only ever meet each other and there are 10^3 - 10^5 of them: the 30 M device-scope atomics of the global tables (the XCDs' L2s are not coherent with each
+// other, so every one of them travels to the memory side: ~20 G atomics/s, 1.5 ms per 2,000-region upload) become LDS atomics. Slot = tag << 32 | smallest window index (the tag:
+// the key's high half; equal tags are taken for equal keys - k_window_confirm compares the bytes anyway, a false candidate only costs that window its sharing), ~0 = empty, so one
+// 64-bit minimum both claims and lowers. A region with more windows than half the table is cut into residue classes of its keys (equal keys, same class), ONE WORKGROUP PER CLASS
+// (`blocks`, host-made: region and class of every workgroup): each computes every key of the region and keeps its own - the first form ran a region's classes one after the other in
+// one workgroup, and the few regions of 10^5 windows (13 classes) held the launch for milliseconds.
+constexpr uint32_t kWinSlots = 16384, kWinPassWindows = 8192, kWinThreads = 1024, kWinHapStage = 1024;
+OCT_DEVICE uint32_t window_pass_of(unsigned long long key, uint32_t n_pass) { return ((uint32_t)(key >> 32) * 0x9e3779b1u >> 8) % n_pass; }
+OCT_DEVICE uint32_t window_slot_of(unsigned long long key) { return ((uint32_t)key * 0x85ebca6bu >> 12) & (kWinSlots - 1); }
+inline uint32_t window_passes(uint64_t n_windows) { return (uint32_t)((n_windows + kWinPassWindows - 1) / kWinPassWindows); }
+inline size_t window_region_lds_bytes() { return (size_t)kWinSlots * 8 + (size_t)(kWinHapStage + 1) * 4; }
+OCT_MAX_THREADS(1024) OCT_KERNEL(k_window_region)(DevBatch b, const uint64_t* pwinv, const uint64_t* prefix, const uint32_t* reg_hap0, const uint2* blocks)
+{
+    OCT_DYN_SMEM(smem);
+    unsigned long long* tab = (unsigned long long*)smem;          // [kWinSlots]
+    uint32_t* hoff_l = (uint32_t*)(tab + kWinSlots);              // [kWinHapStage + 1]: the region's haplotype offsets (regions with more haplotypes read them from memory)
+    const uint32_t tid = hw::thread_idx(), nt = hw::block_dim();
+    const uint32_t g = blocks[hw::block_idx()].x, pass = blocks[hw::block_idx()].y;
+    const uint32_t h0 = reg_hap0[g], h1 = reg_hap0[g + 1];
+    if (h0 == h1) return;
+    const bool staged = h1 - h0 <= kWinHapStage;
+    if (staged) for (uint32_t i = tid; i <= h1 - h0; i += nt) hoff_l[i] = b.hoff[h0 + i];
+    for (uint32_t i = tid; i < kWinSlots; i += nt) tab[i] = ~0ull;
+    hw::block_sync();
+    auto hoff_at = [&](uint32_t hp) -> uint32_t { return staged ? hoff_l[hp - h0] : b.hoff[hp]; };
+    const uint32_t lo = hoff_at(h0), hi = hoff_at(h1);
+    const uint32_t n_pass = (hi - lo + kWinPassWindows - 1) / kWinPassWindows;
+    // Every window's key (never 0), as k_window_insert made it, FOUR windows of a thread at a time: the haplotypes first (LDS), then the twelve loads of the four keys in one
+    // basic block (addresses clamped instead of guarded, so that they are all in flight together - one window at a time, a thread waited three dependent round trips per
+    // window and a workgroup of a 10^5-window region took a millisecond), then the table. The second loop makes the keys again instead of reading them back (two multiplies and two mixes per window against 8 B stored and loaded).
+    constexpr uint32_t U = 4;
+    struct Four { unsigned long long key[U]; uint32_t hap[U]; };
+    auto keys_of = [&](uint32_t x0, uint32_t& h) -> Four {
+        Four f; uint32_t ho[U], off[U], end[U];
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t x = x0 + u * nt < hi ? x0 + u * nt : hi - 1;
+            while (hoff_at(h + 1) <= x) ++h;
+            f.hap[u] = h; ho[u] = hoff_at(h); off[u] = x - ho[u];
+            const uint32_t Lh = hoff_at(h + 1) - ho[u];
+            end[u] = off[u] + b.window_len < Lh ? off[u] + b.window_len : Lh;
+        }
+        uint64_t pe[U], po[U], pi[U];
+        for (uint32_t u = 0; u < U; ++u) { const uint64_t* pre = prefix + (size_t)ho[u] + f.hap[u]; pe[u] = pre[end[u]]; po[u] = pre[off[u]]; pi[u] = pwinv[off[u]]; }
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint64_t sum = (pe[u] - po[u]) * pi[u];                            // the window's polynomial, independent of where it starts
+            f.key[u] = (mix64(sum ^ mix64((uint64_t)(end[u] - off[u]) << 32 | g)) & ((uint64_t)b.dedup_hash_mask << 32 | b.dedup_hash_mask)) | 1ull;
+        }
+        return f;
+    };
+    {
+        uint32_t h = h0;
+        for (uint32_t x0 = lo + tid; x0 < hi; x0 += U * nt) {
+            const Four f = keys_of(x0, h);
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t x = x0 + u * nt;
+                const unsigned long long key = f.key[u];
+                if (x >= hi || (n_pass > 1 && window_pass_of(key, n_pass) != pass)) continue;
+                const unsigned long long word = (key & 0xffffffff00000000ull) | x;
+                uint32_t slot = window_slot_of(key);
+                for (uint32_t step = 0; step < kWinSlots; ++step, slot = (slot + 1) & (kWinSlots - 1)) {    // (a full table - more distinct keys in a class than slots - leaves the window to itself)
+                    unsigned long long seen = tab[slot];
+                    if (seen == ~0ull) seen = hw::atomic_cas_lds_u64(&tab[slot], ~0ull, word);
+                    if (seen == ~0ull) break;                                                                // claimed
+                    if ((seen >> 32) == (key >> 32)) { if (seen > word) hw::atomic_min_lds_u64(&tab[slot], word); break; }
+                }
+            }
+        }
+    }
+    hw::block_sync();
+    uint32_t h = h0;
+    for (uint32_t x0 = lo + tid; x0 < hi; x0 += U * nt) {
+        const Four f = keys_of(x0, h);                                               // (which of the four are ours, and their haplotypes)
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t x = x0 + u * nt;
+            const unsigned long long key = f.key[u];
+            if (x >= hi || (n_pass > 1 && window_pass_of(key, n_pass) != pass)) continue;
+            uint32_t first = x, slot = window_slot_of(key);
+            for (uint32_t step = 0; step < kWinSlots; ++step, slot = (slot + 1) & (kWinSlots - 1)) {
+                const unsigned long long seen = tab[slot];
+                if (seen == ~0ull) break;
+                if ((seen >> 32) == (key >> 32)) { first = (uint32_t)seen; break; }
+            }
+            uint32_t cand = x;
+            if (first != x) {                                                        // the candidate: same length (the region is the same by construction), k_window_confirm compares the bytes
+                uint32_t a = h0, c = h1;                                             // the haplotype of `first`: the last one of the region that starts at or before it
+                while (c - a > 1) { const uint32_t mid = (a + c) >> 1; if (hoff_at(mid) <= first) a = mid; else c = mid; }
+                const uint32_t hx = f.hap[u], ho = hoff_at(hx), Lh = hoff_at(hx + 1) - ho, ho2 = hoff_at(a), Lh2 = hoff_at(a + 1) - ho2;
+                if (window_len_at(b, x - ho, Lh) == window_len_at(b, first - ho2, Lh2)) cand = first;
+            }
+            b.canon[x] = cand;
+        }
+    }
+}
 OCT_DEVICE bool window_position_equal(const DevBatch& b, uint32_t a, uint32_t c)       // the seven arrays at a and at c
 {
     return b.hbases[a] == b.hbases[c] && b.go[a] == b.go[c] && b.ge[a] == b.ge[c] && b.maskF[a] == b.maskF[c] && b.priorF[a] == b.priorF[c]

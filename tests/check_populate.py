@@ -790,3 +790,46 @@ def check_input_contract(backend):
             assert e.value.code == abi.EINVAL, str(e.value)
         rb = eng.upload(batch); rb.free()                            # the arrays themselves are fine
     eng.close()
+
+
+def check_window_tables(backend, tol=0.0):
+    """Canonical windows through the per-region table in LDS (k_window_region, the default) and through the tables in global memory (OCT_PHMM_WINDOW_LDS=0): a region whose
+    windows fit one pass, one that needs two passes over its keys (more than 8,192 windows) and one with a single haplotype, in one batch; copies, copies with an edit, shorter
+    copies. Same matrix as the oracle and as without sharing, and both forms share exactly the same pairs."""
+    import os
+    rng = np.random.default_rng(4242)
+    regions = []
+    for R, H, Lh in ((8 if backend == "sim" else 30, 8, 260), (6 if backend == "sim" else 24, 26, 340), (5, 1, 200)):
+        g = synth.make_region(rng, R, min(H, 3), T=60, Lh=Lh, B=8, flank=(20, 20), positions="none")
+        haps = list(g["haps"])
+        while len(haps) < H:
+            src = haps[int(rng.integers(0, min(H, 3)))].copy()
+            kind = len(haps) % 3
+            if kind == 1:
+                src[int(rng.integers(5, Lh - 5))] = ord("ACGT"[int(rng.integers(0, 4))])
+            elif kind == 2:
+                src = src[:-int(rng.integers(1, 9))]
+            haps.append(src)
+        g["haps"] = haps
+        regions.append(g)
+    batch = synth.batch_from_regions(regions)
+    assert int(batch.hap_offsets[8 + 26] - batch.hap_offsets[8]) > 8192          # the second region: two passes
+    old = {k: os.environ.get(k) for k in ("OCT_PHMM_DEDUP", "OCT_PHMM_WINDOW_LDS")}
+    res = {}
+    try:
+        for dedup, lds in (("0", "1"), ("1", "1"), ("1", "0")):
+            os.environ["OCT_PHMM_DEDUP"] = dedup; os.environ["OCT_PHMM_WINDOW_LDS"] = lds
+            eng = make_engine(backend, max_indel_error=8)
+            rb = eng.upload(batch); rb.run(); res[(dedup, lds)] = (rb.download().copy(), rb.stats()); rb.free(); eng.close()
+        os.environ["OCT_PHMM_DEDUP"] = "1"; os.environ["OCT_PHMM_WINDOW_LDS"] = "1"
+        compare(backend, batch, tol, max_indel_error=8)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert np.array_equal(res[("0", "1")][0], res[("1", "1")][0]) and np.array_equal(res[("1", "1")][0], res[("1", "0")][0])
+    a, c = res[("1", "1")][1], res[("1", "0")][1]
+    assert a["n_pairs_shared"] > 20 and a == c, (a, c)
+    return a

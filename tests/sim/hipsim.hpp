@@ -198,6 +198,8 @@ inline uint32_t wave_sum_u32(uint32_t v)
 }
 inline uint32_t atomic_max_lds_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_add_lds_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+inline unsigned long long atomic_cas_lds_u64(unsigned long long* p, unsigned long long expected, unsigned long long v) { const auto o = *p; if (o == expected) *p = v; return o; }
+inline void atomic_min_lds_u64(unsigned long long* p, unsigned long long v) { if (v < *p) *p = v; }
 inline void block_sync() { hipsim::block_sync_impl(); }
 inline int atomic_min_i32(int32_t* p, int32_t v) { const int32_t o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long atomic_min_u64(unsigned long long* p, unsigned long long v) { const auto o = *p; if (v < o) *p = v; return o; }

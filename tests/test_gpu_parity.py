@@ -394,6 +394,10 @@ def test_gpu_lane_per_pair_mapper(monkeypatch):
     cp.check_device_kmer_mapper("gpu", TOL)
 
 
+def test_gpu_canonical_windows_through_lds_and_global_tables_agree():
+    assert cp.check_window_tables("gpu", TOL)["n_pairs_shared"] > 20
+
+
 def test_gpu_upload_refuses_what_the_input_contract_excludes():
     cp.check_input_contract("gpu")
 

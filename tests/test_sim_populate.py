@@ -176,3 +176,7 @@ def test_sim_read_records_staged_in_chunks(chunk, monkeypatch):
 
 def test_sim_upload_refuses_what_the_input_contract_excludes():
     cp.check_input_contract("sim")
+
+
+def test_sim_canonical_windows_through_lds_and_global_tables_agree():
+    assert cp.check_window_tables("sim")["n_pairs_shared"] > 20

@@ -38,6 +38,8 @@ cp.check_basic("sim"); cp.check_generic_bytes("sim"); cp.check_late_traceback_st
 os.environ.pop("OCT_PHMM_REC_CHUNK", None)
 cp.check_linked_chunks("sim")                      # templates of linked chunks, ragged reads
 cp.check_page_locked_caller_buffers("sim")         # page-locked arrays / out: the direct upload path, results landing in the caller's buffer
+cp.check_window_tables("sim")                      # canonical windows: the table of a region in LDS (one and two key classes) and the tables in global memory
+cp.check_input_contract("sim")                     # what an upload refuses, single- and multi-threaded checks
 print("SANITIZED-OK")
 """
 
