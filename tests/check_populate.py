@@ -812,6 +812,10 @@ def check_window_tables(backend, tol=0.0):
             haps.append(src)
         g["haps"] = haps
         regions.append(g)
+    # more haplotypes than the workgroup stages offsets for (kWinHapStage = 1,024): short ones, each a copy of one of three
+    g = synth.make_region(rng, 3, 3, T=30, Lh=90, B=8, flank=(10, 10), positions="none")
+    g["haps"] = [g["haps"][i % 3].copy() for i in range(1030)]
+    regions.append(g)
     batch = synth.batch_from_regions(regions)
     assert int(batch.hap_offsets[8 + 26] - batch.hap_offsets[8]) > 8192          # the second region: two passes
     old = {k: os.environ.get(k) for k in ("OCT_PHMM_DEDUP", "OCT_PHMM_WINDOW_LDS")}
