@@ -649,6 +649,18 @@ def main():
                 out["ccs256x12"] = {"ms": dt * 1e3, "gcups": ks["band_cells"] / dt / 1e9, "dtype": "int32", "band": 16, "dp_tasks": ks["n_dp_score_only"] + ks["n_dp_traceback"],
                                     "verified_rows": kv["verified_rows"], "verified_max_abs_diff": kv["verified_max_abs_diff"],
                                     "workload": "ccs256x12: 256 unsplit HiFi-like reads of 10-14 kb x 12 haplotypes of 16 kb, band 16, int32 lanes, no mapping-quality floor"}
+                # the same shape with eight times the reads: enough tasks (one per 16 lanes, int32) to fill the chip - ccs256x12 is 1.3 waves per SIMD
+                keng = engine.Engine(kcfg)
+                kregs = [synth.config_region("ccs2048x12", seed=42, B=16, positions="none")]
+                kb = keng.upload(synth.batch_from_regions(kregs))
+                dt = timed_resident(kb, 2)
+                ks = kb.stats()
+                kgot = kb.download().copy()
+                kb.free(); keng.close()
+                kv = verify_against_reference(kgot, kregs, 16, frac=0.01, cfg=kcfg)
+                out["ccs2048x12"] = {"ms": dt * 1e3, "gcups": ks["band_cells"] / dt / 1e9, "dtype": "int32", "band": 16, "dp_tasks": ks["n_dp_score_only"] + ks["n_dp_traceback"],
+                                     "verified_rows": kv["verified_rows"], "verified_max_abs_diff": kv["verified_max_abs_diff"],
+                                     "workload": "ccs2048x12: 2,048 unsplit HiFi-like reads of 10-14 kb x 12 haplotypes of 16 kb, band 16, int32 lanes"}
         if world == 1 and extras and not sim:
             out.update(region_call_legs(stream_regs_for_calls, stream_resident_for_calls, B))
         if world == 1 and not args.no_small_batch:

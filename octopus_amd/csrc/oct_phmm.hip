@@ -153,6 +153,7 @@ struct oct_phmm_batch {
     double* d_aln_lik = nullptr; uint32_t* d_aln_mpos = nullptr; uint32_t* d_aln_n = nullptr; uint32_t* d_aln_ops = nullptr; uint32_t* d_err_flags = nullptr;
     double* early_out = nullptr;  // oct_phmm_populate: copy every slice's rows to the caller as soon as its epilogue is done
     bool stream = false;          // streaming DP path (k_dp_wide): band 128/256, or band 64 with reads/haplotypes too long for LDS
+    bool rows32 = false;          // ... its row form k_dp_rows: band 16 with int32 lanes (four tasks per wave, fast-cost and generic lists, read record rows, operands shared along the row)
     bool multi_wave = false;      // ... its multi-wave form k_dp_mw: bands 128 / 256 with int32 lanes (one task per workgroup, fast-cost and generic lists)
     bool map_big = false;         // haplotypes too long for the LDS-resident k-mer mapper
     int  map_lanes = 0;           // > 0: k_kmer_map_lanes with this many lanes (= reads) per workgroup
@@ -216,6 +217,7 @@ inline int  dedup()           { const char* e = get("OCT_PHMM_DEDUP"); return !e
 inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_HASH_BITS", &n) && n >= 1 && n < 32 ? (1u << n) - 1u : 0xffffffffu; }   // test hook: collisions
 inline int  device_sized()    { const char* e = get("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
 inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
+inline bool dp_rows()         { const char* e = get("OCT_PHMM_DP_ROWS"); return !e || atoi(e) != 0; }                             // 0: long reads at band 16 with int32 lanes keep k_dp_wide (generic cost for every task, operands per lane) instead of k_dp_rows
 inline bool multi_wave()      { const char* e = get("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
 inline int  mw_planes()       { const char* e = get("OCT_PHMM_MW_PLANES"); return !e ? -1 : atoi(e); }                              // k_dp_mw: -1 by task count, 0 one plane per wave (B / 64 waves per task), 1 all planes in one wave
 inline bool host_mapped()     { const char* e = get("OCT_PHMM_HOST_MAPPED"); return !e || atoi(e) != 0; }                                    // region-sized one-shot calls: inputs read and results written through mapped pinned host memory by kernels (0: DMA copies)
@@ -517,6 +519,13 @@ bool launch_dp_wide_inst(bool w16, const DpParams& p, rt::Stream s)
     else     OCT_LAUNCH((k_dp_wide<B, TR, false>), blocks, kBlockWaves * 64, 0, s, p);
     return rt::launch_ok();
 }
+bool launch_dp_rows(bool tr, bool gen, const DpParams& p, rt::Stream s)      // long reads at band 16, int32 lanes: one task per row of 16 lanes (k_dp_rows)
+{
+    const uint32_t waves = (p.n_tasks + 3) / 4, blocks = (waves + kBlockWaves - 1) / kBlockWaves;
+    if (tr) { if (gen) OCT_LAUNCH((k_dp_rows<true, true>), blocks, kBlockWaves * 64, 0, s, p); else OCT_LAUNCH((k_dp_rows<true, false>), blocks, kBlockWaves * 64, 0, s, p); }
+    else    { if (gen) OCT_LAUNCH((k_dp_rows<false, true>), blocks, kBlockWaves * 64, 0, s, p); else OCT_LAUNCH((k_dp_rows<false, false>), blocks, kBlockWaves * 64, 0, s, p); }
+    return rt::launch_ok();
+}
 bool launch_dp_wide(int band, bool tr, bool w16, const DpParams& p, rt::Stream s)
 {
     switch (band) {
@@ -657,7 +666,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
             const uint32_t n_blocks_s = std::min((ps.n_tasks / G + ps.groups_per_block - 1) / ps.groups_per_block, kDslMaxBlocks);
             if (!launch_dp_pair(B, gen, b->fast_adds, p, ps, n_blocks, n_blocks_s, lds, st)) return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         } else
-        if (!(b->multi_wave ? launch_dp_mw(B, one_wave, tr, gen, p, st) : b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
+        if (!(b->multi_wave ? launch_dp_mw(B, one_wave, tr, gen, p, st) : b->rows32 ? launch_dp_rows(tr, gen, p, st) : b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
                         : h->wide ? launch_dp32(B, tr, p, n_blocks, lds, st) : launch_dp(B, tr, gen, b->fast_adds, p, n_blocks, lds, st)))
             return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         if (h->timing) { RT(rt::event_record(e1, st)); b->timers.emplace_back(e0, e1); b->timer_kind.push_back(kind); }
@@ -1105,6 +1114,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         const bool fits = h->band <= 64 && dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)h->band, true, h->wide ? 0u : dp_rec_chunk(b->t_cap, b->lh_cap, (uint32_t)h->band, true)) <= rt::kMaxLdsBytes;
         b->stream = h->band > 64 || !fits;      // long reads at any band stream their operands (PacBioCCS.config: max-indel-errors=16 with 10-20 kb reads)
         b->multi_wave = h->band >= 128 && h->wide && tune::multi_wave();
+        b->rows32 = b->stream && h->band == 16 && h->wide && tune::dp_rows();
         if (b->t_cap + 2 * (uint32_t)h->band >= 32768) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long (walk events hold 15-bit coordinates)");
     }
     {
@@ -1153,7 +1163,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
     rt::Stream s = h->stream;
     DevBatch& d = b->d;
     d.n_reads = R->n_reads; d.n_rows = n_rows; d.n_haps = H->n_haps; d.n_regions = G; d.n_pairs = b->n_pairs;
-    d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions; d.wide = ((h->wide || b->stream) && !b->multi_wave) ? 1 : 0;   // 1: every task takes the generic lists
+    d.band = h->band; d.nuc_prior = h->cfg.nuc_prior; d.max_pos = h->cfg.max_mapping_positions; d.wide = ((h->wide || b->stream) && !b->multi_wave && !b->rows32) ? 1 : 0;   // 1: every task takes the generic lists
     d.use_mapq = h->cfg.use_mapping_quality; d.mapq_cap = h->cfg.mapping_quality_cap; d.mapq_trigger = h->cfg.mapping_quality_cap_trigger;
     oct_phmm_batch* bp = b.get();
     Packer pk;
@@ -1231,7 +1241,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
         d.rrec_stride = dp_rec_n(b->t_cap, (uint32_t)h->band);
         pk.dalloc(&d.rrec, (size_t)R->n_reads * d.rrec_stride);
     }
-    if (b->multi_wave && R->n_reads) {                    // ... and so does the multi-wave streaming kernel (16 bytes per entry: both cost flavours)
+    if ((b->multi_wave || b->rows32) && R->n_reads) {                    // ... and so does the multi-wave streaming kernel (16 bytes per entry: both cost flavours)
         d.rrec_stride = dp_rec_n(b->t_cap, (uint32_t)h->band);
         pk.dalloc(&d.rrecW, (size_t)R->n_reads * d.rrec_stride);
     }
@@ -2443,7 +2453,7 @@ extern "C" int oct_phmm_align_windows(oct_phmm_handle* h, uint32_t n,
     // every window is its own haplotype and a DP task group must stay within one haplotype: give each window a whole
     // group (one real task + G-1 padding copies). This is a test seam, not the throughput path.
     for (uint32_t i = 0; i < n; ++i) {
-        const int gen = ((h->wide || b->stream) && !b->multi_wave) || !(racgt[i] && hclean[i]);
+        const int gen = ((h->wide || b->stream) && !b->multi_wave && !b->rows32) || !(racgt[i] && hclean[i]);
         tasks[gen].push_back(DevTask {i, i, i, 0}); origin[gen].push_back(i);
         for (uint32_t k = 1; k < G; ++k) tasks[gen].push_back(DevTask {kPadTask, i, i, 0});
     }

@@ -30,6 +30,8 @@ OCT_DEVICE uint32_t dpp_row_shr1_z(uint32_t v) { return (uint32_t)__builtin_amdg
 OCT_DEVICE uint32_t dpp_row_shl1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }
 OCT_DEVICE uint32_t dpp_wave_shr1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 OCT_DEVICE uint32_t dpp_wave_shl1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+// rotation inside each 16-lane row: lane i <- lane i+1, the row's last lane <- its first (row_ror:15)
+OCT_DEVICE uint32_t dpp_row_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F, 0xf, 0xf, false); }
 // rotations of the whole wave: lane i <- lane i-1 with lane 0 <- lane 63 (ror), lane i <- lane i+1 with lane 63 <- lane 0 (rol)
 OCT_DEVICE uint32_t dpp_wave_ror1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x13C, 0xf, 0xf, false); }
 OCT_DEVICE uint32_t dpp_wave_rol1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x134, 0xf, 0xf, false); }

@@ -2024,6 +2024,138 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Long reads at band 16 with int32 lanes (unsplit PacBio reads at max-indel-errors 16: the realignment path): four tasks per wave, one per DPP row of 16
+// lanes, operands streamed - k_dp_wide<16, *, false> rebuilt (round 4, step 8). k_dp_wide made the read operand of every iteration out of two 64-bit words with per-lane shifts
+// and range tests (12 instructions), took the generic byte-test cost for every task (2 x 12), tested for the rolling initialiser and the end cells in every iteration, and every
+// lane loaded its own table entry per iteration (each entry of a window 16 times over): 82 vector instructions and 768 B of loads per wave-iteration. Here
+//   * the read operand is one word of the read's record row (DevBatch::rrecW: v_perm selector | padded base << 8 | quality << 24), pure-ACGT reads on clean haplotypes take the
+//     fast cost (perm + min; the lists of k_classify as on every other path), and the loop runs in three phases (initialiser / steady / end cells);
+//   * the operands TRAVEL along the row instead of being loaded per lane: lane i's table entry of iteration k + 1 is lane i + 1's of iteration k, its read record lane i - 1's -
+//     one DPP row shift each, the row's last / first lane taking the one new value. The new values of sixteen iterations are ONE coalesced load per lane (entry k0 + 17 + lane,
+//     record k0 + 1 + lane), rotated down the row by one lane per iteration so that the taker finds its value at the row's first lane: a sixteenth of the loads, and no chunk of
+//     eight entries per lane in registers (the first form of this kernel kept two: 124 registers and spills).
+// Same recurrence, same traceback words and tile layout as k_dp_wide<16, TRACE, false>: k_walk<16, 1, 1> and k_walk_rows<16, 1> serve both.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool TRACE, bool GENERIC>
+OCT_KERNEL(k_dp_rows)(DpParams p)
+{
+    constexpr int B = 16, ROWS = 4, CH = 8;
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
+    const uint32_t row = lane / B, li = lane % B;
+    const uint32_t group = hw::block_idx() * kBlockWaves + wave;           // = the wave's task group (ROWS tasks)
+    const DevTask* tasks = p.tasks; uint32_t n_tasks = p.n_tasks;
+    if (p.ref.totals) { uint32_t first; task_list_range(p.ref, first, n_tasks); tasks += first; }   // device-sized launch: the grid is the host's bound
+    if (group * ROWS >= n_tasks) return;                                   // whole waves only (n_tasks is a multiple of ROWS)
+    const uint32_t task = group * ROWS + row;
+    const DevTask t = tasks[task];
+    const uint32_t ro = p.roff[t.read], T = p.roff[t.read + 1] - ro;
+    uint32_t t_hi = T, t_lo = T;                                           // the rows iterate together: to the longest read's end, the end-cell phase from the shortest's
+    for (int m = B; m < 64; m <<= 1) { const uint32_t a = hw::shfl_xor(t_hi, m), c = hw::shfl_xor(t_lo, m); t_hi = a > t_hi ? a : t_hi; t_lo = c < t_lo ? c : t_lo; }
+    t_hi = hw::readfirstlane(t_hi); t_lo = hw::readfirstlane(t_lo);
+    const uint32_t KC = (t_hi + (uint32_t)B + 15u) & ~15u;                 // whole tiles of 16 iterations
+    const uint2* tab = (p.rrev[t.read] ? p.tabR : p.tabF) + p.hoff[t.hap] + t.off;
+    const uint32_t* rrow = p.rrecW + (size_t)t.read * p.rrec_stride;       // entry j = read position j - B: selector | base << 8 | quality << 24
+    const uint32_t NUCW = (uint32_t)(int32_t)(int16_t)(p.nuc4 & 0xffffu);
+    uint32_t M1 = INF32, I1 = INF32, D1 = INF32, M2 = INF32, I2 = INF32, D2 = INF32;
+    uint32_t best = INF32, best_s = 0; bool have = false;
+    // operand indices are clamped to the task's own window (+ 1) and to the record row: a row whose own iterations are over (a shorter read than the wave's longest) keeps
+    // re-reading its last entry - those iterations feed no end cell
+    const uint32_t e_max = T + 2 * (uint32_t)B, r_max = p.rrec_stride - 1;
+    auto tab_at = [&](uint32_t e) -> uint2 { return tab[e < e_max ? e : e_max]; };
+    auto rec_at = [&](uint32_t j) -> uint32_t { return rrow[j < r_max ? j : r_max]; };
+    uint2 cE = tab_at(li), nE = tab_at(li + 1);                            // table entries of x = k + li and x + 1
+    uint32_t rw = rec_at((uint32_t)B - li);                                // read record of t = k - li
+    uint2 Fe = tab_at(17u + li); uint32_t Fr = rec_at((uint32_t)B + 1u + li);   // the sixteen values this tile's iterations hand to the rows' last / first lanes, element u at lane u
+    uint32_t GO = cE.y & 0xffffu, GE = cE.y >> 16;
+    auto cost = [&](const uint32_t rec, const uint2 a, uint32_t& flag) -> uint32_t {   // update_match_state (:121-132), already shifted by the trace bits
+        if constexpr (GENERIC) {
+            const uint32_t rc = (rec >> 8) & 0x1ffu, q4 = (rec >> 24) << 2;
+            const uint32_t h = a.x & 0xffu, m = (a.x >> 8) & 0xffu, p4 = ((a.x >> 16) & 0xffu) << 2, isn = a.x >> 24;
+            const uint32_t inner = rc == m ? p4 : q4;
+            uint32_t c = min_i32(q4, inner);
+            if (rc == h) c = 0;
+            flag = rc != h ? 0x8000u : 0u;
+            return min_i32(c, isn ? 8u : INF32);
+        } else {
+            const uint32_t cp = hw::perm(a.x, a.x, rec) & 0xffu;                   // this read base's cap at this haplotype position (0xff: none); only selector byte 0 counts
+            const uint32_t q = rec >> 24;
+            const uint32_t c = cp < q ? cp : q;                                    // min(quality, cap)
+            flag = c ? 0x8000u : 0u;                                               // the walk charges exactly c inside a flank
+            return c << 2;
+        }
+    };
+    uint32_t* const bpt = TRACE ? p.bp + (size_t)group * p.k_cap * 1024 + (size_t)lane * 16 : nullptr;   // this lane's 16-word line in tile 0 (+ tile * 1024 + (k & 15))
+    auto run_chunk = [&](uint32_t k0, auto init_c, auto cap_c) __attribute__((always_inline)) {
+        constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value;
+        uint32_t bw[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const uint32_t k = k0 + (uint32_t)u;
+            const uint32_t GOn = nE.y & 0xffffu, GEn = nE.y >> 16;
+            if constexpr (INIT) { if (k == li) { M1 = NUL32; M2 = NUL32; } }                  // rolling initialiser
+            const uint32_t x2 = min_i32(M2, I2);
+            const uint32_t dsh = min_i32(D2 + GEn, x2 + GOn);                                 // :293
+            uint32_t fE, fO;
+            const uint32_t m1 = min_i32(M1, min_i32(I1, D1));                                 // :284
+            if constexpr (CAP) { if (k == T + li && (int32_t)m1 < (int32_t)best) { best = m1; best_s = 2 * k; have = true; } }   // :285-291
+            M1 = m1 + cost(rw, cE, fE);                                                       // :292
+            I1 = min_i32(I2 + GE, M2 + GO) + NUCW;                                            // :295
+            uint32_t bpe = 0;
+            if constexpr (TRACE) { const uint32_t tm = M1 & 3u, ti = I1 & 3u; M1 ^= tm; I1 = (I1 & ~3u) | 1u; bpe = tm | ti << 2 | fE; }
+            const uint32_t ish = min_i32(I1 + GE, M1 + GO) + NUCW;                            // :318
+            D1 = hw::dpp_row_shr1(INF32, dsh);                                                // :294 one diagonal up inside the row, infinity_ into its first diagonal
+            if constexpr (TRACE) { const uint32_t td = D1 & 3u; D1 |= 3u; bpe |= td << 4; }
+            const uint32_t m2 = min_i32(x2, D2);                                              // :308
+            if constexpr (CAP) { if (k == T + li && (int32_t)m2 < (int32_t)best) { best = m2; best_s = 2 * k + 1; have = true; } }
+            M2 = m2 + cost(rw, nE, fO);                                                       // :316
+            const uint32_t y1 = min_i32(M1, I1);
+            D2 = min_i32(D1 + GEn, y1 + GOn);                                                 // :317
+            I2 = hw::dpp_row_shl1(INF32, ish);                                                // :318-319 one diagonal down, infinity_ into the row's last diagonal
+            if constexpr (TRACE) {
+                const uint32_t tm = M2 & 3u, ti = I2 & 3u, td = D2 & 3u;
+                M2 ^= tm; I2 = (I2 & ~3u) | 1u; D2 |= 3u;
+                bw[u] = bpe | (tm | ti << 2 | td << 4) << 6 | fO >> 1;
+            }
+            // the operands move on: x + 1 becomes x; the row's last lane takes the tile's next new entry (at the row's first lane now: one rotation brings it over and leaves the
+            // one after it there), every other lane its upper neighbour's; the read record comes from the lower neighbour, the row's first lane takes the next new one
+            cE = nE; GO = GOn; GE = GEn;
+            Fe.x = hw::dpp_row_rol1(Fe.x); Fe.y = hw::dpp_row_rol1(Fe.y);
+            nE.x = hw::dpp_row_shl1(Fe.x, nE.x); nE.y = hw::dpp_row_shl1(Fe.y, nE.y);
+            rw = hw::dpp_row_shr1(Fr, rw);
+            Fr = hw::dpp_row_rol1(Fr);
+        }
+        if constexpr (TRACE) {                                                                // this lane's CH words of the tile: half of its 64-byte line
+            uint4* dst = (uint4*)(bpt + (size_t)(k0 >> 4) * 1024 + (k0 & 15u));
+            dst[0] = make_uint4(bw[0], bw[1], bw[2], bw[3]); dst[1] = make_uint4(bw[4], bw[5], bw[6], bw[7]);
+        }
+    };
+    auto run_tile = [&](uint32_t k0, auto init_c, auto cap_c) __attribute__((always_inline)) {   // sixteen iterations; the next tile's new values in flight meanwhile
+        const uint2 Pe = tab_at(k0 + 33u + li); const uint32_t Pr = rec_at((uint32_t)B + k0 + 17u + li);
+        run_chunk(k0, init_c, cap_c); run_chunk(k0 + CH, init_c, cap_c);
+        Fe = Pe; Fr = Pr;                                                                     // (sixteen rotations have brought Fe / Fr back to where they started: replaced whole)
+    };
+    const uint32_t k_cap0 = (t_lo & ~15u) > (uint32_t)B ? (t_lo & ~15u) : (uint32_t)B;       // no row has an end cell before iteration t_lo
+    uint32_t k = 0;
+    if (t_lo < (uint32_t)B) run_tile(0, BoolC<true>{}, BoolC<true>{}); else run_tile(0, BoolC<true>{}, BoolC<false>{});   // B = 16: the initialiser's iterations are the first tile
+    for (k = 16; k < k_cap0 && k < KC; k += 16) run_tile(k, BoolC<false>{}, BoolC<false>{});
+    for (; k < KC; k += 16) run_tile(k, BoolC<false>{}, BoolC<true>{});
+
+    // first minimum over the row's end cells: per lane the candidates were visited in increasing diagonal order, so strict < kept the first
+    uint32_t kv = have ? (best ^ 0x80000000u) : 0xffffffffu, ks = have ? best_s : 0xffffffffu;
+    for (int m = 1; m < B; m <<= 1) {
+        const uint32_t ov = hw::shfl_xor(kv, m), os = hw::shfl_xor(ks, m);
+        if (ov < kv || (ov == kv && os < ks)) { kv = ov; ks = os; }
+    }
+    if (li == 0) {
+        const bool none = kv == 0xffffffffu;                                                  // no end cell below infinity_: minscore stays infinity_, minscoreidx -1 (:269-270)
+        const uint32_t biased = none ? (INF32 ^ 0x80000000u) : kv;
+        const int32_t score = (int32_t)biased >> 2;
+        if constexpr (TRACE) { TraceEnd e; e.score = score; e.sidx = none ? -1 : (int32_t)ks; p.ends[task] = e; }
+        else if (t.pair != kPadTask) hw::atomic_min_i32(p.pair_best + t.pair, score);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Long reads at bands 128 / 256, int32 lanes (BASELINE.json configs[4]): ONE TASK PER WORKGROUP, its B band diagonals over B / 64 waves, one diagonal
 // per lane. A long-read batch holds ~10^3 tasks of ~10^4 dependent iterations: with one wave per task (k_dp_wide) a SIMD holds one wave and the launch
 // runs at the latency of a 4-diagonal dependency chain per lane; here the same batch puts four waves on every SIMD and a wave's chain is a quarter
@@ -2751,12 +2883,38 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
         const uint32_t fl_cols = (uint32_t)(hw::ballot(col_fl) >> rowbase) & 0xffffu;
         const uint32_t ev_cols = (uint32_t)(hw::ballot(col_fl && ((mine >> (hshift + 15 - par)) & 1u)) >> rowbase) & 0xffffu;
         if (n > 0 && nev + (uint32_t)__builtin_popcount(ev_cols) > kWalkRowEvents) n = 0;       // no room to queue them: one at a time (which prices on overflow)
+        // Long reads (round 4, step 8): a run that went through the whole rest of its line goes on through the NEXT staged lines of the same band lane - a HiFi read walks
+        // thousands of match columns straight down one band lane, and one pass per 16 of them (~330 instructions at a lone wave's latency) was 10 ms for 7,000 walks of
+        // 13,000 columns. Only between the flanks (nothing to count or queue there: the extension is a pure move) and never for an early-stopping walk.
+        int32_t n_ext = 0;
+        if (K > 1 && w.k_cap > 16) {                                                              // (wave-uniform: reads longer than ~240 bases; region-sized walks of short reads skip the three ballots)
+            bool full = runs && turns == 0u && n == kk + 1 && stop_below_x == INT32_MIN;
+            int32_t room = 0;
+            if (full) {
+                const int32_t x1 = x - n, y1 = y - n;                                           // after the first line's columns
+                room = y1 - 1 < x1 ? y1 - 1 : x1;                                               // (the last read base, the window's left edge: plain steps)
+                if (want_flank) { const int32_t r = x1 - lhs; room = room < r ? room : r; }     // columns x1 - 1 ... x1 - room stay at or above lhs: outside the left flank
+                if (x1 > mid_hi) room = 0;                                                      // (still inside the right flank)
+                room = room < 0 ? 0 : room;
+            }
+#pragma unroll
+            for (uint32_t a = 1; a < K; ++a) {
+                const bool ext = full && room > 0 && kt >= (int32_t)a && (uint32_t)(st_top - kt) + a < K;
+                const uint32_t m2 = ext ? rowt[(((uint32_t)(st_top - kt) + a) * B + (uint32_t)i) * LS + l16] : 0u;
+                const uint32_t t2 = (uint32_t)(hw::ballot(ext && ((m2 >> (hshift + 6 * par)) & 3u) != 0u) >> rowbase) & 0xffffu;
+                int32_t n2 = ext ? (t2 ? 15 - (31 - (int32_t)__builtin_clz(t2)) : 16) : 0;     // words 15, 14, ... down to the one above the first turn
+                n2 = n2 < room ? n2 : room;
+                n_ext += n2; room -= n2;
+                full = ext && n2 == 16;
+            }
+        }
         if (n > 0) {
             if ((ev_cols >> l16) & 1u)
                 evbuf[nev + (uint32_t)__builtin_popcount(ev_cols & ((1u << l16) - 1u))] = (uint32_t)(y - 1 - j) << 15 | (uint32_t)(x - 1 - j);   // (kind 0: a match column)
             nev += (uint32_t)__builtin_popcount(ev_cols); msz += __builtin_popcount(fl_cols);
             sidx -= 2 * n; x -= n; y -= n;
         }
+        if (n_ext > 0) { sidx -= 2 * n_ext; x -= n_ext; y -= n_ext; }                           // (only ever behind a first line taken whole: n > 0)
         // ---- plain steps, this row on its own, until the next run starts, the staged window ends or the walk does. The loop holds only what nearly every
         //      step needs (the word is in the window, the event - if any - fits the queue) and keeps its flags in one register word (separate bools become
         //      scalar mask arithmetic around every exit); anything else leaves it for ONE general step below ----

@@ -308,6 +308,10 @@ def config_region(name: str, seed: int = 42, B: int = 16, positions: str = "true
                            q_values=(8, 15), indels_per_read=40)
     if name == "long512x8":     # eight times configs[4]'s reads: enough tasks to put several waves on every SIMD (a throughput figure, not a latency one)
         return make_region(rng, 512, 8, T=10_000, Lh=20_000, B=256, flank=(400, 400), positions=positions, q_values=(8, 15), indels_per_read=40)
+    if name == "ccs2048x12":    # eight times the reads of ccs256x12: a batch that fills the chip with one task per 16 lanes (ccs256x12 is 1.3 waves per SIMD)
+        g = make_region(rng, 2048, 12, T=14_000, Lh=16_000, B=B, flank=(300, 300), positions=positions, q_values=(20, 40), indels_per_read=6)
+        g["read_len"] = rng.integers(10_000, 14_001, 2048).astype(np.int64)
+        return g
     if name == "ccs256x12":     # UNSPLIT long reads at the PacBio configuration's band (max-indel-errors=16) with the int32 lanes the realigner's model takes for long reads
         # (option_collation.cpp:1687-1693): 256 HiFi-like reads of 10-14 kb (Q20-40, six indel errors each) against 12 haplotypes of 16 kb. The CALLING path of that
         # configuration never sees this shape - it cuts reads into 500-base linked chunks (linked_stream below) - the realignment path does.

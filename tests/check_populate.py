@@ -290,6 +290,34 @@ def check_long_reads_at_narrow_bands(backend, tol=0.0, T=1400, Lh=3600, n_reads=
         g, rng = small_region(seed, R=n_reads, H=2, T=T, Lh=Lh, B=band, flank=(Lh // 3, Lh // 3))      # wide inactive flanks: most candidates need the traceback
         g["quals"][:] = np.clip(g["quals"], 5, 20)
         out.append(compare(backend, synth.batch_from_regions([g]), tol, max_indel_error=band, use_int_scores=bits))
+    # int32 lanes, the row kernel (k_dp_rows): reads of different lengths in one wave (the rows iterate to the longest one's end, a shorter one stops fetching), reads and
+    # haplotypes with an 'N' (generic lists beside the fast-cost ones), bands 16 / 32 / 64; the same bytes as the one-cost streaming kernel (OCT_PHMM_DP_ROWS=0)
+    import os
+    old = os.environ.get("OCT_PHMM_DP_ROWS")
+    try:
+        for band, seed, scale in ((16, 81, 1.0), (32, 82, 0.8), (64, 83, 1.6)):
+            Tb, Lb = int(T * scale), int(Lh * scale)
+            g, rng = small_region(seed, R=n_reads + 3, H=2, T=Tb, Lh=Lb, B=band, flank=(Lb // 3, Lb // 4))
+            g["quals"][:] = np.clip(g["quals"], 5, 30)
+            g["read_len"] = rng.integers(Tb // 3, Tb + 1, n_reads + 3).astype(np.int64); g["read_len"][0] = Tb
+            g["reads"][1, Tb // 5] = ord("N")
+            g["haps"][1][Lb // 2] = ord("N")
+            batch = synth.batch_from_regions([g])
+            os.environ.pop("OCT_PHMM_DP_ROWS", None)
+            out.append(compare(backend, batch, tol, max_indel_error=band, use_int_scores=1))
+            res = []
+            for rows in ("1", "0"):
+                os.environ["OCT_PHMM_DP_ROWS"] = rows
+                eng = make_engine(backend, max_indel_error=band, use_int_scores=1)
+                rb = eng.upload(batch); rb.run(); res.append((rb.download().copy(), rb.stats(), rb.kernel_time_by_kind() if hasattr(rb, "kernel_time_by_kind") else None)); rb.free(); eng.close()
+            assert np.array_equal(res[0][0], res[1][0])
+            for k in ("n_pairs", "n_candidates", "n_fast_path", "n_dp_score_only", "n_dp_traceback", "band_cells"):
+                assert res[0][1][k] == res[1][1][k], k
+    finally:
+        if old is None:
+            os.environ.pop("OCT_PHMM_DP_ROWS", None)
+        else:
+            os.environ["OCT_PHMM_DP_ROWS"] = old
     return out
 
 

@@ -122,6 +122,7 @@ inline uint32_t dpp_wave_shl1_z(uint32_t v);
 inline uint32_t dpp_wave_shr1(uint32_t fill, uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return l == 0 ? -1 : (int)l - 1; }, fill); }
 inline uint32_t dpp_wave_shl1(uint32_t fill, uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return l == 63 ? -1 : (int)l + 1; }, fill); }
 inline uint32_t dpp_wave_shr1_z(uint32_t v) { return dpp_wave_shr1(0u, v); }
+inline uint32_t dpp_row_rol1(uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return (int)((l & ~15u) | ((l + 1) & 15u)); }, 0u); }
 inline uint32_t dpp_wave_ror1(uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return (int)((l + 63) & 63); }, 0u); }
 inline uint32_t dpp_wave_rol1(uint32_t v) { return hipsim::xchg_read(v, [](uint32_t l) { return (int)((l + 1) & 63); }, 0u); }
 inline uint32_t dpp_wave_shl1_z(uint32_t v) { return dpp_wave_shl1(0u, v); }

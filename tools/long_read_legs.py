@@ -16,7 +16,7 @@ for leg in legs:
     elif leg == "ccs-linked":
         cfg, regs = abi.Config.default(max_indel_error=16), synth.linked_stream(42, 1000, B=16)
     else:
-        cfg, regs = abi.Config.default(max_indel_error=16, use_int_scores=1, use_mapping_quality=0), [synth.config_region("ccs256x12", seed=42, B=16, positions="none")]
+        cfg, regs = abi.Config.default(max_indel_error=16, use_int_scores=1, use_mapping_quality=0), [synth.config_region(leg if leg.startswith("ccs") else "ccs256x12", seed=42, B=16, positions="none")]
     eng = engine.Engine(cfg)
     eng.set_timing(True)
     rb = eng.upload(synth.batch_from_regions(regs))
