@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The long-read legs of bench.py on their own (resident timing only; bench.py and tests/test_gpu_fullsize.py verify them): long64x8 / long512x8 (configs[4] and 8 x its reads,
-band 256, int32), ccs-linked (PacBioCCS.config: 500-base linked chunks, band 16, int16), ccs256x12 (unsplit 10-14 kb reads at band 16, int32).   python tools/long_read_legs.py [leg ...]"""
+band 256, int32), ccs-linked (PacBioCCS.config: 500-base linked chunks, band 16, int16), ccs256x12 (unsplit 10-14 kb reads at band 16, int32), ccs2048x12 (eight times its reads).   python tools/long_read_legs.py [leg ...]"""
 import json
 import sys
 import time
@@ -9,7 +9,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from octopus_amd import abi, engine, synth   # noqa: E402
 
-legs = sys.argv[1:] or ["long64x8", "long512x8", "ccs-linked", "ccs256x12"]
+legs = sys.argv[1:] or ["long64x8", "long512x8", "ccs-linked", "ccs256x12", "ccs2048x12"]
 for leg in legs:
     if leg in ("long64x8", "long512x8"):
         cfg, regs = abi.Config.default(max_indel_error=256, use_int_scores=1), [synth.config_region(leg, seed=42, B=256, positions="none")]
