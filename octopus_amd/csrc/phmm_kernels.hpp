@@ -922,7 +922,11 @@ OCT_KERNEL(k_window_candidate)(DevBatch b, uint32_t n_bases, const unsigned long
 // (`blocks`, host-made: region and class of every workgroup): each computes every key of the region and keeps its own - the first form ran a region's classes one after the other in
 // one workgroup, and the few regions of 10^5 windows (13 classes) held the launch for milliseconds.
 constexpr uint32_t kWinSlots = 16384, kWinPassWindows = 8192, kWinThreads = 1024, kWinHapStage = 1024;
-OCT_DEVICE uint32_t window_pass_of(unsigned long long key, uint32_t n_pass) { return ((uint32_t)(key >> 32) * 0x9e3779b1u >> 8) % n_pass; }
+// The key's class, 0 .. n_pass - 1: a multiply-high of the hashed tag. NOT `(tag * c >> 8) % n_pass`: where the compiler can see that both operands fit 24 bits it divides through a
+// float reciprocal, and this toolchain's expansion (ROCm 7.2, gfx950) returns 0xffffff instead of n - 1 for 2.8 % of 24-bit dividends at n = 11 (and at 22, 23; quotients off by one
+// likewise - tools/urem_probe.hip, profiles/r04_step8_urem24_probe.txt). Keys with that "class" belonged to no workgroup, their windows kept whatever canon[] held, and
+// k_window_confirm followed the garbage: a memory fault on region-server batches holding a region of eleven classes. The simulator's host compiler divides exactly.
+OCT_DEVICE uint32_t window_pass_of(unsigned long long key, uint32_t n_pass) { return (uint32_t)(((unsigned long long)((uint32_t)(key >> 32) * 0x9e3779b1u) * n_pass) >> 32); }
 OCT_DEVICE uint32_t window_slot_of(unsigned long long key) { return ((uint32_t)key * 0x85ebca6bu >> 12) & (kWinSlots - 1); }
 inline uint32_t window_passes(uint64_t n_windows) { return (uint32_t)((n_windows + kWinPassWindows - 1) / kWinPassWindows); }
 inline size_t window_region_lds_bytes() { return (size_t)kWinSlots * 8 + (size_t)(kWinHapStage + 1) * 4; }
