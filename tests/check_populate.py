@@ -841,7 +841,7 @@ def check_window_tables(backend, tol=0.0):
         g["haps"] = haps
         regions.append(g)
     # more haplotypes than the workgroup stages offsets for (kWinHapStage = 1,024): short ones, each a copy of one of three
-    g = synth.make_region(rng, 3, 3, T=30, Lh=85, B=8, flank=(10, 10), positions="none")
+    g = synth.make_region(rng, 1, 3, T=30, Lh=85, B=8, flank=(10, 10), positions="none")
     g["haps"] = [g["haps"][i % 3].copy() for i in range(1030)]          # 87,550 windows: ELEVEN key classes (a class function with `% 11` lost keys on the GPU: see k_window_region)
     regions.append(g)
     batch = synth.batch_from_regions(regions)
