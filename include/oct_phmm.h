@@ -353,6 +353,16 @@ int  oct_phmm_align(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_p
                     const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                     const oct_phmm_positions* positions, oct_phmm_alignments* out, oct_phmm_status* status);
 
+/* The reference's realigner maps every read WITHOUT a cap on the number of candidate positions (read_realigner.cpp:128,137 call
+ * map_query_to_target with the default max_mapping_positions, kmer_mapper.hpp:120-124); this library keeps at most
+ * cfg.max_mapping_positions (<= 15) tied diagonals per pair, in ascending order. A read that lies inside a tandem repeat or a
+ * homopolymer longer than itself ties on more diagonals than that, and the reference may pick one of the later ones. After an
+ * oct_phmm_align call whose positions came from the device mapper (positions == NULL): counts[pair] = how many candidates the mapper
+ * kept for that pair (n_pairs must be the call's pair count), *n_saturated = the pairs with counts == cfg.max_mapping_positions, i.e.
+ * whose candidate list may be cut short - the caller re-aligns exactly those with its own uncapped positions (oct_phmm_positions) or its
+ * CPU path (INTEGRATION.md section 3b does the latter). Either output may be NULL. */
+int  oct_phmm_align_candidate_counts(const oct_phmm_handle* h, uint8_t* counts, size_t n_pairs, uint32_t* n_saturated);
+
 /* ---- test seam: the raw band kernel ------------------------------------------------------------ */
 /* simd::PairHMM::align on explicit windows (simd_pair_hmm.hpp:438-509): what the reference's golden tests
  * drive (test/unit/core/models/pair_hmm_tests.cpp:63-85). Window i has truth_len = target_len + 2B - 1.

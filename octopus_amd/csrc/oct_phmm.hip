@@ -38,6 +38,12 @@ struct DevPool {
     std::multimap<size_t, void*> free_blocks;
     std::unordered_map<void*, size_t> live;
     size_t cached = 0;
+    // What all the pools of one device may hold back between them (a region server runs several handles per GPU, INTEGRATION's populate patch one per caller thread:
+    // with a cap per handle a handle could report out-of-memory while its siblings sat on tens of GB of free blocks - ADVICE r04). Read and updated without a lock:
+    // a bound, not an invariant.
+    static std::atomic<size_t>& device_cached(int dev) { static std::atomic<size_t> c[64]; return c[(unsigned)dev & 63u]; }
+    int device = 0;
+    static constexpr size_t kDeviceCacheCap = (size_t)128 << 30;
     static constexpr size_t kCacheCap = (size_t)64 << 30;       // (288 GB of HBM: a handle that streams 6,250-region batches - 20 GB resident each - paid a 20 GB hipMalloc + hipFree, 0.4 s, per call with the cap at 16 GB)
     // Powers of two up to 1 GB (a thread's region calls differ in size by orders of magnitude - 20 to 5,000 reads, 1 to 200 haplotypes: with finer classes most
     // calls of a run's first thousands met a size nobody had freed yet and paid a hipMalloc, which synchronises the device), eight classes per octave beyond
@@ -56,7 +62,7 @@ struct DevPool {
         const size_t c = size_class(n);
         auto it = free_blocks.lower_bound(c);             // the smallest cached block that fits, if it is not wastefully large (small blocks: up to 8x, nobody misses those bytes)
         if (it != free_blocks.end() && (it->first <= c + c / 2 || it->first <= std::min<size_t>(8 * c, (size_t)64 << 20))) {
-            *p = it->second; const size_t got = it->first; free_blocks.erase(it); cached -= got; live[*p] = got; return true;
+            *p = it->second; const size_t got = it->first; free_blocks.erase(it); cached -= got; device_cached(device) -= got; live[*p] = got; return true;
         }
         if (!rt::dev_malloc(p, c)) {
             rt::clear_error();
@@ -72,10 +78,10 @@ struct DevPool {
         auto it = live.find(p);
         if (it == live.end()) { rt::dev_free(p); return; }
         const size_t c = it->second; live.erase(it);
-        if (cached + c > kCacheCap) { rt::dev_free(p); return; }
-        free_blocks.emplace(c, p); cached += c;
+        if (cached + c > kCacheCap || device_cached(device).load() + c > kDeviceCacheCap) { rt::dev_free(p); return; }
+        free_blocks.emplace(c, p); cached += c; device_cached(device) += c;
     }
-    void trim() { for (auto& kv : free_blocks) rt::dev_free(kv.second); free_blocks.clear(); cached = 0; }
+    void trim() { for (auto& kv : free_blocks) rt::dev_free(kv.second); free_blocks.clear(); device_cached(device) -= cached; cached = 0; }
 };
 
 struct oct_phmm_handle {
@@ -103,6 +109,7 @@ struct oct_phmm_handle {
     size_t bp_budget = (size_t)96 << 30;
     // error model for in-call penalty vectors (oct_phmm_set_error_model)
     bool has_model = false; oct_phmm_error_model model {};
+    std::vector<uint8_t> last_align_counts; bool last_align_device_map = false;   // oct_phmm_align_candidate_counts
     int fail_bp_allocs = 0;                              // test hook, see ensure_bp
     bool probe_ready = false; rt::Stream probe_stream {}; unsigned long long* d_probe = nullptr; unsigned long long* h_probe = nullptr;   // oct_phmm_probe_clock
     oct_phmm_error_model* d_model = nullptr;             // device copy, made on first use
@@ -328,7 +335,7 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
     {   // Big batch with arrays in page-locked caller memory (oct_phmm_host_alloc, hipHostMalloc, hipHostRegister): the DMA engine reads those arrays themselves; the
         // others (the library's own small tables, pageable caller arrays) go through the staging halves one by one
         std::vector<char> direct(n_in, 0); bool any = false;
-        if (tune::pinned_direct()) for (size_t i = 0; i < n_in; ++i) if (items[i].bytes >= tune::pinned_min_bytes((size_t)1 << 20) && rt::host_is_pinned(items[i].src)) { direct[i] = 1; any = true; }
+        if (tune::pinned_direct()) for (size_t i = 0; i < n_in; ++i) if (items[i].bytes >= tune::pinned_min_bytes((size_t)1 << 20) && rt::host_is_pinned(items[i].src, items[i].bytes)) { direct[i] = 1; any = true; }
         if (any) {
             if (h->stage_bytes < kStageMax) {
                 rt::host_pinned_free(h->stage); h->stage = nullptr; h->stage_bytes = 0;
@@ -923,6 +930,7 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     std::unique_ptr<oct_phmm_handle> h(new (std::nothrow) oct_phmm_handle());
     if (!h) return OCT_PHMM_EHIP;
     h->cfg = *cfg; h->band = band; h->wide = cfg->use_int_scores != 0; h->lanes_c = band > 64 ? band / 64 : 1;
+    h->pool.device = cfg->device_id;
     if (h->cfg.mapping_quality_cap_trigger >= 0 && h->cfg.mapping_quality_cap_trigger >= h->cfg.mapping_quality_cap)
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
     h->timing = tune::timing();
@@ -994,10 +1002,25 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
     return upload_impl(h, R, H, regions, flank, positions, out, status, false, 0);
 }
 
+static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
+                            const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                            const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
+                            bool one_shot);
 static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
                        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                        const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
                        bool one_shot)
+{
+    const int rc = upload_impl_body(h, R, H_in, regions, flank, positions, out, status, align_mode, max_cigar_ops, one_shot);
+    // An upload that fails after its copies were enqueued returns to a caller who may free the arrays at once - and page-locked arrays are read by the copy
+    // engines directly (Packer::commit): nothing of this handle is in flight any more when the error is reported (the error path only).
+    if (rc != OCT_PHMM_OK && h) { rt::set_device(h->cfg.device_id); rt::stream_sync(h->stream); rt::clear_error(); }
+    return rc;
+}
+static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
+                            const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                            const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
+                            bool one_shot)
 {
     if (!h || !R || !H_in || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
     *out = nullptr;
@@ -1899,9 +1922,11 @@ extern "C" int oct_phmm_test_set(const char* name, const char* value)
     tune::switch_table_used().store(true, std::memory_order_release);
     // tune::get hands out pointers into the table's strings and its callers read them after the lock is gone (atoll on another thread's upload): a value that is
     // replaced or removed moves to a list that is never freed instead of dying under a reader (a few bytes per oct_phmm_test_set call, tests and tools only)
-    static std::list<std::string> retired;
+    // (the NODE is kept, not a moved-to string: a short value lives inside its std::string object, so moving it copies the characters and the reader's pointer would be left
+    // pointing into the erased node - ADVICE r04)
+    static std::list<std::map<std::string, std::string>::node_type> retired;
     auto it = tune::switch_table().find(name);
-    if (it != tune::switch_table().end()) { retired.push_back(std::move(it->second)); tune::switch_table().erase(it); }
+    if (it != tune::switch_table().end()) retired.push_back(tune::switch_table().extract(it));
     if (value) tune::switch_table().emplace(name, value);
     return OCT_PHMM_OK;
 }
@@ -2061,7 +2086,7 @@ extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads
     bool early = false;
     if (rc == OCT_PHMM_OK && out && b->n_out) {                // results come back through a pinned landing zone: slice by slice while a big batch computes, behind the
         const size_t bytes = (size_t)b->n_out * sizeof(double);  // epilogue of a small one - one stream synchronisation per call, no staged copy into pageable memory
-        if (bytes >= tune::pinned_min_bytes(kPinnedOutMinBytes) && tune::pinned_direct() && rt::host_is_pinned(out)) { b->early_out = out; b->out_landing = out; early = true; }   // the caller's own page-locked buffer IS the landing zone
+        if (bytes >= tune::pinned_min_bytes(kPinnedOutMinBytes) && tune::pinned_direct() && rt::host_is_pinned(out, bytes)) { b->early_out = out; b->out_landing = out; early = true; }   // the caller's own page-locked buffer IS the landing zone
         else if (h->out_stage_bytes < bytes) {
             const size_t roomy = std::max(bytes + bytes / 2, (size_t)1 << 20);     // (a region thread's calls differ in size: no regrowth per call)
             rt::host_pinned_free(h->out_stage); h->out_stage = nullptr; h->out_stage_bytes = 0;
@@ -2387,6 +2412,8 @@ extern "C" int oct_phmm_align(oct_phmm_handle* h, const oct_phmm_reads* reads, c
     RT(rt::d2h(out->mapping_position, b->d_aln_mpos, np * sizeof(uint32_t), h->stream));
     RT(rt::d2h(out->n_cigar_ops, b->d_aln_n, np * sizeof(uint32_t), h->stream));
     RT(rt::d2h(ops.data(), b->d_aln_ops, np * cap * sizeof(uint32_t), h->stream));
+    h->last_align_counts.assign(np, 0); h->last_align_device_map = b->device_map;
+    RT(rt::d2h(h->last_align_counts.data(), b->d.npos, np, h->stream));        // oct_phmm_align_candidate_counts: did the mapper's output reach max_mapping_positions?
     RT(rt::stream_sync(h->stream));
     if (flags & 1u) return fail(status, OCT_PHMM_EOVERFLOW, "Pair HMM alignment overflowed");
     uint32_t needed = 0;
@@ -2397,6 +2424,19 @@ extern "C" int oct_phmm_align(oct_phmm_handle* h, const oct_phmm_reads* reads, c
     }
     if (needed) { fail(status, OCT_PHMM_EINVAL, "max_cigar_ops too small"); if (status) status->required_extension = needed; return OCT_PHMM_EINVAL; }
     return ok(status);
+}
+
+extern "C" int oct_phmm_align_candidate_counts(const oct_phmm_handle* h, uint8_t* counts, size_t n_pairs, uint32_t* n_saturated)
+{
+    if (!h || (!counts && !n_saturated)) return OCT_PHMM_EINVAL;
+    if (counts && n_pairs != h->last_align_counts.size()) return OCT_PHMM_EINVAL;
+    if (counts && n_pairs) memcpy(counts, h->last_align_counts.data(), n_pairs);
+    if (n_saturated) {
+        uint32_t n = 0;
+        if (h->last_align_device_map) for (uint8_t c : h->last_align_counts) if ((int)c >= h->cfg.max_mapping_positions) ++n;
+        *n_saturated = n;
+    }
+    return OCT_PHMM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -745,6 +745,13 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
         auto visit = [&](uint32_t slot, uint32_t p) {
             ++st_cand;
             const uint32_t known = slot == 0 ? mm_state : 0u;
+#if defined(OCTPHMM_SIM)
+            if (known) {    // CPU suite only: the mapper's account must be what the bytes say at THIS position (a stale pair_mm beside other positions would turn a mismatch into penalty 0 silently - ADVICE r04)
+                const uint32_t i1 = first_mismatch(target, truth + p, 0, T), i2 = i1 == T ? T : first_mismatch(target, truth + p, i1 + 1, T);
+                const uint32_t want = i1 == T ? 1u : i2 == T ? 2u : 3u;
+                if (want != known || (known == 2 && i1 != mm_i1) || !pos_in_range(p, T, Lh, 0)) { fprintf(stderr, "k_classify: pair_mm drifted from the bases (pair %llu, state %u, bytes say %u)\n", (unsigned long long)e, known, want); abort(); }
+            }
+#endif
             if (b.align_mode) {                                                                     // hmm::align, pair_hmm.hpp:861-872
                 bool same = known ? known == 1 : true;                                              // try_naive_align :321-341
                 if (!known) for (uint32_t tt = 0; tt < T; ++tt) if (target[tt] != truth[p + tt]) { same = false; break; }

@@ -43,6 +43,12 @@ inline bool host_is_pinned(const void* p)
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // (an address the runtime has never seen: an error, and a sticky one)
     return a.type == hipMemoryTypeHost;
 }
+// ... the whole array [p, p + bytes): a hipHostRegister'ed range may end before the array does, and the copy engines are pointed at all of it
+inline bool host_is_pinned(const void* p, size_t bytes)
+{
+    if (!host_is_pinned(p)) return false;
+    return bytes <= 1 || host_is_pinned((const char*)p + bytes - 1);
+}
 inline bool h2d(void* d, const void* h, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); return true; }
 inline bool d2h(void* h, const void* d, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); return true; }
 inline bool dev_memset(void* d, int v, size_t n, Stream s) { if (n) OCT_RT_CHECK(hipMemsetAsync(d, v, n, s)); return true; }

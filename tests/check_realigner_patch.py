@@ -66,6 +66,36 @@ def scenario(rng, n_reads, T, Lh, band, short=False):
                 reverse=rng.integers(0, 2, n_reads).astype(np.uint8))
 
 
+def repeat_scenario(rng, band=16, T=60):
+    """reads that lie ENTIRELY inside a (CA)n run / a poly-A run longer than themselves. Every 6-mer of such a read occurs at every (second) position of
+    the run, so it ties on (run - T) / period + 1 diagonals - 36 and 61 here, more than the 15 slots of the ABI: the reference maps realigned reads without a cap
+    (read_realigner.cpp:128,137) and model.align sees all of them. A few carry one substitution (so the DP, not the exact-match shortcut, decides among the ties),
+    a few start at the run's far end (where a capped, ascending candidate list never reaches), and ordinary reads sit beside them."""
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    Lh = 520
+    hap = acgt[rng.integers(0, 4, Lh)]
+    ca0, ca_n, a0, a_n = 70, 130, 290, 120
+    hap[ca0:ca0 + ca_n] = np.frombuffer(b"CA" * (ca_n // 2), np.uint8)
+    hap[a0:a0 + a_n] = ord("A")
+    hap[a0 - 1] = ord("G"); hap[a0 + a_n] = ord("C"); hap[ca0 - 1] = ord("T"); hap[ca0 + ca_n] = ord("G")
+    start = 20_000
+    reads, quals, rbegin = [], [], []
+    def add(o, sub=None, shift=0):
+        s = hap[o:o + T].copy()
+        if sub is not None:
+            s[sub] = ord("G") if s[sub] != ord("G") else ord("T")
+        reads.append(s); quals.append(np.full(T, 30, np.uint8)); rbegin.append(start + o + shift)
+    for o in (ca0, ca0 + 2, ca0 + 34, ca0 + ca_n - T, ca0 + ca_n - T - 2):
+        add(o); add(o, sub=T // 2); add(o, shift=4)
+    for o in (a0, a0 + 1, a0 + 30, a0 + a_n - T):
+        add(o); add(o, sub=T // 3, shift=-3)
+    for o in (20, 210, 430):                                      # ordinary reads: unique mapping, the device's result stays
+        add(o); add(o, sub=7)
+    n = len(reads)
+    return dict(hap=hap, hap_begin=start, reads=reads, quals=quals, rbegin=np.asarray(rbegin, np.int64), mapq=rng.integers(20, 70, n).astype(np.uint8),
+                reverse=rng.integers(0, 2, n).astype(np.uint8))
+
+
 def realign(which, sc, band, want_ll=True, use_mapq=True, mapq_cap=False):
     flat, lens = default_tables()
     cat = lambda xs: (np.concatenate(xs).astype(np.uint8), np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.uint32))
@@ -107,6 +137,15 @@ def check(backend, tol=0.0, golden=False):
         kinds |= {c for cig in want["cigar"] for c in cig if c in "=XID"}
         n += n_reads
     assert kinds == set("=XID"), kinds                                            # every operation the seam can emit was compared
+    # reads inside repeats longer than themselves: more tied diagonals than the ABI's 15 slots (the seam re-aligns exactly those the reference's way)
+    sc = repeat_scenario(rng)
+    want = stored[len(SCENARIOS)] if golden else realign("ref", sc, 16)
+    got = realign(lib, sc, 16)
+    assert want["rc"] == 0 and got["rc"] == 0, (want["rc"], got["rc"])
+    assert want["begin"] == got["begin"] and want["end"] == got["end"], [k for k in range(len(sc["reads"])) if want["begin"][k] != got["begin"][k]]
+    assert want["cigar"] == got["cigar"], [(a, b) for a, b in zip(want["cigar"], got["cigar"]) if a != b][:3]
+    assert np.max(np.abs(np.asarray(want["loglik"]) - np.asarray(got["loglik"]))) <= tol
+    n += len(sc["reads"])
     if golden:
         return n
     sc = scenario(rng, 9, 80, 200, 16, short=True)

@@ -22,6 +22,9 @@ for band, n_reads, T, Lh, want_ll, use_mapq, cap in cr.SCENARIOS:
     res = cr.realign("ref", sc, band, want_ll, use_mapq, cap)
     assert res["rc"] == 0
     out.append(res)
+res = cr.realign("ref", cr.repeat_scenario(rng), 16)               # reads inside repeats longer than themselves (more tied diagonals than the ABI's 15 slots)
+assert res["rc"] == 0
+out.append(res)
 cr.GOLDEN.write_text(json.dumps({"source": "reference read_realigner.cpp:83-155 via oracle/ref_realigner_bridge.cpp, scenarios of tests/check_realigner_patch.py (seed 91)",
                                  "results": out}))
 print(sum(len(r["cigar"]) for r in out), "reads ->", cr.GOLDEN)

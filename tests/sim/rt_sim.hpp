@@ -35,6 +35,7 @@ inline bool host_is_pinned(const void* p)
     --it;
     return (const char*)p < it->first + it->second;
 }
+inline bool host_is_pinned(const void* p, size_t bytes) { return host_is_pinned(p) && (bytes <= 1 || host_is_pinned((const char*)p + bytes - 1)); }
 inline bool h2d(void* d, const void* h, size_t n, Stream) { if (n) memcpy(d, h, n); return true; }
 inline bool d2h(void* h, const void* d, size_t n, Stream) { if (n) memcpy(h, d, n); return true; }
 inline bool dev_memset(void* d, int v, size_t n, Stream) { if (n) memset(d, v, n); return true; }

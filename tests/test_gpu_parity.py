@@ -411,7 +411,7 @@ def test_gpu_patched_read_realigner_seam_equals_the_reference_functions():
     (prebuilt oracle/_ref/libref_realigner_patched_gpu.so), against the reference's own functions' committed output: region, CIGAR, log-likelihood per read."""
     import check_realigner_patch as cr
     require_reference_build(cr.have("patched_gpu"), "oracle/_ref/libref_realigner_patched_gpu.so")
-    assert cr.check("gpu", TOL, golden=True) == 69
+    assert cr.check("gpu", TOL, golden=True) == 98
 
 
 def test_gpu_linked_chunks_of_long_reads_and_ragged_reads():
