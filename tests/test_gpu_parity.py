@@ -224,6 +224,17 @@ def test_gpu_long_reads_at_narrow_bands_stream():
     ca.compare_align("gpu", batch, max_cigar_ops=256, max_indel_error=16, use_int_scores=1)
 
 
+def test_gpu_multi_region_shape_fuzz_slice():
+    """A 100-scenario slice of the multi-region shape fuzz (tests/check_shapes.py; the round's full run is profiles/r05_final_gpu_fuzz.log): 1-64 regions, every
+    haplotype count 1-48 and up to 400, R 20-5,000, ragged reads, linked chunks, NULL and given penalty vectors, random switches, through oct_phmm_populate, the
+    resident API and the region server from 8 threads; sampled regions against the REFERENCE's own populate (oracle/_ref/libref_array.so must be on the box)."""
+    import check_shapes
+    require_reference_build(oracle.have_ref_array(), "oracle/_ref/libref_array.so")
+    with check_shapes.worker_pool(10) as pool:
+        st = check_shapes.check_shapes("gpu", range(5000, 5100), pool=pool)
+    assert st["scenarios"] == 100 and st["sampled_regions"] >= 150 and st["server_calls"] > 100 and st["resident"] > 5 and st["null_vectors"] > 5, st
+
+
 def test_gpu_random_scenarios():
     import check_fuzz
     assert check_fuzz.check_fuzz("gpu", seed=7, n=120, tol=TOL) == 120
