@@ -115,6 +115,34 @@ def verify_against_reference(got: np.ndarray, regions, B: int, frac: float = 0.0
                                  else "CPU oracle restatement (no reference build on this box)")}
 
 
+def host_topology():
+    """Sockets, cores and hardware threads of the HOST (from /proc/cpuinfo), beside what the cgroup lets this process use: `cpu_baseline.cores` is the latter, and
+    the north star's ">= 50 x a single socket" can only be argued from a stated per-core rate times a stated core count."""
+    import os
+    phys, cores_of, n_threads, model = set(), {}, 0, ""
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = (x.strip() for x in line.split(":", 1)); cur[k] = v
+            elif cur:
+                n_threads += 1; pid = cur.get("physical id", "0"); phys.add(pid); cores_of.setdefault(pid, set()).add(cur.get("core id", str(n_threads)))
+                model = cur.get("model name", model); cur = {}
+        if cur:
+            n_threads += 1; pid = cur.get("physical id", "0"); phys.add(pid); cores_of.setdefault(pid, set()).add(cur.get("core id", str(n_threads)))
+    except OSError:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    cps = max((len(c) for c in cores_of.values()), default=0)
+    return {"host_sockets": len(phys), "host_cores_per_socket": cps, "host_threads": n_threads, "host_cpu_model": model,
+            "affinity_threads": len(os.sched_getaffinity(0)), "cgroup_cpu_quota": quota}
+
+
 def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
     """The reference's CPU path on the host cores, on a bounded sample of the same workload. Preferred (kind "reference"): the reference's OWN
     HaplotypeLikelihoodArray::populate (haplotype_likelihood_array.cpp + model + pair_hmm.hpp + its SSE2 kernels, built in place into
@@ -179,6 +207,24 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
             out["loglik_per_s"] = pairs / secs
             out["sample"] = (f"{R} reads x {H} haplotypes of the same generator, {reps_a} repetition(s) of the reference's own "
                              f"HaplotypeLikelihoodArray::populate (built in place, {isa_used} kernels, its thread pool of {cores} workers over haplotypes)")
+            # how that scales with threads on this host: the reader multiplies the per-thread rate by a socket's cores, we do not (vs_baseline stays as measured)
+            isa_key = isa_used.lower()
+            curve = {}
+            for n in (1, 2, 4, 8, 16):
+                if n > cores:
+                    break
+                if n == cores:
+                    curve[str(n)] = out["value"]; continue
+                secs_n = oracle.ref_array_time_populate(cfg, batch, n, 1, isa=isa_key)
+                if secs_n > 0:
+                    curve[str(n)] = cells / secs_n / 1e9
+            out["scaling"] = {"unit": "GCUPS by threads of the reference's populate thread pool", "by_threads": curve}
+            if "1" in curve:
+                out["per_thread_gcups"] = curve["1"]
+    out.update(host_topology())
+    if out.get("host_cores_per_socket") and out.get("per_thread_gcups"):
+        out["socket_projection_note"] = (f"one socket of this host = {out['host_cores_per_socket']} cores; at perfect scaling of the single-thread rate that would be "
+                                         f"{out['per_thread_gcups'] * out['host_cores_per_socket']:.1f} GCUPS - a projection, not a measurement (the lease grants {cores} threads)")
     return out
 
 

@@ -130,6 +130,7 @@ struct oct_phmm_batch {
     struct Slice {                     // whole haplotypes [hap0, hap1) = pairs [pair0, pair1) = outputs [out0, out1)
         uint32_t hap0 = 0, hap1 = 0, blk0 = 0, blk1 = 0, n_tiles = 0; uint64_t pair0 = 0, pair1 = 0, out0 = 0, out1 = 0;
         uint4* cnt = nullptr; uint4* tile_sums = nullptr; uint4* d_totals = nullptr; uint4 totals {};
+        bool scan_fused = false;      // this run scanned the counts tile-locally (k_scan_fused): k_emit adds the tile prefixes, a flavour's traceback and late-start lists share one launch
         uint4* cnt_late = nullptr; uint4* tile_sums_late = nullptr; uint4* d_totals_late = nullptr; uint4 totals_late {};   // right-flank-only traceback tasks (x fast, y generic)
         DevTask* d_tasks = nullptr; size_t tasks_cap = 0; TraceEnd* d_ends = nullptr; size_t ends_cap = 0;
         unsigned long long* d_keys = nullptr; size_t keys_cap = 0;   // align mode: per traceback task
@@ -224,6 +225,8 @@ inline int  dedup()           { const char* e = get("OCT_PHMM_DEDUP"); return !e
 inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_HASH_BITS", &n) && n >= 1 && n < 32 ? (1u << n) - 1u : 0xffffffffu; }   // test hook: collisions
 inline int  device_sized()    { const char* e = get("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
 inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
+inline bool late_start()      { const char* e = get("OCT_PHMM_LATE_START"); return !e || atoi(e) != 0; }                          // 0: every traceback task writes all of its backpointer tiles (A/B)
+inline bool scan_fused()      { const char* e = get("OCT_PHMM_SCAN_FUSED"); return !e || atoi(e) != 0; }                          // 0: the task counts are scanned by k_scan_bases / k_scan_tiles x 3 + k_hap_bases per array, and the late-start lists get launches of their own (round 4's chain, A/B)
 inline bool dp_rows()         { const char* e = get("OCT_PHMM_DP_ROWS"); return !e || atoi(e) != 0; }                             // 0: long reads at band 16 with int32 lanes keep k_dp_wide (generic cost for every task, operands per lane) instead of k_dp_rows
 inline bool multi_wave()      { const char* e = get("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
 inline int  mw_planes()       { const char* e = get("OCT_PHMM_MW_PLANES"); return !e ? -1 : atoi(e); }                              // k_dp_mw: -1 by task count, 0 one plane per wave (B / 64 waves per task), 1 all planes in one wave
@@ -644,7 +647,10 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     // spreads over the chip: one group per wave until there are enough workgroups for every CU
     p.groups_per_block = kBlockWaves * std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerWave, n_groups / (kBlockWaves * 2048)));
     if (dsl) p.groups_per_block = kBlockWaves;             // (region-sized by construction)
-    p.late = late ? 1 : 0; p.hap_region = b->d.hap_region; p.reg_rhs = b->d.reg_rhs;
+    // late traceback start is PERMITTED wherever the walk may stop early (below); which task groups take it is geometry (dp_groups). `late`: the launch is a late-start list.
+    (void)late;
+    p.late = (tr && !seam_walk && !b->align_mode && b->fast_adds && !b->stream && !h->wide && tune::late_start()) ? 1 : 0;
+    p.hap_region = b->d.hap_region; p.reg_rhs = b->d.reg_rhs; p.reg_lhs = b->d.reg_lhs;
     uint32_t chunk_groups = n_groups;
     if (tr) {
         const size_t per_group = (size_t)p.k_cap * 4096 * (b->stream ? C : 1);
@@ -1281,7 +1287,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     if (tune::dedup() > 0) b->dedup = !align_mode && !b->stream && !h->wide && H->n_haps > G;
     for (uint32_t g = 0; g < G && b->dedup; ++g) if (g_hap[g + 1] - g_hap[g] > 65535) b->dedup = false;     // (the matcher's table holds 16-bit haplotype numbers within a region)
     if (b->dedup) { pk.dalloc(&d.canon, (size_t)n_hap_bases + 1); pk.dalloc(&d.pair_rep, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_hash, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_fast, (size_t)b->n_pairs + 1); }
-    pk.dalloc(&d.stats, (size_t)kStatSlots * kStatStride + 8);
+    pk.dalloc(&d.stats, (size_t)kStatSlots * kStatStride + 8);      // + error key, overflow flag, k_scan_fused's per-slice counters (eight 32-bit words)
     pk.dalloc(&b->d_hap_base, (size_t)H->n_haps + 1);
     // late traceback start (k_dp): packed int16 kernels only, no lane can wrap (a failed traceback is then impossible,
     // so a walk may stop once it has left the right flank), populate only, and only where the three extra scan launches do not show
@@ -1573,7 +1579,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     const bool mapped_out = b->early_out && !b->out_landing && S == 1 && !b->align_mode && b->n_out <= kHostMappedOutMax && b->stat_stage && tune::host_mapped();
     const uint32_t mapped_stripes = tune::map_stats() ? kStatSlots : (uint32_t)std::min<uint64_t>(kStatSlots, (b->n_pairs + 255) / 256);   // (k_classify's workgroups own the counters; the mapper's only with OCT_PHMM_MAP_STATS)
     if (mapped_out) memset(b->stat_stage, 0, kStatWords * sizeof(unsigned long long));
-    if (!b->stats_clear) RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
+    if (!b->stats_clear) RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 6) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
     b->stats_clear = false;
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
     if (b->dedup) RT(rt::dev_memset(d.pair_rep, 0xff, (size_t)b->n_pairs * sizeof(uint32_t), s0));      // kNoPair: every pair is computed itself until k_dedup_verify says otherwise
@@ -1632,6 +1638,17 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         }
         if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one
         const uint64_t n_scan = np + 1;
+        sl.scan_fused = false;
+        if (tune::scan_fused() && n_scan < 0xffffffffull) {       // any size: both count arrays, the haplotype bases and the totals in ONE launch (k_scan_fused)
+            const uint32_t n_tf = (uint32_t)((n_scan + kScanFusedTile - 1) / kScanFusedTile);
+            uint32_t* done = (uint32_t*)(d.stats + (size_t)kStatSlots * kStatStride + 2) + i;
+            OCT_LAUNCH(k_scan_fused, n_tf * (sl.cnt_late ? 2u : 1u), kHapBaseThreads, 17 * sizeof(uint4), s, d, sl.hap0, sl.hap1, sl.cnt, sl.cnt_late, sl.pair0, (uint32_t)n_scan, n_tf,
+                       sl.tile_sums, sl.tile_sums_late, b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G, done); RT(rt::launch_ok());
+            sl.scan_fused = true;
+            sl.totals_late = make_uint4(0, 0, 0, 0);
+            if (!b->dsl) { RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s)); if (sl.cnt_late) RT(rt::d2h(&sl.totals_late, sl.d_totals_late, sizeof(uint4), s)); }
+            return OCT_PHMM_OK;
+        }
         long long one_launch_max = kScanBasesOneLaunchMax; tune::number("OCT_PHMM_SCAN_ONE_LAUNCH_MAX", &one_launch_max);      // (test hook: 0 = the tiled scan for every device-sized batch)
         if (b->dsl && (long long)n_scan <= one_launch_max) {  // region-sized: scans and per-haplotype bases of both count arrays in one launch
             OCT_LAUNCH(k_scan_bases, sl.cnt_late ? 2 : 1, kHapBaseThreads, 16 * sizeof(uint4), s, d, sl.hap0, sl.hap1, sl.cnt, sl.cnt_late, sl.pair0, (uint32_t)n_scan,
@@ -1679,8 +1696,10 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             }
             TaskArrays ta {}; ta.t[0] = sl.d_tasks; TaskArrays tl {};
             TaskListRef ref {sl.d_totals, sl.cnt_late ? sl.d_totals_late : nullptr, 0, d.dsl_overflow};
+            const bool join = sl.scan_fused;                       // a flavour's traceback and late-start lists in one launch (k_scan_fused checked that BOTH fit the scratch)
             OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
-                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, ref, G); RT(rt::launch_ok());
+                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, ref, G,
+                       sl.scan_fused ? (const uint4*)sl.tile_sums : nullptr, sl.scan_fused ? (const uint4*)sl.tile_sums_late : nullptr); RT(rt::launch_ok());
             // Region-sized and latency-bound: the score-only DP runs on a second stream beside the traceback DP (a region's two lists together are about one
             // wave per SIMD; OCT_PHMM_DSL_FORK_EARLY=0: beside the traceback WALK instead, as round 2's lockstep walker wanted it).
             rt::Stream aux = h->slice_stream(1);
@@ -1696,9 +1715,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             bool forked = false, score_done[2] = {false, false};
             if (!merge && (b->stream || tune::dsl_fork_early())) { RT(rt::event_record(b->ev_fork, s)); forked = true; }     // (long reads: see the host-sized path)
             for (int list : {4, 5, (int)kTraceFast, (int)kTraceGen}) {
-                if (list >= 4 && !sl.cnt_late) continue;
+                if (list >= 4 && (!sl.cnt_late || join)) continue;
                 if (!flavour_live(list)) continue;
-                ref.list = list;
+                ref.list = list; ref.join_late = (join && sl.cnt_late) ? 1 : 0;
                 const int fl = (list == kTraceGen || list == 5) ? 1 : 0;
                 const bool ride = merge && !score_done[fl];
                 const int rc = run_dp_kind(h, b, 0, list == 4 ? kTraceFast : list == 5 ? kTraceGen : list, sl.d_tasks, b->dsl_trace_cap, sl.d_ends, h->cfg.nuc_prior, nullptr, status,
@@ -1711,7 +1730,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 RT(rt::stream_wait_event(aux, b->ev_fork));
                 for (int list : {(int)kScoreFast, (int)kScoreGen}) {
                     if (!flavour_live(list) || score_done[list == kScoreGen ? 1 : 0]) continue;
-                    ref.list = list;
+                    ref.list = list; ref.join_late = 0;
                     const int rc = run_dp_kind(h, b, 0, list, sl.d_tasks, b->dsl_list_bound, sl.d_ends, h->cfg.nuc_prior, nullptr, status, &aux, false, ref);
                     if (rc != OCT_PHMM_OK) return rc;
                 }
@@ -1739,7 +1758,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             h->pool.release(sl.d_tasks); sl.d_tasks = nullptr; sl.tasks_cap = 0;
             void* p = nullptr; RT(h->pool.alloc(&p, (total + total / 8) * sizeof(DevTask))); sl.d_tasks = (DevTask*)p; sl.tasks_cap = total + total / 8;
         }
-        const size_t n_trace = (size_t)std::max(std::max(totals.y, totals.w), std::max(late.x, late.y));
+        const bool join = sl.scan_fused;                         // a flavour's traceback list and its late-start list (which lies right behind it) in ONE DP launch and ONE walk
+        const size_t n_trace = join ? (size_t)std::max(totals.y + late.x, totals.w + late.y) : (size_t)std::max(std::max(totals.y, totals.w), std::max(late.x, late.y));
         if (n_trace > sl.ends_cap) {
             h->pool.release(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
             void* p = nullptr; RT(h->pool.alloc(&p, (n_trace + n_trace / 8) * sizeof(TraceEnd))); sl.d_ends = (TraceEnd*)p; sl.ends_cap = n_trace + n_trace / 8;
@@ -1749,12 +1769,13 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             void* p = nullptr; RT(h->pool.alloc(&p, (n_trace + n_trace / 8) * sizeof(unsigned long long))); sl.d_keys = (unsigned long long*)p; sl.keys_cap = n_trace + n_trace / 8;
         }
         if (total) {
-            TaskArrays ta;
-            ta.t[0] = sl.d_tasks; ta.t[1] = ta.t[0] + totals.x; ta.t[2] = ta.t[1] + totals.y; ta.t[3] = ta.t[2] + totals.z;
-            TaskArrays tl;                                       // late-start traceback tasks: [0] fast-cost kernel, [1] generic
-            tl.t[0] = ta.t[3] + totals.w; tl.t[1] = tl.t[0] + late.x; tl.t[2] = tl.t[1] + late.y; tl.t[3] = tl.t[2];
+            // physical order (task_list_range): score-only fast, traceback fast, LATE fast, score-only generic, traceback generic, LATE generic
+            TaskArrays ta, tl;                                   // tl: late-start traceback tasks, [0] fast-cost kernel, [1] generic
+            ta.t[0] = sl.d_tasks; ta.t[1] = ta.t[0] + totals.x; tl.t[0] = ta.t[1] + totals.y; ta.t[2] = tl.t[0] + late.x; ta.t[3] = ta.t[2] + totals.z;
+            tl.t[1] = ta.t[3] + totals.w; tl.t[2] = tl.t[1] + late.y; tl.t[3] = tl.t[2];
             OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
-                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, TaskListRef {nullptr, nullptr, 0, nullptr}, G); RT(rt::launch_ok());
+                       (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, TaskListRef {nullptr, nullptr, 0, nullptr}, G,
+                       sl.scan_fused ? (const uint4*)sl.tile_sums : nullptr, sl.scan_fused ? (const uint4*)sl.tile_sums_late : nullptr); RT(rt::launch_ok());
             static const int order[kNumKinds] = {kTraceFast, kTraceGen, kScoreFast, kScoreGen};   // traceback first: its walk then overlaps the score-only DP of the next slice
             // A single-slice (region-sized) batch is latency-bound: its score-only DP runs beside the traceback DP + walk on a second stream.
             const bool side = S == 1 && total < 200000 && (totals.x + totals.z) > 0 && (totals.y + totals.w) > 0;   // big launches fill the chip on their own
@@ -1762,7 +1783,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             bool forked = false;                                 // (side) the score-only DP starts beside the first traceback launch's walk: see phase2_device_sized
             // ... except for long reads: a traceback launch of ~10^2 tasks is a few hundred latency-bound waves that leave the chip's issue slots to the score-only DP
             if (side && b->stream) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
-            for (int lk = 0; lk < 2; ++lk) {                     // late-start traceback launches first (the longest walks of the slice start earliest)
+            for (int lk = 0; lk < 2 && !join; ++lk) {            // late-start traceback launches first (the longest walks of the slice start earliest)
                 const uint32_t n = lk ? late.y : late.x;
                 const int rc = run_dp_kind(h, b, i, lk ? kTraceGen : kTraceFast, tl.t[lk], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, nullptr, true,
                                            TaskListRef {nullptr, nullptr, 0, nullptr}, side && !forked && n ? &b->ev_fork : nullptr);
@@ -1771,7 +1792,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             }
             for (int k : order) {
                 const bool score_kind = k == kScoreFast || k == kScoreGen;
-                const uint32_t n = k == 0 ? totals.x : k == 1 ? totals.y : k == 2 ? totals.z : totals.w;
+                const uint32_t n = k == 0 ? totals.x : k == 1 ? totals.y + (join ? late.x : 0u) : k == 2 ? totals.z : totals.w + (join ? late.y : 0u);   // (join: the late-start list lies right behind)
                 if (side && score_kind && !forked) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
                 if (side && score_kind && n) RT(rt::stream_wait_event(aux, b->ev_fork));
                 const int rc = run_dp_kind(h, b, i, k, ta.t[k], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, side && score_kind ? &aux : nullptr, false,

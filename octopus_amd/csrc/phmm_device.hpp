@@ -109,6 +109,7 @@ struct TaskListRef {
     int list;                   // 0..3 = Kind, 4 = late-start fast, 5 = late-start generic
     const unsigned long long* overflow;   // set by the scan when a traceback list outgrew the scratch the host provisioned: every list then reads as empty
                                           // and the host repeats the step with host-sized launches (oct_phmm_batch_wait)
+    int join_late;              // `list` is a traceback kind: the flavour's late-start list (which lies right behind it in the array) belongs to this launch too
 };
 
 struct DpParams {
@@ -127,8 +128,10 @@ struct DpParams {
     uint32_t  groups_per_block;
     uint32_t  rec_chunk;                              // k_dp / k_dp_pair: iterations' worth of read records a wave keeps in LDS at a time (a multiple of 4); 0 = the whole reads
     // late traceback start (tasks whose window touches only the RIGHT inactive flank): the traceback words are needed, and written, only for the
-    // last iterations; everything before runs the score-only recurrence. 0 = off.
-    int late; const uint32_t* hap_region; const uint32_t* reg_rhs;
+    // last iterations; everything before runs the score-only recurrence. 0 = off; 1 = permitted (the walk stops early, WalkParams::early_stop): a task group
+    // whose tasks ALL start at or behind the left flank's end (off >= reg_lhs: k_classify's class 3, pure geometry) starts late - the groups of a late-start list
+    // by construction, and whichever other group happens to qualify.
+    int late; const uint32_t* hap_region; const uint32_t* reg_rhs; const uint32_t* reg_lhs;
 };
 
 struct WalkParams {

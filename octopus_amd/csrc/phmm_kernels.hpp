@@ -101,7 +101,7 @@ OCT_DEVICE void read_record_thread(const DevBatch& b, uint64_t g)
 OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks, uint32_t flag_blocks)
 {
     // the last workgroup also clears the step's counters (+ error key + overflow flag behind them), so that the first run after an upload needs no memset launch
-    if (hw::block_idx() + 1 == hw::grid_dim()) for (uint32_t i = hw::thread_idx(); i < kStatSlots * kStatStride + 2; i += hw::block_dim()) b.stats[i] = 0ull;
+    if (hw::block_idx() + 1 == hw::grid_dim()) for (uint32_t i = hw::thread_idx(); i < kStatSlots * kStatStride + 6; i += hw::block_dim()) b.stats[i] = 0ull;   // (+ error key, overflow flag, k_scan_fused's eight 32-bit counters)
     if (hw::block_idx() >= table_blocks + flag_blocks) { read_record_thread(b, (uint64_t)(hw::block_idx() - table_blocks - flag_blocks) * hw::block_dim() + hw::thread_idx()); return; }
     if (hw::block_idx() >= table_blocks) { read_flags_wave(b, (hw::block_idx() - table_blocks) * (hw::block_dim() / 64) + (hw::thread_idx() >> 6), hw::thread_idx() & 63u); return; }
     const uint32_t g = hw::block_idx() * hw::block_dim() + hw::thread_idx();
@@ -1324,6 +1324,83 @@ OCT_KERNEL(k_scan_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, 
     }
 }
 
+// Any size, ONE launch (round 5): the scan of both count arrays, the per-haplotype bases and the totals - what took k_scan_tiles x 3 + k_hap_bases per array
+// (eight launches and their gaps with late-start lists: a region server's device batch is a chain of dependent launches). Workgroup
+// (tile, array) scans its tile of 8,192 items IN PLACE, tile-locally, and leaves the tile's total in tile_sums; the workgroup that finishes LAST (a device-scope
+// counter; no workgroup ever waits for another) turns the tile totals into tile prefixes and computes the haplotype bases and totals of both arrays from
+// local count + prefix of its tile. Readers of the counts (k_emit) add the tile prefix themselves: ScanView.
+struct ScanView { const uint4* cnt; const uint4* tile_pref; };       // tile_pref null: cnt is scanned globally (k_scan_tiles, k_scan_bases)
+constexpr uint32_t kScanFusedShift = 13, kScanFusedTile = 1u << kScanFusedShift;     // = kHapBaseThreads x 8
+OCT_DEVICE uint4 scanned(const ScanView& v, uint64_t i) { const uint4 c = v.cnt[i]; return v.tile_pref ? add4(c, v.tile_pref[i >> kScanFusedShift]) : c; }
+OCT_KERNEL(k_scan_fused)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, uint4* cnt1, uint64_t pair0, uint32_t n_scan, uint32_t n_tiles,
+                         uint4* tile_sums0, uint4* tile_sums1, uint4* hap_base0, uint4* hap_base1, uint4* totals0, uint4* totals1, uint32_t group, uint32_t* done)
+{
+    OCT_DYN_SMEM(smem);
+    uint4* sh = (uint4*)smem;                                   // [16] + one word for the verdict
+    uint32_t* verdict = (uint32_t*)(sh + 16);
+    const uint32_t tid = hw::thread_idx();
+    const uint32_t n_arr = cnt1 ? 2u : 1u, which = hw::block_idx() / n_tiles, tile = hw::block_idx() % n_tiles;
+    {
+        uint4* cnt = which ? cnt1 : cnt0;
+        constexpr uint32_t PER = kScanFusedTile / kHapBaseThreads;
+        const uint32_t i0 = tile * kScanFusedTile + tid * PER;
+        uint4 v[PER], sum = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) { v[j] = i0 + j < n_scan ? cnt[i0 + j] : make_uint4(0, 0, 0, 0); sum = add4(sum, v[j]); }
+        uint4 tile_total;
+        uint4 run = block_scan_excl(sum, sh, &tile_total);
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) if (i0 + j < n_scan) { cnt[i0 + j] = run; run = add4(run, v[j]); }
+        if (tid == 0) (which ? tile_sums1 : tile_sums0)[tile] = tile_total;
+    }
+    // who is last? (every thread's stores are ordered before the workgroup's one increment: fence, barrier, fence + atomic by thread 0)
+    hw::device_fence();
+    hw::block_sync();
+    if (tid == 0) { hw::device_fence(); *verdict = hw::atomic_add_u32(done, 1u) + 1u == n_tiles * n_arr ? 1u : 0u; }
+    hw::block_sync();
+    if (!*verdict) return;
+    hw::device_fence();                                         // the other workgroups' counts and tile totals, not this CU's stale lines
+    if (tid == 0) *done = 0u;                                   // (a repeated step finds the counter as the upload left it)
+    uint4 all[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    for (uint32_t a = 0; a < n_arr; ++a) {
+        uint4* cnt = a ? cnt1 : cnt0; uint4* tsum = a ? tile_sums1 : tile_sums0; uint4* hap_base = a ? hap_base1 : hap_base0;
+        // tile totals -> exclusive tile prefixes, in place (1,024 tiles per round: 8 M pairs)
+        uint4 carry = make_uint4(0, 0, 0, 0);
+        for (uint32_t t0 = 0; t0 < n_tiles; t0 += kHapBaseThreads) {
+            const uint4 mine = t0 + tid < n_tiles ? tsum[t0 + tid] : make_uint4(0, 0, 0, 0);
+            uint4 round_total;
+            const uint4 ex = block_scan_excl(mine, sh, &round_total);
+            if (t0 + tid < n_tiles) tsum[t0 + tid] = add4(carry, ex);
+            carry = add4(carry, round_total);
+        }
+        hw::block_sync();                                       // the prefixes are read across threads below
+        const ScanView view {cnt, tsum};
+        const uint32_t n = hap1 - hap0;
+        const uint32_t per = (n + kHapBaseThreads - 1) / kHapBaseThreads;
+        const uint32_t lo = hap0 + (tid * per < n ? tid * per : n), hi = hap0 + ((tid + 1) * per < n ? (tid + 1) * per : n);
+        auto up = [&](uint32_t c) { return (c + group - 1) / group * group; };
+        auto padded = [&](uint32_t h) {
+            const uint4 x = scanned(view, b.hap_pair_off[h] - pair0), z = scanned(view, b.hap_pair_off[h + 1] - pair0);
+            return make_uint4(up(z.x - x.x), up(z.y - x.y), up(z.z - x.z), up(z.w - x.w));
+        };
+        uint4 sum = make_uint4(0, 0, 0, 0);
+        for (uint32_t h = lo; h < hi; h += 4) {                 // (four at a time: eight independent loads in flight, see k_hap_bases)
+            uint4 v[4];
+            for (uint32_t u = 0; u < 4; ++u) v[u] = h + u < hi ? padded(h + u) : make_uint4(0, 0, 0, 0);
+            for (uint32_t u = 0; u < 4; ++u) sum = add4(sum, v[u]);
+        }
+        uint4 run = block_scan_excl(sum, sh, &all[a]);
+        for (uint32_t h = lo; h < hi; h += 4) {
+            uint4 v[4];
+            for (uint32_t u = 0; u < 4; ++u) v[u] = h + u < hi ? padded(h + u) : make_uint4(0, 0, 0, 0);
+            for (uint32_t u = 0; u < 4; ++u) if (h + u < hi) { hap_base[h + u] = run; run = add4(run, v[u]); }
+        }
+        if (tid == 0) *(a ? totals1 : totals0) = all[a];
+    }
+    // one traceback launch takes a flavour's traceback list AND its late-start list: together they must fit the scratch the host provisioned
+    if (tid == 0 && b.dsl_trace_cap && (all[0].y + all[1].x > b.dsl_trace_cap || all[0].w + all[1].y > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
+}
+
 struct TaskArrays { DevTask* t[kNumKinds]; };
 
 // A region-sized call's inputs, from the handle's pinned staging buffer (mapped into the device) to their device block: a kernel starts sooner than a DMA copy
@@ -1335,20 +1412,31 @@ OCT_KERNEL(k_copy_from_host)(uint4* dst, const uint4* src, uint32_t n16)
 }
 
 // Device-sized launches: first task and length of one of the six task lists, from k_hap_bases' totals in device memory (uniform: scalar loads)
+// Physical order of the lists in the array: score-only fast, traceback fast, LATE fast, score-only generic, traceback generic, LATE generic - a flavour's
+// late-start list lies right behind its traceback list, so that ONE traceback launch and ONE walk take both (ref.join_late; round 5: the second traceback
+// launch of a region-sized step was a single round of workgroups on an otherwise idle chip, and its walk one more link in the chain).
 OCT_DEVICE void task_list_range(const TaskListRef& ref, uint32_t& first, uint32_t& n)
 {
     const uint4 a = *ref.totals;
     const uint4 l = ref.totals_late ? *ref.totals_late : make_uint4(0, 0, 0, 0);
     const uint32_t c[6] = {a.x, a.y, a.z, a.w, l.x, l.y};
+    constexpr int order[6] = {0, 1, 4, 2, 3, 5};            // list ids in physical order
     first = 0; n = 0;
-    for (int k = 0; k < 6; ++k) { if (k < ref.list) first += c[k]; if (k == ref.list) n = c[k]; }
+    bool before = true;
+    for (int k = 0; k < 6; ++k) {
+        const int id = order[k];
+        if (id == ref.list) { before = false; n = c[id]; if (ref.join_late && (id == 1 || id == 3)) n += c[id == 1 ? 4 : 5]; }
+        else if (before) first += c[id];
+    }
     if (ref.overflow && *ref.overflow) { first = 0; n = 0; }
 }
 
 // Pass 2: write the DP tasks of every pair at hap_base + (scanned count - scanned count at the haplotype's first pair).
 OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt, const uint4* hap_base, TaskArrays out,
-                   const uint4* cnt_late, const uint4* hap_base_late, TaskArrays out_late, TaskListRef ref, uint32_t group)
+                   const uint4* cnt_late, const uint4* hap_base_late, TaskArrays out_late, TaskListRef ref, uint32_t group,
+                   const uint4* tile_pref, const uint4* tile_pref_late)      // tile prefixes of k_scan_fused's tile-local scans (null: the counts are scanned globally)
 {
+    const ScanView sv {cnt, tile_pref}, sv_late {cnt_late, tile_pref_late};
     const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
     const uint64_t e_wave = wave_first_index(pair0);
     if (e >= pair1) return;
@@ -1366,7 +1454,7 @@ OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt,
     const uint32_t h = upper_bound_near(b.hap_pair_off, b.n_haps + 1, e_wave, e);
     const uint32_t r = b.reg_read0[b.hap_region[h]] + (uint32_t)(e - b.hap_pair_off[h]);
     const bool generic = b.wide || !(b.racgt[r] && b.hclean[h]);
-    const uint4 s = cnt[e - pair0], s0 = cnt[b.hap_pair_off[h] - pair0], z = cnt[b.hap_pair_off[h + 1] - pair0], hb = hap_base[h];
+    const uint4 s = scanned(sv, e - pair0), s0 = scanned(sv, b.hap_pair_off[h] - pair0), z = scanned(sv, b.hap_pair_off[h + 1] - pair0), hb = hap_base[h];
     uint32_t at_score = generic ? hb.z + (s.z - s0.z) : hb.x + (s.x - s0.x);
     uint32_t at_trace = generic ? hb.w + (s.w - s0.w) : hb.y + (s.y - s0.y);
     // one past the haplotype's last real task of each list: whoever writes the task before it also writes the padding copies behind it
@@ -1374,7 +1462,7 @@ OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt,
     DevTask* ts = out.t[generic ? kScoreGen : kScoreFast]; DevTask* tt = out.t[generic ? kTraceGen : kTraceFast];
     uint32_t at_late = 0, end_late = 0; DevTask* tl = nullptr;
     if (cnt_late) {
-        const uint4 q = cnt_late[e - pair0], q0 = cnt_late[b.hap_pair_off[h] - pair0], qz = cnt_late[b.hap_pair_off[h + 1] - pair0], qb = hap_base_late[h];
+        const uint4 q = scanned(sv_late, e - pair0), q0 = scanned(sv_late, b.hap_pair_off[h] - pair0), qz = scanned(sv_late, b.hap_pair_off[h + 1] - pair0), qb = hap_base_late[h];
         at_late = generic ? qb.y + (q.y - q0.y) : qb.x + (q.x - q0.x); tl = out_late.t[generic ? 1 : 0];
         end_late = generic ? qb.y + (qz.y - q0.y) : qb.x + (qz.x - q0.x);
     }
@@ -1669,8 +1757,12 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                 // boundary no later than the first possible end cell, so end-cell ties see their labels.
                 uint32_t k_sw = 0;
                 if (p.late) {
+                    // (a task that also touches the LEFT flank - its window starts before the flank's end, off < reg_lhs: k_classify's class 2 - needs its whole
+                    // traceback: its first needed iteration is 0, and so is the group's)
                     auto first_needed = [&](const DevTask& t, uint32_t T) -> uint32_t {
-                        const uint32_t Lh = p.hoff[t.hap + 1] - p.hoff[t.hap], L = T + 2 * B - 1, rhs = p.reg_rhs[p.hap_region[t.hap]];
+                        const uint32_t reg = p.hap_region[t.hap];
+                        if (t.off < p.reg_lhs[reg]) return 0u;
+                        const uint32_t Lh = p.hoff[t.hap + 1] - p.hoff[t.hap], L = T + 2 * B - 1, rhs = p.reg_rhs[reg];
                         const uint32_t rhs_w = t.off + L + rhs < Lh ? 0u : (t.off + L + rhs - Lh < L ? t.off + L + rhs - Lh : L);   // right flank in window coordinates (pair_hmm.hpp:580-587)
                         const uint32_t rhs_begin = L - rhs_w;
                         return rhs_begin > (uint32_t)B + 2 ? rhs_begin - B - 2 : 0u;        // cells with x >= rhs_begin - 2 lie on iterations k >= x - (B - 1) - 1

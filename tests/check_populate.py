@@ -610,7 +610,8 @@ def check_launch_modes(backend, tol=0.0):
     must give the same bytes, and both must equal the oracle: packed int16, int32 lanes, the streaming kernels, generic bytes, several regions
     with templates, and the late traceback start."""
     import os
-    SW = ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP", "OCT_PHMM_SCAN_ONE_LAUNCH_MAX", "OCT_PHMM_HOST_MAPPED")
+    SW = ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP", "OCT_PHMM_SCAN_ONE_LAUNCH_MAX", "OCT_PHMM_HOST_MAPPED",
+          "OCT_PHMM_SCAN_FUSED", "OCT_PHMM_LATE_START")
     keep = {k: os.environ.get(k) for k in SW + ("OCT_PHMM_LATE_MIN_PAIRS",)}
     rng = np.random.default_rng(4711)
     n = repeated = 0
@@ -631,9 +632,11 @@ def check_launch_modes(backend, tol=0.0):
         for case_no, (B, kw, late, batch) in enumerate(cases):
             os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = "0" if late else "1000000000000"
             outs = []
-            modes = ("default", "host", "budget", "overflow", "two_launches")
+            # old_chain / old_chain_host (round 5): the round-4 launch chain - k_scan_bases or the tiled scans per count array, late-start lists in launches of their own -
+            # against the default (k_scan_fused, a flavour's traceback and late-start lists in one DP launch and one walk); no_late_start: every task writes all its tiles
+            modes = ("default", "host", "budget", "overflow", "two_launches", "old_chain", "old_chain_host", "no_late_start")
             if backend == "sim" and case_no >= 3:                   # (every lane is a coroutine there: the chunked and the multi-region forms on the first three shapes only)
-                modes = ("default", "host", "overflow")
+                modes = ("default", "host", "overflow", "old_chain")
             for mode in modes:
                 for k in SW:
                     os.environ.pop(k, None)
@@ -641,15 +644,19 @@ def check_launch_modes(backend, tol=0.0):
                     os.environ["OCT_PHMM_DSL_MERGE_DP"] = "0"       # k_dp_pair launch, the tiled scan instead of the one-workgroup one, DMA copies instead of mapped pinned memory
                     os.environ["OCT_PHMM_SCAN_ONE_LAUNCH_MAX"] = "0"
                     os.environ["OCT_PHMM_HOST_MAPPED"] = "0"
-                if mode == "host":
+                if mode in ("host", "old_chain_host"):
                     os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"
+                if mode in ("old_chain", "old_chain_host"):
+                    os.environ["OCT_PHMM_SCAN_FUSED"] = "0"
+                if mode == "no_late_start":
+                    os.environ["OCT_PHMM_LATE_START"] = "0"
                 if mode == "budget":
                     os.environ["OCT_PHMM_BP_BUDGET_KB"] = "8"
                 if mode == "overflow":                              # scratch for one task group: the scan flags the batch, the wait repeats it host-sized
                     os.environ["OCT_PHMM_DSL_TRACE_PER_PAIR"] = "-1"
                 eng = make_engine(backend, max_indel_error=B, **kw)
                 rb = eng.upload(batch)
-                assert rb.device_sized() == (mode in ("default", "overflow", "two_launches")), (mode, B)
+                assert rb.device_sized() == (mode in ("default", "overflow", "two_launches", "old_chain", "no_late_start")), (mode, B)
                 rb.run(); outs.append(rb.download().copy())
                 if mode == "overflow":
                     repeated += 0 if rb.device_sized() else 1

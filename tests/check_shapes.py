@@ -32,6 +32,12 @@ SWITCH_SETS = [
     {"OCT_PHMM_MAP_MISMATCHES": "0"},
     {"OCT_PHMM_SCAN_ONE_LAUNCH_MAX": "0"},
     {"OCT_PHMM_LANE_MAPPER": "1", "OCT_PHMM_DEDUP": "1", "OCT_PHMM_SLICES": "3"},
+    {"OCT_PHMM_SCAN_FUSED": "0"},                                   # round 4's launch chain (scans per count array, late-start lists in launches of their own)
+    {"OCT_PHMM_LATE_MIN_PAIRS": "0"},                               # late-start lists for every batch
+    {"OCT_PHMM_LATE_MIN_PAIRS": "0", "OCT_PHMM_DEVICE_SIZED": "0"},
+    {"OCT_PHMM_LATE_MIN_PAIRS": "0", "OCT_PHMM_SCAN_FUSED": "0"},
+    {"OCT_PHMM_LATE_START": "0"},
+    {"OCT_PHMM_SLICES": "4", "OCT_PHMM_LATE_MIN_PAIRS": "0"},
 ]
 
 
