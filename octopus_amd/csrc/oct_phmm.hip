@@ -227,6 +227,7 @@ inline int  device_sized()    { const char* e = get("OCT_PHMM_DEVICE_SIZED"); re
 inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
 inline bool late_start()      { const char* e = get("OCT_PHMM_LATE_START"); return !e || atoi(e) != 0; }                          // 0: every traceback task writes all of its backpointer tiles (A/B)
 inline bool scan_fused()      { const char* e = get("OCT_PHMM_SCAN_FUSED"); return !e || atoi(e) != 0; }                          // 0: the task counts are scanned by k_scan_bases / k_scan_tiles x 3 + k_hap_bases per array, and the late-start lists get launches of their own (round 4's chain, A/B)
+inline int  join_late()       { const char* e = get("OCT_PHMM_JOIN_LATE"); return !e ? -1 : atoi(e); }                                // a flavour's traceback and late-start lists in one DP launch and one walk: -1 one-slice batches only, 0 never, 1 always
 inline bool dp_rows()         { const char* e = get("OCT_PHMM_DP_ROWS"); return !e || atoi(e) != 0; }                             // 0: long reads at band 16 with int32 lanes keep k_dp_wide (generic cost for every task, operands per lane) instead of k_dp_rows
 inline bool multi_wave()      { const char* e = get("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
 inline int  mw_planes()       { const char* e = get("OCT_PHMM_MW_PLANES"); return !e ? -1 : atoi(e); }                              // k_dp_mw: -1 by task count, 0 one plane per wave (B / 64 waves per task), 1 all planes in one wave
@@ -420,6 +421,26 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
     return ok;
 }
 
+// Byte-set questions over the input arrays, eight bytes per step (the compiler left the byte loops scalar: 0.17 ms of a 16-region upload, the only thing that made a
+// device-sized batch of 150 k pairs slower than a host-sized one). high bit of every byte of the result: clear where the byte of x equals c.
+inline uint64_t swar_ne(uint64_t x, uint8_t c) { const uint64_t y = x ^ (0x0101010101010101ull * c); return ((y & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | y; }
+bool any_byte_outside_acgt(const uint8_t* p, size_t n)
+{
+    uint64_t bad = 0; size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t x; memcpy(&x, p + i, 8); bad |= swar_ne(x, 'A') & swar_ne(x, 'C') & swar_ne(x, 'G') & swar_ne(x, 'T'); }
+    uint32_t tail = 0;
+    for (; i < n; ++i) tail |= ((p[i] == 'A') | (p[i] == 'C') | (p[i] == 'G') | (p[i] == 'T')) ? 0u : 1u;
+    return (bad & 0x8080808080808080ull) != 0 || tail != 0;
+}
+bool any_byte_equals(const uint8_t* p, size_t n, uint8_t c)
+{
+    uint64_t all_ne = ~0ull; size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t x; memcpy(&x, p + i, 8); all_ne &= swar_ne(x, c); }
+    uint32_t tail = 0;
+    for (; i < n; ++i) tail |= p[i] == c ? 1u : 0u;
+    return (~all_ne & 0x8080808080808080ull) != 0 || tail != 0;
+}
+
 bool monotone(const uint32_t* off, uint32_t n) { for (uint32_t i = 0; i < n; ++i) if (off[i + 1] < off[i]) return false; return true; }
 
 // kernel dispatch over (band, traceback, generic bytes, 32-bit adds)
@@ -611,16 +632,20 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 constexpr uint32_t kScanBasesOneLaunchMax = 2 * 8192;
 constexpr size_t   kPinnedOutMinBytes = (size_t)8 << 20;  // results from here on: is the caller's `out` page-locked? (the question costs microseconds: not asked for region-sized calls)
 constexpr uint64_t kLaneMapMinPairs = 200000;          // k-mer mapper: one lane per pair from here on (k_kmer_map_lanes), one wave per pair below
-constexpr uint64_t kDslMaxPairs = 100000;              // device-sized launches (no read-back inside the step, grids sized by the host's bound) up to here; beyond, the read-back costs less than the
-                                                       // bound's empty workgroups and the scan of every base for the cost flavours: first 6 / 8 / 12 / 16 / 64 regions of the configs[3] stream
-                                                       // (50 k / 70 k / 110 k / 150 k / 660 k pairs), one populate from host buffers: 0.54 / 0.60 / 1.04 / 1.31 / 4.14 ms device-sized, 0.57 / 0.57 / 0.97 / 1.21 / 3.56 host-sized
+constexpr uint64_t kDslMaxPairs = 400000;              // device-sized launches (no read-back inside the step, grids sized by the host's bound) up to here. Round 4 stopped at 100 k: first 6 / 8 / 12 / 16 / 64
+                                                       // regions of the configs[3] stream (50 k / 70 k / 110 k / 150 k / 660 k pairs), one populate from host buffers: 0.54 / 0.60 / 1.04 / 1.31 / 4.14 ms
+                                                       // device-sized, 0.57 / 0.57 / 0.97 / 1.21 / 3.56 host-sized. Round 5 (gpurun_out/r05_s01): on the DEVICE the two forms take the same time (16 regions:
+                                                       // run + wait 0.643 against 0.650 ms, 64 regions 2.21 against 2.24) - the difference was the upload's byte-by-byte scan for the cost flavours
+                                                       // (0.17 / 0.29 ms), now eight bytes per step (any_byte_outside_acgt). What the device-sized form buys a caller who has other work - the region
+                                                       // server's workers - is that oct_phmm_batch_run never waits.
 constexpr uint64_t kWalkRowsMaxPairs = 49152;          // traceback walks of batches up to here: one walk per 16-lane row (k_walk_rows)
 constexpr uint64_t kDslMergeMaxPairs = 12000;          // device-sized step: up to here the traceback and the score-only list of a flavour share one launch (k_dp_pair)
 constexpr uint32_t kDslMaxBlocks = 1024;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
 int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
                 int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false,
                 TaskListRef ref = TaskListRef {nullptr, nullptr, 0, nullptr}, const rt::Event* after_first_dp = nullptr,
-                int paired_score_list = -1, uint32_t paired_score_bound = 0)     // device-sized traceback launch: the score-only list of the same flavour rides along (k_dp_pair)
+                int paired_score_list = -1, uint32_t paired_score_bound = 0,     // device-sized traceback launch: the score-only list of the same flavour rides along (k_dp_pair)
+                bool joined_late = false)                                        // host-sized traceback launch: the flavour's late-start list lies behind the list and is part of `n_tasks`
 {
     if (!n_tasks) return OCT_PHMM_OK;
     const bool dsl = ref.totals != nullptr;
@@ -648,8 +673,9 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     p.groups_per_block = kBlockWaves * std::max<uint32_t>(1, std::min<uint32_t>(kGroupsPerWave, n_groups / (kBlockWaves * 2048)));
     if (dsl) p.groups_per_block = kBlockWaves;             // (region-sized by construction)
     // late traceback start is PERMITTED wherever the walk may stop early (below); which task groups take it is geometry (dp_groups). `late`: the launch is a late-start list.
-    (void)late;
-    p.late = (tr && !seam_walk && !b->align_mode && b->fast_adds && !b->stream && !h->wide && tune::late_start()) ? 1 : 0;
+    // (a launch of a traceback list proper, beside late-start lists of its own, has no such group by construction: p.late stays 0 and its groups skip the question)
+    const bool may_start_late = tr && !seam_walk && !b->align_mode && b->fast_adds && !b->stream && !h->wide && tune::late_start();
+    p.late = (may_start_late && (late || ref.join_late || joined_late || !b->late_ok)) ? 1 : 0;
     p.hap_region = b->d.hap_region; p.reg_rhs = b->d.reg_rhs; p.reg_lhs = b->d.reg_lhs;
     uint32_t chunk_groups = n_groups;
     if (tr) {
@@ -1109,7 +1135,6 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     const bool want_dirty = dsl_wanted && !gen_device;
     {
         std::mutex mx;
-        auto not_acgt = [](uint8_t c) -> uint32_t { return ((c == 'A') | (c == 'C') | (c == 'G') | (c == 'T')) ? 0u : 1u; };
         const size_t read_grain = std::max<size_t>(1, (size_t)R->n_reads / std::max<size_t>(1, (size_t)n_read_bases >> 20));      // reads per ~1 MB of qualities
         host_parallel(R->n_reads, read_grain, [&](size_t r0, size_t r1) {
             uint32_t v = 0, shortest = 0xffffffffu, dd = 0; uint64_t best = 0;
@@ -1119,7 +1144,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
                 for (uint32_t i = 0; i < n; ++i) { sq += q[i]; o |= q[i]; }
                 v |= o; best = std::max<uint64_t>(best, sq); shortest = std::min(shortest, n);
             }
-            if (want_dirty && r1 > r0) { const uint8_t* rb = (const uint8_t*)R->bases; for (size_t i = R->offsets[r0]; i < R->offsets[r1]; ++i) dd |= not_acgt(rb[i]); }
+            if (want_dirty && r1 > r0) dd |= any_byte_outside_acgt((const uint8_t*)R->bases + R->offsets[r0], (size_t)R->offsets[r1] - R->offsets[r0]) ? 1u : 0u;
             std::lock_guard<std::mutex> lk(mx); q_or |= v; dirty |= dd; sum_q_max = std::max(sum_q_max, best); t_min = std::min(t_min, shortest);
         });
         any_empty = R->n_reads && t_min == 0;
@@ -1131,7 +1156,8 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
                 v |= go | ge | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
                 a = std::max(a, go); e = std::max(e, ge);           // (as bytes: with no sign bit anywhere - checked below - these are the values)
             }
-            if (want_dirty) { const uint8_t* hb = (const uint8_t*)H->bases; for (size_t i = lo; i < hi; ++i) dd |= not_acgt(hb[i]) | (H->snv_mask_fwd[i] == '0' ? 1u : 0u) | (H->snv_mask_rev[i] == '0' ? 1u : 0u); }
+            if (want_dirty) dd |= (any_byte_outside_acgt((const uint8_t*)H->bases + lo, hi - lo) || any_byte_equals((const uint8_t*)H->snv_mask_fwd + lo, hi - lo, '0')
+                                   || any_byte_equals((const uint8_t*)H->snv_mask_rev + lo, hi - lo, '0')) ? 1u : 0u;
             std::lock_guard<std::mutex> lk(mx); pen_or |= v; dirty |= dd; gomax = std::max(gomax, a); gemax = std::max(gemax, e);
         });
         if (pen_or & 0x80u) return fail(status, OCT_PHMM_EINVAL, "negative penalty");
@@ -1287,7 +1313,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     if (tune::dedup() > 0) b->dedup = !align_mode && !b->stream && !h->wide && H->n_haps > G;
     for (uint32_t g = 0; g < G && b->dedup; ++g) if (g_hap[g + 1] - g_hap[g] > 65535) b->dedup = false;     // (the matcher's table holds 16-bit haplotype numbers within a region)
     if (b->dedup) { pk.dalloc(&d.canon, (size_t)n_hap_bases + 1); pk.dalloc(&d.pair_rep, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_hash, (size_t)b->n_pairs + 1); pk.dalloc(&d.pair_fast, (size_t)b->n_pairs + 1); }
-    pk.dalloc(&d.stats, (size_t)kStatSlots * kStatStride + 8);      // + error key, overflow flag, k_scan_fused's per-slice counters (eight 32-bit words)
+    pk.dalloc(&d.stats, (size_t)kStatSlots * kStatStride + 8);
     pk.dalloc(&b->d_hap_base, (size_t)H->n_haps + 1);
     // late traceback start (k_dp): packed int16 kernels only, no lane can wrap (a failed traceback is then impossible,
     // so a walk may stop once it has left the right flank), populate only, and only where the three extra scan launches do not show
@@ -1338,8 +1364,9 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
                 RT(h->get_event(&sl.matched));
             }
             b->slices.push_back(sl);
-            pk.dalloc(&b->slices.back().tile_sums, (size_t)sl.n_tiles + 1);
-            if (b->late_ok) pk.dalloc(&b->slices.back().tile_sums_late, (size_t)sl.n_tiles + 1);
+            const size_t n_tile_sums = std::max<size_t>((size_t)sl.n_tiles, (size_t)((sl.pair1 - sl.pair0 + 1 + kScanLocalTile - 1) / kScanLocalTile)) + 1;   // (256-pair tiles of the workgroup-local scan)
+            pk.dalloc(&b->slices.back().tile_sums, n_tile_sums);
+            if (b->late_ok) pk.dalloc(&b->slices.back().tile_sums_late, n_tile_sums);
         }
     }
     {
@@ -1579,7 +1606,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     const bool mapped_out = b->early_out && !b->out_landing && S == 1 && !b->align_mode && b->n_out <= kHostMappedOutMax && b->stat_stage && tune::host_mapped();
     const uint32_t mapped_stripes = tune::map_stats() ? kStatSlots : (uint32_t)std::min<uint64_t>(kStatSlots, (b->n_pairs + 255) / 256);   // (k_classify's workgroups own the counters; the mapper's only with OCT_PHMM_MAP_STATS)
     if (mapped_out) memset(b->stat_stage, 0, kStatWords * sizeof(unsigned long long));
-    if (!b->stats_clear) RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 6) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
+    if (!b->stats_clear) RT(rt::dev_memset(d.stats, 0, ((size_t)kStatSlots * kStatStride + 2) * sizeof(unsigned long long), s0));   // counters + the (inverted) error key + the overflow flag behind them
     b->stats_clear = false;
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
     if (b->dedup) RT(rt::dev_memset(d.pair_rep, 0xff, (size_t)b->n_pairs * sizeof(uint32_t), s0));      // kNoPair: every pair is computed itself until k_dedup_verify says otherwise
@@ -1629,22 +1656,23 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 RT(rt::launch_ok());
             }
         }
-        const uint32_t pair_blocks = (uint32_t)((np + 255) / 256);
-        OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late); RT(rt::launch_ok());
-        if (b->dedup && sl.n_seg_tiles) {                     // pairs whose candidates equal an earlier pair's of the same read drop their tasks
+        // The scan of the task counts starts in the kernel that makes them: its workgroups store tile-local prefixes and tile totals (k_scan_finish does the rest in
+        // one workgroup). The grid then covers pair1 itself, the scan's extra entry.
+        const uint64_t n_scan = np + 1;
+        sl.scan_fused = tune::scan_fused() && n_scan < 0xffffffffull;
+        const bool verify_runs = b->dedup && sl.n_seg_tiles;
+        const uint32_t pair_blocks = (uint32_t)(((sl.scan_fused ? n_scan : np) + 255) / 256);
+        uint4* const ts = sl.scan_fused ? sl.tile_sums : nullptr; uint4* const ts_late = sl.scan_fused ? sl.tile_sums_late : nullptr;
+        OCT_LAUNCH(k_classify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late, verify_runs ? nullptr : ts, verify_runs ? nullptr : ts_late); RT(rt::launch_ok());
+        if (verify_runs) {                                    // pairs whose candidates equal an earlier pair's of the same read drop their tasks
             if (sl.resumes && i > 0) RT(rt::stream_wait_event(s, b->slices[i - 1].matched));     // its reads' tables and the earlier pairs' classes
             OCT_LAUNCH(k_dedup_match, sl.n_seg_tiles, 64, (size_t)kDedupSlots * 64 * (sizeof(uint32_t) + sizeof(uint16_t)), s, d, (const DedupSeg*)b->d_segs + sl.seg0, sl.n_segs); RT(rt::launch_ok());
-            OCT_LAUNCH(k_dedup_verify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late); RT(rt::launch_ok());
+            OCT_LAUNCH(k_dedup_verify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late, ts, ts_late); RT(rt::launch_ok());
         }
         if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one
-        const uint64_t n_scan = np + 1;
-        sl.scan_fused = false;
-        if (tune::scan_fused() && n_scan < 0xffffffffull) {       // any size: both count arrays, the haplotype bases and the totals in ONE launch (k_scan_fused)
-            const uint32_t n_tf = (uint32_t)((n_scan + kScanFusedTile - 1) / kScanFusedTile);
-            uint32_t* done = (uint32_t*)(d.stats + (size_t)kStatSlots * kStatStride + 2) + i;
-            OCT_LAUNCH(k_scan_fused, n_tf * (sl.cnt_late ? 2u : 1u), kHapBaseThreads, 17 * sizeof(uint4), s, d, sl.hap0, sl.hap1, sl.cnt, sl.cnt_late, sl.pair0, (uint32_t)n_scan, n_tf,
-                       sl.tile_sums, sl.tile_sums_late, b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G, done); RT(rt::launch_ok());
-            sl.scan_fused = true;
+        if (sl.scan_fused) {                                  // any size: tile prefixes, haplotype bases and totals of both count arrays in ONE single-workgroup launch
+            OCT_LAUNCH(k_scan_finish, 1, kHapBaseThreads, 16 * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, (const uint4*)sl.cnt_late, sl.pair0, pair_blocks,
+                       sl.tile_sums, sl.tile_sums_late, b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G); RT(rt::launch_ok());
             sl.totals_late = make_uint4(0, 0, 0, 0);
             if (!b->dsl) { RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s)); if (sl.cnt_late) RT(rt::d2h(&sl.totals_late, sl.d_totals_late, sizeof(uint4), s)); }
             return OCT_PHMM_OK;
@@ -1696,7 +1724,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             }
             TaskArrays ta {}; ta.t[0] = sl.d_tasks; TaskArrays tl {};
             TaskListRef ref {sl.d_totals, sl.cnt_late ? sl.d_totals_late : nullptr, 0, d.dsl_overflow};
-            const bool join = sl.scan_fused;                       // a flavour's traceback and late-start lists in one launch (k_scan_fused checked that BOTH fit the scratch)
+            const bool join = sl.scan_fused && tune::join_late() != 0;   // a flavour's traceback and late-start lists in one launch (k_scan_finish checked that BOTH fit the scratch)
             OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
                        (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, ref, G,
                        sl.scan_fused ? (const uint4*)sl.tile_sums : nullptr, sl.scan_fused ? (const uint4*)sl.tile_sums_late : nullptr); RT(rt::launch_ok());
@@ -1758,7 +1786,10 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             h->pool.release(sl.d_tasks); sl.d_tasks = nullptr; sl.tasks_cap = 0;
             void* p = nullptr; RT(h->pool.alloc(&p, (total + total / 8) * sizeof(DevTask))); sl.d_tasks = (DevTask*)p; sl.tasks_cap = total + total / 8;
         }
-        const bool join = sl.scan_fused;                         // a flavour's traceback list and its late-start list (which lies right behind it) in ONE DP launch and ONE walk
+        // a flavour's traceback list and its late-start list (which lies right behind it) in ONE DP launch and ONE walk: one-slice batches, where the step is a chain of
+        // dependent launches (a region server's device batch; 16 regions: the second traceback launch and its walk were 233 of 868 us). Batches of several slices keep
+        // the two launches: the 12.8 M-pair step lost 6 % of its traceback DP with them joined (17.8 against 2 x 8.36 ms per launch; profiles/EXPERIMENTS.md)
+        const bool join = sl.scan_fused && (tune::join_late() >= 0 ? tune::join_late() != 0 : S == 1);
         const size_t n_trace = join ? (size_t)std::max(totals.y + late.x, totals.w + late.y) : (size_t)std::max(std::max(totals.y, totals.w), std::max(late.x, late.y));
         if (n_trace > sl.ends_cap) {
             h->pool.release(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
@@ -1778,11 +1809,13 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                        sl.scan_fused ? (const uint4*)sl.tile_sums : nullptr, sl.scan_fused ? (const uint4*)sl.tile_sums_late : nullptr); RT(rt::launch_ok());
             static const int order[kNumKinds] = {kTraceFast, kTraceGen, kScoreFast, kScoreGen};   // traceback first: its walk then overlaps the score-only DP of the next slice
             // A single-slice (region-sized) batch is latency-bound: its score-only DP runs beside the traceback DP + walk on a second stream.
-            const bool side = S == 1 && total < 200000 && (totals.x + totals.z) > 0 && (totals.y + totals.w) > 0;   // big launches fill the chip on their own
+            const bool side = S == 1 && total < 200000 && (totals.x + totals.z) > 0 && (totals.y + totals.w + late.x + late.y) > 0;   // big launches fill the chip on their own
             rt::Stream aux = h->slice_stream(1);
             bool forked = false;                                 // (side) the score-only DP starts beside the first traceback launch's walk: see phase2_device_sized
             // ... except for long reads: a traceback launch of ~10^2 tasks is a few hundred latency-bound waves that leave the chip's issue slots to the score-only DP
-            if (side && b->stream) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
+            // ... and (round 5) for every such batch: joined with its late-start list the first traceback launch is the whole traceback DP, and a score-only DP that
+            // waits for it runs behind it instead of beside it (16 regions: 204 + 190 us one after the other). OCT_PHMM_DSL_FORK_EARLY=0: beside the first walk.
+            if (side && (b->stream || tune::dsl_fork_early())) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
             for (int lk = 0; lk < 2 && !join; ++lk) {            // late-start traceback launches first (the longest walks of the slice start earliest)
                 const uint32_t n = lk ? late.y : late.x;
                 const int rc = run_dp_kind(h, b, i, lk ? kTraceGen : kTraceFast, tl.t[lk], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, nullptr, true,
@@ -1796,7 +1829,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 if (side && score_kind && !forked) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
                 if (side && score_kind && n) RT(rt::stream_wait_event(aux, b->ev_fork));
                 const int rc = run_dp_kind(h, b, i, k, ta.t[k], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, side && score_kind ? &aux : nullptr, false,
-                                           TaskListRef {nullptr, nullptr, 0, nullptr}, side && !score_kind && !forked && n ? &b->ev_fork : nullptr);
+                                           TaskListRef {nullptr, nullptr, 0, nullptr}, side && !score_kind && !forked && n ? &b->ev_fork : nullptr, -1, 0, join && !score_kind);
                 if (rc != OCT_PHMM_OK) return rc;
                 forked = forked || (side && !score_kind && n);
             }
@@ -2098,9 +2131,13 @@ extern "C" int oct_phmm_batch_genotype_likelihoods(oct_phmm_handle* h, oct_phmm_
 extern "C" void* oct_phmm_host_alloc(size_t bytes) { void* p = nullptr; return rt::host_pinned_malloc(&p, bytes) ? p : nullptr; }
 extern "C" void oct_phmm_host_free(void* p) { rt::host_pinned_free(p); }
 
-extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
-                                 const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
-                                 const oct_phmm_positions* positions, double* out, oct_phmm_status* status)
+// oct_phmm_populate in two halves, so that a caller who owns the handle (the region server's workers) can prepare its next batch on another handle while this one
+// computes: populate_begin returns when the step is enqueued (device-sized batches: no wait at all; host-sized ones wait once, for the task counts), populate_end waits
+// for the results. in_place (populate_end): a one-slice batch leaves its results in the handle's pinned landing zone and is NOT copied into `out` - *in_place points at
+// them, valid until the handle's next call (the server scatters them straight into its callers' matrices).
+struct PopulateCall { oct_phmm_batch* b = nullptr; bool early = false; };
+static int populate_begin(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps, const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                          const oct_phmm_positions* positions, double* out, oct_phmm_status* status, PopulateCall* pc)
 {
     oct_phmm_batch* b = nullptr;
     int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, false, 0, true);
@@ -2117,9 +2154,32 @@ extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads
         if (!early && h->out_stage_bytes >= bytes) { b->early_out = out; early = true; }
     }
     if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_run(h, b, status);
-    if (rc == OCT_PHMM_OK) rc = early ? oct_phmm_batch_wait(h, b, status) : oct_phmm_batch_download(h, b, out, status);
-    if (rc == OCT_PHMM_OK && early && b->slices.size() == 1 && !b->out_landing) memcpy(out, h->out_stage, (size_t)b->n_out * sizeof(double));
+    if (rc != OCT_PHMM_OK) { oct_phmm_batch_free(h, b); b = nullptr; }
+    pc->b = b; pc->early = early;
+    return rc;
+}
+static int populate_end(oct_phmm_handle* h, PopulateCall* pc, double* out, oct_phmm_status* status, const double** in_place = nullptr)
+{
+    oct_phmm_batch* b = pc->b;
+    if (!b) return fail(status, OCT_PHMM_EINVAL, "no call in flight");
+    int rc = pc->early ? oct_phmm_batch_wait(h, b, status) : oct_phmm_batch_download(h, b, out, status);
+    if (in_place) *in_place = nullptr;
+    if (rc == OCT_PHMM_OK && pc->early && b->slices.size() == 1 && !b->out_landing) {
+        if (in_place) *in_place = (const double*)h->out_stage;
+        else memcpy(out, h->out_stage, (size_t)b->n_out * sizeof(double));
+    }
     oct_phmm_batch_free(h, b);
+    pc->b = nullptr;
+    return rc;
+}
+
+extern "C" int oct_phmm_populate(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps,
+                                 const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
+                                 const oct_phmm_positions* positions, double* out, oct_phmm_status* status)
+{
+    PopulateCall pc;
+    int rc = populate_begin(h, reads, haps, regions, flank, positions, out, status, &pc);
+    if (rc == OCT_PHMM_OK) rc = populate_end(h, &pc, out, status);
     return rc;
 }
 
@@ -2130,7 +2190,7 @@ struct oct_phmm_server {
     struct Request {
         const oct_phmm_reads* R; const oct_phmm_haplotypes* H; const oct_phmm_flank_state* flank; const oct_phmm_positions* pos;
         double* out; oct_phmm_status st; int rc = OCT_PHMM_OK; bool done = false;
-        std::condition_variable cv;                       // one per call: finishing a batch wakes exactly its callers
+        std::mutex m; std::condition_variable cv;         // one pair per call: finishing a batch wakes exactly its callers, and nobody queues for the server's lock to return
     };
 #if defined(OCTPHMM_SIM)
     static constexpr int kWorkers = 1;                   // the CPU wave simulator is single-threaded
@@ -2138,156 +2198,225 @@ struct oct_phmm_server {
     static constexpr int kWorkers = 3;                   // device queues per GPU: while one worker's batch computes, the others gather and upload the calls that arrived since
                                                          // (configs[3] regions, 16 / 64 / 128 callers: 2 workers 13.6 / 12.7 / 15.5 k regions/s, 3: 13.9 / 17.0 / 16.8, 4: 13.5 / 16.7 / 18.4, 6: 9.6 / 16.6 / 16.8 - profiles/r04_step3_server_sweep.log)
 #endif
-    std::vector<oct_phmm_handle*> hs;                    // kWorkers handles per device, device-major
+    static constexpr int kSlots = 2;                     // handles per worker (round 5): while the batch on one computes, the worker gathers, checks, packs and enqueues the next on the other
+    std::vector<oct_phmm_handle*> hs;                    // kSlots handles per worker, worker-major; kWorkers workers per device, device-major
     uint32_t max_regions = 256;
     std::mutex mu; std::condition_variable cv_work;
     std::deque<Request*> queue;
     bool stop = false;
-    std::vector<std::thread> workers;                    // one per handle; all of them drain the one queue, so an idle device takes the next calls
+    std::vector<std::thread> workers;                    // all of them drain the one queue, so an idle device takes the next calls
     uint64_t n_calls = 0, n_batches = 0;
     std::vector<uint64_t> n_calls_by_device;
     int busy_workers = 0;                                // workers between taking calls and answering them (under mu)
     static constexpr int kLingerSteps = 6;
     int linger_us = [] { long long v; return tune::number("OCT_PHMM_SERVER_LINGER_US", &v) && v >= 0 && v <= 10000 ? (int)v : 0; }();    // 0 (default): take what is there. Measured: 25 us x 6 steps doubles the regions per device batch (13 -> 22 at 128 callers) and LOSES 5 - 20 % throughput
                                                          // (profiles/r04_step3_server_sweep.log): a bigger device batch is not cheaper per region, the step is a chain of ~25 small launches either way
+    bool pipelined = [] { long long v; return !(tune::number("OCT_PHMM_SERVER_PIPELINE", &v) && v == 0); }();      // 0: a worker answers a batch before it takes the next calls (round 4's loop, A/B)
     std::atomic<bool> has_model {false};                 // oct_phmm_server_set_error_model: calls may leave their penalty vectors NULL
     // the model travels to the handles through their own worker threads (under mu): a handle is only ever touched by its worker
     oct_phmm_error_model pending_model {}; bool pending_has_model = false; uint64_t model_version = 0; std::vector<uint64_t> worker_version;
     // OCT_PHMM_SERVER_PROFILE=1: where a worker's time goes (ns, summed over workers), printed by oct_phmm_server_destroy
     bool profile = tune::server_profile();
-    std::atomic<uint64_t> ns_idle {0}, ns_concat {0}, ns_upload {0}, ns_run {0}, ns_download {0}, ns_scatter {0}, ns_single {0};
+    std::atomic<uint64_t> ns_idle {0}, ns_concat {0}, ns_begin {0}, ns_end {0}, ns_scatter {0}, ns_single {0};
     static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     std::vector<int> device_of;                          // worker -> index into the device list
 
     static uint32_t rows_of(const oct_phmm_reads* R) { return R->row_offsets ? R->n_rows : R->n_reads; }
+    static void answer(Request* q) { std::lock_guard<std::mutex> lk(q->m); q->done = true; q->cv.notify_one(); }      // under the call's own lock: the request lives on its caller's stack
 
-    void serve_one(oct_phmm_handle* h, Request* q) { q->rc = oct_phmm_populate(h, q->R, q->H, nullptr, q->flank, q->pos, q->out, &q->st); }
-
-    // concatenate the calls' arrays into one flat batch with one region per call
-    void serve_many(oct_phmm_handle* h, std::vector<Request*>& qs)
+    void serve_one(oct_phmm_handle* h, Request* q)
     {
-        std::string rb, hb, mf, mr; std::vector<uint8_t> rq, mq, rv, has_flank, sub; bool any_sub = false;
-        for (Request* q : qs) if (q->H->substitution_mask) any_sub = true; std::vector<uint32_t> roff {0}, hoff {0}, row_off {0}, reg_rows {0}, reg_haps {0};
+        try { q->rc = oct_phmm_populate(h, q->R, q->H, nullptr, q->flank, q->pos, q->out, &q->st); }
+        catch (const std::exception&) { q->rc = fail(&q->st, OCT_PHMM_EHIP, "host allocation"); }
+    }
+
+    // The calls of one device batch concatenated into one flat batch with a region per call. The buffers belong to a worker's slot and keep their capacity from batch to batch
+    // (round 4 grew fresh std::strings and vectors per batch, element by element: a third of the 0.6 - 0.8 ms a worker spent between two of its batches).
+    struct Concat {
+        std::vector<char> rb, hb, mf, mr; std::vector<uint8_t> rq, mq, rv, has_flank, sub; std::vector<uint32_t> roff, hoff, row_off, reg_rows, reg_haps;
         std::vector<int64_t> rbeg, hbeg; std::vector<int8_t> go, ge, pf, pr; std::vector<oct_phmm_flank_state> fl;
-        bool templates = false;
-        for (Request* q : qs) if (q->R->row_offsets) templates = true;
-        size_t n_out = 0;
-        const uint64_t t_begin = profile ? now_ns() : 0;
-        for (Request* q : qs) {
-            const oct_phmm_reads* R = q->R; const oct_phmm_haplotypes* H = q->H;
-            const uint32_t nb = R->n_reads ? R->offsets[R->n_reads] : 0, hn = H->n_haps ? H->offsets[H->n_haps] : 0;
-            rb.append(R->bases, nb); rq.insert(rq.end(), R->qualities, R->qualities + nb);
-            for (uint32_t r = 0; r < R->n_reads; ++r) roff.push_back(roff.back() + (R->offsets[r + 1] - R->offsets[r]));
-            mq.insert(mq.end(), R->mapping_quality, R->mapping_quality + R->n_reads); rv.insert(rv.end(), R->reverse_strand, R->reverse_strand + R->n_reads);
-            rbeg.insert(rbeg.end(), R->ref_begin, R->ref_begin + R->n_reads);
-            const uint32_t read0 = (uint32_t)mq.size() - R->n_reads;
-            if (templates) for (uint32_t row = 0; row < rows_of(R); ++row) row_off.push_back(read0 + (R->row_offsets ? R->row_offsets[row + 1] : row + 1));
-            hb.append(H->bases, hn);
-            for (uint32_t k = 0; k < H->n_haps; ++k) hoff.push_back(hoff.back() + (H->offsets[k + 1] - H->offsets[k]));
-            hbeg.insert(hbeg.end(), H->ref_begin, H->ref_begin + H->n_haps);
-            if (any_sub) { if (H->substitution_mask) sub.insert(sub.end(), H->substitution_mask, H->substitution_mask + hn); else sub.insert(sub.end(), hn, (uint8_t)0); }
-            if (H->gap_open) {                             // (a device batch holds either calls with vectors or calls without, run())
-                go.insert(go.end(), H->gap_open, H->gap_open + hn); ge.insert(ge.end(), H->gap_extend, H->gap_extend + hn);
-                mf.append(H->snv_mask_fwd, hn); mr.append(H->snv_mask_rev, hn);
-                pf.insert(pf.end(), H->snv_prior_fwd, H->snv_prior_fwd + hn); pr.insert(pr.end(), H->snv_prior_rev, H->snv_prior_rev + hn);
+        std::vector<double> spill;                        // results of a batch of several slices (the landing zone of a one-slice batch is read in place)
+        oct_phmm_reads R {}; oct_phmm_haplotypes H {}; oct_phmm_regions G {}; size_t n_out = 0;
+        template <class V, class T> static void put(V& v, const T* src, size_t n) { const size_t o = v.size(); v.resize(o + n); if (n) memcpy(v.data() + o, src, n * sizeof(T)); }
+        void build(const std::vector<Request*>& qs)
+        {
+            bool any_sub = false, templates = false;
+            size_t nb = 0, hn = 0, nr = 0, nh = 0, nrows = 0;
+            for (Request* q : qs) {
+                if (q->H->substitution_mask) any_sub = true;
+                if (q->R->row_offsets) templates = true;
+                nb += q->R->n_reads ? q->R->offsets[q->R->n_reads] : 0; hn += q->H->n_haps ? q->H->offsets[q->H->n_haps] : 0; nr += q->R->n_reads; nh += q->H->n_haps; nrows += rows_of(q->R);
             }
-            reg_rows.push_back(reg_rows.back() + rows_of(R)); reg_haps.push_back(reg_haps.back() + H->n_haps);
-            has_flank.push_back(q->flank ? 1 : 0); fl.push_back(q->flank ? *q->flank : oct_phmm_flank_state {0, 0});
-            n_out += (size_t)rows_of(R) * H->n_haps;
+            const bool given = qs.front()->H->gap_open != nullptr;   // (a device batch holds either calls with vectors or calls without, run())
+            for (auto* v : {&rb, &hb, &mf, &mr}) v->clear();
+            for (auto* v : {&rq, &mq, &rv, &has_flank, &sub}) v->clear();
+            for (auto* v : {&roff, &hoff, &row_off, &reg_rows, &reg_haps}) v->clear();
+            rbeg.clear(); hbeg.clear(); fl.clear(); for (auto* v : {&go, &ge, &pf, &pr}) v->clear();
+            rb.reserve(nb); rq.reserve(nb); roff.reserve(nr + 1); mq.reserve(nr); rv.reserve(nr); rbeg.reserve(nr); if (templates) row_off.reserve(nrows + 1);
+            hb.reserve(hn); hoff.reserve(nh + 1); hbeg.reserve(nh); if (any_sub && !given) sub.reserve(hn);
+            if (given) { go.reserve(hn); ge.reserve(hn); mf.reserve(hn); mr.reserve(hn); pf.reserve(hn); pr.reserve(hn); }
+            roff.push_back(0); hoff.push_back(0); row_off.push_back(0); reg_rows.assign(1, 0); reg_haps.assign(1, 0);
+            n_out = 0;
+            for (Request* q : qs) {
+                const oct_phmm_reads* Rq = q->R; const oct_phmm_haplotypes* Hq = q->H;
+                const uint32_t b1 = Rq->n_reads ? Rq->offsets[Rq->n_reads] : 0, h1 = Hq->n_haps ? Hq->offsets[Hq->n_haps] : 0;
+                const uint32_t rbase = roff.back() - (Rq->n_reads ? Rq->offsets[0] : 0), hbase = hoff.back() - (Hq->n_haps ? Hq->offsets[0] : 0);
+                const uint32_t rb0 = Rq->n_reads ? Rq->offsets[0] : 0, hb0 = Hq->n_haps ? Hq->offsets[0] : 0;
+                put(rb, Rq->bases + rb0, b1 - rb0); put(rq, Rq->qualities + rb0, b1 - rb0);
+                { const size_t o = roff.size(); roff.resize(o + Rq->n_reads); for (uint32_t r = 0; r < Rq->n_reads; ++r) roff[o + r] = rbase + Rq->offsets[r + 1]; }
+                put(mq, Rq->mapping_quality, Rq->n_reads); put(rv, Rq->reverse_strand, Rq->n_reads); put(rbeg, Rq->ref_begin, Rq->n_reads);
+                const uint32_t read0 = (uint32_t)mq.size() - Rq->n_reads;
+                if (templates) for (uint32_t row = 0; row < rows_of(Rq); ++row) row_off.push_back(read0 + (Rq->row_offsets ? Rq->row_offsets[row + 1] : row + 1));
+                put(hb, Hq->bases + hb0, h1 - hb0);
+                { const size_t o = hoff.size(); hoff.resize(o + Hq->n_haps); for (uint32_t k = 0; k < Hq->n_haps; ++k) hoff[o + k] = hbase + Hq->offsets[k + 1]; }
+                put(hbeg, Hq->ref_begin, Hq->n_haps);
+                if (any_sub && !given) { if (Hq->substitution_mask) put(sub, Hq->substitution_mask + hb0, h1 - hb0); else sub.resize(sub.size() + (h1 - hb0), (uint8_t)0); }
+                if (given) {
+                    put(go, Hq->gap_open + hb0, h1 - hb0); put(ge, Hq->gap_extend + hb0, h1 - hb0); put(mf, Hq->snv_mask_fwd + hb0, h1 - hb0); put(mr, Hq->snv_mask_rev + hb0, h1 - hb0);
+                    put(pf, Hq->snv_prior_fwd + hb0, h1 - hb0); put(pr, Hq->snv_prior_rev + hb0, h1 - hb0);
+                }
+                reg_rows.push_back(reg_rows.back() + rows_of(Rq)); reg_haps.push_back(reg_haps.back() + Hq->n_haps);
+                has_flank.push_back(q->flank ? 1 : 0); fl.push_back(q->flank ? *q->flank : oct_phmm_flank_state {0, 0});
+                n_out += (size_t)rows_of(Rq) * Hq->n_haps;
+            }
+            const uint32_t n_reads = (uint32_t)mq.size(), n_rows = reg_rows.back();
+            R = oct_phmm_reads {n_reads, rb.data(), rq.data(), roff.data(), mq.data(), rv.data(), rbeg.data(), templates ? n_rows : 0, templates ? row_off.data() : nullptr};
+            H = oct_phmm_haplotypes {(uint32_t)hbeg.size(), hb.data(), hoff.data(), hbeg.data(), given ? go.data() : nullptr, given ? ge.data() : nullptr,
+                                     given ? mf.data() : nullptr, given ? pf.data() : nullptr, given ? mr.data() : nullptr, given ? pr.data() : nullptr,
+                                     !given && any_sub ? sub.data() : nullptr};
+            G = oct_phmm_regions {(uint32_t)qs.size(), reg_rows.data(), reg_haps.data(), has_flank.data(), fl.data()};
+            if (spill.size() < n_out + 1) spill.resize(n_out + 1);
         }
-        const uint32_t n_reads = (uint32_t)mq.size(), n_rows = reg_rows.back();
-        oct_phmm_reads R {n_reads, rb.data(), rq.data(), roff.data(), mq.data(), rv.data(), rbeg.data(), templates ? n_rows : 0, templates ? row_off.data() : nullptr};
-        const bool given = qs.front()->H->gap_open != nullptr;
-        oct_phmm_haplotypes H {(uint32_t)hbeg.size(), hb.data(), hoff.data(), hbeg.data(), given ? go.data() : nullptr, given ? ge.data() : nullptr,
-                               given ? mf.data() : nullptr, given ? pf.data() : nullptr, given ? mr.data() : nullptr, given ? pr.data() : nullptr,
-                               !given && any_sub ? sub.data() : nullptr};
-        oct_phmm_regions G {(uint32_t)qs.size(), reg_rows.data(), reg_haps.data(), has_flank.data(), fl.data()};
-        std::vector<double> out(n_out + 1);
+    };
+    // one device batch between populate_begin and populate_end
+    struct Flight { std::vector<Request*> qs; PopulateCall pc; oct_phmm_handle* h = nullptr; int slot = 0; bool active = false; };
+
+    // gather -> check -> pack -> enqueue; the calls' arrays are not read after this returns (upload_impl packed them into the handle's pinned image)
+    bool begin_many(oct_phmm_handle* h, Concat& c, std::vector<Request*>& qs, Flight& f)
+    {
+        const uint64_t t0 = profile ? now_ns() : 0;
+        c.build(qs);
+        const uint64_t t1 = profile ? now_ns() : 0;
         oct_phmm_status st;
-        int rc;
-        uint64_t t_scatter = 0;
-        if (!profile) {
-            rc = oct_phmm_populate(h, &R, &H, &G, nullptr, nullptr, out.data(), &st);
-        } else {                                           // the same three steps, timed one by one
-            const uint64_t t0 = now_ns(); ns_concat += t0 - t_begin;
-            oct_phmm_batch* bt = nullptr;
-            rc = oct_phmm_batch_upload(h, &R, &H, &G, nullptr, nullptr, &bt, &st);
-            const uint64_t t1 = now_ns(); ns_upload += t1 - t0;
-            if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_run(h, bt, &st);
-            const uint64_t t2 = now_ns(); ns_run += t2 - t1;
-            if (rc == OCT_PHMM_OK) rc = oct_phmm_batch_download(h, bt, out.data(), &st);
-            oct_phmm_batch_free(h, bt);
-            t_scatter = now_ns(); ns_download += t_scatter - t2;
+        const int rc = populate_begin(h, &c.R, &c.H, &c.G, nullptr, nullptr, c.spill.data(), &st, &f.pc);
+        if (profile) { ns_concat += t1 - t0; ns_begin += now_ns() - t1; }
+        if (rc != OCT_PHMM_OK) return false;
+        f.qs = std::move(qs); f.h = h; f.active = true;
+        return true;
+    }
+    // wait -> scatter -> wake the callers. One region's error must not reach the others: a failed batch is answered call by call.
+    void end_many(Concat& c, Flight& f)
+    {
+        const uint64_t t0 = profile ? now_ns() : 0;
+        oct_phmm_status st; const double* in_place = nullptr;
+        const int rc = populate_end(f.h, &f.pc, c.spill.data(), &st, &in_place);
+        const uint64_t t1 = profile ? now_ns() : 0;
+        if (rc != OCT_PHMM_OK) { for (Request* q : f.qs) { serve_one(f.h, q); answer(q); } }
+        else {
+            const double* p = in_place ? in_place : c.spill.data();
+            for (Request* q : f.qs) {
+                const size_t n = (size_t)rows_of(q->R) * q->H->n_haps;
+                if (n) memcpy(q->out, p, n * sizeof(double));
+                p += n; q->rc = OCT_PHMM_OK; memset(&q->st, 0, sizeof(q->st));
+                answer(q);
+            }
         }
-        if (rc != OCT_PHMM_OK) { for (Request* q : qs) serve_one(h, q); return; }      // one region's error must not reach the others: answer each on its own
-        const double* p = out.data();
-        for (Request* q : qs) {
-            const size_t n = (size_t)rows_of(q->R) * q->H->n_haps;
-            if (n) memcpy(q->out, p, n * sizeof(double));
-            p += n; q->rc = OCT_PHMM_OK; memset(&q->st, 0, sizeof(q->st));
-        }
-        if (profile) ns_scatter += now_ns() - t_scatter;
+        if (profile) { ns_end += t1 - t0; ns_scatter += now_ns() - t1; }
+        f.qs.clear(); f.active = false;
     }
 
     void run(int w)
     {
-        oct_phmm_handle* h = hs[w];
+        oct_phmm_handle* hslot[kSlots]; for (int k = 0; k < kSlots; ++k) hslot[k] = hs[(size_t)w * kSlots + k];
+        Concat concat[kSlots];
+        Flight flight;                                     // the batch that is on the device (at most one per worker; its successor is prepared beside it)
+        std::deque<std::vector<Request*>> groups;          // batches taken from the queue that wait for a handle
+        int next_slot = 0;
+        uint64_t taken = 0, batches = 0;                   // since the last time the counters went to the server's (under mu)
+        bool w_busy = false;                               // counted in busy_workers
+#if defined(OCTPHMM_SIM)
+        static std::mutex sim_mu;                          // the wave simulator runs one kernel at a time: workers of several "devices" take turns
+#endif
+        auto finish = [&] {
+            if (!flight.active) return;
+#if defined(OCTPHMM_SIM)
+            std::lock_guard<std::mutex> sim_lk(sim_mu);
+#endif
+            end_many(concat[flight.slot], flight);
+        };
         for (;;) {
-            std::vector<Request*> take;
-            {
-                const uint64_t t_idle = profile ? now_ns() : 0;
-                std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return stop || !queue.empty(); });
-                if (profile) ns_idle += now_ns() - t_idle;
-                if (queue.empty() && stop) return;
-                if (worker_version[(size_t)w] != model_version) {          // a new error model since this worker's last batch: install it before taking calls
-                    oct_phmm_set_error_model(h, pending_has_model ? &pending_model : nullptr);
-                    worker_version[(size_t)w] = model_version;
-                }
-                // Bounded linger: when another worker's batch is on the device, the calls that woke this worker are mostly the first of a burst (the callers of
-                // the batch that just finished come back one after the other) - a device batch of 3 regions costs nearly what one of 30 does, so wait while
-                // calls keep arriving, at most kLingerSteps x kLingerUs. With the device idle nothing waits.
-                if (linger_us > 0 && busy_workers > 0 && queue.size() < max_regions) {
-                    for (int step = 0; step < kLingerSteps && !stop; ++step) {
-                        const size_t before = queue.size();
-                        cv_work.wait_for(lk, std::chrono::microseconds(linger_us), [&] { return stop || queue.size() >= max_regions; });
-                        if (queue.size() == before || busy_workers == 0) break;
+            if (groups.empty()) {
+                std::vector<Request*> take;
+                {
+                    const uint64_t t_idle = profile ? now_ns() : 0;
+                    std::unique_lock<std::mutex> lk(mu);
+                    n_calls += taken; n_batches += batches; n_calls_by_device[(size_t)device_of[(size_t)w]] += taken; taken = 0; batches = 0;
+                    if (!flight.active) {
+                        if (w_busy) { --busy_workers; w_busy = false; }
+                        cv_work.wait(lk, [&] { return stop || !queue.empty(); });
                     }
+                    if (profile) ns_idle += now_ns() - t_idle;
+                    if (queue.empty() && stop && !flight.active) return;
+                    if (worker_version[(size_t)w] != model_version && !flight.active) {      // a new error model since this worker's last batch: install it before taking calls
+                        for (int k = 0; k < kSlots; ++k) oct_phmm_set_error_model(hslot[k], pending_has_model ? &pending_model : nullptr);
+                        worker_version[(size_t)w] = model_version;
+                    }
+                    // Bounded linger: when another worker's batch is on the device, the calls that woke this worker are mostly the first of a burst (the callers of
+                    // the batch that just finished come back one after the other) - wait while calls keep arriving, at most kLingerSteps x kLingerUs. With the device idle nothing waits.
+                    if (linger_us > 0 && busy_workers > 0 && !flight.active && queue.size() < max_regions) {
+                        for (int step = 0; step < kLingerSteps && !stop; ++step) {
+                            const size_t before = queue.size();
+                            cv_work.wait_for(lk, std::chrono::microseconds(linger_us), [&] { return stop || queue.size() >= max_regions; });
+                            if (queue.size() == before || busy_workers == 0) break;
+                        }
+                    }
+                    // (a worker whose model is stale takes no calls while its batch is in flight: it answers that batch first, installs the model, then takes them)
+                    if (worker_version[(size_t)w] == model_version)
+                        while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
+                    if (!take.empty() && !w_busy) { ++busy_workers; w_busy = true; }
                 }
-                while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
-                ++busy_workers;
+                if (take.empty()) { finish(); continue; }      // nothing new arrived while the batch computed: answer it, then wait for calls
+                taken += take.size();
+                std::vector<Request*> batchable, batchable_gen, single;       // calls that leave their penalty vectors to the library batch among themselves
+                for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : q->H->gap_open ? batchable : batchable_gen).push_back(q);
+                if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
+                if (batchable_gen.size() == 1) { single.push_back(batchable_gen[0]); batchable_gen.clear(); }
+                if (!single.empty()) {                         // calls with positions of their own, empty calls, lone calls: one by one on a free handle
+                    if (!pipelined) finish();
+                    const uint64_t t_single = profile ? now_ns() : 0;
+                    oct_phmm_handle* hfree = hslot[flight.active ? 1 - flight.slot : next_slot];
+                    for (Request* q : single) {
+#if defined(OCTPHMM_SIM)
+                        std::lock_guard<std::mutex> sim_lk(sim_mu);
+#endif
+                        serve_one(hfree, q); answer(q); ++batches;
+                    }
+                    if (profile) ns_single += now_ns() - t_single;
+                }
+                if (!batchable.empty()) groups.push_back(std::move(batchable));
+                if (!batchable_gen.empty()) groups.push_back(std::move(batchable_gen));
+                if (groups.empty()) continue;
             }
-            std::vector<Request*> batchable, single;
-            for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : batchable).push_back(q);
-            std::vector<Request*> batchable_gen;          // calls that leave their penalty vectors to the library batch among themselves
-            for (auto it = batchable.begin(); it != batchable.end();) { if (!(*it)->H->gap_open) { batchable_gen.push_back(*it); it = batchable.erase(it); } else ++it; }
-            if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
-            if (batchable_gen.size() == 1) { single.push_back(batchable_gen[0]); batchable_gen.clear(); }
+            // the next batch goes onto the handle that is free; the batch in flight (if any) keeps computing meanwhile
+            std::vector<Request*> qs = std::move(groups.front()); groups.pop_front();
+            if (!pipelined) finish();
+            const int slot = flight.active ? 1 - flight.slot : next_slot;
+            Flight nf; nf.slot = slot;
+            bool started = false;
             {
 #if defined(OCTPHMM_SIM)
-                static std::mutex sim_mu;                // the wave simulator runs one kernel at a time: workers of several "devices" take turns
                 std::lock_guard<std::mutex> sim_lk(sim_mu);
 #endif
-                for (std::vector<Request*>* group : {&batchable, &batchable_gen}) {
-                    if (group->empty()) continue;
-                    bool served = false;
-                    try { serve_many(h, *group); served = true; } catch (const std::exception&) {}      // e.g. bad_alloc while concatenating
-                    if (!served) for (Request* q : *group) {
-                        try { serve_one(h, q); } catch (const std::exception&) { q->rc = fail(&q->st, OCT_PHMM_EHIP, "host allocation"); }
-                    }
-                }
-                const uint64_t t_single = profile ? now_ns() : 0;
-                for (Request* q : single) {
-                    try { serve_one(h, q); } catch (const std::exception&) { q->rc = fail(&q->st, OCT_PHMM_EHIP, "host allocation"); }
-                }
-                if (profile) ns_single += now_ns() - t_single;
+                try { started = begin_many(hslot[slot], concat[slot], qs, nf); } catch (const std::exception&) { started = false; }      // e.g. bad_alloc while concatenating
             }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                n_calls += take.size(); n_batches += (batchable.empty() ? 0 : 1) + (batchable_gen.empty() ? 0 : 1) + single.size();
-                n_calls_by_device[(size_t)device_of[(size_t)w]] += take.size();
-                --busy_workers;
-                for (Request* q : take) { q->done = true; q->cv.notify_one(); }     // under the lock: the request lives on its caller's stack
+            ++batches;
+            finish();                                          // the batch that was computing meanwhile: wait, scatter, wake its callers
+            if (started) { flight = std::move(nf); next_slot = 1 - slot; }
+            else for (Request* q : qs) {                       // the batch could not be uploaded as one (an error in one of its regions, no memory): every call on its own
+#if defined(OCTPHMM_SIM)
+                std::lock_guard<std::mutex> sim_lk(sim_mu);
+#endif
+                serve_one(hslot[slot], q); answer(q);
             }
         }
     }
@@ -2306,7 +2435,7 @@ extern "C" int oct_phmm_server_create_multi(const oct_phmm_config* cfg, const in
 #if !defined(OCTPHMM_SIM)
         { long long v; if (tune::number("OCT_PHMM_SERVER_WORKERS", &v) && v >= 1 && v <= 8) n_workers = (int)v; }      // A/B switch: device queues (worker threads + handles) per device
 #endif
-        for (int w = 0; w < n_workers; ++w) {
+        for (int w = 0; w < n_workers * oct_phmm_server::kSlots; ++w) {
             oct_phmm_handle* h = nullptr;
             const int rc = oct_phmm_create(&c, &h);
             if (rc != OCT_PHMM_OK) { for (auto* k : s->hs) oct_phmm_destroy(k); delete s; return rc; }
@@ -2314,14 +2443,15 @@ extern "C" int oct_phmm_server_create_multi(const oct_phmm_config* cfg, const in
             // hipMalloc in the middle of a run stalled every caller for up to a second, once per worker and growth step
             { long long gb = 4; tune::number("OCT_PHMM_SERVER_BP_BUDGET_GB", &gb); if (gb >= 1) h->bp_budget = std::min<size_t>(h->bp_budget, (size_t)gb << 30); }
 #if !defined(OCTPHMM_SIM)
-            (void)ensure_bp(h, 0, std::min<size_t>(h->bp_budget, (size_t)1 << 30));
+            (void)ensure_bp(h, 0, h->bp_budget);            // (all of it: device-sized batches provision two traceback tasks per pair, and a worker's biggest batch comes late in a run)
 #endif
-            s->hs.push_back(h); s->device_of.push_back((int)dv);
+            s->hs.push_back(h); if (w % oct_phmm_server::kSlots == 0) s->device_of.push_back((int)dv);
         }
     }
-    s->n_calls_by_device.assign(n_devices, 0); s->worker_version.assign(s->hs.size(), 0);
+    const size_t n_workers_total = s->hs.size() / oct_phmm_server::kSlots;
+    s->n_calls_by_device.assign(n_devices, 0); s->worker_version.assign(n_workers_total, 0);
     if (max_regions_per_batch) s->max_regions = max_regions_per_batch;
-    for (size_t w = 0; w < s->hs.size(); ++w) s->workers.emplace_back([s, w] { s->run((int)w); });
+    for (size_t w = 0; w < n_workers_total; ++w) s->workers.emplace_back([s, w] { s->run((int)w); });
     *out = s;
     return OCT_PHMM_OK;
 }
@@ -2341,9 +2471,9 @@ extern "C" void oct_phmm_server_destroy(oct_phmm_server* s)
     for (auto& t : s->workers) if (t.joinable()) t.join();
     for (auto* h : s->hs) oct_phmm_destroy(h);
     if (s->profile)
-        fprintf(stderr, "{\"server_profile_ms\": {\"workers\": %zu, \"calls\": %llu, \"batches\": %llu, \"idle\": %.2f, \"concat\": %.2f, \"upload\": %.2f, \"run\": %.2f, "
-                        "\"download\": %.2f, \"scatter\": %.2f, \"single_calls\": %.2f}}\n", s->hs.size(), (unsigned long long)s->n_calls, (unsigned long long)s->n_batches,
-                s->ns_idle / 1e6, s->ns_concat / 1e6, s->ns_upload / 1e6, s->ns_run / 1e6, s->ns_download / 1e6, s->ns_scatter / 1e6, s->ns_single / 1e6);
+        fprintf(stderr, "{\"server_profile_ms\": {\"workers\": %zu, \"calls\": %llu, \"batches\": %llu, \"idle\": %.2f, \"concat\": %.2f, \"check_pack_enqueue\": %.2f, "
+                        "\"wait_for_results\": %.2f, \"scatter_and_wake\": %.2f, \"single_calls\": %.2f}}\n", s->workers.size(), (unsigned long long)s->n_calls, (unsigned long long)s->n_batches,
+                s->ns_idle / 1e6, s->ns_concat / 1e6, s->ns_begin / 1e6, s->ns_end / 1e6, s->ns_scatter / 1e6, s->ns_single / 1e6);
     delete s;
 }
 
@@ -2370,12 +2500,12 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
     }
     oct_phmm_server::Request q; q.R = reads; q.H = haps; q.flank = flank; q.pos = positions; q.out = out; memset(&q.st, 0, sizeof(q.st));
     {
-        std::unique_lock<std::mutex> lk(s->mu);
+        std::lock_guard<std::mutex> lk(s->mu);
         if (s->stop) return fail(status, OCT_PHMM_EINVAL, "server is shutting down");
         s->queue.push_back(&q);
         s->cv_work.notify_one();
-        q.cv.wait(lk, [&] { return q.done; });
     }
+    { std::unique_lock<std::mutex> lk(q.m); q.cv.wait(lk, [&] { return q.done; }); }      // (the call's own lock: a batch's callers do not queue for the server's to return)
     if (status) *status = q.st;
     return q.rc;
 }

@@ -115,10 +115,6 @@ OCT_DEVICE uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, 
 OCT_DEVICE unsigned long long atomic_max_u64(unsigned long long* p, unsigned long long v) { return atomicMax(p, v); }
 OCT_DEVICE unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 OCT_DEVICE uint32_t atomic_and_u32(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
-OCT_DEVICE uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
-// release + acquire at device scope: this workgroup's stores are visible to the other CUs (and XCDs: their L2s are not coherent with each other), and loads behind
-// the fence do not come out of this CU's stale lines (k_scan_fused's last-workgroup hand-over)
-OCT_DEVICE void device_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); }
 OCT_DEVICE uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 OCT_DEVICE unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long expected, unsigned long long v) { return atomicCAS(p, expected, v); }
 // 64-bit mailboxes in LDS between the waves of a workgroup (k_dp_mw): value and tag travel in ONE store / ONE load, re-read until the tag is right

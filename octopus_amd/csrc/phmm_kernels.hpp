@@ -101,7 +101,7 @@ OCT_DEVICE void read_record_thread(const DevBatch& b, uint64_t g)
 OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks, uint32_t flag_blocks)
 {
     // the last workgroup also clears the step's counters (+ error key + overflow flag behind them), so that the first run after an upload needs no memset launch
-    if (hw::block_idx() + 1 == hw::grid_dim()) for (uint32_t i = hw::thread_idx(); i < kStatSlots * kStatStride + 6; i += hw::block_dim()) b.stats[i] = 0ull;   // (+ error key, overflow flag, k_scan_fused's eight 32-bit counters)
+    if (hw::block_idx() + 1 == hw::grid_dim()) for (uint32_t i = hw::thread_idx(); i < kStatSlots * kStatStride + 2; i += hw::block_dim()) b.stats[i] = 0ull;
     if (hw::block_idx() >= table_blocks + flag_blocks) { read_record_thread(b, (uint64_t)(hw::block_idx() - table_blocks - flag_blocks) * hw::block_dim() + hw::thread_idx()); return; }
     if (hw::block_idx() >= table_blocks) { read_flags_wave(b, (hw::block_idx() - table_blocks) * (hw::block_dim() / 64) + (hw::thread_idx() >> 6), hw::thread_idx() & 63u); return; }
     const uint32_t g = hw::block_idx() * hw::block_dim() + hw::thread_idx();
@@ -715,11 +715,46 @@ OCT_DEVICE bool pair_views_same(const DevBatch& b, const PairView& v, const Pair
     return true;
 }
 
+// Workgroup-local exclusive scan of one uint4 per thread over the 256 threads of k_classify / k_dedup_verify (the first half of the task-count scan, see
+// k_scan_finish): returns the thread's exclusive prefix inside its workgroup, *total = the workgroup's sum. sh: 4 words of LDS.
+OCT_DEVICE uint4 block256_scan_excl(uint4 v, uint4* sh, uint4* total)
+{
+    const uint32_t tid = hw::thread_idx(), lane = tid & 63u, wv = tid >> 6;
+    uint4 inc = v;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const int src = (int)(lane >= d ? lane - d : lane);
+        const uint4 o = make_uint4(hw::shfl(inc.x, src), hw::shfl(inc.y, src), hw::shfl(inc.z, src), hw::shfl(inc.w, src));
+        if (lane >= d) inc = make_uint4(inc.x + o.x, inc.y + o.y, inc.z + o.z, inc.w + o.w);
+    }
+    hw::block_sync();                                           // (an earlier scan's reads of sh are over)
+    if (lane == 63) sh[wv] = inc;
+    hw::block_sync();
+    uint4 before = make_uint4(0, 0, 0, 0), all = make_uint4(0, 0, 0, 0);
+    for (uint32_t w = 0; w < 4; ++w) {
+        const uint4 t = sh[w];
+        if (w < wv) before = make_uint4(before.x + t.x, before.y + t.y, before.z + t.z, before.w + t.w);
+        all = make_uint4(all.x + t.x, all.y + t.y, all.z + t.z, all.w + t.w);
+    }
+    *total = all;
+    return make_uint4(before.x + inc.x - v.x, before.y + inc.y - v.y, before.z + inc.z - v.z, before.w + inc.w - v.w);
+}
+// store the counts of pairs [pair0, pair1) of this workgroup scanned tile-locally (+ the extra entry at pair1, whose thread counts nothing), and the tile's total
+OCT_DEVICE void store_scanned_local(uint4 mine, uint64_t e, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* tile_sums, uint4* sh)
+{
+    uint4 total;
+    const uint4 ex = block256_scan_excl(mine, sh, &total);
+    if (e <= pair1) cnt[e - pair0] = ex;
+    if (hw::thread_idx() == 0) tile_sums[hw::block_idx()] = total;
+}
+
 // Pass 1: one thread per (read, haplotype) pair. Runs the candidate-position logic and the scalar fast path, leaves the
 // best fast-path penalty in pair_best, classifies every remaining candidate as score-only or traceback DP.
 // A batch is processed in slices of whole haplotypes (pairs [pair0, pair1)); `cnt` is the slice's own scan array (pair1 - pair0 + 1 entries).
-OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* cnt_late)
+// tile_sums != null: the counts are stored scanned across the workgroup (store_scanned_local; the grid then covers pair1 itself, the scan's extra entry)
+OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* cnt_late, uint4* tile_sums, uint4* tile_sums_late)
 {
+    __shared__ uint4 sh_scan[4];
+    uint4 my_cnt = make_uint4(0, 0, 0, 0), my_late = make_uint4(0, 0, 0, 0);
     const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
     const uint64_t e_wave = wave_first_index(pair0);
     unsigned long long st_cand = 0, st_fast = 0, st_score = 0, st_trace = 0, st_cells = 0, st_pairs = 0;
@@ -793,10 +828,18 @@ OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, u
         if (b.canon) { b.pair_hash[e] = cls ? pair_hash_final(dedup_acc, cls, best, Lh, b.dedup_hash_mask) : 0u; b.pair_fast[e] = best; }
         if (b.align_mode) b.pair_key[e] = key;
         const bool generic = b.wide || !clean;
-        cnt[e - pair0] = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
-        if (e + 1 == pair1) cnt[pair1 - pair0] = make_uint4(0, 0, 0, 0);                               // the scan's extra entry (totals land here)
-        if (cnt_late) { cnt_late[e - pair0] = generic ? make_uint4(0, n_late, 0, 0) : make_uint4(n_late, 0, 0, 0); if (e + 1 == pair1) cnt_late[pair1 - pair0] = make_uint4(0, 0, 0, 0); }
+        my_cnt = generic ? make_uint4(0, 0, n_score, n_trace) : make_uint4(n_score, n_trace, 0, 0);
+        my_late = generic ? make_uint4(0, n_late, 0, 0) : make_uint4(n_late, 0, 0, 0);
+        if (!tile_sums) {
+            cnt[e - pair0] = my_cnt;
+            if (e + 1 == pair1) cnt[pair1 - pair0] = make_uint4(0, 0, 0, 0);                           // the scan's extra entry (totals land here)
+            if (cnt_late) { cnt_late[e - pair0] = my_late; if (e + 1 == pair1) cnt_late[pair1 - pair0] = make_uint4(0, 0, 0, 0); }
+        }
         st_pairs = 1;
+    }
+    if (tile_sums) {
+        store_scanned_local(my_cnt, e, pair0, pair1, cnt, tile_sums, sh_scan);
+        if (cnt_late) store_scanned_local(my_late, e, pair0, pair1, cnt_late, tile_sums_late, sh_scan);
     }
     st_cand = wave_sum(st_cand); st_fast = wave_sum(st_fast); st_score = wave_sum(st_score);
     st_trace = wave_sum(st_trace); st_cells = wave_sum(st_cells); st_pairs = wave_sum(st_pairs);
@@ -1125,11 +1168,15 @@ OCT_KERNEL(k_dedup_match)(DevBatch b, const DedupSeg* segs, uint32_t n_segs)
 
 // Verify: one thread per pair. A candidate whose fast-path minimum, task classes, haplotype length, positions and canonical windows equal
 // those of the pair it points at drops its DP tasks (classes, scan counts) and keeps the pointer; any other candidate forgets it.
-OCT_KERNEL(k_dedup_verify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* cnt_late)
+// tile_sums != null: k_classify left RAW counts; this kernel stores them scanned across the workgroup once the shared pairs' counts are dropped (store_scanned_local)
+OCT_KERNEL(k_dedup_verify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* cnt_late, uint4* tile_sums, uint4* tile_sums_late)
 {
+    __shared__ uint4 sh_scan[4];
     const uint64_t e = pair0 + (uint64_t)hw::block_idx() * hw::block_dim() + hw::thread_idx();
     const uint64_t e_wave = wave_first_index(pair0);
     unsigned long long st_score = 0, st_trace = 0, st_cells = 0, st_pairs = 0;
+    uint4 my_cnt = make_uint4(0, 0, 0, 0), my_late = make_uint4(0, 0, 0, 0);
+    if (tile_sums && e < pair1) { my_cnt = cnt[e - pair0]; if (cnt_late) my_late = cnt_late[e - pair0]; }
     if (e < pair1) {
         const uint32_t h2 = b.pair_rep[e];                                     // the matcher's candidate: the HAPLOTYPE whose pair with this read looked the same
         if (h2 != kNoPair) {
@@ -1146,12 +1193,16 @@ OCT_KERNEL(k_dedup_verify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cn
                 st_score = n_score; st_trace = n_trace; st_cells = (unsigned long long)(n_score + n_trace) * 2ull * (uint32_t)b.band * (T + (uint32_t)b.band); st_pairs = 1;
                 b.pair_cls[e] = 0;
                 b.pair_rep[e] = (uint32_t)shared;                                     // from here on: the pair whose result this one reads
-                cnt[e - pair0] = make_uint4(0, 0, 0, 0);
-                if (cnt_late) cnt_late[e - pair0] = make_uint4(0, 0, 0, 0);
+                my_cnt = make_uint4(0, 0, 0, 0); my_late = make_uint4(0, 0, 0, 0);
+                if (!tile_sums) { cnt[e - pair0] = my_cnt; if (cnt_late) cnt_late[e - pair0] = my_late; }
             } else {
                 b.pair_rep[e] = kNoPair;
             }
         }
+    }
+    if (tile_sums) {
+        store_scanned_local(my_cnt, e, pair0, pair1, cnt, tile_sums, sh_scan);
+        if (cnt_late) store_scanned_local(my_late, e, pair0, pair1, cnt_late, tile_sums_late, sh_scan);
     }
     st_score = wave_sum(st_score); st_trace = wave_sum(st_trace); st_cells = wave_sum(st_cells); st_pairs = wave_sum(st_pairs);
     if ((hw::thread_idx() & 63) == 0 && st_pairs) {
@@ -1324,53 +1375,39 @@ OCT_KERNEL(k_scan_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, 
     }
 }
 
-// Any size, ONE launch (round 5): the scan of both count arrays, the per-haplotype bases and the totals - what took k_scan_tiles x 3 + k_hap_bases per array
-// (eight launches and their gaps with late-start lists: a region server's device batch is a chain of dependent launches). Workgroup
-// (tile, array) scans its tile of 8,192 items IN PLACE, tile-locally, and leaves the tile's total in tile_sums; the workgroup that finishes LAST (a device-scope
-// counter; no workgroup ever waits for another) turns the tile totals into tile prefixes and computes the haplotype bases and totals of both arrays from
-// local count + prefix of its tile. Readers of the counts (k_emit) add the tile prefix themselves: ScanView.
+// Any size, TWO launches (round 5) instead of k_scan_tiles x 3 + k_hap_bases per count array (eight launches and their gaps with late-start lists: a region
+// server's device batch is a chain of dependent launches):
+//   * the kernel that makes the counts - k_classify, or k_dedup_verify where pairs are shared - scans them across its own workgroup (a "tile" of 256 pairs) and
+//     stores every pair's tile-local exclusive prefix and the tile's total (block_scan_local);
+//   * k_scan_finish, ONE workgroup: tile totals -> tile prefixes (in place), per-haplotype bases and totals of both count arrays from local prefix + tile prefix.
+// Readers of the counts (k_emit) add the tile prefix themselves: ScanView. (First form of the round: one launch whose last workgroup did the second step behind a
+// device-scope counter - 55 us for 150 k pairs against 48 us for the eight launches it replaced, and 10 % on the 12.8 M-pair step: every workgroup's release fence is a
+// write-back of its XCD's L2 on this chip, 392 of them per slice beside other slices' backpointer stores. profiles/EXPERIMENTS.md.)
 struct ScanView { const uint4* cnt; const uint4* tile_pref; };       // tile_pref null: cnt is scanned globally (k_scan_tiles, k_scan_bases)
-constexpr uint32_t kScanFusedShift = 13, kScanFusedTile = 1u << kScanFusedShift;     // = kHapBaseThreads x 8
-OCT_DEVICE uint4 scanned(const ScanView& v, uint64_t i) { const uint4 c = v.cnt[i]; return v.tile_pref ? add4(c, v.tile_pref[i >> kScanFusedShift]) : c; }
-OCT_KERNEL(k_scan_fused)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, uint4* cnt1, uint64_t pair0, uint32_t n_scan, uint32_t n_tiles,
-                         uint4* tile_sums0, uint4* tile_sums1, uint4* hap_base0, uint4* hap_base1, uint4* totals0, uint4* totals1, uint32_t group, uint32_t* done)
+constexpr uint32_t kScanLocalShift = 8, kScanLocalTile = 1u << kScanLocalShift;      // = the 256 threads of k_classify / k_dedup_verify
+OCT_DEVICE uint4 scanned(const ScanView& v, uint64_t i) { const uint4 c = v.cnt[i]; return v.tile_pref ? add4(c, v.tile_pref[i >> kScanLocalShift]) : c; }
+OCT_KERNEL(k_scan_finish)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* cnt0, const uint4* cnt1, uint64_t pair0, uint32_t n_tiles,
+                          uint4* tile_sums0, uint4* tile_sums1, uint4* hap_base0, uint4* hap_base1, uint4* totals0, uint4* totals1, uint32_t group)
 {
     OCT_DYN_SMEM(smem);
-    uint4* sh = (uint4*)smem;                                   // [16] + one word for the verdict
-    uint32_t* verdict = (uint32_t*)(sh + 16);
+    uint4* sh = (uint4*)smem;                                   // [16]
     const uint32_t tid = hw::thread_idx();
-    const uint32_t n_arr = cnt1 ? 2u : 1u, which = hw::block_idx() / n_tiles, tile = hw::block_idx() % n_tiles;
-    {
-        uint4* cnt = which ? cnt1 : cnt0;
-        constexpr uint32_t PER = kScanFusedTile / kHapBaseThreads;
-        const uint32_t i0 = tile * kScanFusedTile + tid * PER;
-        uint4 v[PER], sum = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) { v[j] = i0 + j < n_scan ? cnt[i0 + j] : make_uint4(0, 0, 0, 0); sum = add4(sum, v[j]); }
-        uint4 tile_total;
-        uint4 run = block_scan_excl(sum, sh, &tile_total);
-#pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) if (i0 + j < n_scan) { cnt[i0 + j] = run; run = add4(run, v[j]); }
-        if (tid == 0) (which ? tile_sums1 : tile_sums0)[tile] = tile_total;
-    }
-    // who is last? (every thread's stores are ordered before the workgroup's one increment: fence, barrier, fence + atomic by thread 0)
-    hw::device_fence();
-    hw::block_sync();
-    if (tid == 0) { hw::device_fence(); *verdict = hw::atomic_add_u32(done, 1u) + 1u == n_tiles * n_arr ? 1u : 0u; }
-    hw::block_sync();
-    if (!*verdict) return;
-    hw::device_fence();                                         // the other workgroups' counts and tile totals, not this CU's stale lines
-    if (tid == 0) *done = 0u;                                   // (a repeated step finds the counter as the upload left it)
+    const uint32_t n_arr = cnt1 ? 2u : 1u;
     uint4 all[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     for (uint32_t a = 0; a < n_arr; ++a) {
-        uint4* cnt = a ? cnt1 : cnt0; uint4* tsum = a ? tile_sums1 : tile_sums0; uint4* hap_base = a ? hap_base1 : hap_base0;
-        // tile totals -> exclusive tile prefixes, in place (1,024 tiles per round: 8 M pairs)
+        const uint4* cnt = a ? cnt1 : cnt0; uint4* tsum = a ? tile_sums1 : tile_sums0; uint4* hap_base = a ? hap_base1 : hap_base0;
+        // tile totals -> exclusive tile prefixes, in place: eight consecutive tiles per thread and round (coalesced runs, one workgroup scan per 8,192 tiles = 2 M pairs)
+        constexpr uint32_t PER = 8;
         uint4 carry = make_uint4(0, 0, 0, 0);
-        for (uint32_t t0 = 0; t0 < n_tiles; t0 += kHapBaseThreads) {
-            const uint4 mine = t0 + tid < n_tiles ? tsum[t0 + tid] : make_uint4(0, 0, 0, 0);
+        for (uint32_t t0 = 0; t0 < n_tiles; t0 += kHapBaseThreads * PER) {
+            const uint32_t i0 = t0 + tid * PER;
+            uint4 v[PER], sum = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (uint32_t j = 0; j < PER; ++j) { v[j] = i0 + j < n_tiles ? tsum[i0 + j] : make_uint4(0, 0, 0, 0); sum = add4(sum, v[j]); }
             uint4 round_total;
-            const uint4 ex = block_scan_excl(mine, sh, &round_total);
-            if (t0 + tid < n_tiles) tsum[t0 + tid] = add4(carry, ex);
+            uint4 run = add4(carry, block_scan_excl(sum, sh, &round_total));
+#pragma unroll
+            for (uint32_t j = 0; j < PER; ++j) if (i0 + j < n_tiles) { tsum[i0 + j] = run; run = add4(run, v[j]); }
             carry = add4(carry, round_total);
         }
         hw::block_sync();                                       // the prefixes are read across threads below
@@ -1397,7 +1434,7 @@ OCT_KERNEL(k_scan_fused)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, 
         }
         if (tid == 0) *(a ? totals1 : totals0) = all[a];
     }
-    // one traceback launch takes a flavour's traceback list AND its late-start list: together they must fit the scratch the host provisioned
+    // one traceback launch may take a flavour's traceback list AND its late-start list: together they must fit the scratch the host provisioned
     if (tid == 0 && b.dsl_trace_cap && (all[0].y + all[1].x > b.dsl_trace_cap || all[0].w + all[1].y > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
 }
 
@@ -1514,7 +1551,10 @@ template <bool V> struct BoolC { static constexpr bool value = V; };
 
 // LDS footprint of one DP workgroup (bytes) — must match the carve-up in k_dp.
 OCT_HD constexpr uint32_t dp_rec_n(uint32_t t_cap, uint32_t B) { return (t_cap + 2 * B + 12) & ~3u; }
-constexpr uint32_t kTileStride = 66;   // dwords per row of the 16 x 64 backpointer transpose tile (66: conflict-free both ways)
+#ifndef OCT_TILE_STRIDE
+#define OCT_TILE_STRIDE 66             // (a build-time knob for A/B libraries: tools/build_variant.sh)
+#endif
+constexpr uint32_t kTileStride = OCT_TILE_STRIDE;   // dwords per row of the 16 x 64 backpointer transpose tile (66: conflict-free both ways)
 // rec_chunk (k_dp / k_dp_pair only): 0 = a wave stages its reads' records whole (index j = read position j - B, T + 2B + 12 entries per row); n = it stages n iterations'
 // worth at a time (n + 2B + 12 entries) and restages every n iterations. 500-base reads (the chunks the reference's PacBio configuration cuts long reads into)
 // against 1.8 kb haplotypes would otherwise take 115 KB of LDS per workgroup = one wave per SIMD.

@@ -209,8 +209,6 @@ inline unsigned long long atomic_max_u64(unsigned long long* p, unsigned long lo
 inline unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { const auto o = *p; *p = o + v; return o; }
 inline uint32_t atomic_and_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o & v; return o; }
 inline uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; if (v < o) *p = v; return o; }
-inline uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
-inline void device_fence() {}
 inline unsigned long long atomic_cas_u64(unsigned long long* p, unsigned long long expected, unsigned long long v) { const auto o = *p; if (o == expected) *p = v; return o; }
 inline void lds_store_u64(unsigned long long* p, unsigned long long v) { *(volatile unsigned long long*)p = v; }
 inline unsigned long long lds_load_u64(const unsigned long long* p) { return *(const volatile unsigned long long*)p; }
