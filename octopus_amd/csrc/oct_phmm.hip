@@ -631,7 +631,7 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 // cost ~20 us whatever the size
 constexpr uint32_t kScanBasesOneLaunchMax = 2 * 8192;
 constexpr size_t   kPinnedOutMinBytes = (size_t)8 << 20;  // results from here on: is the caller's `out` page-locked? (the question costs microseconds: not asked for region-sized calls)
-constexpr uint64_t kLaneMapMinPairs = 200000;          // k-mer mapper: one lane per pair from here on (k_kmer_map_lanes), one wave per pair below
+constexpr uint64_t kLaneMapMinPairs = 120000;          // k-mer mapper: one lane per pair from here on (k_kmer_map_lanes), one wave per pair below
 constexpr uint64_t kDslMaxPairs = 400000;              // device-sized launches (no read-back inside the step, grids sized by the host's bound) up to here. Round 4 stopped at 100 k: first 6 / 8 / 12 / 16 / 64
                                                        // regions of the configs[3] stream (50 k / 70 k / 110 k / 150 k / 660 k pairs), one populate from host buffers: 0.54 / 0.60 / 1.04 / 1.31 / 4.14 ms
                                                        // device-sized, 0.57 / 0.57 / 0.97 / 1.21 / 3.56 host-sized. Round 5 (gpurun_out/r05_s01): on the DEVICE the two forms take the same time (16 regions:
@@ -645,7 +645,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
                 int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false,
                 TaskListRef ref = TaskListRef {nullptr, nullptr, 0, nullptr}, const rt::Event* after_first_dp = nullptr,
                 int paired_score_list = -1, uint32_t paired_score_bound = 0,     // device-sized traceback launch: the score-only list of the same flavour rides along (k_dp_pair)
-                bool joined_late = false)                                        // host-sized traceback launch: the flavour's late-start list lies behind the list and is part of `n_tasks`
+                uint32_t joined_late_from = 0xffffffffu)                         // host-sized traceback launch: the flavour's late-start list lies behind the list proper (this many tasks) and is part of `n_tasks`
 {
     if (!n_tasks) return OCT_PHMM_OK;
     const bool dsl = ref.totals != nullptr;
@@ -675,7 +675,8 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     // late traceback start is PERMITTED wherever the walk may stop early (below); which task groups take it is geometry (dp_groups). `late`: the launch is a late-start list.
     // (a launch of a traceback list proper, beside late-start lists of its own, has no such group by construction: p.late stays 0 and its groups skip the question)
     const bool may_start_late = tr && !seam_walk && !b->align_mode && b->fast_adds && !b->stream && !h->wide && tune::late_start();
-    p.late = (may_start_late && (late || ref.join_late || joined_late || !b->late_ok)) ? 1 : 0;
+    p.late = (may_start_late && (late || ref.join_late || joined_late_from != 0xffffffffu)) ? 1 : 0;
+    p.late_from = late ? 0u : joined_late_from;
     p.hap_region = b->d.hap_region; p.reg_rhs = b->d.reg_rhs; p.reg_lhs = b->d.reg_lhs;
     uint32_t chunk_groups = n_groups;
     if (tr) {
@@ -692,6 +693,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     for (uint32_t g0 = 0; g0 < n_groups; g0 += chunk_groups) {
         const uint32_t ng = std::min(chunk_groups, n_groups - g0);
         p.tasks = tasks + (size_t)g0 * G; p.n_tasks = ng * G;
+        if (!late && joined_late_from != 0xffffffffu) p.late_from = joined_late_from > g0 * G ? joined_late_from - g0 * G : 0u;      // (relative to this chunk's first task)
         p.bp = h->bp[slice]; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
         uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
         if (dsl) n_blocks = std::min(n_blocks, kDslMaxBlocks);
@@ -1789,7 +1791,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         // a flavour's traceback list and its late-start list (which lies right behind it) in ONE DP launch and ONE walk: one-slice batches, where the step is a chain of
         // dependent launches (a region server's device batch; 16 regions: the second traceback launch and its walk were 233 of 868 us). Batches of several slices keep
         // the two launches: the 12.8 M-pair step lost 6 % of its traceback DP with them joined (17.8 against 2 x 8.36 ms per launch; profiles/EXPERIMENTS.md)
-        const bool join = sl.scan_fused && (tune::join_late() >= 0 ? tune::join_late() != 0 : S == 1);
+        const bool join = sl.scan_fused && (tune::join_late() >= 0 ? tune::join_late() != 0 : (S == 1 && np <= 2000000));
         const size_t n_trace = join ? (size_t)std::max(totals.y + late.x, totals.w + late.y) : (size_t)std::max(std::max(totals.y, totals.w), std::max(late.x, late.y));
         if (n_trace > sl.ends_cap) {
             h->pool.release(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
@@ -1829,7 +1831,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 if (side && score_kind && !forked) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
                 if (side && score_kind && n) RT(rt::stream_wait_event(aux, b->ev_fork));
                 const int rc = run_dp_kind(h, b, i, k, ta.t[k], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, side && score_kind ? &aux : nullptr, false,
-                                           TaskListRef {nullptr, nullptr, 0, nullptr}, side && !score_kind && !forked && n ? &b->ev_fork : nullptr, -1, 0, join && !score_kind);
+                                           TaskListRef {nullptr, nullptr, 0, nullptr}, side && !score_kind && !forked && n ? &b->ev_fork : nullptr, -1, 0,
+                                           join && !score_kind ? (k == kTraceFast ? totals.y : totals.w) : 0xffffffffu);
                 if (rc != OCT_PHMM_OK) return rc;
                 forked = forked || (side && !score_kind && n);
             }
@@ -2205,12 +2208,13 @@ struct oct_phmm_server {
     std::deque<Request*> queue;
     bool stop = false;
     std::vector<std::thread> workers;                    // all of them drain the one queue, so an idle device takes the next calls
-    uint64_t n_calls = 0, n_batches = 0;
+    std::atomic<uint64_t> n_calls {0}, n_batches {0};    // counted when the calls are taken / the batch is enqueued: a caller that has its answer finds itself counted
     std::vector<uint64_t> n_calls_by_device;
     int busy_workers = 0;                                // workers between taking calls and answering them (under mu)
     static constexpr int kLingerSteps = 6;
     int linger_us = [] { long long v; return tune::number("OCT_PHMM_SERVER_LINGER_US", &v) && v >= 0 && v <= 10000 ? (int)v : 0; }();    // 0 (default): take what is there. Measured: 25 us x 6 steps doubles the regions per device batch (13 -> 22 at 128 callers) and LOSES 5 - 20 % throughput
                                                          // (profiles/r04_step3_server_sweep.log): a bigger device batch is not cheaper per region, the step is a chain of ~25 small launches either way
+    bool gather = [] { long long v; return !(tune::number("OCT_PHMM_SERVER_GATHER", &v) && v == 0); }();          // 0: a worker whose batch is on the device takes whatever has arrived at once (A/B)
     bool pipelined = [] { long long v; return !(tune::number("OCT_PHMM_SERVER_PIPELINE", &v) && v == 0); }();      // 0: a worker answers a batch before it takes the next calls (round 4's loop, A/B)
     std::atomic<bool> has_model {false};                 // oct_phmm_server_set_error_model: calls may leave their penalty vectors NULL
     // the model travels to the handles through their own worker threads (under mu): a handle is only ever touched by its worker
@@ -2332,7 +2336,6 @@ struct oct_phmm_server {
         Flight flight;                                     // the batch that is on the device (at most one per worker; its successor is prepared beside it)
         std::deque<std::vector<Request*>> groups;          // batches taken from the queue that wait for a handle
         int next_slot = 0;
-        uint64_t taken = 0, batches = 0;                   // since the last time the counters went to the server's (under mu)
         bool w_busy = false;                               // counted in busy_workers
 #if defined(OCTPHMM_SIM)
         static std::mutex sim_mu;                          // the wave simulator runs one kernel at a time: workers of several "devices" take turns
@@ -2350,10 +2353,16 @@ struct oct_phmm_server {
                 {
                     const uint64_t t_idle = profile ? now_ns() : 0;
                     std::unique_lock<std::mutex> lk(mu);
-                    n_calls += taken; n_batches += batches; n_calls_by_device[(size_t)device_of[(size_t)w]] += taken; taken = 0; batches = 0;
                     if (!flight.active) {
                         if (w_busy) { --busy_workers; w_busy = false; }
                         cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+                    } else if (gather) {
+                        // This worker's batch is on the device: the calls that have arrived since are the first of the next burst (its own callers come back when it
+                        // ends, the other workers' when theirs do). A batch of two costs the device what one of ten does, so there is no hurry - but the next batch
+                        // should be enqueued when this one ends. Wait until half as many calls wait as the batch in flight holds, or until it has left the device.
+                        const size_t want = std::max<size_t>(1, std::min<size_t>(max_regions, flight.qs.size() / 2));
+                        while (!stop && queue.size() < want && !rt::stream_idle(flight.h->stream))
+                            cv_work.wait_for(lk, std::chrono::microseconds(30), [&] { return stop || queue.size() >= want; });
                     }
                     if (profile) ns_idle += now_ns() - t_idle;
                     if (queue.empty() && stop && !flight.active) return;
@@ -2374,9 +2383,9 @@ struct oct_phmm_server {
                     if (worker_version[(size_t)w] == model_version)
                         while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
                     if (!take.empty() && !w_busy) { ++busy_workers; w_busy = true; }
+                    n_calls += take.size(); n_calls_by_device[(size_t)device_of[(size_t)w]] += take.size();
                 }
                 if (take.empty()) { finish(); continue; }      // nothing new arrived while the batch computed: answer it, then wait for calls
-                taken += take.size();
                 std::vector<Request*> batchable, batchable_gen, single;       // calls that leave their penalty vectors to the library batch among themselves
                 for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : q->H->gap_open ? batchable : batchable_gen).push_back(q);
                 if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
@@ -2389,7 +2398,7 @@ struct oct_phmm_server {
 #if defined(OCTPHMM_SIM)
                         std::lock_guard<std::mutex> sim_lk(sim_mu);
 #endif
-                        serve_one(hfree, q); answer(q); ++batches;
+                        ++n_batches; serve_one(hfree, q); answer(q);
                     }
                     if (profile) ns_single += now_ns() - t_single;
                 }
@@ -2399,17 +2408,17 @@ struct oct_phmm_server {
             }
             // the next batch goes onto the handle that is free; the batch in flight (if any) keeps computing meanwhile
             std::vector<Request*> qs = std::move(groups.front()); groups.pop_front();
-            if (!pipelined) finish();
+            if (!pipelined || (flight.active && rt::stream_idle(flight.h->stream))) finish();      // (a batch that has left the device: its callers first)
             const int slot = flight.active ? 1 - flight.slot : next_slot;
             Flight nf; nf.slot = slot;
             bool started = false;
+            ++n_batches;
             {
 #if defined(OCTPHMM_SIM)
                 std::lock_guard<std::mutex> sim_lk(sim_mu);
 #endif
                 try { started = begin_many(hslot[slot], concat[slot], qs, nf); } catch (const std::exception&) { started = false; }      // e.g. bad_alloc while concatenating
             }
-            ++batches;
             finish();                                          // the batch that was computing meanwhile: wait, scatter, wake its callers
             if (started) { flight = std::move(nf); next_slot = 1 - slot; }
             else for (Request* q : qs) {                       // the batch could not be uploaded as one (an error in one of its regions, no memory): every call on its own
@@ -2472,7 +2481,7 @@ extern "C" void oct_phmm_server_destroy(oct_phmm_server* s)
     for (auto* h : s->hs) oct_phmm_destroy(h);
     if (s->profile)
         fprintf(stderr, "{\"server_profile_ms\": {\"workers\": %zu, \"calls\": %llu, \"batches\": %llu, \"idle\": %.2f, \"concat\": %.2f, \"check_pack_enqueue\": %.2f, "
-                        "\"wait_for_results\": %.2f, \"scatter_and_wake\": %.2f, \"single_calls\": %.2f}}\n", s->workers.size(), (unsigned long long)s->n_calls, (unsigned long long)s->n_batches,
+                        "\"wait_for_results\": %.2f, \"scatter_and_wake\": %.2f, \"single_calls\": %.2f}}\n", s->workers.size(), (unsigned long long)s->n_calls.load(), (unsigned long long)s->n_batches.load(),
                 s->ns_idle / 1e6, s->ns_concat / 1e6, s->ns_begin / 1e6, s->ns_end / 1e6, s->ns_scatter / 1e6, s->ns_single / 1e6);
     delete s;
 }
@@ -2534,8 +2543,8 @@ extern "C" int oct_phmm_server_stats(const oct_phmm_server* s, uint64_t* n_calls
 {
     if (!s) return OCT_PHMM_EINVAL;
     std::lock_guard<std::mutex> lk(const_cast<oct_phmm_server*>(s)->mu);
-    if (n_calls) *n_calls = s->n_calls;
-    if (n_batches) *n_batches = s->n_batches;
+    if (n_calls) *n_calls = s->n_calls.load();
+    if (n_batches) *n_batches = s->n_batches.load();
     return OCT_PHMM_OK;
 }
 

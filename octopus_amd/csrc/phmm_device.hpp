@@ -132,6 +132,8 @@ struct DpParams {
     // whose tasks ALL start at or behind the left flank's end (off >= reg_lhs: k_classify's class 3, pure geometry) starts late - the groups of a late-start list
     // by construction, and whichever other group happens to qualify.
     int late; const uint32_t* hap_region; const uint32_t* reg_rhs; const uint32_t* reg_lhs;
+    uint32_t late_from;                               // the launch's first task that belongs to a late-start list (0: the launch IS one; a joined launch: the length of the traceback list proper) -
+                                                      // the groups before it skip the question (three dependent loads per group: 4 % of a 10 M-task traceback launch)
 };
 
 struct WalkParams {

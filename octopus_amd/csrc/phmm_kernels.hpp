@@ -1452,7 +1452,7 @@ OCT_KERNEL(k_copy_from_host)(uint4* dst, const uint4* src, uint32_t n16)
 // Physical order of the lists in the array: score-only fast, traceback fast, LATE fast, score-only generic, traceback generic, LATE generic - a flavour's
 // late-start list lies right behind its traceback list, so that ONE traceback launch and ONE walk take both (ref.join_late; round 5: the second traceback
 // launch of a region-sized step was a single round of workgroups on an otherwise idle chip, and its walk one more link in the chain).
-OCT_DEVICE void task_list_range(const TaskListRef& ref, uint32_t& first, uint32_t& n)
+OCT_DEVICE void task_list_range(const TaskListRef& ref, uint32_t& first, uint32_t& n, uint32_t* n_main = nullptr)   // n_main: the tasks of the list proper (behind them: the joined late-start list)
 {
     const uint4 a = *ref.totals;
     const uint4 l = ref.totals_late ? *ref.totals_late : make_uint4(0, 0, 0, 0);
@@ -1462,10 +1462,10 @@ OCT_DEVICE void task_list_range(const TaskListRef& ref, uint32_t& first, uint32_
     bool before = true;
     for (int k = 0; k < 6; ++k) {
         const int id = order[k];
-        if (id == ref.list) { before = false; n = c[id]; if (ref.join_late && (id == 1 || id == 3)) n += c[id == 1 ? 4 : 5]; }
+        if (id == ref.list) { before = false; n = c[id]; if (n_main) *n_main = n; if (ref.join_late && (id == 1 || id == 3)) n += c[id == 1 ? 4 : 5]; }
         else if (before) first += c[id];
     }
-    if (ref.overflow && *ref.overflow) { first = 0; n = 0; }
+    if (ref.overflow && *ref.overflow) { first = 0; n = 0; if (n_main) *n_main = 0; }
 }
 
 // Pass 2: write the DP tasks of every pair at hap_base + (scanned count - scanned count at the haplotype's first pair).
@@ -1584,7 +1584,8 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
     uint32_t* tile = tiles + wave * 16 * kTileStride;
 
     const DevTask* tasks = p.tasks; uint32_t n_tasks = p.n_tasks;
-    if (p.ref.totals) { uint32_t first; task_list_range(p.ref, first, n_tasks); tasks += first; }   // device-sized launch: this kernel's list, from device memory
+    uint32_t late_from = p.late_from;                   // first task of the launch that may start its traceback late (the joined late-start list; 0: a late-start list on its own)
+    if (p.ref.totals) { uint32_t first, n_main; task_list_range(p.ref, first, n_tasks, &n_main); tasks += first; late_from = p.ref.join_late ? n_main : p.late_from; }   // device-sized launch: this kernel's list, from device memory
     const uint32_t n_groups = n_tasks / G;
     const uint32_t NUC = p.nuc4;
     // State words are kept biased by 0x8000 per half (null_score_ -> 0x0000, infinity_ -> 0xF800): a wrapping add is bit-identical to the
@@ -1796,7 +1797,7 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                 // Scores are the same in both forms (labels only break ties inside an iteration and are reset after it); k_sw is a tile
                 // boundary no later than the first possible end cell, so end-cell ties see their labels.
                 uint32_t k_sw = 0;
-                if (p.late) {
+                if (p.late && g * G >= late_from) {
                     // (a task that also touches the LEFT flank - its window starts before the flank's end, off < reg_lhs: k_classify's class 2 - needs its whole
                     // traceback: its first needed iteration is 0, and so is the group's)
                     auto first_needed = [&](const DevTask& t, uint32_t T) -> uint32_t {

@@ -31,6 +31,7 @@ inline bool device_is_gfx950(int d)
 inline bool stream_create(Stream* s) { OCT_RT_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return true; }
 inline void stream_destroy(Stream s) { (void)hipStreamDestroy(s); }
 inline bool stream_sync(Stream s) { OCT_RT_CHECK(hipStreamSynchronize(s)); return true; }
+inline bool stream_idle(Stream s) { const hipError_t e = hipStreamQuery(s); if (e == hipErrorNotReady) { (void)hipGetLastError(); return false; } return true; }   // everything enqueued so far has run (errors: let the wait report them)
 inline bool dev_malloc(void** p, size_t n) { OCT_RT_CHECK(hipMalloc(p, n ? n : 16)); return true; }
 inline void dev_free(void* p) { if (p) (void)hipFree(p); }
 inline bool mem_info(size_t* free_b, size_t* total_b) { OCT_RT_CHECK(hipMemGetInfo(free_b, total_b)); return true; }

@@ -19,6 +19,7 @@ inline bool device_is_gfx950(int) { return true; }
 inline bool stream_create(Stream* s) { *s = 0; return true; }
 inline void stream_destroy(Stream) {}
 inline bool stream_sync(Stream) { return true; }
+inline bool stream_idle(Stream) { return true; }
 inline bool dev_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); if (*p) memset(*p, 0xCD, n ? n : 16); return *p != nullptr; }
 inline void dev_free(void* p) { free(p); }
 inline bool mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)288 << 30; return true; }
