@@ -1134,7 +1134,9 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     // A batch that may take device-sized launches also learns here whether every base is one of ACGT and every SNV mask byte set (a clean batch launches no generic kernels).
     uint32_t q_or = 0, pen_or = 0, gomax = 0, gemax = 0, t_min = 0xffffffffu, dirty = 0; uint64_t sum_q_max = 0; bool any_empty = false;
     const bool dsl_wanted = !align_mode && tune::device_sized() != 0 && (b->n_pairs <= kDslMaxPairs || tune::device_sized() > 0);
-    const bool want_dirty = dsl_wanted && !gen_device;
+    // (region-sized calls only: from a few regions on the scan - the first touch of every base and mask byte, 0.1 ms of a 16-region upload although it takes eight bytes
+    // per step - costs the host more than the three near-empty launches of the generic lists cost the device, and the region server's workers are bound by their host work)
+    const bool want_dirty = dsl_wanted && !gen_device && b->n_pairs <= 20000;
     {
         std::mutex mx;
         const size_t read_grain = std::max<size_t>(1, (size_t)R->n_reads / std::max<size_t>(1, (size_t)n_read_bases >> 20));      // reads per ~1 MB of qualities
@@ -2198,8 +2200,9 @@ struct oct_phmm_server {
 #if defined(OCTPHMM_SIM)
     static constexpr int kWorkers = 1;                   // the CPU wave simulator is single-threaded
 #else
-    static constexpr int kWorkers = 3;                   // device queues per GPU: while one worker's batch computes, the others gather and upload the calls that arrived since
-                                                         // (configs[3] regions, 16 / 64 / 128 callers: 2 workers 13.6 / 12.7 / 15.5 k regions/s, 3: 13.9 / 17.0 / 16.8, 4: 13.5 / 16.7 / 18.4, 6: 9.6 / 16.6 / 16.8 - profiles/r04_step3_server_sweep.log)
+    static constexpr int kWorkers = 2;                   // worker threads per GPU, each with kSlots handles (round 5, pipelined workers on the configs[3] regions, 16 / 64 / 128 callers: 1 worker 12.0 / 18.7 / 16.7 k
+                                                         // regions/s, 2: 11.6 / 20.6 - 23.6 / 18.3, 3: 8.4 / 18.2 / 17.9 - gpurun_out/r05_s03; round 4, one handle per worker: 2 workers 13.6 / 12.7 / 15.5, 3: 13.9 / 17.0 / 16.8,
+                                                         // 4: 13.5 / 16.7 / 18.4). More workers mean smaller batches, and a batch of 6 costs the device what one of 12 does.
 #endif
     static constexpr int kSlots = 2;                     // handles per worker (round 5): while the batch on one computes, the worker gathers, checks, packs and enqueues the next on the other
     std::vector<oct_phmm_handle*> hs;                    // kSlots handles per worker, worker-major; kWorkers workers per device, device-major
@@ -2359,8 +2362,9 @@ struct oct_phmm_server {
                     } else if (gather) {
                         // This worker's batch is on the device: the calls that have arrived since are the first of the next burst (its own callers come back when it
                         // ends, the other workers' when theirs do). A batch of two costs the device what one of ten does, so there is no hurry - but the next batch
-                        // should be enqueued when this one ends. Wait until half as many calls wait as the batch in flight holds, or until it has left the device.
-                        const size_t want = std::max<size_t>(1, std::min<size_t>(max_regions, flight.qs.size() / 2));
+                        // should be enqueued when this one ends. Wait until as many calls wait as the batch in flight holds (two batches of a size, turn and turn about:
+                        // what a steady crowd of callers settles into), or until that batch has left the device (few callers: answer it, then take what has come).
+                        const size_t want = std::max<size_t>(1, std::min<size_t>(max_regions, flight.qs.size()));
                         while (!stop && queue.size() < want && !rt::stream_idle(flight.h->stream))
                             cv_work.wait_for(lk, std::chrono::microseconds(30), [&] { return stop || queue.size() >= want; });
                     }
@@ -2388,10 +2392,12 @@ struct oct_phmm_server {
                 if (take.empty()) { finish(); continue; }      // nothing new arrived while the batch computed: answer it, then wait for calls
                 std::vector<Request*> batchable, batchable_gen, single;       // calls that leave their penalty vectors to the library batch among themselves
                 for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : q->H->gap_open ? batchable : batchable_gen).push_back(q);
-                if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
-                if (batchable_gen.size() == 1) { single.push_back(batchable_gen[0]); batchable_gen.clear(); }
+                if (!pipelined) {                              // (a lone call skips the concatenation; a pipelined worker sends it through the asynchronous path like any batch)
+                    if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
+                    if (batchable_gen.size() == 1) { single.push_back(batchable_gen[0]); batchable_gen.clear(); }
+                }
                 if (!single.empty()) {                         // calls with positions of their own, empty calls, lone calls: one by one on a free handle
-                    if (!pipelined) finish();
+                    if (!pipelined || (flight.active && rt::stream_idle(flight.h->stream))) finish();
                     const uint64_t t_single = profile ? now_ns() : 0;
                     oct_phmm_handle* hfree = hslot[flight.active ? 1 - flight.slot : next_slot];
                     for (Request* q : single) {
