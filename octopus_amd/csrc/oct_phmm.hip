@@ -589,10 +589,15 @@ bool launch_dp_mw(int band, bool one_wave, bool tr, bool gen, const DpParams& p,
 // Read records of the packed int16 kernels: whole reads in LDS while three workgroups then fit on a CU (150-base reads: 47 KB with traceback tiles, 30 KB without), else
 // the largest chunk of iterations (a multiple of 32, at least 64) with which three do, else two - 500-base chunks of long reads against 1.8 kb haplotypes: 115 KB -> 75 KB
 // with traceback (one wave per SIMD -> two), 98 -> 51 KB without (-> three). OCT_PHMM_REC_CHUNK=n forces a chunk (test hook: restaging on small reads; 0 = never).
-uint32_t dp_rec_chunk(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool trace)
+// dense (round 5): a mid-size batch (a region server's device batch: a few rounds of workgroups, both DP forms on the chip at once) takes 64-iteration chunks where that lets a
+// fourth traceback workgroup (46 -> 39 KB) and a sixth or seventh score-only one (30 -> 22 KB) onto a CU - the launch is bound by rounds x wave latency, not by issue slots:
+// 16 regions of the configs[3] stream 1.054 -> 0.983 ms per populate; the 12.8 M-pair step does not care (traceback 8.60 -> 8.58 ms per launch, score-only 6.25 -> 6.48).
+uint32_t dp_rec_chunk(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool trace, bool dense = false)
 {
     long long v;
     if (tune::number("OCT_PHMM_REC_CHUNK", &v)) return v > 0 ? (uint32_t)((v + 3) & ~3ll) : 0u;
+    if (dense && t_cap > 100 && dp_lds_bytes(t_cap, lh_cap, B, trace, 64) <= rt::kMaxLdsBytes / (trace ? 4 : 6) - 512
+        && dp_lds_bytes(t_cap, lh_cap, B, trace) > rt::kMaxLdsBytes / (trace ? 4 : 6) - 512) return 64u;
     if (t_cap <= 128) return 0;
     for (size_t per_cu : {(size_t)3, (size_t)2}) {
         const size_t budget = rt::kMaxLdsBytes / per_cu - 1024;
@@ -654,7 +659,8 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     const uint32_t C = (uint32_t)h->lanes_c;
     const uint32_t G = b->stream ? (B < 64 ? 64u / (uint32_t)B : 1u) : (h->wide ? 1 : 2) * (64 / B);
     const bool tr = kind == kTraceFast || kind == kTraceGen, gen = kind == kScoreGen || kind == kTraceGen;
-    const uint32_t rec_chunk = (b->stream || h->wide) ? 0u : dp_rec_chunk(b->t_cap, b->lh_cap, (uint32_t)B, tr);
+    const bool dense = b->n_pairs > 20000 && b->n_pairs <= kDslMaxPairs;        // (a region-sized call is one round of workgroups: nothing to gain from a restage every 64 iterations)
+    const uint32_t rec_chunk = (b->stream || h->wide) ? 0u : dp_rec_chunk(b->t_cap, b->lh_cap, (uint32_t)B, tr, dense);
     const size_t lds = b->stream ? 0 : dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr, rec_chunk);
     if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
     DpParams p {};
@@ -2332,79 +2338,104 @@ struct oct_phmm_server {
         f.qs.clear(); f.active = false;
     }
 
+    // A worker = two threads around kSlots handles. The GATHERER takes calls, concatenates, checks, packs and enqueues them on a free slot (begin_many: no wait on the
+    // device for device-sized batches); the FINISHER waits for the slots' batches in the order they were begun, scatters the results and wakes the callers at once -
+    // a batch that has left the device is never held up by the next one's preparation (round 5's first pipelined form finished a batch only between two steps of the
+    // gatherer: up to 0.6 ms of a ~3 ms call). OCT_PHMM_SERVER_PIPELINE=0: one slot, i.e. round 4's take - run - answer loop.
+    struct Slot { Concat concat; Flight flight; bool flying = false; };
+    struct Worker {
+        Slot slot[kSlots]; std::mutex m; std::condition_variable cv_free, cv_flying; bool quit = false; std::thread finisher;
+        int n_flying() const { int n = 0; for (const Slot& s : slot) n += s.flying ? 1 : 0; return n; }
+    };
+    std::vector<std::unique_ptr<Worker>> wk;
+#if defined(OCTPHMM_SIM)
+    std::mutex sim_mu;                                     // the wave simulator runs one kernel at a time: the workers of several "devices" take turns
+#endif
+
+    void finish_loop(int w)
+    {
+        Worker& W = *wk[(size_t)w];
+        const int n_slots = pipelined ? kSlots : 1;
+        for (int k = 0;; k = (k + 1) % n_slots) {          // slots fly in turn
+            {
+                std::unique_lock<std::mutex> lk(W.m);
+                W.cv_flying.wait(lk, [&] { return W.quit || W.slot[k].flying; });
+                if (!W.slot[k].flying) return;              // (quit, and nothing left in the air)
+            }
+            {
+#if defined(OCTPHMM_SIM)
+                std::lock_guard<std::mutex> sim_lk(sim_mu);
+#endif
+                end_many(W.slot[k].concat, W.slot[k].flight);
+            }
+            { std::lock_guard<std::mutex> lk(W.m); W.slot[k].flying = false; }
+            W.cv_free.notify_all();
+            cv_work.notify_all();                           // (a gatherer that waits for calls OR for its batch to land)
+        }
+    }
+
     void run(int w)
     {
+        Worker& W = *wk[(size_t)w];
+        const int n_slots = pipelined ? kSlots : 1;
         oct_phmm_handle* hslot[kSlots]; for (int k = 0; k < kSlots; ++k) hslot[k] = hs[(size_t)w * kSlots + k];
-        Concat concat[kSlots];
-        Flight flight;                                     // the batch that is on the device (at most one per worker; its successor is prepared beside it)
-        std::deque<std::vector<Request*>> groups;          // batches taken from the queue that wait for a handle
-        int next_slot = 0;
+        std::deque<std::vector<Request*>> groups;          // batches taken from the queue that wait for a slot
+        int next_slot = 0; size_t last_batch = 1;
         bool w_busy = false;                               // counted in busy_workers
-#if defined(OCTPHMM_SIM)
-        static std::mutex sim_mu;                          // the wave simulator runs one kernel at a time: workers of several "devices" take turns
-#endif
-        auto finish = [&] {
-            if (!flight.active) return;
-#if defined(OCTPHMM_SIM)
-            std::lock_guard<std::mutex> sim_lk(sim_mu);
-#endif
-            end_many(concat[flight.slot], flight);
-        };
+        auto flying = [&] { std::lock_guard<std::mutex> lk(W.m); return W.n_flying(); };
+        auto wait_all_landed = [&] { std::unique_lock<std::mutex> lk(W.m); W.cv_free.wait(lk, [&] { return W.n_flying() == 0; }); };
         for (;;) {
             if (groups.empty()) {
                 std::vector<Request*> take;
                 {
                     const uint64_t t_idle = profile ? now_ns() : 0;
                     std::unique_lock<std::mutex> lk(mu);
-                    if (!flight.active) {
+                    if (flying() == 0) {
                         if (w_busy) { --busy_workers; w_busy = false; }
                         cv_work.wait(lk, [&] { return stop || !queue.empty(); });
                     } else if (gather) {
-                        // This worker's batch is on the device: the calls that have arrived since are the first of the next burst (its own callers come back when it
-                        // ends, the other workers' when theirs do). A batch of two costs the device what one of ten does, so there is no hurry - but the next batch
-                        // should be enqueued when this one ends. Wait until as many calls wait as the batch in flight holds (two batches of a size, turn and turn about:
-                        // what a steady crowd of callers settles into), or until that batch has left the device (few callers: answer it, then take what has come).
-                        const size_t want = std::max<size_t>(1, std::min<size_t>(max_regions, flight.qs.size()));
-                        while (!stop && queue.size() < want && !rt::stream_idle(flight.h->stream))
-                            cv_work.wait_for(lk, std::chrono::microseconds(30), [&] { return stop || queue.size() >= want; });
+                        // A batch of this worker is on the device: the calls that have arrived since are the first of the next burst (its own callers come back when it
+                        // lands, the other workers' when theirs do). A batch of two costs the device what one of ten does, so there is no hurry - but the next batch should
+                        // be enqueued when this one ends. Wait until as many calls wait as the last batch held (two batches of a size, turn and turn about: what a steady
+                        // crowd of callers settles into), or until nothing of this worker's is on the device any more (few callers: take what has come).
+                        const size_t want = std::max<size_t>(1, std::min<size_t>(max_regions, last_batch));
+                        while (!stop && queue.size() < want && flying() > 0)
+                            cv_work.wait_for(lk, std::chrono::microseconds(50), [&] { return stop || queue.size() >= want; });
                     }
                     if (profile) ns_idle += now_ns() - t_idle;
-                    if (queue.empty() && stop && !flight.active) return;
-                    if (worker_version[(size_t)w] != model_version && !flight.active) {      // a new error model since this worker's last batch: install it before taking calls
+                    if (queue.empty() && stop) { lk.unlock(); wait_all_landed(); return; }
+                    if (worker_version[(size_t)w] != model_version) {      // a new error model since this worker's last batch: install it (nothing of ours in the air) before taking calls
+                        lk.unlock(); wait_all_landed(); lk.lock();
                         for (int k = 0; k < kSlots; ++k) oct_phmm_set_error_model(hslot[k], pending_has_model ? &pending_model : nullptr);
                         worker_version[(size_t)w] = model_version;
                     }
-                    // Bounded linger: when another worker's batch is on the device, the calls that woke this worker are mostly the first of a burst (the callers of
-                    // the batch that just finished come back one after the other) - wait while calls keep arriving, at most kLingerSteps x kLingerUs. With the device idle nothing waits.
-                    if (linger_us > 0 && busy_workers > 0 && !flight.active && queue.size() < max_regions) {
+                    // Bounded linger (OCT_PHMM_SERVER_LINGER_US, off by default): with other workers' batches on the device, wait while calls keep arriving
+                    if (linger_us > 0 && busy_workers > 0 && queue.size() < max_regions) {
                         for (int step = 0; step < kLingerSteps && !stop; ++step) {
                             const size_t before = queue.size();
                             cv_work.wait_for(lk, std::chrono::microseconds(linger_us), [&] { return stop || queue.size() >= max_regions; });
                             if (queue.size() == before || busy_workers == 0) break;
                         }
                     }
-                    // (a worker whose model is stale takes no calls while its batch is in flight: it answers that batch first, installs the model, then takes them)
-                    if (worker_version[(size_t)w] == model_version)
-                        while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
+                    while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
                     if (!take.empty() && !w_busy) { ++busy_workers; w_busy = true; }
                     n_calls += take.size(); n_calls_by_device[(size_t)device_of[(size_t)w]] += take.size();
                 }
-                if (take.empty()) { finish(); continue; }      // nothing new arrived while the batch computed: answer it, then wait for calls
+                if (take.empty()) continue;
                 std::vector<Request*> batchable, batchable_gen, single;       // calls that leave their penalty vectors to the library batch among themselves
                 for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : q->H->gap_open ? batchable : batchable_gen).push_back(q);
                 if (!pipelined) {                              // (a lone call skips the concatenation; a pipelined worker sends it through the asynchronous path like any batch)
                     if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
                     if (batchable_gen.size() == 1) { single.push_back(batchable_gen[0]); batchable_gen.clear(); }
                 }
-                if (!single.empty()) {                         // calls with positions of their own, empty calls, lone calls: one by one on a free handle
-                    if (!pipelined || (flight.active && rt::stream_idle(flight.h->stream))) finish();
+                if (!single.empty()) {                         // calls with positions of their own, empty calls: one by one, on a slot that is on the ground
                     const uint64_t t_single = profile ? now_ns() : 0;
-                    oct_phmm_handle* hfree = hslot[flight.active ? 1 - flight.slot : next_slot];
+                    { std::unique_lock<std::mutex> lk(W.m); W.cv_free.wait(lk, [&] { return !W.slot[next_slot].flying; }); }
                     for (Request* q : single) {
 #if defined(OCTPHMM_SIM)
                         std::lock_guard<std::mutex> sim_lk(sim_mu);
 #endif
-                        ++n_batches; serve_one(hfree, q); answer(q);
+                        ++n_batches; serve_one(hslot[next_slot], q); answer(q);
                     }
                     if (profile) ns_single += now_ns() - t_single;
                 }
@@ -2412,26 +2443,30 @@ struct oct_phmm_server {
                 if (!batchable_gen.empty()) groups.push_back(std::move(batchable_gen));
                 if (groups.empty()) continue;
             }
-            // the next batch goes onto the handle that is free; the batch in flight (if any) keeps computing meanwhile
+            // the next batch goes onto the next slot as soon as that slot's last batch has landed; the other slot's batch keeps computing meanwhile
             std::vector<Request*> qs = std::move(groups.front()); groups.pop_front();
-            if (!pipelined || (flight.active && rt::stream_idle(flight.h->stream))) finish();      // (a batch that has left the device: its callers first)
-            const int slot = flight.active ? 1 - flight.slot : next_slot;
-            Flight nf; nf.slot = slot;
+            const int k = next_slot;
+            { std::unique_lock<std::mutex> lk(W.m); W.cv_free.wait(lk, [&] { return !W.slot[k].flying; }); }
+            Slot& S = W.slot[k];
+            S.flight = Flight {}; S.flight.slot = k;
+            last_batch = qs.size();
             bool started = false;
             ++n_batches;
             {
 #if defined(OCTPHMM_SIM)
                 std::lock_guard<std::mutex> sim_lk(sim_mu);
 #endif
-                try { started = begin_many(hslot[slot], concat[slot], qs, nf); } catch (const std::exception&) { started = false; }      // e.g. bad_alloc while concatenating
+                try { started = begin_many(hslot[k], S.concat, qs, S.flight); } catch (const std::exception&) { started = false; }      // e.g. bad_alloc while concatenating
             }
-            finish();                                          // the batch that was computing meanwhile: wait, scatter, wake its callers
-            if (started) { flight = std::move(nf); next_slot = 1 - slot; }
-            else for (Request* q : qs) {                       // the batch could not be uploaded as one (an error in one of its regions, no memory): every call on its own
+            if (started) {
+                { std::lock_guard<std::mutex> lk(W.m); S.flying = true; }
+                W.cv_flying.notify_all();
+                next_slot = (k + 1) % n_slots;
+            } else for (Request* q : qs) {                     // the batch could not be uploaded as one (an error in one of its regions, no memory): every call on its own
 #if defined(OCTPHMM_SIM)
                 std::lock_guard<std::mutex> sim_lk(sim_mu);
 #endif
-                serve_one(hslot[slot], q); answer(q);
+                serve_one(hslot[k], q); answer(q);
             }
         }
     }
@@ -2466,7 +2501,11 @@ extern "C" int oct_phmm_server_create_multi(const oct_phmm_config* cfg, const in
     const size_t n_workers_total = s->hs.size() / oct_phmm_server::kSlots;
     s->n_calls_by_device.assign(n_devices, 0); s->worker_version.assign(n_workers_total, 0);
     if (max_regions_per_batch) s->max_regions = max_regions_per_batch;
-    for (size_t w = 0; w < n_workers_total; ++w) s->workers.emplace_back([s, w] { s->run((int)w); });
+    for (size_t w = 0; w < n_workers_total; ++w) s->wk.emplace_back(new oct_phmm_server::Worker());
+    for (size_t w = 0; w < n_workers_total; ++w) {
+        s->wk[w]->finisher = std::thread([s, w] { s->finish_loop((int)w); });
+        s->workers.emplace_back([s, w] { s->run((int)w); });
+    }
     *out = s;
     return OCT_PHMM_OK;
 }
@@ -2483,7 +2522,8 @@ extern "C" void oct_phmm_server_destroy(oct_phmm_server* s)
     if (!s) return;
     { std::lock_guard<std::mutex> lk(s->mu); s->stop = true; }
     s->cv_work.notify_all();
-    for (auto& t : s->workers) if (t.joinable()) t.join();
+    for (auto& t : s->workers) if (t.joinable()) t.join();          // (every gatherer leaves with nothing of its own in the air)
+    for (auto& W : s->wk) { { std::lock_guard<std::mutex> lk(W->m); W->quit = true; } W->cv_flying.notify_all(); if (W->finisher.joinable()) W->finisher.join(); }
     for (auto* h : s->hs) oct_phmm_destroy(h);
     if (s->profile)
         fprintf(stderr, "{\"server_profile_ms\": {\"workers\": %zu, \"calls\": %llu, \"batches\": %llu, \"idle\": %.2f, \"concat\": %.2f, \"check_pack_enqueue\": %.2f, "
