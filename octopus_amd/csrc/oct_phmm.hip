@@ -636,7 +636,7 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 // cost ~20 us whatever the size
 constexpr uint32_t kScanBasesOneLaunchMax = 2 * 8192;
 constexpr size_t   kPinnedOutMinBytes = (size_t)8 << 20;  // results from here on: is the caller's `out` page-locked? (the question costs microseconds: not asked for region-sized calls)
-constexpr uint64_t kLaneMapMinPairs = 120000;          // k-mer mapper: one lane per pair from here on (k_kmer_map_lanes), one wave per pair below
+constexpr uint64_t kLaneMapMinPairs = 200000;          // k-mer mapper: one lane per pair from here on (k_kmer_map_lanes), one wave per pair below
 constexpr uint64_t kDslMaxPairs = 400000;              // device-sized launches (no read-back inside the step, grids sized by the host's bound) up to here. Round 4 stopped at 100 k: first 6 / 8 / 12 / 16 / 64
                                                        // regions of the configs[3] stream (50 k / 70 k / 110 k / 150 k / 660 k pairs), one populate from host buffers: 0.54 / 0.60 / 1.04 / 1.31 / 4.14 ms
                                                        // device-sized, 0.57 / 0.57 / 0.97 / 1.21 / 3.56 host-sized. Round 5 (gpurun_out/r05_s01): on the DEVICE the two forms take the same time (16 regions:
@@ -981,7 +981,11 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     { long long v; if (tune::number("OCT_PHMM_BP_BUDGET_GB", &v) && v > 0) h->bp_budget = (size_t)v << 30;
       if (tune::number("OCT_PHMM_BP_BUDGET_KB", &v) && v > 0) h->bp_budget = (size_t)v << 10; }   // KB: test hook, forces chunked traceback launches on small batches
     { long long v; if (tune::number("OCT_PHMM_TEST_FAIL_BP_ALLOCS", &v) && v > 0) h->fail_bp_allocs = (int)v; }
-    if (!rt::stream_create(&h->stream)) return OCT_PHMM_EHIP;
+    // The handle's own stream carries the chain a caller waits for (mapper -> classifier -> traceback DP -> walk -> epilogue); the score-only DP of a region-sized or
+    // mid-size batch runs beside it on the second stream and is off the critical path as long as the traceback DP gets its CUs first: stream 0 at the device's highest
+    // priority, the others normal (OCT_PHMM_STREAM_PRIORITY=0: all normal, A/B).
+    { long long v; const bool prio = !(tune::number("OCT_PHMM_STREAM_PRIORITY", &v) && v == 0);
+      if (!rt::stream_create_priority(&h->stream, prio)) return OCT_PHMM_EHIP; }
     for (auto& es : h->extra_streams) if (!rt::stream_create(&es)) return OCT_PHMM_EHIP;
     if (!rt::event_create(&h->ev_ready)) return OCT_PHMM_EHIP;
     *out = h.release();
@@ -1033,7 +1037,7 @@ extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
 static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
                        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                        const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
-                       bool one_shot = false);
+                       bool one_shot = false, int flavour_hint = -1);
 
 extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
                                      const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
@@ -1045,13 +1049,13 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
 static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
                             const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                             const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
-                            bool one_shot);
+                            bool one_shot, int flavour_hint);
 static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
                        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                        const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
-                       bool one_shot)
+                       bool one_shot, int flavour_hint)
 {
-    const int rc = upload_impl_body(h, R, H_in, regions, flank, positions, out, status, align_mode, max_cigar_ops, one_shot);
+    const int rc = upload_impl_body(h, R, H_in, regions, flank, positions, out, status, align_mode, max_cigar_ops, one_shot, flavour_hint);
     // An upload that fails after its copies were enqueued returns to a caller who may free the arrays at once - and page-locked arrays are read by the copy
     // engines directly (Packer::commit): nothing of this handle is in flight any more when the error is reported (the error path only).
     if (rc != OCT_PHMM_OK && h) { rt::set_device(h->cfg.device_id); rt::stream_sync(h->stream); rt::clear_error(); }
@@ -1060,7 +1064,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
 static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
                             const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                             const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
-                            bool one_shot)
+                            bool one_shot, int flavour_hint)      // flavour_hint: -1 unknown; 0 / 1 = the caller has looked at every base and SNV mask byte: all of them ACGT / set, or not (the region server's callers do, each on its own thread)
 {
     if (!h || !R || !H_in || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
     *out = nullptr;
@@ -1142,7 +1146,8 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     const bool dsl_wanted = !align_mode && tune::device_sized() != 0 && (b->n_pairs <= kDslMaxPairs || tune::device_sized() > 0);
     // (region-sized calls only: from a few regions on the scan - the first touch of every base and mask byte, 0.1 ms of a 16-region upload although it takes eight bytes
     // per step - costs the host more than the three near-empty launches of the generic lists cost the device, and the region server's workers are bound by their host work)
-    const bool want_dirty = dsl_wanted && !gen_device && b->n_pairs <= 20000;
+    const bool want_dirty = dsl_wanted && !gen_device && b->n_pairs <= 20000 && flavour_hint < 0;
+    if (flavour_hint >= 0) dirty = flavour_hint ? 1u : 0u;
     {
         std::mutex mx;
         const size_t read_grain = std::max<size_t>(1, (size_t)R->n_reads / std::max<size_t>(1, (size_t)n_read_bases >> 20));      // reads per ~1 MB of qualities
@@ -1393,7 +1398,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         const uint64_t cap = std::min<uint64_t>((uint64_t)8 << 30, h->bp_budget);
         b->dsl = b->slices.size() == 1 && dsl_wanted && b->n_pairs > 0 && bp_bytes <= cap && list_bound < 0x7fffffffull;
         b->dsl_list_bound = b->dsl ? (uint32_t)list_bound : 0; b->dsl_total_bound = b->dsl ? (size_t)total_bound : 0; b->dsl_trace_cap = b->dsl ? (uint32_t)trace_cap : 0;
-        if (b->dsl && want_dirty && !d.wide) {
+        if (b->dsl && (want_dirty || (flavour_hint >= 0 && !gen_device)) && !d.wide) {
             // which of the two cost flavours can occur at all (k_hap_tables / read_flags_thread decide per read and haplotype): a clean region launches no generic kernels
             b->dsl_flavours = dirty ? 3 : 1;
         } else b->dsl_flavours = d.wide ? 2 : 3;            // bit 0: fast-cost lists may hold tasks, bit 1: generic lists may
@@ -2148,10 +2153,10 @@ extern "C" void oct_phmm_host_free(void* p) { rt::host_pinned_free(p); }
 // them, valid until the handle's next call (the server scatters them straight into its callers' matrices).
 struct PopulateCall { oct_phmm_batch* b = nullptr; bool early = false; };
 static int populate_begin(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps, const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
-                          const oct_phmm_positions* positions, double* out, oct_phmm_status* status, PopulateCall* pc)
+                          const oct_phmm_positions* positions, double* out, oct_phmm_status* status, PopulateCall* pc, int flavour_hint = -1)
 {
     oct_phmm_batch* b = nullptr;
-    int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, false, 0, true);
+    int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, false, 0, true, flavour_hint);
     bool early = false;
     if (rc == OCT_PHMM_OK && out && b->n_out) {                // results come back through a pinned landing zone: slice by slice while a big batch computes, behind the
         const size_t bytes = (size_t)b->n_out * sizeof(double);  // epilogue of a small one - one stream synchronisation per call, no staged copy into pageable memory
@@ -2201,6 +2206,7 @@ struct oct_phmm_server {
     struct Request {
         const oct_phmm_reads* R; const oct_phmm_haplotypes* H; const oct_phmm_flank_state* flank; const oct_phmm_positions* pos;
         double* out; oct_phmm_status st; int rc = OCT_PHMM_OK; bool done = false;
+        int flavour = -1;                                 // 0: every base of the call is one of ACGT and no SNV mask byte is '0' (looked at by the CALLER's thread); 1: not so; -1: not looked at
         std::mutex m; std::condition_variable cv;         // one pair per call: finishing a batch wakes exactly its callers, and nobody queues for the server's lock to return
     };
 #if defined(OCTPHMM_SIM)
@@ -2311,7 +2317,8 @@ struct oct_phmm_server {
         c.build(qs);
         const uint64_t t1 = profile ? now_ns() : 0;
         oct_phmm_status st;
-        const int rc = populate_begin(h, &c.R, &c.H, &c.G, nullptr, nullptr, c.spill.data(), &st, &f.pc);
+        int flavour = 0; for (Request* q : qs) flavour = q->flavour < 0 ? -1 : (flavour < 0 ? -1 : (flavour | q->flavour));
+        const int rc = populate_begin(h, &c.R, &c.H, &c.G, nullptr, nullptr, c.spill.data(), &st, &f.pc, flavour);
         if (profile) { ns_concat += t1 - t0; ns_begin += now_ns() - t1; }
         if (rc != OCT_PHMM_OK) return false;
         f.qs = std::move(qs); f.h = h; f.active = true;
@@ -2554,6 +2561,11 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
         if (!out && (size_t)rows * haps->n_haps) return fail(status, OCT_PHMM_EINVAL, "null output");
     }
     oct_phmm_server::Request q; q.R = reads; q.H = haps; q.flank = flank; q.pos = positions; q.out = out; memset(&q.st, 0, sizeof(q.st));
+    if (haps->gap_open && reads->n_reads && haps->n_haps) {      // which cost flavours the call's tasks can have: looked up HERE, on the caller's thread (the workers are what a busy server waits for)
+        const size_t r0 = reads->offsets[0], r1 = reads->offsets[reads->n_reads], h0 = haps->offsets[0], h1 = haps->offsets[haps->n_haps];
+        q.flavour = (any_byte_outside_acgt((const uint8_t*)reads->bases + r0, r1 - r0) || any_byte_outside_acgt((const uint8_t*)haps->bases + h0, h1 - h0)
+                     || any_byte_equals((const uint8_t*)haps->snv_mask_fwd + h0, h1 - h0, '0') || any_byte_equals((const uint8_t*)haps->snv_mask_rev + h0, h1 - h0, '0')) ? 1 : 0;
+    }
     {
         std::lock_guard<std::mutex> lk(s->mu);
         if (s->stop) return fail(status, OCT_PHMM_EINVAL, "server is shutting down");

@@ -29,6 +29,14 @@ inline bool device_is_gfx950(int d)
     return __builtin_strncmp(p.gcnArchName, "gfx950", 6) == 0;
 }
 inline bool stream_create(Stream* s) { OCT_RT_CHECK(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return true; }
+// high = true: the device's highest stream priority (its workgroups are dispatched before those of normal streams when both wait for a CU)
+inline bool stream_create_priority(Stream* s, bool high)
+{
+    int least = 0, greatest = 0;
+    if (!high || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest == least) { (void)hipGetLastError(); return stream_create(s); }
+    OCT_RT_CHECK(hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest));
+    return true;
+}
 inline void stream_destroy(Stream s) { (void)hipStreamDestroy(s); }
 inline bool stream_sync(Stream s) { OCT_RT_CHECK(hipStreamSynchronize(s)); return true; }
 inline bool stream_idle(Stream s) { const hipError_t e = hipStreamQuery(s); if (e == hipErrorNotReady) { (void)hipGetLastError(); return false; } return true; }   // everything enqueued so far has run (errors: let the wait report them)

@@ -17,6 +17,7 @@ inline bool device_count(int* n) { *n = 1; return true; }
 inline bool set_device(int) { return true; }
 inline bool device_is_gfx950(int) { return true; }
 inline bool stream_create(Stream* s) { *s = 0; return true; }
+inline bool stream_create_priority(Stream* s, bool) { return stream_create(s); }
 inline void stream_destroy(Stream) {}
 inline bool stream_sync(Stream) { return true; }
 inline bool stream_idle(Stream) { return true; }
