@@ -702,7 +702,8 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         if (!late && joined_late_from != 0xffffffffu) p.late_from = joined_late_from > g0 * G ? joined_late_from - g0 * G : 0u;      // (relative to this chunk's first task)
         p.bp = h->bp[slice]; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
         uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
-        if (dsl) n_blocks = std::min(n_blocks, kDslMaxBlocks);
+        long long dsl_blocks = kDslMaxBlocks; tune::number("OCT_PHMM_DSL_MAX_BLOCKS", &dsl_blocks);      // (A/B: more, shorter-lived workgroups let the streams' priorities act between them)
+        if (dsl) n_blocks = std::min<uint32_t>(n_blocks, (uint32_t)std::max<long long>(64, dsl_blocks));
         rt::Event e0 {}, e1 {};
         if (h->timing) { RT(h->get_event(&e0)); RT(h->get_event(&e1)); RT(rt::event_record(e0, st)); }
         // (a device-sized launch does not know its task count: region-sized, so the spread-out form)
@@ -710,7 +711,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         if (paired_score_list >= 0 && g0 == 0) {
             DpParams ps = p;                                   // same tables (same flavour), the score-only list of the same task array, no traceback scratch
             ps.ref.list = (uint32_t)paired_score_list; ps.tasks = tasks; ps.n_tasks = paired_score_bound / G * G; ps.bp = nullptr; ps.ends = nullptr; ps.late = 0;
-            const uint32_t n_blocks_s = std::min((ps.n_tasks / G + ps.groups_per_block - 1) / ps.groups_per_block, kDslMaxBlocks);
+            const uint32_t n_blocks_s = std::min<uint32_t>((ps.n_tasks / G + ps.groups_per_block - 1) / ps.groups_per_block, (uint32_t)std::max<long long>(64, dsl_blocks));
             if (!launch_dp_pair(B, gen, b->fast_adds, p, ps, n_blocks, n_blocks_s, lds, st)) return fail(status, OCT_PHMM_EHIP, "DP kernel launch");
         } else
         if (!(b->multi_wave ? launch_dp_mw(B, one_wave, tr, gen, p, st) : b->rows32 ? launch_dp_rows(tr, gen, p, st) : b->stream ? launch_dp_wide(B, tr, !h->wide, p, st)
