@@ -1393,9 +1393,10 @@ OCT_KERNEL(k_scan_finish)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4*
     uint4* sh = (uint4*)smem;                                   // [16]
     const uint32_t tid = hw::thread_idx();
     const uint32_t n_arr = cnt1 ? 2u : 1u;
-    uint4 all[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    uint4 all0 = make_uint4(0, 0, 0, 0), all1 = make_uint4(0, 0, 0, 0);          // (two names, not an array indexed by the loop: that lived in scratch memory)
     for (uint32_t a = 0; a < n_arr; ++a) {
         const uint4* cnt = a ? cnt1 : cnt0; uint4* tsum = a ? tile_sums1 : tile_sums0; uint4* hap_base = a ? hap_base1 : hap_base0;
+        uint4 all_a;
         // tile totals -> exclusive tile prefixes, in place: eight consecutive tiles per thread and round (coalesced runs, one workgroup scan per 8,192 tiles = 2 M pairs)
         constexpr uint32_t PER = 8;
         uint4 carry = make_uint4(0, 0, 0, 0);
@@ -1426,16 +1427,17 @@ OCT_KERNEL(k_scan_finish)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4*
             for (uint32_t u = 0; u < 4; ++u) v[u] = h + u < hi ? padded(h + u) : make_uint4(0, 0, 0, 0);
             for (uint32_t u = 0; u < 4; ++u) sum = add4(sum, v[u]);
         }
-        uint4 run = block_scan_excl(sum, sh, &all[a]);
+        uint4 run = block_scan_excl(sum, sh, &all_a);
         for (uint32_t h = lo; h < hi; h += 4) {
             uint4 v[4];
             for (uint32_t u = 0; u < 4; ++u) v[u] = h + u < hi ? padded(h + u) : make_uint4(0, 0, 0, 0);
             for (uint32_t u = 0; u < 4; ++u) if (h + u < hi) { hap_base[h + u] = run; run = add4(run, v[u]); }
         }
-        if (tid == 0) *(a ? totals1 : totals0) = all[a];
+        if (tid == 0) *(a ? totals1 : totals0) = all_a;
+        if (a) all1 = all_a; else all0 = all_a;
     }
     // one traceback launch may take a flavour's traceback list AND its late-start list: together they must fit the scratch the host provisioned
-    if (tid == 0 && b.dsl_trace_cap && (all[0].y + all[1].x > b.dsl_trace_cap || all[0].w + all[1].y > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
+    if (tid == 0 && b.dsl_trace_cap && (all0.y + all1.x > b.dsl_trace_cap || all0.w + all1.y > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
 }
 
 struct TaskArrays { DevTask* t[kNumKinds]; };
@@ -1456,15 +1458,14 @@ OCT_DEVICE void task_list_range(const TaskListRef& ref, uint32_t& first, uint32_
 {
     const uint4 a = *ref.totals;
     const uint4 l = ref.totals_late ? *ref.totals_late : make_uint4(0, 0, 0, 0);
-    const uint32_t c[6] = {a.x, a.y, a.z, a.w, l.x, l.y};
-    constexpr int order[6] = {0, 1, 4, 2, 3, 5};            // list ids in physical order
-    first = 0; n = 0;
-    bool before = true;
-    for (int k = 0; k < 6; ++k) {
-        const int id = order[k];
-        if (id == ref.list) { before = false; n = c[id]; if (n_main) *n_main = n; if (ref.join_late && (id == 1 || id == 3)) n += c[id == 1 ? 4 : 5]; }
-        else if (before) first += c[id];
-    }
+    // (scalar selects, no indexed arrays: those went to scratch memory in every kernel's prologue)
+    const uint32_t sf = a.x, tf = a.y, lf = l.x, sg = a.z, tg = a.w, lg = l.y;       // in physical order
+    const int id = ref.list;
+    const bool join = ref.join_late != 0;
+    first = id == 0 ? 0u : id == 1 ? sf : id == 4 ? sf + tf : id == 2 ? sf + tf + lf : id == 3 ? sf + tf + lf + sg : sf + tf + lf + sg + tg;
+    const uint32_t own = id == 0 ? sf : id == 1 ? tf : id == 4 ? lf : id == 2 ? sg : id == 3 ? tg : lg;
+    n = own + (join && id == 1 ? lf : join && id == 3 ? lg : 0u);
+    if (n_main) *n_main = own;
     if (ref.overflow && *ref.overflow) { first = 0; n = 0; if (n_main) *n_main = 0; }
 }
 

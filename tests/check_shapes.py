@@ -38,6 +38,11 @@ SWITCH_SETS = [
     {"OCT_PHMM_LATE_MIN_PAIRS": "0", "OCT_PHMM_SCAN_FUSED": "0"},
     {"OCT_PHMM_LATE_START": "0"},
     {"OCT_PHMM_SLICES": "4", "OCT_PHMM_LATE_MIN_PAIRS": "0"},
+    {"OCT_PHMM_JOIN_LATE": "0", "OCT_PHMM_LATE_MIN_PAIRS": "0"},     # late-start lists in launches of their own behind the new scan
+    {"OCT_PHMM_JOIN_LATE": "1", "OCT_PHMM_LATE_MIN_PAIRS": "0", "OCT_PHMM_SLICES": "2"},
+    {"OCT_PHMM_REC_CHUNK": "64"},
+    {"OCT_PHMM_DSL_MAX_BLOCKS": "64", "OCT_PHMM_LATE_MIN_PAIRS": "0"},
+    {"OCT_PHMM_DP_ROWS": "0"},
 ]
 
 
