@@ -38,13 +38,18 @@ struct DevPool {
     std::multimap<size_t, void*> free_blocks;
     std::unordered_map<void*, size_t> live;
     size_t cached = 0;
+    std::mutex mu;                                       // a pool is its handle's, i.e. one thread's - except when ANOTHER handle's allocation fails and that handle trims its siblings' caches
     // What all the pools of one device may hold back between them (a region server runs several handles per GPU, INTEGRATION's populate patch one per caller thread:
-    // with a cap per handle a handle could report out-of-memory while its siblings sat on tens of GB of free blocks - ADVICE r04). Read and updated without a lock:
-    // a bound, not an invariant.
+    // with a cap per handle a handle could report out-of-memory while its siblings sat on tens of GB of free blocks - ADVICE r04; round 5's 2,000-scenario shape fuzz met exactly that).
     static std::atomic<size_t>& device_cached(int dev) { static std::atomic<size_t> c[64]; return c[(unsigned)dev & 63u]; }
+    static std::mutex& registry_mu() { static std::mutex m; return m; }
+    static std::vector<DevPool*>& registry() { static std::vector<DevPool*> r; return r; }
     int device = 0;
     static constexpr size_t kDeviceCacheCap = (size_t)128 << 30;
     static constexpr size_t kCacheCap = (size_t)64 << 30;       // (288 GB of HBM: a handle that streams 6,250-region batches - 20 GB resident each - paid a 20 GB hipMalloc + hipFree, 0.4 s, per call with the cap at 16 GB)
+    DevPool() { std::lock_guard<std::mutex> lk(registry_mu()); registry().push_back(this); }
+    ~DevPool() { std::lock_guard<std::mutex> lk(registry_mu()); auto& r = registry(); r.erase(std::remove(r.begin(), r.end(), this), r.end()); }
+    DevPool(const DevPool&) = delete; DevPool& operator=(const DevPool&) = delete;
     // Powers of two up to 1 GB (a thread's region calls differ in size by orders of magnitude - 20 to 5,000 reads, 1 to 200 haplotypes: with finer classes most
     // calls of a run's first thousands met a size nobody had freed yet and paid a hipMalloc, which synchronises the device), eight classes per octave beyond
     // (resident many-gigabyte batches are not rounded up by half of themselves).
@@ -57,31 +62,51 @@ struct DevPool {
         const size_t step = p2 >> 3;
         return (n + step - 1) / step * step;
     }
+    // the device has no room: every pool of this device gives its cached (free) blocks back to the runtime - this one's first, then its siblings'
+    static void trim_device(int dev)
+    {
+        std::lock_guard<std::mutex> lk(registry_mu());
+        for (DevPool* q : registry()) if (q->device == dev) q->trim();
+    }
     bool alloc(void** p, size_t n)
     {
         const size_t c = size_class(n);
-        auto it = free_blocks.lower_bound(c);             // the smallest cached block that fits, if it is not wastefully large (small blocks: up to 8x, nobody misses those bytes)
-        if (it != free_blocks.end() && (it->first <= c + c / 2 || it->first <= std::min<size_t>(8 * c, (size_t)64 << 20))) {
-            *p = it->second; const size_t got = it->first; free_blocks.erase(it); cached -= got; device_cached(device) -= got; live[*p] = got; return true;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_blocks.lower_bound(c);             // the smallest cached block that fits, if it is not wastefully large (small blocks: up to 8x, nobody misses those bytes)
+            if (it != free_blocks.end() && (it->first <= c + c / 2 || it->first <= std::min<size_t>(8 * c, (size_t)64 << 20))) {
+                *p = it->second; const size_t got = it->first; free_blocks.erase(it); cached -= got; device_cached(device) -= got; live[*p] = got; return true;
+            }
         }
         if (!rt::dev_malloc(p, c)) {
             rt::clear_error();
-            trim();                                     // give cached blocks back and retry once
-            if (!rt::dev_malloc(p, c)) return false;
+            trim();                                     // give this pool's cached blocks back and retry ...
+            if (!rt::dev_malloc(p, c)) {
+                rt::clear_error();
+                trim_device(device);                    // ... then every sibling's
+                if (!rt::dev_malloc(p, c)) { rt::clear_error(); return false; }
+            }
         }
+        std::lock_guard<std::mutex> lk(mu);
         live[*p] = c;
         return true;
     }
     void release(void* p)
     {
         if (!p) return;
+        std::lock_guard<std::mutex> lk(mu);
         auto it = live.find(p);
         if (it == live.end()) { rt::dev_free(p); return; }
         const size_t c = it->second; live.erase(it);
         if (cached + c > kCacheCap || device_cached(device).load() + c > kDeviceCacheCap) { rt::dev_free(p); return; }
         free_blocks.emplace(c, p); cached += c; device_cached(device) += c;
     }
-    void trim() { for (auto& kv : free_blocks) rt::dev_free(kv.second); free_blocks.clear(); device_cached(device) -= cached; cached = 0; }
+    void trim()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& kv : free_blocks) rt::dev_free(kv.second);
+        free_blocks.clear(); device_cached(device) -= cached; cached = 0;
+    }
 };
 
 struct oct_phmm_handle {
@@ -626,7 +651,11 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
         rt::clear_error();
         h->pool.trim();                                 // cached blocks of earlier batches may be in the way
         got = bytes;
-        if (!rt::dev_malloc(&p, bytes)) { rt::clear_error(); return false; }
+        if (!rt::dev_malloc(&p, bytes)) {
+            rt::clear_error();
+            DevPool::trim_device(h->pool.device);       // ... or the sibling handles' (a region server's, a caller's other threads')
+            if (!rt::dev_malloc(&p, bytes)) { rt::clear_error(); return false; }
+        }
     }
     h->bp[slice] = (uint32_t*)p; h->bp_bytes[slice] = got;
     return true;

@@ -171,6 +171,8 @@ class Runner:
     def engine(self, cfg_kw):
         key = tuple(sorted(cfg_kw.items()))
         if key not in self.engines:
+            if len(self.engines) >= 6:                      # (a handle keeps its traceback scratch and its block cache: hundreds of configurations would fill the device)
+                k0 = next(iter(self.engines)); self.engines.pop(k0).close()
             self.engines[key] = engine.Engine(abi.Config.default(**cfg_kw), lib_path=self.lib_path)
             self.engines[key].set_error_model(self.model)
         return self.engines[key]
@@ -178,7 +180,7 @@ class Runner:
     def server(self, cfg_kw):
         key = tuple(sorted(cfg_kw.items()))
         if key not in self.servers:
-            if len(self.servers) >= 4:                      # (each holds device scratch)
+            if len(self.servers) >= 2:                      # (each holds four handles with 4 GB of reserved scratch)
                 k0 = next(iter(self.servers)); self.servers.pop(k0).close()
             self.servers[key] = engine.Server(abi.Config.default(**cfg_kw), lib_path=self.lib_path)
             self.servers[key].set_error_model(self.model)
@@ -251,7 +253,10 @@ def check_shapes(backend, seeds, scale=None, tol=None, pool=None):
     try:
         items = pool.imap(make_and_expect, [(s, scale) for s in seeds], chunksize=1) if pool is not None else (make_and_expect((s, scale)) for s in seeds)
         for scn, want in items:
-            r.run(scn, want, tol)
+            try:
+                r.run(scn, want, tol)
+            except Exception as e:
+                raise AssertionError(f"scenario seed {scn['seed']} ({len(scn['regions'])} regions, cfg {scn['cfg']}, switches {scn['switches']}, apis {scn['apis']}): {e!r}") from e
     finally:
         r.close()
     return r.stats
