@@ -125,10 +125,13 @@ struct oct_phmm_handle {
     int  lanes_c = 1;                                    // band diagonals per lane on the streaming path (band / 64) for bands 128, 256
     static constexpr int kMaxSlices = 8;
     rt::Stream stream {};                                 // slice 0 / uploads / downloads
-    rt::Stream extra_streams[kMaxSlices - 1] {};          // further slices run on their own streams so that latency-bound and VALU-bound kernels overlap
+    rt::Stream extra_streams[kMaxSlices] {};              // further slices run on their own streams so that latency-bound and VALU-bound kernels overlap
+    bool main_stream_high_priority = false;
+    bool all_slices_aside = false;                        // this run's slices ALL take extra streams (a batch of several slices: the main stream's priority would favour slice 0 in the pipeline:
+                                                          // 12.8 M-pair step 29.2 -> 29.5 ms, stream-hq 22.4 -> 22.8 - gpurun_out/r05_s08); set by oct_phmm_batch_run
     rt::Event ev_ready {};
     uint32_t* bp[kMaxSlices] {}; size_t bp_bytes[kMaxSlices] {};   // traceback scratch per slice, grown on demand
-    rt::Stream slice_stream(int i) const { return i == 0 ? stream : extra_streams[i - 1]; }
+    rt::Stream slice_stream(int i) const { return all_slices_aside ? extra_streams[i] : (i == 0 ? stream : extra_streams[i - 1]); }
     // traceback scratch budget: large, so that all traceback tasks of a batch run in ONE DP launch and ONE walk launch (the walk
     // is a latency-bound pointer chase that needs every task in flight to hide it); MI355X has 288 GB. OCT_PHMM_BP_BUDGET_GB overrides.
     size_t bp_budget = (size_t)96 << 30;
@@ -1018,7 +1021,8 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     // mid-size batch runs beside it on the second stream and is off the critical path as long as the traceback DP gets its CUs first: stream 0 at the device's highest
     // priority, the others normal (OCT_PHMM_STREAM_PRIORITY=0: all normal, A/B).
     { long long v; const bool prio = !(tune::number("OCT_PHMM_STREAM_PRIORITY", &v) && v == 0);
-      if (!rt::stream_create_priority(&h->stream, prio)) return OCT_PHMM_EHIP; }
+      if (!rt::stream_create_priority(&h->stream, prio)) return OCT_PHMM_EHIP;
+      h->main_stream_high_priority = prio; }
     for (auto& es : h->extra_streams) if (!rt::stream_create(&es)) return OCT_PHMM_EHIP;
     if (!rt::event_create(&h->ev_ready)) return OCT_PHMM_EHIP;
     *out = h.release();
@@ -1029,8 +1033,9 @@ extern "C" void oct_phmm_destroy(oct_phmm_handle* h)
 {
     if (!h) return;
     rt::set_device(h->cfg.device_id);
-    for (int i = 0; i < oct_phmm_handle::kMaxSlices; ++i) { rt::stream_sync(h->slice_stream(i)); rt::dev_free(h->bp[i]); }
-    for (int i = 1; i < oct_phmm_handle::kMaxSlices; ++i) rt::stream_destroy(h->slice_stream(i));
+    rt::stream_sync(h->stream);
+    for (auto& es : h->extra_streams) { rt::stream_sync(es); rt::stream_destroy(es); }
+    for (int i = 0; i < oct_phmm_handle::kMaxSlices; ++i) rt::dev_free(h->bp[i]);
     for (auto& kv : h->pool.live) rt::dev_free(kv.first);
     h->pool.live.clear(); h->pool.trim();
     rt::host_pinned_free(h->stage); rt::host_pinned_free(h->out_stage);
@@ -1057,7 +1062,7 @@ extern "C" int oct_phmm_set_timing(oct_phmm_handle* h, int enabled)
 extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
 {
     if (!b) return;
-    if (h && !b->synced) { rt::set_device(h->cfg.device_id); for (int i = 0; i < oct_phmm_handle::kMaxSlices; ++i) rt::stream_sync(h->slice_stream(i)); }   // (a waited batch has nothing in flight)
+    if (h && !b->synced) { rt::set_device(h->cfg.device_id); rt::stream_sync(h->stream); for (auto& es : h->extra_streams) rt::stream_sync(es); }   // (a waited batch has nothing in flight)
     if (!h) h = b->owner;
     if (b->stat_stage) h->stat_stage_free.push_back(b->stat_stage);
     for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
@@ -1659,9 +1664,11 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
     if (b->dedup) RT(rt::dev_memset(d.pair_rep, 0xff, (size_t)b->n_pairs * sizeof(uint32_t), s0));      // kNoPair: every pair is computed itself until k_dedup_verify says otherwise
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
+    h->all_slices_aside = S > 1 && h->main_stream_high_priority;
+    const int first_aside = h->all_slices_aside ? 0 : 1;    // the first slice that runs on a stream other than the handle's own
     if (S > 1) {
         RT(rt::event_record(h->ev_ready, s0));
-        for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(h->slice_stream(i), h->ev_ready));
+        for (int i = first_aside; i < S; ++i) RT(rt::stream_wait_event(h->slice_stream(i), h->ev_ready));
     }
 
     // phase 1 of a slice: candidate mapping, classification + scalar fast path, task counts -> slot offsets (everything up to the one
@@ -1917,7 +1924,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     }
     if (rc != OCT_PHMM_OK) return rc;
     for (int i = std::max(0, S - 2); i < S; ++i) { rc = deliver(i); if (rc != OCT_PHMM_OK) return rc; }
-    for (int i = 1; i < S; ++i) RT(rt::stream_wait_event(s0, b->slices[i].done));
+    for (int i = first_aside; i < S; ++i) RT(rt::stream_wait_event(s0, b->slices[i].done));
     if (!mapped_out) RT(rt::d2h(b->stat_stage ? b->stat_stage : b->h_stat_stripes.data(), d.stats, kStatWords * sizeof(unsigned long long), s0));   // (else: the epilogue left the sums there)
     b->ran = true; b->synced = false;
     return ok(status);
