@@ -46,3 +46,8 @@ def test_product_library_has_no_24_bit_division_and_reports_its_spills(capsys):
                "k_penalty_vectors", "k_genotype_lik", "k_walk_strings")              # per-thread workspaces by design (error model run lists, read-out, the test seam's string walker)
     with_scratch = sorted(k for k, (v, s, scratch) in sp.items() if scratch and not any(a in k for a in allowed))
     assert not with_scratch, with_scratch
+    # ... and where a long-read DP kernel does spill, the spill sits in the loop over task groups (once per group of 10^4 iterations), never inside a DP loop
+    sites = isa_report.spill_sites(asm)
+    for k, (n_scratch, smallest_loop, n_instr) in sites.items():
+        if "k_dp" in k:
+            assert smallest_loop == 0 or smallest_loop > n_instr // 2, (k, n_scratch, smallest_loop, n_instr)

@@ -86,6 +86,25 @@ def spills(asm: str):
     return out
 
 
+def spill_sites(asm: str):
+    """{kernel: (scratch instructions, size of the SMALLEST loop that encloses any of them or 0, instructions in the kernel)} for the kernels that touch scratch memory:
+    does a spill sit in a hot inner loop (every DP iteration pays a memory round trip) or only in the loop over task groups (once per group of 10^2 - 10^4 iterations)?"""
+    out = {}
+    for name, body in _kernel_bodies(asm):
+        sites = [i for i, ins in enumerate(body) if ins.startswith("scratch_")]
+        if not sites:
+            continue
+        labels = {ins[:-1]: i for i, ins in enumerate(body) if ins.endswith(":")}
+        loops = []
+        for i, ins in enumerate(body):
+            m = re.match(r"s_cbranch_\w+ (\S+)", ins) or re.match(r"s_branch (\S+)", ins)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                loops.append((labels[m.group(1)], i))
+        enclosing = [b - a for i in sites for a, b in loops if a <= i <= b]
+        out[name] = (len(sites), min(enclosing) if enclosing else 0, len(body))
+    return out
+
+
 def demangle(names):
     try:
         r = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True, check=True)
@@ -109,8 +128,11 @@ def main(argv):
         for name, i, _ in bad:
             print(f"  24-BIT DIVISION in {names[name][:160]} at instruction {i}")
             rc = 1
+        sites = spill_sites(asm)
         for k, (v, s, scratch) in sorted(spilled.items()):
-            print(f"  spills: {v:3d} VGPR {s:3d} SGPR, {scratch:5d} B scratch  {names[k][:160]}")
+            where = (f"; {sites[k][0]} scratch instructions, smallest loop around any of them: {sites[k][1] or 'none'} of the kernel's {sites[k][2]} instructions"
+                     + (" (the loop over task groups, not a DP loop)" if sites[k][1] > sites[k][2] // 2 else "")) if k in sites else ""
+            print(f"  spills: {v:3d} VGPR {s:3d} SGPR, {scratch:5d} B scratch  {names[k][:140]}{where}")
     return rc
 
 
