@@ -103,6 +103,7 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_batch_kernel_time_by_kind.argtypes = [pv, C.POINTER(C.c_double * 4), C.POINTER(C.c_uint32 * 4)]
         lib.oct_phmm_batch_genotype_likelihoods.argtypes = [pv, pv, pv, pv, pv]
         lib.oct_phmm_align.argtypes = [pv, pv, pv, pv, pv, pv, pv, pv]
+        lib.oct_phmm_align_candidate_counts.argtypes = [pv, pv, C.c_size_t, C.POINTER(C.c_uint32)]
         lib.oct_phmm_set_timing.argtypes = [pv, C.c_int]
         lib.oct_phmm_server_create.argtypes = [C.POINTER(abi.Config), C.c_uint32, C.POINTER(C.c_void_p)]
         lib.oct_phmm_server_destroy.argtypes = [pv]
@@ -365,6 +366,15 @@ class Engine:
         if code != abi.OK and raise_on_error:
             raise EngineError(code, st, "align")
         return abi.alignments_result(arrays, n, max_cigar_ops), st
+
+    def align_candidate_counts(self, n_pairs: int):
+        """oct_phmm_align_candidate_counts: (candidates the device mapper kept per pair in the last align call, pairs whose list filled every slot)."""
+        counts = np.zeros(max(n_pairs, 1), np.uint8)
+        n_sat = C.c_uint32(0)
+        code = self.lib.oct_phmm_align_candidate_counts(self.handle, _ptr(counts), n_pairs, C.byref(n_sat))
+        if code != abi.OK:
+            raise EngineError(code, None, "align_candidate_counts")
+        return counts[:n_pairs], int(n_sat.value)
 
     def set_error_model(self, model: Optional[abi.ErrorModel]):
         """oct_phmm_set_error_model: batches whose six penalty vectors are None (Batch.without_penalty_vectors) get them generated at upload."""

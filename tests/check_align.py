@@ -82,3 +82,40 @@ def check_align_errors(backend):
         eng.align(b2)
     assert e.value.code == abi.EINVAL
     eng.close()
+
+
+def check_align_candidate_counts(backend):
+    """oct_phmm_align_candidate_counts: reads that lie entirely inside a (CA)n run longer than themselves tie on more diagonals than any cap of the ABI keeps (the reference's
+    realigner maps without a cap, read_realigner.cpp:128,137): their pairs report cap candidates and are counted as saturated; ordinary reads report what the oracle's mapper finds.
+    With caller-provided positions nothing is saturated."""
+    rng = np.random.default_rng(61)
+    T, Lh, B = 60, 420, 16
+    g = synth.make_region(rng, 12, 2, T=T, Lh=Lh, B=B, flank=None, positions="none")
+    for h in g["haps"]:
+        h[150:290] = np.frombuffer(b"CA" * 70, np.uint8)
+        h[149] = ord("T"); h[290] = ord("G")
+    inside = [0, 3, 7]
+    for k, r in enumerate(inside):
+        o = 150 + 2 * (5 + 7 * k)
+        g["reads"][r] = g["haps"][0][o:o + T]; g["begin"][r] = o
+    batch = synth.batch_from_regions([g])
+    for cap in (15, 4):
+        cfg = abi.Config.default(max_indel_error=B, max_mapping_positions=cap)
+        eng = make_engine(backend, max_indel_error=B, max_mapping_positions=cap)
+        got, st = eng.align(batch, 96)
+        assert st.code == abi.OK
+        counts, n_sat = eng.align_candidate_counts(batch.n_read_pairs())
+        want = []
+        for (h, r) in batch.read_pairs():
+            hs = bytes(batch.hap_bases[batch.hap_offsets[h]:batch.hap_offsets[h + 1]]); rs = bytes(batch.read_bases[batch.read_offsets[r]:batch.read_offsets[r + 1]])
+            want.append(min(cap, len(oracle.map_query_to_target(rs, hs, 1000))))
+        assert counts.tolist() == want, (cap, counts.tolist(), want)
+        assert n_sat == sum(1 for w in want if w >= cap) and n_sat >= 2 * len(inside)
+        with pytest.raises(Exception):
+            eng.align_candidate_counts(batch.n_read_pairs() + 1)      # not the last call's pair count
+        # caller-provided positions: the library cut nothing short
+        b2 = mapper_positions(synth.batch_from_regions([g]), max_positions=cap, rng=None)
+        eng.align(b2, 96)
+        assert eng.align_candidate_counts(b2.n_read_pairs())[1] == 0
+        eng.close()
+    return True

@@ -203,6 +203,11 @@ def test_gpu_align_best_alignment_and_cigar_per_pair():
     ca.check_align_errors("gpu")
 
 
+def test_gpu_align_candidate_counts_name_the_saturated_pairs():
+    import check_align
+    assert check_align.check_align_candidate_counts("gpu")
+
+
 def test_gpu_align_realigner_sized_batch():
     """read_realigner's shape: many reads against few haplotypes, device mapping; vs the oracle on all pairs."""
     import check_align as ca

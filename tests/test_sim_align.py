@@ -12,3 +12,7 @@ def test_sim_align_positions_options_lanes_and_bands():
 
 def test_sim_align_errors():
     ca.check_align_errors("sim")
+
+
+def test_sim_align_candidate_counts_name_the_saturated_pairs():
+    assert ca.check_align_candidate_counts("sim")
