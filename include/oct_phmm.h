@@ -234,12 +234,14 @@ void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b);
  * arrive while the device is busy are concatenated into one multi-region batch (their regions stay independent: own rows, own
  * haplotypes, own flank state), answered together and scattered back. Results are those of oct_phmm_populate for each call; an
  * error in one region (e.g. OCT_PHMM_ESHORT_HAPLOTYPE) is reported to its caller only. Thread-safe; blocks until the caller's
- * result is in `out`. Calls that bring their own candidate positions are served one by one. */
+ * result is in `out`. Calls that bring their own candidate positions are served one by one. A call's arrays are read on the caller's own thread (pointer and
+ * offset checks, the scan for non-ACGT bases) and by the worker that packs them; they must stay valid until the call returns. */
 typedef struct oct_phmm_server oct_phmm_server;
 int  oct_phmm_server_create(const oct_phmm_config* cfg, uint32_t max_regions_per_batch /* 0 = 256 */, oct_phmm_server** out);
 /* The same server in front of several GPUs of the node (BASELINE configs[3]: independent active regions sharded over the devices, no
- * collective): two worker threads and handles per device, all draining the one queue, so whichever device is free takes the calls that
- * have arrived (work sharing rather than a fixed region -> device map; results do not depend on the device). `cfg->device_id` is ignored. */
+ * collective): two workers per device - each a gatherer and a finisher thread around two handles -, all draining the one queue, so
+ * whichever device is free takes the calls that have arrived (work sharing rather than a fixed region -> device map; results do not depend on the device).
+ * `cfg->device_id` is ignored. */
 int  oct_phmm_server_create_multi(const oct_phmm_config* cfg, const int32_t* device_ids, uint32_t n_devices,
                                   uint32_t max_regions_per_batch /* 0 = 256 */, oct_phmm_server** out);
 void oct_phmm_server_destroy(oct_phmm_server* s);
