@@ -472,6 +472,45 @@ bool any_byte_equals(const uint8_t* p, size_t n, uint8_t c)
     return (~all_ne & 0x8080808080808080ull) != 0 || tail != 0;
 }
 
+// What an upload must know about EVERY byte of its input before it packs it: the contract's range checks (quality <= 127, penalties >= 0, no empty read), the bounds the
+// FASTADD decision needs (largest per-read quality sum, largest gap penalties) and - for device-sized batches - whether any base is outside ACGT / any SNV mask byte '0'.
+// upload_impl makes them itself (one pass per array, threaded from ~2 MB on); the region server's CALLERS make them for their own region before they queue - 64 threads that would
+// otherwise sleep - and a device batch inherits the merge (facts_of_reads / facts_of_haps are what both run).
+struct InputFacts {
+    uint32_t q_or = 0, pen_or = 0, gomax = 0, gemax = 0, t_min = 0xffffffffu; uint64_t sum_q_max = 0;
+    int dirty = -1;                                       // -1 not looked at, 0 every base ACGT and every SNV mask byte set, 1 not so
+    bool have_haps = false;                               // the penalty vectors were looked at (false: the library makes them)
+    void merge(const InputFacts& o)
+    {
+        q_or |= o.q_or; pen_or |= o.pen_or; gomax = std::max(gomax, o.gomax); gemax = std::max(gemax, o.gemax); t_min = std::min(t_min, o.t_min); sum_q_max = std::max(sum_q_max, o.sum_q_max);
+        dirty = (dirty < 0 || o.dirty < 0) ? -1 : (dirty | o.dirty);
+    }
+};
+void facts_of_reads(const oct_phmm_reads* R, size_t r0, size_t r1, bool want_dirty, InputFacts* f)
+{
+    uint32_t v = 0, shortest = 0xffffffffu; uint64_t best = 0;
+    for (size_t r = r0; r < r1; ++r) {
+        const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
+        uint32_t sq = 0, o = 0;                           // reads are < 32,768 bases of quality <= 127
+        for (uint32_t i = 0; i < n; ++i) { sq += q[i]; o |= q[i]; }
+        v |= o; best = std::max<uint64_t>(best, sq); shortest = std::min(shortest, n);
+    }
+    f->q_or |= v; f->sum_q_max = std::max(f->sum_q_max, best); f->t_min = std::min(f->t_min, shortest);
+    if (want_dirty && r1 > r0 && any_byte_outside_acgt((const uint8_t*)R->bases + R->offsets[r0], (size_t)R->offsets[r1] - R->offsets[r0])) f->dirty = 1;
+}
+void facts_of_haps(const oct_phmm_haplotypes* H, size_t lo, size_t hi, bool want_dirty, InputFacts* f)      // bases [lo, hi) of the concatenated haplotypes, vectors given
+{
+    uint32_t v = 0, a = 0, e = 0;
+    for (size_t i = lo; i < hi; ++i) {
+        const uint32_t go = (uint8_t)H->gap_open[i], ge = (uint8_t)H->gap_extend[i];
+        v |= go | ge | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
+        a = std::max(a, go); e = std::max(e, ge);           // (as bytes: with no sign bit anywhere - checked by the caller - these are the values)
+    }
+    f->pen_or |= v; f->gomax = std::max(f->gomax, a); f->gemax = std::max(f->gemax, e);
+    if (want_dirty && (any_byte_outside_acgt((const uint8_t*)H->bases + lo, hi - lo) || any_byte_equals((const uint8_t*)H->snv_mask_fwd + lo, hi - lo, '0')
+                       || any_byte_equals((const uint8_t*)H->snv_mask_rev + lo, hi - lo, '0'))) f->dirty = 1;
+}
+
 bool monotone(const uint32_t* off, uint32_t n) { for (uint32_t i = 0; i < n; ++i) if (off[i + 1] < off[i]) return false; return true; }
 
 // kernel dispatch over (band, traceback, generic bytes, 32-bit adds)
@@ -1075,7 +1114,7 @@ extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
 static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
                        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                        const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
-                       bool one_shot = false, int flavour_hint = -1);
+                       bool one_shot = false, const InputFacts* pre = nullptr);
 
 extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H,
                                      const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
@@ -1087,13 +1126,13 @@ extern "C" int oct_phmm_batch_upload(oct_phmm_handle* h, const oct_phmm_reads* R
 static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
                             const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                             const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
-                            bool one_shot, int flavour_hint);
+                            bool one_shot, const InputFacts* pre);
 static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
                        const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                        const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
-                       bool one_shot, int flavour_hint)
+                       bool one_shot, const InputFacts* pre)
 {
-    const int rc = upload_impl_body(h, R, H_in, regions, flank, positions, out, status, align_mode, max_cigar_ops, one_shot, flavour_hint);
+    const int rc = upload_impl_body(h, R, H_in, regions, flank, positions, out, status, align_mode, max_cigar_ops, one_shot, pre);
     // An upload that fails after its copies were enqueued returns to a caller who may free the arrays at once - and page-locked arrays are read by the copy
     // engines directly (Packer::commit): nothing of this handle is in flight any more when the error is reported (the error path only).
     if (rc != OCT_PHMM_OK && h) { rt::set_device(h->cfg.device_id); rt::stream_sync(h->stream); rt::clear_error(); }
@@ -1102,7 +1141,7 @@ static int upload_impl(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_ph
 static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const oct_phmm_haplotypes* H_in,
                             const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
                             const oct_phmm_positions* positions, oct_phmm_batch** out, oct_phmm_status* status, bool align_mode, uint32_t max_cigar_ops,
-                            bool one_shot, int flavour_hint)      // flavour_hint: -1 unknown; 0 / 1 = the caller has looked at every base and SNV mask byte: all of them ACGT / set, or not (the region server's callers do, each on its own thread)
+                            bool one_shot, const InputFacts* pre)    // pre: somebody has looked at every byte already (the region server's callers, each at its own region on its own thread)
 {
     if (!h || !R || !H_in || !out) return fail(status, OCT_PHMM_EINVAL, "null argument");
     *out = nullptr;
@@ -1182,37 +1221,30 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     // A batch that may take device-sized launches also learns here whether every base is one of ACGT and every SNV mask byte set (a clean batch launches no generic kernels).
     uint32_t q_or = 0, pen_or = 0, gomax = 0, gemax = 0, t_min = 0xffffffffu, dirty = 0; uint64_t sum_q_max = 0; bool any_empty = false;
     const bool dsl_wanted = !align_mode && tune::device_sized() != 0 && (b->n_pairs <= kDslMaxPairs || tune::device_sized() > 0);
+    const bool pre_ok = pre && (gen_device || generate || pre->have_haps);      // (vectors the library makes on host threads are looked at here, below)
+    const int flavour_hint = pre_ok ? pre->dirty : -1;
     // (region-sized calls only: from a few regions on the scan - the first touch of every base and mask byte, 0.1 ms of a 16-region upload although it takes eight bytes
     // per step - costs the host more than the three near-empty launches of the generic lists cost the device, and the region server's workers are bound by their host work)
     const bool want_dirty = dsl_wanted && !gen_device && b->n_pairs <= 20000 && flavour_hint < 0;
     if (flavour_hint >= 0) dirty = flavour_hint ? 1u : 0u;
     {
         std::mutex mx;
-        const size_t read_grain = std::max<size_t>(1, (size_t)R->n_reads / std::max<size_t>(1, (size_t)n_read_bases >> 20));      // reads per ~1 MB of qualities
-        host_parallel(R->n_reads, read_grain, [&](size_t r0, size_t r1) {
-            uint32_t v = 0, shortest = 0xffffffffu, dd = 0; uint64_t best = 0;
-            for (size_t r = r0; r < r1; ++r) {
-                const uint8_t* q = R->qualities + R->offsets[r]; const uint32_t n = R->offsets[r + 1] - R->offsets[r];
-                uint32_t sq = 0, o = 0;                           // reads are < 32,768 bases of quality <= 127
-                for (uint32_t i = 0; i < n; ++i) { sq += q[i]; o |= q[i]; }
-                v |= o; best = std::max<uint64_t>(best, sq); shortest = std::min(shortest, n);
-            }
-            if (want_dirty && r1 > r0) dd |= any_byte_outside_acgt((const uint8_t*)R->bases + R->offsets[r0], (size_t)R->offsets[r1] - R->offsets[r0]) ? 1u : 0u;
-            std::lock_guard<std::mutex> lk(mx); q_or |= v; dirty |= dd; sum_q_max = std::max(sum_q_max, best); t_min = std::min(t_min, shortest);
+        InputFacts all;
+        if (pre_ok) { all = *pre; all.dirty = 0; }
+        else {
+            const size_t read_grain = std::max<size_t>(1, (size_t)R->n_reads / std::max<size_t>(1, (size_t)n_read_bases >> 20));      // reads per ~1 MB of qualities
+            host_parallel(R->n_reads, read_grain, [&](size_t r0, size_t r1) {
+                InputFacts f; f.dirty = 0; facts_of_reads(R, r0, r1, want_dirty, &f);
+                std::lock_guard<std::mutex> lk(mx); all.merge(f); if (f.dirty > 0) dirty = 1;
+            });
+        }
+        if (!gen_device && !(pre_ok && pre->have_haps)) host_parallel(n_hap_bases, (size_t)1 << 18, [&](size_t lo, size_t hi) {       // (device-made vectors come out of validated tables)
+            InputFacts f; f.dirty = 0; facts_of_haps(H, lo, hi, want_dirty, &f);
+            std::lock_guard<std::mutex> lk(mx); all.merge(f); if (f.dirty > 0) dirty = 1;
         });
+        q_or = all.q_or; pen_or = all.pen_or; gomax = all.gomax; gemax = all.gemax; t_min = all.t_min; sum_q_max = all.sum_q_max;
         any_empty = R->n_reads && t_min == 0;
         if (q_or & 0x80u) return fail(status, OCT_PHMM_EINVAL, "base quality > 127");
-        if (!gen_device) host_parallel(n_hap_bases, (size_t)1 << 18, [&](size_t lo, size_t hi) {       // (device-made vectors come out of validated tables)
-            uint32_t v = 0, a = 0, e = 0, dd = 0;
-            for (size_t i = lo; i < hi; ++i) {
-                const uint32_t go = (uint8_t)H->gap_open[i], ge = (uint8_t)H->gap_extend[i];
-                v |= go | ge | (uint8_t)H->snv_prior_fwd[i] | (uint8_t)H->snv_prior_rev[i];
-                a = std::max(a, go); e = std::max(e, ge);           // (as bytes: with no sign bit anywhere - checked below - these are the values)
-            }
-            if (want_dirty) dd |= (any_byte_outside_acgt((const uint8_t*)H->bases + lo, hi - lo) || any_byte_equals((const uint8_t*)H->snv_mask_fwd + lo, hi - lo, '0')
-                                   || any_byte_equals((const uint8_t*)H->snv_mask_rev + lo, hi - lo, '0')) ? 1u : 0u;
-            std::lock_guard<std::mutex> lk(mx); pen_or |= v; dirty |= dd; gomax = std::max(gomax, a); gemax = std::max(gemax, e);
-        });
         if (pen_or & 0x80u) return fail(status, OCT_PHMM_EINVAL, "negative penalty");
     }
 
@@ -2193,10 +2225,10 @@ extern "C" void oct_phmm_host_free(void* p) { rt::host_pinned_free(p); }
 // them, valid until the handle's next call (the server scatters them straight into its callers' matrices).
 struct PopulateCall { oct_phmm_batch* b = nullptr; bool early = false; };
 static int populate_begin(oct_phmm_handle* h, const oct_phmm_reads* reads, const oct_phmm_haplotypes* haps, const oct_phmm_regions* regions, const oct_phmm_flank_state* flank,
-                          const oct_phmm_positions* positions, double* out, oct_phmm_status* status, PopulateCall* pc, int flavour_hint = -1)
+                          const oct_phmm_positions* positions, double* out, oct_phmm_status* status, PopulateCall* pc, const InputFacts* pre = nullptr)
 {
     oct_phmm_batch* b = nullptr;
-    int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, false, 0, true, flavour_hint);
+    int rc = upload_impl(h, reads, haps, regions, flank, positions, &b, status, false, 0, true, pre);
     bool early = false;
     if (rc == OCT_PHMM_OK && out && b->n_out) {                // results come back through a pinned landing zone: slice by slice while a big batch computes, behind the
         const size_t bytes = (size_t)b->n_out * sizeof(double);  // epilogue of a small one - one stream synchronisation per call, no staged copy into pageable memory
@@ -2246,7 +2278,7 @@ struct oct_phmm_server {
     struct Request {
         const oct_phmm_reads* R; const oct_phmm_haplotypes* H; const oct_phmm_flank_state* flank; const oct_phmm_positions* pos;
         double* out; oct_phmm_status st; int rc = OCT_PHMM_OK; bool done = false;
-        int flavour = -1;                                 // 0: every base of the call is one of ACGT and no SNV mask byte is '0' (looked at by the CALLER's thread); 1: not so; -1: not looked at
+        InputFacts facts; bool have_facts = false;        // what an upload must know about every byte of the call (range checks, bounds, cost flavours): made by the CALLER's thread before it queues
         std::mutex m; std::condition_variable cv;         // one pair per call: finishing a batch wakes exactly its callers, and nobody queues for the server's lock to return
     };
 #if defined(OCTPHMM_SIM)
@@ -2357,8 +2389,9 @@ struct oct_phmm_server {
         c.build(qs);
         const uint64_t t1 = profile ? now_ns() : 0;
         oct_phmm_status st;
-        int flavour = 0; for (Request* q : qs) flavour = q->flavour < 0 ? -1 : (flavour < 0 ? -1 : (flavour | q->flavour));
-        const int rc = populate_begin(h, &c.R, &c.H, &c.G, nullptr, nullptr, c.spill.data(), &st, &f.pc, flavour);
+        InputFacts all; all.dirty = 0; bool have = true;
+        for (Request* q : qs) { if (!q->have_facts) { have = false; break; } all.merge(q->facts); all.have_haps = true; }
+        const int rc = populate_begin(h, &c.R, &c.H, &c.G, nullptr, nullptr, c.spill.data(), &st, &f.pc, have ? &all : nullptr);
         if (profile) { ns_concat += t1 - t0; ns_begin += now_ns() - t1; }
         if (rc != OCT_PHMM_OK) return false;
         f.qs = std::move(qs); f.h = h; f.active = true;
@@ -2601,10 +2634,12 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
         if (!out && (size_t)rows * haps->n_haps) return fail(status, OCT_PHMM_EINVAL, "null output");
     }
     oct_phmm_server::Request q; q.R = reads; q.H = haps; q.flank = flank; q.pos = positions; q.out = out; memset(&q.st, 0, sizeof(q.st));
-    if (haps->gap_open && reads->n_reads && haps->n_haps) {      // which cost flavours the call's tasks can have: looked up HERE, on the caller's thread (the workers are what a busy server waits for)
-        const size_t r0 = reads->offsets[0], r1 = reads->offsets[reads->n_reads], h0 = haps->offsets[0], h1 = haps->offsets[haps->n_haps];
-        q.flavour = (any_byte_outside_acgt((const uint8_t*)reads->bases + r0, r1 - r0) || any_byte_outside_acgt((const uint8_t*)haps->bases + h0, h1 - h0)
-                     || any_byte_equals((const uint8_t*)haps->snv_mask_fwd + h0, h1 - h0, '0') || any_byte_equals((const uint8_t*)haps->snv_mask_rev + h0, h1 - h0, '0')) ? 1 : 0;
+    static const bool caller_facts = [] { long long v; return !(tune::number("OCT_PHMM_SERVER_CALLER_FACTS", &v) && v == 0); }();      // 0: the workers look at every byte themselves (A/B)
+    if (caller_facts && haps->gap_open && reads->n_reads && haps->n_haps) {      // everything an upload has to know about the call's bytes: looked up HERE, on the caller's thread (the workers are what a busy server waits for)
+        q.facts.dirty = 0; q.facts.have_haps = true;
+        facts_of_reads(reads, 0, reads->n_reads, true, &q.facts);
+        facts_of_haps(haps, haps->offsets[0], haps->offsets[haps->n_haps], true, &q.facts);
+        q.have_facts = true;
     }
     {
         std::lock_guard<std::mutex> lk(s->mu);

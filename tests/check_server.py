@@ -98,3 +98,36 @@ def check_server_rejects_malformed_calls(backend):
     again, _ = srv.populate(good)
     assert np.array_equal(again, want)
     srv.close()
+
+
+def check_server_contract_violation_reaches_only_its_caller(backend):
+    """The callers' threads collect what an upload must know about their region's bytes (round 5): a call whose read carries a quality above 127, or whose haplotype carries a negative
+    penalty, makes the device batch it rides in fail its upload - the batch is then answered call by call, the offender gets OCT_PHMM_EINVAL from its own populate and every other caller its matrix."""
+    rng = np.random.default_rng(23)
+    reqs = [r for r in make_requests(rng, 14, 8) if r.pos_offsets is None]
+    import copy
+    bad_q = copy.copy(reqs[2]); bad_q._keep = []; bad_q.read_quals = reqs[2].read_quals.copy(); bad_q.read_quals[3] = 200
+    bad_p = copy.copy(reqs[5]); bad_p._keep = []; bad_p.gap_open = reqs[5].gap_open.copy(); bad_p.gap_open[1] = -3
+    calls = list(reqs); calls[2] = bad_q; calls[5] = bad_p
+    cfg = abi.Config.default(max_indel_error=8)
+    srv = engine.Server(cfg, lib_path=build_sim() if backend == "sim" else None)
+    got = [None] * len(calls)
+
+    def worker(t):
+        for i in range(t, len(calls), 4):
+            out, st = srv.populate(calls[i], raise_on_error=False)
+            got[i] = (out.copy(), st.code)
+    for rep in range(2):
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        for i, b in enumerate(calls):
+            out, code = got[i]
+            if i in (2, 5):
+                assert code == abi.EINVAL, (i, code)
+                continue
+            want, wst, _ = oracle.populate(cfg, b)
+            assert code == wst.code, (i, code, wst.code)
+            if code == abi.OK:
+                assert np.max(np.abs(out - want), initial=0.0) <= (0.0 if backend == "sim" else 1e-9)
+    srv.close()
+    return True

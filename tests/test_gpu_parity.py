@@ -203,6 +203,11 @@ def test_gpu_align_best_alignment_and_cigar_per_pair():
     ca.check_align_errors("gpu")
 
 
+def test_gpu_server_contract_violation_reaches_only_its_caller():
+    import check_server
+    assert check_server.check_server_contract_violation_reaches_only_its_caller("gpu")
+
+
 def test_gpu_align_candidate_counts_name_the_saturated_pairs():
     import check_align
     assert check_align.check_align_candidate_counts("gpu")

@@ -52,3 +52,8 @@ def test_sim_region_calls_bench_file_mode_answers_equal_the_oracle(tmp_path):
     cfg = abi.Config.default(max_indel_error=16)
     want = np.concatenate([oracle.populate(cfg, synth.batch_from_regions([g]), n_threads=2)[0] for g in regions])
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_sim_server_contract_violation_reaches_only_its_caller():
+    import check_server
+    assert check_server.check_server_contract_violation_reaches_only_its_caller("sim")
