@@ -212,7 +212,7 @@ struct oct_phmm_batch {
 //                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES, OCT_PHMM_DSL_FORK_EARLY, OCT_PHMM_DSL_MERGE_DP, OCT_PHMM_HOST_MAPPED, OCT_PHMM_SERVER_WORKERS,
 //                round 5: OCT_PHMM_SCAN_FUSED (0: round 4's scan launches and separate late-start launches), OCT_PHMM_JOIN_LATE, OCT_PHMM_LATE_START, OCT_PHMM_REC_CHUNK,
 //                OCT_PHMM_DSL_MAX_BLOCKS, OCT_PHMM_STREAM_PRIORITY, OCT_PHMM_SERVER_PIPELINE (0: one handle per worker, a batch is answered before the next is taken),
-//                OCT_PHMM_SERVER_GATHER (0: a worker whose batch is on the device takes whatever has arrived at once), OCT_PHMM_SERVER_LINGER_US
+//                OCT_PHMM_SERVER_GATHER (0: a worker whose batch is on the device takes whatever has arrived at once), OCT_PHMM_SERVER_CALLER_FACTS, OCT_PHMM_SERVER_LINGER_US
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
 //                OCT_PHMM_DSL_TRACE_PER_PAIR, OCT_PHMM_TEST_FAIL_BP_ALLOCS (the first traceback-scratch allocations "fail"), OCT_PHMM_SCAN_ONE_LAUNCH_MAX
