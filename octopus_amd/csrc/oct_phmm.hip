@@ -127,8 +127,8 @@ struct oct_phmm_handle {
     rt::Stream stream {};                                 // slice 0 / uploads / downloads
     rt::Stream extra_streams[kMaxSlices] {};              // further slices run on their own streams so that latency-bound and VALU-bound kernels overlap
     bool main_stream_high_priority = false;
-    bool all_slices_aside = false;                        // this run's slices ALL take extra streams (a batch of several slices: the main stream's priority would favour slice 0 in the pipeline:
-                                                          // 12.8 M-pair step 29.2 -> 29.5 ms, stream-hq 22.4 -> 22.8 - gpurun_out/r05_s08); set by oct_phmm_batch_run
+    bool all_slices_aside = false;                        // this run's slices ALL take extra streams (OCT_PHMM_SLICES_ASIDE=1, A/B: the main stream's priority favours slice 0 in the pipeline of a
+                                                          // batch of several slices - 12.8 M-pair step 29.2 -> 29.5 ms, stream-hq 22.4 -> 22.8 - but two calls in flight lose more without it); set by oct_phmm_batch_run
     rt::Event ev_ready {};
     uint32_t* bp[kMaxSlices] {}; size_t bp_bytes[kMaxSlices] {};   // traceback scratch per slice, grown on demand
     rt::Stream slice_stream(int i) const { return all_slices_aside ? extra_streams[i] : (i == 0 ? stream : extra_streams[i - 1]); }
@@ -211,7 +211,7 @@ struct oct_phmm_batch {
 //                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED,
 //                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES, OCT_PHMM_DSL_FORK_EARLY, OCT_PHMM_DSL_MERGE_DP, OCT_PHMM_HOST_MAPPED, OCT_PHMM_SERVER_WORKERS,
 //                round 5: OCT_PHMM_SCAN_FUSED (0: round 4's scan launches and separate late-start launches), OCT_PHMM_JOIN_LATE, OCT_PHMM_LATE_START, OCT_PHMM_REC_CHUNK,
-//                OCT_PHMM_DSL_MAX_BLOCKS, OCT_PHMM_STREAM_PRIORITY, OCT_PHMM_SERVER_PIPELINE (0: one handle per worker, a batch is answered before the next is taken),
+//                OCT_PHMM_DSL_MAX_BLOCKS, OCT_PHMM_STREAM_PRIORITY, OCT_PHMM_SLICES_ASIDE, OCT_PHMM_SERVER_PIPELINE (0: one handle per worker, a batch is answered before the next is taken),
 //                OCT_PHMM_SERVER_GATHER (0: a worker whose batch is on the device takes whatever has arrived at once), OCT_PHMM_SERVER_CALLER_FACTS, OCT_PHMM_SERVER_LINGER_US
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
@@ -1696,7 +1696,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
     if (b->dedup) RT(rt::dev_memset(d.pair_rep, 0xff, (size_t)b->n_pairs * sizeof(uint32_t), s0));      // kNoPair: every pair is computed itself until k_dedup_verify says otherwise
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
-    h->all_slices_aside = S > 1 && h->main_stream_high_priority;
+    // (OCT_PHMM_SLICES_ASIDE=1; off by default: with slice 0 on the high-priority stream two populate calls in flight from host buffers reach 0.92-0.95 x the resident rate, with all
+    // slices aside 0.88-0.92 - at 0.2-0.3 ms of the 12.8 M-pair step, profiles/r05_priority_big_batches.md)
+    { long long v; h->all_slices_aside = S > 1 && h->main_stream_high_priority && tune::number("OCT_PHMM_SLICES_ASIDE", &v) && v != 0; }
     const int first_aside = h->all_slices_aside ? 0 : 1;    // the first slice that runs on a stream other than the handle's own
     if (S > 1) {
         RT(rt::event_record(h->ev_ready, s0));
