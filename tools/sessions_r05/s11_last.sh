@@ -1,4 +1,4 @@
-# Round 5, GPU sessions 11 and 13: the final tree - GPU suite, shape-fuzz scenarios (new seeds: 2,000 in session 11, 1,000 in session 13 after the caller-facts step), bench line
+# Round 5, GPU sessions 11, 13 and 14: the final tree - GPU suite, shape-fuzz scenarios with new seeds (2,000 in session 11; 1,000 in 13 after the caller-facts step; 300 in 14 after the slices-aside default went back), smoke, bench line
 cd /root/repo; export TMPDIR=/tmp OCT_PHMM_ENV_SWITCHES=1
 O=gpurun_out/r05_s14; mkdir -p $O
 python -c "from octopus_amd import engine; print(engine.kernel_source_sha())" > $O/kernel_source_sha
