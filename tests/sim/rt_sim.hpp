@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY: host stand-in for octopus_amd/csrc/phmm_rt.hpp so that the library's host API can
 // drive the CPU wave simulator (tests/sim/hipsim.hpp). "Device" memory is plain host memory.
 #pragma once
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 #include <map>
@@ -21,7 +22,18 @@ inline bool stream_create_priority(Stream* s, bool) { return stream_create(s); }
 inline void stream_destroy(Stream) {}
 inline bool stream_sync(Stream) { return true; }
 inline bool stream_idle(Stream) { return true; }
-inline bool dev_malloc(void** p, size_t n) { *p = malloc(n ? n : 16); if (*p) memset(*p, 0xCD, n ? n : 16); return *p != nullptr; }
+// octsim_fail_next_mallocs(min_bytes, count), exported by the simulator's build of the library only: the next `count` device allocations of at least `min_bytes` "fail" (the device is
+// full). What a pool does then - trim its own cache, then its siblings' (DevPool::trim_device) - has no other way to run without a GPU. The counter is shared by all handles.
+inline std::atomic<long>& sim_fail_left() { static std::atomic<long> n {0}; return n; }
+inline std::atomic<size_t>& sim_fail_min() { static std::atomic<size_t> n {0}; return n; }
+inline std::atomic<long>& sim_fail_seen() { static std::atomic<long> n {0}; return n; }
+inline bool sim_malloc_should_fail(size_t n)
+{
+    if (sim_fail_left().load() <= 0 || n < sim_fail_min().load()) return false;
+    if (sim_fail_left().fetch_sub(1) > 0) { ++sim_fail_seen(); return true; }
+    return false;
+}
+inline bool dev_malloc(void** p, size_t n) { if (sim_malloc_should_fail(n)) { *p = nullptr; return false; } *p = malloc(n ? n : 16); if (*p) memset(*p, 0xCD, n ? n : 16); return *p != nullptr; }
 inline void dev_free(void* p) { free(p); }
 inline bool mem_info(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)288 << 30; return true; }
 // "pinned" allocations are remembered, so that the library's fast paths for page-locked caller buffers run in the CPU suite too
@@ -56,3 +68,9 @@ struct Range { explicit Range(const char*) {} };
 }} // namespace octphmm::rt
 
 #define OCT_LAUNCH(kernel, grid, block, smem, stream, ...) hipsim::launch(grid, block, smem, [=]() { kernel(__VA_ARGS__); })
+
+extern "C" inline __attribute__((used, visibility("default"))) long octsim_fail_next_mallocs(size_t min_bytes, long count)     // returns how many allocations have "failed" so far
+{
+    octphmm::rt::sim_fail_min().store(min_bytes); octphmm::rt::sim_fail_left().store(count);
+    return octphmm::rt::sim_fail_seen().load();
+}

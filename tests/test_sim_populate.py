@@ -180,3 +180,40 @@ def test_sim_upload_refuses_what_the_input_contract_excludes():
 
 def test_sim_canonical_windows_through_lds_and_global_tables_agree():
     assert cp.check_window_tables("sim")["n_pairs_shared"] > 20
+
+
+def test_sim_a_full_device_makes_a_pool_trim_its_siblings_and_the_call_still_answers():
+    """ADVICE r04 / round 5's fuzz: a handle whose device allocation fails gives back its own cached blocks, then every sibling handle's (DevPool::trim_device), and retries - instead of
+    reporting out-of-memory while other handles sit on free blocks. The simulator's allocator is told to fail the next two big allocations (the first attempt and the retry behind the pool's
+    own trim; the one behind the siblings' trim succeeds) while two handles hold cached blocks; the call must still equal the oracle; with more failures sprinkled over a call it either still answers right or reports the HIP error, and the handle stays usable."""
+    import ctypes as C
+    import numpy as np
+    import oracle
+    from backends import build_sim, make_engine
+    from octopus_amd import abi, synth
+    lib = C.CDLL(str(build_sim()))
+    lib.octsim_fail_next_mallocs.argtypes = [C.c_size_t, C.c_long]; lib.octsim_fail_next_mallocs.restype = C.c_long
+    rng = np.random.default_rng(3)
+    b1 = synth.batch_from_regions([synth.make_region(rng, 30, 4, T=60, Lh=180, B=8, positions="none")])
+    b2 = synth.batch_from_regions([synth.make_region(rng, 90, 6, T=70, Lh=200, B=8, positions="none")])
+    e1, e2 = make_engine("sim", max_indel_error=8), make_engine("sim", max_indel_error=8)
+    for _ in range(2):
+        e1.populate(b1); e2.populate(b2)                # both pools hold cached blocks now
+    want, _, _ = oracle.populate(abi.Config.default(max_indel_error=8), b2)
+    before = lib.octsim_fail_next_mallocs(1 << 16, 2)
+    got, st = e1.populate(b2)                            # a batch of another size on e1: a new block is needed
+    assert st.code == abi.OK and np.array_equal(got, want)
+    assert lib.octsim_fail_next_mallocs(0, 0) == before + 2       # both failures were met, the third attempt (behind the siblings' trim) got the block
+    got2, _ = e2.populate(b2)                            # the sibling whose cache was trimmed carries on
+    assert np.array_equal(got2, want)
+    b3 = synth.batch_from_regions([synth.make_region(rng, 200, 7, T=80, Lh=230, B=8, positions="none")])
+    want3, _, _ = oracle.populate(abi.Config.default(max_indel_error=8), b3)
+    lib.octsim_fail_next_mallocs(1 << 12, 5)             # five failures wherever they fall (batch block, task lists, traceback scratch: the scratch falls back to smaller chunks)
+    got3, st3 = e1.populate(b3, raise_on_error=False)
+    lib.octsim_fail_next_mallocs(0, 0)
+    assert st3.code in (abi.OK, abi.EHIP)                # either it found room after trimming, or it says so - never a wrong matrix
+    if st3.code == abi.OK:
+        assert np.array_equal(got3, want3)
+    got4, st4 = e1.populate(b3)                          # ... and the handle is usable afterwards
+    assert st4.code == abi.OK and np.array_equal(got4, want3)
+    e1.close(); e2.close()
