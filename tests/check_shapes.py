@@ -73,7 +73,7 @@ def random_region(rng, band, pair_budget, scale):
                           q_profile="hq" if rng.random() < 0.5 else "stress", hap_model="tree" if rng.random() < 0.5 and Lh >= 132 + 12 * int(np.ceil(np.log2(max(H, 2)))) else "edits")
     g["mapq"] = rng.integers(0, 255, R).astype(np.uint8) if rng.random() < 0.5 else g["mapq"]
     if rng.random() < 0.3:                                    # ragged reads
-        g["read_len"] = rng.integers(max(band + 4, T // 3), T + 1, R).astype(np.int64)
+        g["read_len"] = rng.integers(min(T, max(band + 4, T // 3)), T + 1, R).astype(np.int64)   # (toy reads can be shorter than band + 4: then all stay whole)
     if rng.random() < 0.1:                                    # a few non-ACGT bytes: generic kernels beside fast ones in one batch
         g["reads"][rng.integers(0, R), rng.integers(0, min(T, 30))] = ord("N")
         g["haps"][int(rng.integers(0, H))][int(rng.integers(0, Lh))] = ord("N")
