@@ -2564,9 +2564,8 @@ extern "C" int oct_phmm_server_create_multi(const oct_phmm_config* cfg, const in
     for (uint32_t dv = 0; dv < n_devices; ++dv) {
         oct_phmm_config c = *cfg; c.device_id = device_ids[dv];
         int n_workers = oct_phmm_server::kWorkers;
-#if !defined(OCTPHMM_SIM)
-        { long long v; if (tune::number("OCT_PHMM_SERVER_WORKERS", &v) && v >= 1 && v <= 8) n_workers = (int)v; }      // A/B switch: device queues (worker threads + handles) per device
-#endif
+        { long long v; if (tune::number("OCT_PHMM_SERVER_WORKERS", &v) && v >= 1 && v <= 8) n_workers = (int)v; }      // A/B switch: device queues (worker threads + handles) per device (the simulator's
+                                                                                                                         // default is 1; with more, its workers take turns at sim_mu - the ThreadSanitizer run uses 2)
         for (int w = 0; w < n_workers * oct_phmm_server::kSlots; ++w) {
             oct_phmm_handle* h = nullptr;
             const int rc = oct_phmm_create(&c, &h);

@@ -25,15 +25,29 @@ struct uint4 { uint32_t x, y, z, w; };
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 
+// ThreadSanitizer builds (tests/test_sim_sanitizers.py): every lane coroutine is announced as a fiber, or the first swapcontext onto a malloc'ed stack kills the tool
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define HIPSIM_TSAN 1
+extern "C" { void* __tsan_get_current_fiber(void); void* __tsan_create_fiber(unsigned flags); void __tsan_destroy_fiber(void* fiber); void __tsan_switch_to_fiber(void* fiber, unsigned flags); }
+#endif
+#endif
+#ifdef HIPSIM_TSAN
+#define HIPSIM_TO_FIBER(f) __tsan_switch_to_fiber((f), 0)
+#else
+#define HIPSIM_TO_FIBER(f) ((void)0)
+#endif
+
 namespace hipsim {
 
 enum Wait { kRun = 0, kWave = 1, kBlock = 2, kDone = 3 };
 
-struct Lane { ucontext_t ctx; char* stack = nullptr; int wait = kRun; };
+struct Lane { ucontext_t ctx; char* stack = nullptr; int wait = kRun; void* fiber = nullptr; };
 
 struct State {
     std::vector<Lane> lanes;
     ucontext_t sched;
+    void* sched_fiber = nullptr;
     uint32_t cur = 0, bid = 0, bdim = 0, gdim = 0;
     unsigned char* smem = nullptr;
     uint32_t xchg[1024];
@@ -41,11 +55,11 @@ struct State {
 };
 inline State& S() { static State s; return s; }
 
-inline void yield_to_sched(int why) { State& s = S(); s.lanes[s.cur].wait = why; swapcontext(&s.lanes[s.cur].ctx, &s.sched); }
+inline void yield_to_sched(int why) { State& s = S(); s.lanes[s.cur].wait = why; HIPSIM_TO_FIBER(s.sched_fiber); swapcontext(&s.lanes[s.cur].ctx, &s.sched); }
 inline void wave_sync() { yield_to_sched(kWave); }
 inline void block_sync_impl() { yield_to_sched(kBlock); }
 
-inline void lane_entry() { State& s = S(); s.body(); s.lanes[s.cur].wait = kDone; swapcontext(&s.lanes[s.cur].ctx, &s.sched); }
+inline void lane_entry() { State& s = S(); s.body(); s.lanes[s.cur].wait = kDone; HIPSIM_TO_FIBER(s.sched_fiber); swapcontext(&s.lanes[s.cur].ctx, &s.sched); }
 
 // run one workgroup of `bdim` threads
 inline void run_block(uint32_t bid, uint32_t bdim, uint32_t gdim, size_t smem_bytes)
@@ -63,11 +77,17 @@ inline void run_block(uint32_t bid, uint32_t bdim, uint32_t gdim, size_t smem_by
         l.ctx.uc_stack.ss_sp = l.stack; l.ctx.uc_stack.ss_size = kStack; l.ctx.uc_link = &s.sched;
         makecontext(&l.ctx, (void (*)())lane_entry, 0);
         l.wait = kRun;
+#ifdef HIPSIM_TSAN
+        l.fiber = __tsan_create_fiber(0);
+#endif
     }
+#ifdef HIPSIM_TSAN
+    s.sched_fiber = __tsan_get_current_fiber();
+#endif
     for (;;) {
         bool progressed = false, all_done = true;
         for (uint32_t t = 0; t < bdim; ++t) {
-            if (s.lanes[t].wait == kRun) { s.cur = t; swapcontext(&s.sched, &s.lanes[t].ctx); progressed = true; }
+            if (s.lanes[t].wait == kRun) { s.cur = t; HIPSIM_TO_FIBER(s.lanes[t].fiber); swapcontext(&s.sched, &s.lanes[t].ctx); progressed = true; }
             if (s.lanes[t].wait != kDone) all_done = false;
         }
         if (all_done) break;
@@ -88,6 +108,9 @@ inline void run_block(uint32_t bid, uint32_t bdim, uint32_t gdim, size_t smem_by
         }
         if (!progressed) { fprintf(stderr, "hipsim: deadlock (divergent cross-lane op or barrier) in block %u\n", bid); abort(); }
     }
+#ifdef HIPSIM_TSAN
+    for (uint32_t t = 0; t < bdim; ++t) { __tsan_destroy_fiber(s.lanes[t].fiber); s.lanes[t].fiber = nullptr; }
+#endif
 }
 
 template <class F>

@@ -1,5 +1,6 @@
 """The real host + kernel source, compiled for the host with AddressSanitizer and UBSan, through populate / align / read-out on the
-wave simulator ("device" memory is plain malloc there, so any out-of-bounds access of a kernel or of the host API trips a redzone)."""
+wave simulator ("device" memory is plain malloc there, so any out-of-bounds access of a kernel or of the host API trips a redzone) -
+and with ThreadSanitizer through the region server (callers, two gathering workers, their finisher threads, the per-call wake-ups)."""
 import os
 import subprocess
 import sys
@@ -58,3 +59,37 @@ def test_sim_build_is_clean_under_asan_and_ubsan(tmp_path):
     p = subprocess.run([sys.executable, "-c", DRIVER.format(root=str(ROOT), tests=str(ROOT / "tests"), lib=str(lib))],
                        env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0 and "SANITIZED-OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+
+
+TSAN_DRIVER = r"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from pathlib import Path
+import backends
+backends.build_sim = lambda: Path({lib!r})
+import check_server
+calls, batches = check_server.check_server("sim", n_threads=6, per_thread=8)                       # OCT_PHMM_SERVER_WORKERS=2: two workers gather from one queue
+assert batches < calls
+check_server.check_server("sim", n_threads=4, per_thread=5, seed=23, devices=[0, 0])               # ... and two "devices" with two workers each
+check_server.check_server_rejects_malformed_calls("sim")
+check_server.check_server_contract_violation_reaches_only_its_caller("sim")
+print("TSAN-OK")
+"""
+
+
+@pytest.mark.skipif(os.environ.get("OCT_RUN_SANITIZERS") != "1", reason="three minutes (ThreadSanitizer build of the whole library): set OCT_RUN_SANITIZERS=1")
+def test_region_server_is_clean_under_thread_sanitizer(tmp_path):
+    """Round 5 rebuilt the server around threads (per worker a gatherer and a finisher, callers that compute their regions' input facts and sleep on their own
+    condition variable): the simulator's lane coroutines are announced to the tool as fibers (tests/sim/hipsim.hpp), device work takes turns at the server's sim_mu,
+    everything else - queues, slots, counters, wake-ups - runs as in the product. Any report fails the test."""
+    rt = subprocess.run([CLANG, "-print-file-name=libclang_rt.tsan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not rt or not Path(rt).exists():
+        pytest.skip("no ThreadSanitizer runtime next to the ROCm clang")
+    lib = tmp_path / "libphmm_sim_tsan.so"
+    subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DOCTPHMM_SIM", "-fsanitize=thread", "-fno-omit-frame-pointer",
+                    f"-I{ROOT / 'tests' / 'sim'}", f"-I{ROOT / 'octopus_amd' / 'csrc'}", "-Wno-unused-function", str(ROOT / "octopus_amd" / "csrc" / "oct_phmm.hip"), "-o", str(lib)], check=True)
+    env = dict(os.environ, LD_PRELOAD=rt, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:history_size=4:second_deadlock_stack=1:exitcode=0",
+               OCT_PHMM_ENV_SWITCHES="1", OCT_PHMM_SERVER_WORKERS="2")
+    p = subprocess.run([sys.executable, "-c", TSAN_DRIVER.format(root=str(ROOT), tests=str(ROOT / "tests"), lib=str(lib))], env=env, capture_output=True, text=True, timeout=2400)
+    assert p.returncode == 0 and "TSAN-OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+    assert "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[:6000]
