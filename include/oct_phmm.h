@@ -300,10 +300,8 @@ typedef struct oct_phmm_error_model {
     int32_t use_snv_model;                     /* 0: no SNV model (PacBio sequencers, error_model_factory.cpp:480-483): masks = the haplotype itself, priors = 100 (model.cpp:69-73) */
 } oct_phmm_error_model;
 void oct_phmm_error_model_default(oct_phmm_error_model* model);
-/* NOT covered: the reference's CustomRepeatBasedIndelErrorModel (core/models/error/custom_repeat_based_indel_error_model.cpp), which `--sequence-error-model <file>` builds from
- * a model FILE of motif -> penalty rows (error_model_factory.cpp:572-590) - its look-ups are keyed by motif strings (std::unordered_map, with an iteration-order-dependent default),
- * not by this struct's period tables. A caller that runs such a model passes the six vectors itself (the reference's own reset() computes them once per haplotype:
- * haplotype_likelihood_model.cpp:60-78, exactly what INTEGRATION.md's populate patch hands over), which every entry point accepts. */
+/* The reference's CustomRepeatBasedIndelErrorModel (core/models/error/custom_repeat_based_indel_error_model.cpp), which `--sequence-error-model <file>` builds from a model
+ * FILE of motif -> penalty rows (make_error_model(path), error_model_factory.cpp:572-590): see "a model read from a file" below (oct_phmm_custom_indel_model_*). */
 /* Every parameter set the reference's factory holds (error_model_factory.cpp:220-517), by the names --sequence-error-model takes (option_parser.cpp:571-573;
  * matched like the reference's operator>>: case-insensitive, "PCR-free" also as "PCRF"):
  *   library preparation  PCR, PCR-free, 10X, MDA;  sequencer  HiSeq-2000, HiSeq-2500, HiSeq-4000, X10, NovaSeq, BGISEQ-500, PacBio, PacBioCCS.
@@ -326,6 +324,38 @@ int  oct_phmm_penalty_vectors(const oct_phmm_error_model* model, uint32_t n_haps
  * oct_phmm_haplotypes whose SIX vector pointers are all NULL and generate the vectors inside the call (HaplotypeLikelihoodModel::reset
  * for every haplotype): on host threads for region-sized calls, on the device (one haplotype per lane) from a few thousand haplotypes. */
 int  oct_phmm_set_error_model(oct_phmm_handle* h, const oct_phmm_error_model* model);
+/* ---- a model read from a file: CustomRepeatBasedIndelErrorModel ---------------------------------------------------------------------- */
+/* `--sequence-error-model <path>` (option_collation.cpp:1621-1631): make_error_model(path) (error_model_factory.cpp:572-590) reads the file with make_penalty_map
+ * (custom_repeat_based_indel_error_model.cpp:105-159) into a CustomRepeatBasedIndelErrorModel and pairs it with the DEFAULT configuration's SNV model (:587).
+ * Rows are "<motif>:<p0>,<p1>,..." (gap-open penalties by number of periods), "<motif>+:..." (gap-extension penalties), '#' comments; a repeat's penalty is looked up
+ * by its own motif, then by the row of min(period, 10) letters N, then the default (:68-103). _parse accepts and refuses exactly the texts the reference does
+ * (OCT_PHMM_EINVAL where it throws "Bad model" / MalformedErrorModelFile: no open row, a row without numbers, an entry that is not [+-]?digits or does not fit int8,
+ * a missing ':'), and reproduces its defaults - entry 0 of the first row in the iteration order of the reference's std::unordered_map (:38-40, :53-58), obtained from
+ * the same container filled by the same calls (this library and the reference build against the same libstdc++) - and 3 for extension without '+' rows (hpp:28).
+ * _create takes rows the caller already holds (e.g. the reference's two maps) with the two defaults stated; has_extend = 0 means "no extension map" (every repeat gets
+ * default_extend), has_extend = 1 with n_extend = 0 an empty one. The vectors are those of RepeatBasedIndelErrorModel::do_set_penalties's vector overload
+ * (repeat_based_indel_error_model.cpp:67-83) bit for bit (tests/test_error_model.py against the reference's own class compiled in place). Look-ups are keyed by strings:
+ * host threads at every batch size (the built-in models' device path does not apply). */
+typedef struct oct_phmm_custom_indel_model oct_phmm_custom_indel_model;
+typedef struct oct_phmm_motif_penalties { const char* motif; uint32_t motif_len; const int8_t* penalties; uint32_t n_penalties; } oct_phmm_motif_penalties;
+int  oct_phmm_custom_indel_model_parse(const char* text, size_t len, oct_phmm_custom_indel_model** out);
+int  oct_phmm_custom_indel_model_create(const oct_phmm_motif_penalties* open, uint32_t n_open, int8_t default_open,
+                                        const oct_phmm_motif_penalties* extend, uint32_t n_extend, int32_t has_extend, int8_t default_extend,
+                                        oct_phmm_custom_indel_model** out);
+void oct_phmm_custom_indel_model_destroy(oct_phmm_custom_indel_model* m);
+/* what a model holds (any pointer may be NULL) */
+int  oct_phmm_custom_indel_model_info(const oct_phmm_custom_indel_model* m, int8_t* default_open, int8_t* default_extend, uint32_t* n_open_rows, uint32_t* n_extend_rows,
+                                      int32_t* has_extend);
+/* oct_phmm_penalty_vectors with the gap vectors from `indel` and the SNV vectors from `snv` (NULL: oct_phmm_error_model_default, what the reference pairs a file with) */
+int  oct_phmm_custom_penalty_vectors(const oct_phmm_custom_indel_model* indel, const oct_phmm_error_model* snv, uint32_t n_haps, const char* bases, const uint32_t* offsets,
+                                     const uint8_t* substitution_mask,
+                                     int8_t* gap_open, int8_t* gap_extend, char* snv_mask_fwd, int8_t* snv_prior_fwd, char* snv_mask_rev, int8_t* snv_prior_rev,
+                                     oct_phmm_status* status);
+/* oct_phmm_set_error_model / oct_phmm_server_set_error_model with such a model: calls that leave their six vector pointers NULL get them from it (the handle / server keeps
+ * its own reference: the caller may destroy `indel` afterwards). A penalty outside [0, 127] in a row then fails the upload like a caller's own vector would.
+ * oct_phmm_set_error_model (also with NULL) takes the custom model away again. */
+int  oct_phmm_set_custom_error_model(oct_phmm_handle* h, const oct_phmm_custom_indel_model* indel, const oct_phmm_error_model* snv);
+int  oct_phmm_server_set_custom_error_model(oct_phmm_server* s, const oct_phmm_custom_indel_model* indel, const oct_phmm_error_model* snv);
 /* Test seam: the vectors the last upload of this batch generated (device or host path), concatenated like the haplotypes. */
 int  oct_phmm_batch_penalty_vectors(oct_phmm_handle* h, oct_phmm_batch* b, int8_t* gap_open, int8_t* gap_extend, char* snv_mask_fwd,
                                     int8_t* snv_prior_fwd, char* snv_mask_rev, int8_t* snv_prior_rev, oct_phmm_status* status);

@@ -25,6 +25,7 @@
 #include "phmm_readout.hpp"
 #include "phmm_error_model.hpp"
 #include "phmm_error_model_tables.hpp"
+#include "phmm_custom_error_model.h"
 
 using namespace octphmm;
 
@@ -137,6 +138,7 @@ struct oct_phmm_handle {
     size_t bp_budget = (size_t)96 << 30;
     // error model for in-call penalty vectors (oct_phmm_set_error_model)
     bool has_model = false; oct_phmm_error_model model {};
+    std::shared_ptr<const em::CustomIndelModel> custom;   // oct_phmm_set_custom_error_model: gap penalties from a model file's rows (host threads only), SNV vectors from `model`
     std::vector<uint8_t> last_align_counts; bool last_align_device_map = false;   // oct_phmm_align_candidate_counts
     int fail_bp_allocs = 0;                              // test hook, see ensure_bp
     bool probe_ready = false; rt::Stream probe_stream {}; unsigned long long* d_probe = nullptr; unsigned long long* h_probe = nullptr;   // oct_phmm_probe_clock
@@ -869,16 +871,23 @@ OCT_KERNEL(k_penalty_vectors_wave)(const oct_phmm_error_model* model, const uint
 namespace {
 
 // one haplotype on the calling thread; the workspace grows until the run lists fit (pathological repeat structure only)
-void host_penalty_vectors_one(const oct_phmm_error_model& m, const uint8_t* s, uint32_t n, const uint8_t* sub, std::vector<uint32_t>& w, PenaltyOut out, size_t o)
+void host_penalty_vectors_one(const oct_phmm_error_model& m, const uint8_t* s, uint32_t n, const uint8_t* sub, std::vector<uint32_t>& w, PenaltyOut out, size_t o,
+                              const em::CustomIndelModel* custom = nullptr)
 {
     for (uint32_t grow = 1; ; grow *= 4) {
         const size_t need = em::workspace_words(n, grow);
         if (w.size() < need) w.resize(need);
-        if (em::penalty_vectors(m, s, n, sub, w.data(), grow, out.go + o, out.ge + o, out.mf + o, out.pf + o, out.mr + o, out.pr + o) == em::kOk) return;
+        if (!custom) {
+            if (em::penalty_vectors(m, s, n, sub, w.data(), grow, out.go + o, out.ge + o, out.mf + o, out.pf + o, out.mr + o, out.pr + o) == em::kOk) return;
+        } else if (em::custom_indel_penalties(*custom, s, n, w.data(), grow, out.go + o, out.ge + o) == em::kOk) {     // the file's rows for the gaps, `m` for the SNV vectors only
+            em::snv_priors(em::Seq {}, m, s, n, sub, w.data(), out.mf + o, out.pf + o, out.mr + o, out.pr + o);
+            return;
+        }
     }
 }
 
-void host_penalty_vectors(const oct_phmm_error_model& m, uint32_t n_haps, const uint8_t* bases, const uint32_t* off, const uint8_t* sub, PenaltyOut out)
+void host_penalty_vectors(const oct_phmm_error_model& m, uint32_t n_haps, const uint8_t* bases, const uint32_t* off, const uint8_t* sub, PenaltyOut out,
+                          const em::CustomIndelModel* custom = nullptr)
 {
     static const unsigned kCores = std::thread::hardware_concurrency();     // (asked once, see host_parallel)
     unsigned T = kCores ? std::min(kCores, 16u) : 1;
@@ -889,7 +898,7 @@ void host_penalty_vectors(const oct_phmm_error_model& m, uint32_t n_haps, const 
     auto work = [&] {
         std::vector<uint32_t> w;
         for (uint32_t h = next.fetch_add(1); h < n_haps; h = next.fetch_add(1))
-            host_penalty_vectors_one(m, bases + off[h], off[h + 1] - off[h], sub ? sub + off[h] : nullptr, w, out, off[h]);
+            host_penalty_vectors_one(m, bases + off[h], off[h + 1] - off[h], sub ? sub + off[h] : nullptr, w, out, off[h], custom);
     };
     std::vector<std::thread> th;
     for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
@@ -991,8 +1000,87 @@ extern "C" int oct_phmm_set_error_model(oct_phmm_handle* h, const oct_phmm_error
     if (!h) return OCT_PHMM_EINVAL;
     if (model && !model_is_valid(model)) return OCT_PHMM_EINVAL;
     h->has_model = model != nullptr;
+    h->custom.reset();
     if (model) h->model = *model;
     if (h->d_model) { rt::set_device(h->cfg.device_id); rt::stream_sync(h->stream); h->pool.release(h->d_model); h->d_model = nullptr; }
+    return OCT_PHMM_OK;
+}
+
+// ---- CustomRepeatBasedIndelErrorModel: the indel model of `--sequence-error-model <file>` (phmm_custom_error_model.h) -----------------------------------------
+struct oct_phmm_custom_indel_model { std::shared_ptr<const em::CustomIndelModel> m; };
+
+extern "C" int oct_phmm_custom_indel_model_parse(const char* text, size_t len, oct_phmm_custom_indel_model** out)
+{
+    if (!out || (len && !text)) return OCT_PHMM_EINVAL;
+    *out = nullptr;
+    try {
+        auto m = std::make_shared<em::CustomIndelModel>();
+        if (!em::parse_custom_indel_model(text, len, *m)) return OCT_PHMM_EINVAL;     // "Bad model" / MalformedErrorModelFile
+        *out = new oct_phmm_custom_indel_model {std::move(m)};
+    } catch (const std::exception&) { return OCT_PHMM_EHIP; }
+    return OCT_PHMM_OK;
+}
+
+extern "C" int oct_phmm_custom_indel_model_create(const oct_phmm_motif_penalties* open, uint32_t n_open, int8_t default_open,
+                                                  const oct_phmm_motif_penalties* extend, uint32_t n_extend, int32_t has_extend, int8_t default_extend,
+                                                  oct_phmm_custom_indel_model** out)
+{
+    if (!out || (n_open && !open) || (n_extend && !extend) || (n_extend && !has_extend)) return OCT_PHMM_EINVAL;
+    *out = nullptr;
+    try {
+        auto m = std::make_shared<em::CustomIndelModel>();
+        auto put = [](em::CustomIndelModel::Map& rows, const oct_phmm_motif_penalties* r, uint32_t n) {
+            for (uint32_t i = 0; i < n; ++i) {
+                if (!r[i].motif || !r[i].motif_len || !r[i].penalties || !r[i].n_penalties) return false;
+                rows.emplace(std::string(r[i].motif, r[i].motif_len), std::vector<int8_t>(r[i].penalties, r[i].penalties + r[i].n_penalties));
+            }
+            return true;
+        };
+        if (!put(m->open, open, n_open) || !put(m->extend, extend, n_extend)) return OCT_PHMM_EINVAL;
+        m->has_extend = has_extend != 0; m->default_open = default_open; m->default_extend = default_extend;
+        *out = new oct_phmm_custom_indel_model {std::move(m)};
+    } catch (const std::exception&) { return OCT_PHMM_EHIP; }
+    return OCT_PHMM_OK;
+}
+
+extern "C" void oct_phmm_custom_indel_model_destroy(oct_phmm_custom_indel_model* m) { delete m; }
+
+extern "C" int oct_phmm_custom_indel_model_info(const oct_phmm_custom_indel_model* m, int8_t* default_open, int8_t* default_extend, uint32_t* n_open_rows, uint32_t* n_extend_rows, int32_t* has_extend)
+{
+    if (!m) return OCT_PHMM_EINVAL;
+    if (default_open) *default_open = m->m->default_open;
+    if (default_extend) *default_extend = m->m->default_extend;
+    if (n_open_rows) *n_open_rows = (uint32_t)m->m->open.size();
+    if (n_extend_rows) *n_extend_rows = (uint32_t)m->m->extend.size();
+    if (has_extend) *has_extend = m->m->has_extend ? 1 : 0;
+    return OCT_PHMM_OK;
+}
+
+extern "C" int oct_phmm_custom_penalty_vectors(const oct_phmm_custom_indel_model* indel, const oct_phmm_error_model* snv, uint32_t n_haps, const char* bases, const uint32_t* offsets,
+                                               const uint8_t* substitution_mask, int8_t* gap_open, int8_t* gap_extend, char* snv_mask_fwd,
+                                               int8_t* snv_prior_fwd, char* snv_mask_rev, int8_t* snv_prior_rev, oct_phmm_status* status)
+{
+    if (!indel || (n_haps && (!bases || !offsets || !gap_open || !gap_extend || !snv_mask_fwd || !snv_prior_fwd || !snv_mask_rev || !snv_prior_rev)))
+        return fail(status, OCT_PHMM_EINVAL, "null argument");
+    if (n_haps && !monotone(offsets, n_haps)) return fail(status, OCT_PHMM_EINVAL, "offsets not monotone");
+    oct_phmm_error_model dflt;
+    if (!snv) { oct_phmm_error_model_default(&dflt); snv = &dflt; }                    // make_snv_error_model(default_model_config), error_model_factory.cpp:587
+    if (!model_is_valid(snv)) return fail(status, OCT_PHMM_EINVAL, "negative penalty in the error model's tables");
+    try {
+        host_penalty_vectors(*snv, n_haps, (const uint8_t*)bases, offsets, substitution_mask,
+                             PenaltyOut {gap_open, gap_extend, (uint8_t*)snv_mask_fwd, snv_prior_fwd, (uint8_t*)snv_mask_rev, snv_prior_rev}, indel->m.get());
+    } catch (const std::exception&) { return fail(status, OCT_PHMM_EHIP, "host allocation"); }
+    return ok(status);
+}
+
+extern "C" int oct_phmm_set_custom_error_model(oct_phmm_handle* h, const oct_phmm_custom_indel_model* indel, const oct_phmm_error_model* snv)
+{
+    if (!h || !indel) return OCT_PHMM_EINVAL;
+    oct_phmm_error_model dflt;
+    if (!snv) { oct_phmm_error_model_default(&dflt); snv = &dflt; }
+    const int rc = oct_phmm_set_error_model(h, snv);
+    if (rc != OCT_PHMM_OK) return rc;
+    h->custom = indel->m;                                  // shared: the caller may destroy its model object
     return OCT_PHMM_OK;
 }
 
@@ -1166,13 +1254,14 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     // OCT_PHMM_PENALTIES=host|device|lanes overrides.
     bool gen_device = generate && H->n_haps >= 512;
     if (tune::penalties_where()) gen_device = generate && tune::penalties_where() == 2;
+    if (h->custom) gen_device = false;                                       // a model file's rows are looked up by motif string: host threads at every size
     std::vector<int8_t> gen_go, gen_ge, gen_pf, gen_pr; std::vector<char> gen_mf, gen_mr;
     if (generate && !gen_device) {
         const size_t nb = H->offsets[H->n_haps];
         try {
             gen_go.resize(nb + 1); gen_ge.resize(nb + 1); gen_pf.resize(nb + 1); gen_pr.resize(nb + 1); gen_mf.resize(nb + 1); gen_mr.resize(nb + 1);
             host_penalty_vectors(h->model, H->n_haps, (const uint8_t*)H->bases, H->offsets, sub_mask,
-                                 PenaltyOut {gen_go.data(), gen_ge.data(), (uint8_t*)gen_mf.data(), gen_pf.data(), (uint8_t*)gen_mr.data(), gen_pr.data()});
+                                 PenaltyOut {gen_go.data(), gen_ge.data(), (uint8_t*)gen_mf.data(), gen_pf.data(), (uint8_t*)gen_mr.data(), gen_pr.data()}, h->custom.get());
         } catch (const std::exception&) { return fail(status, OCT_PHMM_EHIP, "host allocation"); }
         Hv.gap_open = gen_go.data(); Hv.gap_extend = gen_ge.data(); Hv.snv_mask_fwd = gen_mf.data(); Hv.snv_prior_fwd = gen_pf.data();
         Hv.snv_mask_rev = gen_mr.data(); Hv.snv_prior_rev = gen_pr.data();
@@ -2308,6 +2397,7 @@ struct oct_phmm_server {
     std::atomic<bool> has_model {false};                 // oct_phmm_server_set_error_model: calls may leave their penalty vectors NULL
     // the model travels to the handles through their own worker threads (under mu): a handle is only ever touched by its worker
     oct_phmm_error_model pending_model {}; bool pending_has_model = false; uint64_t model_version = 0; std::vector<uint64_t> worker_version;
+    std::shared_ptr<const em::CustomIndelModel> pending_custom;     // oct_phmm_server_set_custom_error_model
     // OCT_PHMM_SERVER_PROFILE=1: where a worker's time goes (ns, summed over workers), printed by oct_phmm_server_destroy
     bool profile = tune::server_profile();
     std::atomic<uint64_t> ns_idle {0}, ns_concat {0}, ns_begin {0}, ns_end {0}, ns_scatter {0}, ns_single {0};
@@ -2488,7 +2578,10 @@ struct oct_phmm_server {
                     if (queue.empty() && stop) { lk.unlock(); wait_all_landed(); return; }
                     if (worker_version[(size_t)w] != model_version) {      // a new error model since this worker's last batch: install it (nothing of ours in the air) before taking calls
                         lk.unlock(); wait_all_landed(); lk.lock();
-                        for (int k = 0; k < kSlots; ++k) oct_phmm_set_error_model(hslot[k], pending_has_model ? &pending_model : nullptr);
+                        for (int k = 0; k < kSlots; ++k) {
+                            if (pending_has_model && pending_custom) { const oct_phmm_custom_indel_model cm {pending_custom}; oct_phmm_set_custom_error_model(hslot[k], &cm, &pending_model); }
+                            else oct_phmm_set_error_model(hslot[k], pending_has_model ? &pending_model : nullptr);
+                        }
                         worker_version[(size_t)w] = model_version;
                     }
                     // Bounded linger (OCT_PHMM_SERVER_LINGER_US, off by default): with other workers' batches on the device, wait while calls keep arriving
@@ -2659,9 +2752,23 @@ extern "C" int oct_phmm_server_set_error_model(oct_phmm_server* s, const oct_phm
     if (model && !model_is_valid(model)) return OCT_PHMM_EINVAL;
     std::lock_guard<std::mutex> lk(s->mu);
     s->pending_has_model = model != nullptr;
+    s->pending_custom.reset();
     if (model) s->pending_model = *model;
     ++s->model_version;                                    // every worker installs it on its own handle before its next batch (run())
     s->has_model = model != nullptr;
+    return OCT_PHMM_OK;
+}
+
+extern "C" int oct_phmm_server_set_custom_error_model(oct_phmm_server* s, const oct_phmm_custom_indel_model* indel, const oct_phmm_error_model* snv)
+{
+    if (!s || !indel) return OCT_PHMM_EINVAL;
+    oct_phmm_error_model dflt;
+    if (!snv) { oct_phmm_error_model_default(&dflt); snv = &dflt; }
+    if (!model_is_valid(snv)) return OCT_PHMM_EINVAL;
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->pending_has_model = true; s->pending_model = *snv; s->pending_custom = indel->m;
+    ++s->model_version;
+    s->has_model = true;
     return OCT_PHMM_OK;
 }
 

@@ -117,6 +117,13 @@ def load(path: Optional[Path] = None) -> C.CDLL:
         lib.oct_phmm_set_error_model.argtypes = [pv, C.POINTER(abi.ErrorModel)]
         lib.oct_phmm_batch_penalty_vectors.argtypes = [pv] * 9
         lib.oct_phmm_server_set_error_model.argtypes = [pv, C.POINTER(abi.ErrorModel)]
+        lib.oct_phmm_custom_indel_model_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.oct_phmm_custom_indel_model_create.argtypes = [pv, C.c_uint32, C.c_int8, pv, C.c_uint32, C.c_int32, C.c_int8, C.POINTER(C.c_void_p)]
+        lib.oct_phmm_custom_indel_model_destroy.argtypes = [pv]; lib.oct_phmm_custom_indel_model_destroy.restype = None
+        lib.oct_phmm_custom_indel_model_info.argtypes = [pv, C.POINTER(C.c_int8), C.POINTER(C.c_int8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
+        lib.oct_phmm_custom_penalty_vectors.argtypes = [pv, C.POINTER(abi.ErrorModel), C.c_uint32] + [pv] * 10
+        lib.oct_phmm_set_custom_error_model.argtypes = [pv, pv, C.POINTER(abi.ErrorModel)]
+        lib.oct_phmm_server_set_custom_error_model.argtypes = [pv, pv, C.POINTER(abi.ErrorModel)]
         _LIBS[key] = lib
     return _LIBS[key]
 
@@ -218,6 +225,68 @@ def penalty_vectors(model: abi.ErrorModel, hap_bases: np.ndarray, hap_offsets: n
     code = lib.oct_phmm_penalty_vectors(C.byref(model), len(off) - 1, _ptr(bases), _ptr(off), _ptr(sub), _ptr(go), _ptr(ge), _ptr(mf), _ptr(pf), _ptr(mr), _ptr(pr), C.byref(st))
     if code != abi.OK:
         raise EngineError(code, st, "penalty_vectors")
+    return go[:n], ge[:n], mf[:n], pf[:n], mr[:n], pr[:n]
+
+
+class _MotifPenalties(C.Structure):
+    """oct_phmm_motif_penalties"""
+    _fields_ = [("motif", C.c_char_p), ("motif_len", C.c_uint32), ("penalties", C.POINTER(C.c_int8)), ("n_penalties", C.c_uint32)]
+
+
+class CustomIndelModel:
+    """oct_phmm_custom_indel_model: the reference's CustomRepeatBasedIndelErrorModel - from a model file's text (oct_phmm_custom_indel_model_parse; EngineError EINVAL where the
+    reference refuses the file) or from rows the caller holds (`open_rows` / `extend_rows`: {motif: penalties}; extend_rows None = no extension map)."""
+
+    def __init__(self, text=None, *, open_rows=None, extend_rows=None, default_open=0, default_extend=3, lib_path: Optional[Path] = None):
+        self.lib = load(lib_path)
+        self.ptr = C.c_void_p()
+        if text is not None:
+            raw = text.encode() if isinstance(text, str) else bytes(text)
+            code = self.lib.oct_phmm_custom_indel_model_parse(raw, len(raw), C.byref(self.ptr))
+        else:
+            keep = []
+
+            def rows(d):
+                arr = (_MotifPenalties * max(len(d), 1))()
+                for i, (motif, pen) in enumerate(d.items()):
+                    mb = motif.encode() if isinstance(motif, str) else bytes(motif)
+                    pa = np.ascontiguousarray(pen, dtype=np.int8); keep.extend([mb, pa])
+                    arr[i] = _MotifPenalties(mb, len(mb), pa.ctypes.data_as(C.POINTER(C.c_int8)), len(pa))
+                return arr, len(d)
+            oa, no = rows(open_rows or {})
+            ea, ne = rows(extend_rows or {})
+            code = self.lib.oct_phmm_custom_indel_model_create(oa, no, default_open, ea, ne, 0 if extend_rows is None else 1, default_extend, C.byref(self.ptr))
+        if code != abi.OK:
+            raise EngineError(code, None, "custom_indel_model")
+
+    def info(self):
+        do, de, no, ne, he = C.c_int8(), C.c_int8(), C.c_uint32(), C.c_uint32(), C.c_int32()
+        self.lib.oct_phmm_custom_indel_model_info(self.ptr, C.byref(do), C.byref(de), C.byref(no), C.byref(ne), C.byref(he))
+        return dict(default_open=do.value, default_extend=de.value, open_rows=no.value, extend_rows=ne.value, has_extend=bool(he.value))
+
+    def close(self):
+        if self.ptr:
+            self.lib.oct_phmm_custom_indel_model_destroy(self.ptr); self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def custom_penalty_vectors(indel: CustomIndelModel, snv: Optional[abi.ErrorModel], hap_bases: np.ndarray, hap_offsets: np.ndarray, substitution_mask=None):
+    """oct_phmm_custom_penalty_vectors (host entry, no device): gap vectors from the model file's rows, SNV vectors from `snv` (None: the default model, as the reference pairs them)."""
+    lib = indel.lib
+    bases = np.ascontiguousarray(hap_bases, dtype=np.uint8); off = np.ascontiguousarray(hap_offsets, dtype=np.uint32)
+    n = int(off[-1]) if len(off) else 0
+    go, ge, pf, pr = (np.zeros(max(n, 1), np.int8) for _ in range(4)); mf, mr = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+    sub = None if substitution_mask is None else np.ascontiguousarray(substitution_mask, dtype=np.uint8)
+    st = abi.Status()
+    code = lib.oct_phmm_custom_penalty_vectors(indel.ptr, None if snv is None else C.byref(snv), len(off) - 1, _ptr(bases), _ptr(off), _ptr(sub),
+                                               _ptr(go), _ptr(ge), _ptr(mf), _ptr(pf), _ptr(mr), _ptr(pr), C.byref(st))
+    if code != abi.OK:
+        raise EngineError(code, st, "custom_penalty_vectors")
     return go[:n], ge[:n], mf[:n], pf[:n], mr[:n], pr[:n]
 
 
@@ -382,6 +451,12 @@ class Engine:
         if code != abi.OK:
             raise EngineError(code, None, "set_error_model")
 
+    def set_custom_error_model(self, indel: "CustomIndelModel", snv: Optional[abi.ErrorModel] = None):
+        """oct_phmm_set_custom_error_model: NULL-vector batches get their gap vectors from a model file's rows (set_error_model takes it away again)."""
+        code = self.lib.oct_phmm_set_custom_error_model(self.handle, indel.ptr, None if snv is None else C.byref(snv))
+        if code != abi.OK:
+            raise EngineError(code, None, "set_custom_error_model")
+
     def probe_clock(self, window_ms: float = 5.0) -> float:
         """oct_phmm_probe_clock: shader clock (GHz) sustained over the window, beside whatever else runs on the device."""
         g = C.c_double(0)
@@ -476,6 +551,11 @@ class Server:
         code = self.lib.oct_phmm_server_set_error_model(self.ptr, None if model is None else C.byref(model))
         if code != abi.OK:
             raise EngineError(code, None, "server_set_error_model")
+
+    def set_custom_error_model(self, indel: "CustomIndelModel", snv: Optional[abi.ErrorModel] = None):
+        code = self.lib.oct_phmm_server_set_custom_error_model(self.ptr, indel.ptr, None if snv is None else C.byref(snv))
+        if code != abi.OK:
+            raise EngineError(code, None, "server_set_custom_error_model")
 
     def stats(self):
         a, b = C.c_uint64(0), C.c_uint64(0)

@@ -3,6 +3,7 @@
 // extern "C" bridge over the REFERENCE's own error-model classes, compiled in place from /root/reference/src/core/models/error:
 //   BasicRepeatBasedIndelErrorModel (basic_repeat_based_indel_error_model.cpp over repeat_based_indel_error_model.cpp)
 //   BasicRepeatBasedSNVErrorModel   (repeat_based_snv_error_model.cpp)
+//   CustomRepeatBasedIndelErrorModel + make_penalty_map (custom_repeat_based_indel_error_model.cpp): the model read from a file
 // with the reference's tandem library, on the stand-in Haplotype of oracle/ref_shim. Pins oracle/error_model_oracle.c.
 #include <cstdint>
 #include <cstring>
@@ -48,4 +49,25 @@ extern "C" void ref_sort_by_length(const uint32_t* lengths, uint32_t n, uint32_t
     for (uint32_t i = 0; i < n; ++i) v.emplace_back(i, lengths[i], i);
     std::sort(std::begin(v), std::end(v), [] (const auto& lhs, const auto& rhs) { return lhs.length < rhs.length; });
     for (uint32_t i = 0; i < n; ++i) out_ids[i] = v[i].period;
+}
+
+// The model `--sequence-error-model <file>` builds: make_penalty_map on the file's text, then the construction of make_error_model(path)
+// (error_model_factory.cpp:572-590: no open map -> MalformedErrorModelFile; two-map or one-map constructor), then set_penalties (vector overload).
+// Returns 0, 1 if the reference throws while reading the text, 2 for its MalformedErrorModelFile.
+#include <memory>
+#include "core/models/error/custom_repeat_based_indel_error_model.hpp"
+extern "C" int ref_custom_indel_penalties(const char* text, size_t len, const char* seq, uint32_t n, int8_t* gap_open, int8_t* gap_extend)
+{
+    try {
+        auto params = make_penalty_map(std::string(text, len));
+        if (!params.open) return 2;
+        std::unique_ptr<CustomRepeatBasedIndelErrorModel> model;
+        if (params.extend) model = std::make_unique<CustomRepeatBasedIndelErrorModel>(std::move(*params.open), std::move(*params.extend));
+        else model = std::make_unique<CustomRepeatBasedIndelErrorModel>(std::move(*params.open));
+        Haplotype h; h.sequence_.assign(seq, seq + n);
+        std::vector<std::int8_t> go, ge;
+        model->set_penalties(h, go, ge);
+        if (n) { std::memcpy(gap_open, go.data(), n); std::memcpy(gap_extend, ge.data(), n); }
+        return 0;
+    } catch (const std::exception&) { return 1; }
 }

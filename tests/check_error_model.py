@@ -191,3 +191,155 @@ def check_align_and_server_generate_the_vectors(backend, tol=0.0):
                 assert np.max(np.abs(go - wo), initial=0.0) <= tol
     srv.close()
     return len(reqs)
+
+
+# ---- the model read from a file: CustomRepeatBasedIndelErrorModel (oct_phmm_custom_indel_model_*) ------------------------------------------------------------------
+def ref_custom_indel(text: bytes, seq: bytes):
+    """The reference's own make_penalty_map + CustomRepeatBasedIndelErrorModel::set_penalties (oracle/ref_errmodel_bridge.cpp): (rc, gap_open, gap_extend)."""
+    import ctypes as C
+    n = len(seq)
+    go, ge = np.zeros(max(n, 1), np.int8), np.zeros(max(n, 1), np.int8)
+    f = oracle.ref().ref_custom_indel_penalties
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+    rc = f(text, len(text), seq, n, go.ctypes.data, ge.ctypes.data)
+    return rc, go[:n], ge[:n]
+
+
+MOTIFS = [b"A", b"C", b"G", b"T", b"N", b"AC", b"CA", b"CG", b"GC", b"AT", b"TA", b"NN", b"ACG", b"CAG", b"AAT", b"NNN", b"AAAC", b"ACGT", b"NNNN", b"ACGTA", b"AAAAC", b"NNNNN",
+          b"a", b"AN", b"ACGTAC", b"NNNNNNNNNN"]
+
+
+def random_model_text(rng, well_formed=True):
+    """A model file: open rows, maybe '+' rows, comments, blank lines, with or without the final newline; ill-formed ones carry one defect."""
+    lines = []
+    n_open = int(rng.integers(1, 9))
+    for m in rng.choice(len(MOTIFS), n_open, replace=bool(rng.random() < 0.2)):
+        lines.append(MOTIFS[int(m)] + b":" + b",".join(b"%d" % int(v) for v in rng.integers(0, 60, int(rng.integers(1, 24)))))
+    if rng.random() < 0.6:
+        for m in rng.choice(len(MOTIFS), int(rng.integers(1, 6)), replace=False):
+            lines.append(MOTIFS[int(m)] + b"+:" + b",".join(b"%d" % int(v) for v in rng.integers(0, 20, int(rng.integers(1, 12)))))
+    rng.shuffle(lines)
+    for _ in range(int(rng.integers(0, 3))):
+        lines.insert(int(rng.integers(0, len(lines) + 1)), b"# a comment: with, a colon" if rng.random() < 0.7 else b"")
+    text = b"\n".join(lines) + (b"\n" if rng.random() < 0.7 else b"")
+    if not well_formed:
+        defect = int(rng.integers(0, 8))
+        body = text.rstrip(b"\n")
+        text = [body + b"\nA:\n", body + b"\nAC:1,,2\n", body + b"\nA:1, 2\n", body.replace(b"\n", b"\r\n") + b"\r\n", body + b"\nC:x\n", body + b"\nG:128\n", body + b"\n:4,4\n",
+                body + b"\nACG"][defect]
+    return text
+
+
+FIXED_TEXTS = [(b"", False), (b"# nothing but a comment\n", False), (b"\n\n", False), (b":1,2\n", False), (b"A:\n", False), (b"A:", False), (b"A:1,,2\n", False), (b"A:1, 2\n", False),
+               (b"A:1\r\n", False), (b"A:x\n", False), (b"A:300\n", False), (b"A:-129\n", False), (b"A:-128,127\n", True), (b"+:1\n", False), (b"A+:1\n", False), (b"A", False),
+               (b"A:1,2", True), (b"A:1,\n", False), (b"A:1,", True), (b"A:+5,-3\n", True), (b"A:1\n\n\nC:2\n", True), (b"A\nB:1\n", True), (b"A:99999999999\n", False),
+               (b"A:2147483648\n", False), (b"A:+\n", False), (b"A:-\n", False), (b"A:1\nA:9\n", True), (b"N:7\nNN:6\nA+:2\nN+:1,1,4\n", True), (b"#c\nAC:5\n#d", True), (b"A:1\n#", True),
+               (b"A:007\n", True), (b"A: \n", False), (b"A:1.5\n", False)]
+
+
+def check_custom_model_file(lib_path=None, n_models=70, n_strings=24):
+    """Model files read by the product and by the reference's own make_penalty_map: the same texts accepted and refused; for the accepted ones gap-open and gap-extension
+    vectors equal CustomRepeatBasedIndelErrorModel's on corpus strings (motif rows, N rows, the iteration-order default), the four SNV vectors equal the default model's."""
+    rng = np.random.default_rng(2025)
+    seqs, subs, bases, off = corpus(5, n_strings)
+    seqs = list(seqs) + [b"", b"A", b"ACGT", b"ACGTTGCAAGTC"]                       # ... and strings without any repeat: the two defaults everywhere
+    bases = np.frombuffer(b"".join(seqs), np.uint8); off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint32)
+    snv_want = engine.penalty_vectors(engine.default_error_model(lib_path), bases, off, lib_path=lib_path)[2:]
+    texts = [(t, ok) for t, ok in FIXED_TEXTS] + [(random_model_text(rng, True), None) for _ in range(n_models)] + [(random_model_text(rng, False), None) for _ in range(n_models // 2)]
+    n_ok = n_bad = n_default_hits = 0
+    for text, expect_ok in texts:
+        rc_ref = ref_custom_indel(text, b"ACGT")[0]
+        try:
+            model = engine.CustomIndelModel(text, lib_path=lib_path)
+        except engine.EngineError as e:
+            assert e.code == abi.EINVAL and rc_ref != 0, (text, rc_ref)
+            assert expect_ok in (None, False), text
+            n_bad += 1
+            continue
+        assert rc_ref == 0, (text, rc_ref)
+        assert expect_ok in (None, True), text
+        got = engine.custom_penalty_vectors(model, None, bases, off)
+        info = model.info()
+        for i, seq in enumerate(seqs):
+            _, go, ge = ref_custom_indel(text, seq)
+            assert np.array_equal(got[0][off[i]:off[i + 1]], go), ("gap_open", text, seq)
+            assert np.array_equal(got[1][off[i]:off[i + 1]], ge), ("gap_extend", text, seq)
+            n_default_hits += int(np.count_nonzero(go == info["default_open"]))
+        for g, w in zip(got[2:], snv_want):
+            assert np.array_equal(g, w)
+        # the same model from rows + stated defaults (what a caller holding the reference's two maps passes)
+        open_rows, extend_rows = {}, None
+        for line in text.split(b"\n"):
+            if line and not line.startswith(b"#") and b":" in line and b"\n" not in line:
+                motif, row = line.split(b":", 1)
+                vals = [int(v) for v in row.split(b",") if v != b""]
+                if motif.endswith(b"+"):
+                    extend_rows = {} if extend_rows is None else extend_rows
+                    extend_rows.setdefault(motif[:-1], vals)
+                else:
+                    open_rows.setdefault(motif, vals)
+        if b"A\nB" not in text:
+            twin = engine.CustomIndelModel(open_rows=open_rows, extend_rows=extend_rows, default_open=info["default_open"], default_extend=info["default_extend"], lib_path=lib_path)
+            assert twin.info() == info, (text, twin.info(), info)
+            again = engine.custom_penalty_vectors(twin, None, bases, off)
+            assert all(np.array_equal(a, b) for a, b in zip(again, got)), text
+            twin.close()
+        model.close()
+        n_ok += 1
+    assert n_ok >= n_models and n_bad >= n_models // 2 and n_default_hits > 0
+    return n_ok, n_bad
+
+
+def check_custom_model_in_calls(backend, tol=0.0):
+    """oct_phmm_set_custom_error_model / oct_phmm_server_set_custom_error_model: NULL-vector calls get the file model's vectors (on host threads, whatever OCT_PHMM_PENALTIES says)."""
+    lib_path = build_sim() if backend == "sim" else None
+    rng = np.random.default_rng(404)
+    text = b"# test model\nA:40,38,30,22,14,9,5,3\nT:40,38,30,22,14,9,5,3\nN:45,40,33,25,16,11,6,4\nCG:44,40,30,20,10\nNN:46,42,36,28,20,12\nNNN:47,44,40,30\nN+:3,3,4,6\nNN+:3,4,5\n"
+    model = engine.CustomIndelModel(text, lib_path=lib_path)
+    g = synth.make_region(rng, 12, 5, T=50, Lh=170, B=8, flank=(20, 20), positions="none")
+    for h in g["haps"][1:4]:
+        a = int(rng.integers(30, 90)); h[a:a + 12] = ord("A"); h[a + 20:a + 36] = np.frombuffer(b"CG" * 8, np.uint8); h[a + 40:a + 52] = np.frombuffer(b"ACT" * 4, np.uint8)
+    batch = synth.batch_from_regions([g])
+    want_vec = engine.custom_penalty_vectors(model, None, batch.hap_bases, batch.hap_offsets)
+    basic_vec = engine.penalty_vectors(engine.default_error_model(lib_path), batch.hap_bases, batch.hap_offsets, lib_path=lib_path)
+    assert not np.array_equal(want_vec[0], basic_vec[0])                        # the file's rows, not the built-in tables
+    given = synth.batch_from_regions([g])
+    given.gap_open, given.gap_extend, given.snv_mask_fwd, given.snv_prior_fwd, given.snv_mask_rev, given.snv_prior_rev = want_vec
+    old = os.environ.get("OCT_PHMM_PENALTIES")
+    try:
+        for where in ("host", "device"):
+            os.environ["OCT_PHMM_PENALTIES"] = where
+            eng = make_engine(backend, max_indel_error=8)
+            want, _ = eng.populate(given)
+            eng.set_custom_error_model(model)
+            rb = eng.upload(batch.without_penalty_vectors())
+            for name, gvec, wvec in zip(NAMES, rb.penalty_vectors(), want_vec):
+                assert np.array_equal(gvec, wvec), (where, name)
+            rb.run(); got = rb.download().copy(); rb.free()
+            assert np.max(np.abs(got - want), initial=0.0) <= tol
+            eng.set_error_model(engine.default_error_model(lib_path))            # ... takes the file model away again
+            rb = eng.upload(batch.without_penalty_vectors())
+            assert np.array_equal(rb.penalty_vectors()[0], basic_vec[0]); rb.free()
+            eng.close()
+    finally:
+        if old is None:
+            os.environ.pop("OCT_PHMM_PENALTIES", None)
+        else:
+            os.environ["OCT_PHMM_PENALTIES"] = old
+    # a row with a negative penalty: the host entry hands it over, an upload refuses it like a caller's own vector
+    neg = engine.CustomIndelModel(b"A:-3\nN:5\n", lib_path=lib_path)
+    eng = make_engine(backend, max_indel_error=8)
+    eng.set_custom_error_model(neg)
+    _, st = eng.populate(batch.without_penalty_vectors(), raise_on_error=False)
+    assert st.code == abi.EINVAL
+    eng.close(); neg.close()
+    # the region server
+    srv = engine.Server(abi.Config.default(max_indel_error=8), lib_path=lib_path)
+    srv.set_custom_error_model(model)
+    model.close()                                                               # the server keeps its own reference
+    ref_eng = make_engine(backend, max_indel_error=8)
+    want, _ = ref_eng.populate(given); ref_eng.close()
+    got, st = srv.populate(batch.without_penalty_vectors(), raise_on_error=False)
+    assert st.code == abi.OK and np.max(np.abs(got - want), initial=0.0) <= tol
+    srv.close()
+    return got.size

@@ -26,3 +26,14 @@ def test_sim_align_and_server_generate_the_vectors():
 
 def test_sim_both_device_kernels_equal_the_host_entry_on_corpus_strings():
     assert ce.check_device_kernels_on_the_corpus("sim", 150) == 150
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="reference build absent")
+def test_model_files_are_read_and_applied_like_the_reference_custom_model():
+    """CustomRepeatBasedIndelErrorModel (`--sequence-error-model <file>`): 33 fixed texts + 105 random ones accepted / refused like make_penalty_map, vectors equal the reference class's."""
+    n_ok, n_bad = ce.check_custom_model_file(build_sim())
+    assert n_ok >= 80 and n_bad >= 50
+
+
+def test_sim_calls_generate_the_vectors_from_a_model_file():
+    assert ce.check_custom_model_in_calls("sim") > 0

@@ -397,6 +397,16 @@ def test_gpu_align_and_server_generate_the_penalty_vectors():
     assert ce.check_align_and_server_generate_the_vectors("gpu", TOL) >= 5
 
 
+def test_gpu_model_file_vectors_equal_the_reference_custom_model_and_feed_the_calls():
+    """CustomRepeatBasedIndelErrorModel (`--sequence-error-model <file>`) through the product library: files accepted / refused like the reference's reader, vectors equal its
+    class's; NULL-vector calls of a handle and of the region server run on them."""
+    require_reference_build(oracle.have_ref(), "oracle/_ref/libref_phmm.so")
+    import check_error_model as ce
+    n_ok, n_bad = ce.check_custom_model_file(None)
+    assert n_ok >= 80 and n_bad >= 50
+    assert ce.check_custom_model_in_calls("gpu", TOL) > 0
+
+
 def test_gpu_mapper_mismatch_account_feeds_the_fast_path():
     """k_kmer_map's account of the base mismatches along the mapped position (pair_mm) against the oracle and against the run without it."""
     assert len(cp.check_mapper_mismatch_account("gpu", TOL)) == 5
