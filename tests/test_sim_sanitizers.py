@@ -30,6 +30,8 @@ cp.check_shared_pairs("sim")                       # canonical windows, matcher,
 cp.check_launch_modes("sim")                       # device- and host-sized launches, forced scratch overflow, the multi-region forms (two DP launches, tiled scan, DMA copies)
 import check_error_model as ce
 ce.check_device_kernels_on_the_corpus("sim", 40)   # both penalty-vector kernels
+ce.check_custom_model_file(backends.build_sim(), n_models=30, n_strings=8)     # round 5: the model-file reader (malformed texts too) and its string-keyed look-ups
+ce.check_custom_model_in_calls("sim")
 import os
 os.environ["OCT_PHMM_LANE_MAPPER"] = "1"           # round 4: one lane per pair (probes, the pass over the hash rows, the wave's counting of undecided pairs), the mismatch account
 cp.check_device_kmer_mapper("sim"); cp.check_ragged_and_edges("sim"); cp.check_mapper_mismatch_account("sim")
