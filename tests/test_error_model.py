@@ -35,5 +35,11 @@ def test_model_files_are_read_and_applied_like_the_reference_custom_model():
     assert n_ok >= 80 and n_bad >= 50
 
 
+@pytest.mark.skipif(not oracle.have_ref(), reason="reference build absent")
+def test_edited_model_files_are_accepted_and_refused_like_the_reference_reader():
+    ok, bad = ce.check_custom_model_mutations(build_sim())
+    assert ok > 300 and bad > 800
+
+
 def test_sim_calls_generate_the_vectors_from_a_model_file():
     assert ce.check_custom_model_in_calls("sim") > 0
