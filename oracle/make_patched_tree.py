@@ -6,8 +6,9 @@ rules depend on.
 
 First seam (INTEGRATION.md section 2), HaplotypeLikelihoodArray::populate:
   core/models/haplotype_likelihood_array.cpp   src/core/models/haplotype_likelihood_array.cpp with the two populate() definitions (:51-103, :105-199)
-                                               cut out and replaced by #include "oracle/integration/populate_on_device.inc" (pack -> oct_phmm_populate -> scatter)
-  core/models/haplotype_likelihood_array.hpp   unchanged copy (so that its `#include "haplotype_likelihood_model.hpp"` finds the header below)
+                                               RENAMED populate_on_host (the fallback for regions the device path does not take) and followed by
+                                               #include "oracle/integration/populate_on_device.inc": the new populate() bodies (pack -> oct_phmm_populate -> scatter)
+  core/models/haplotype_likelihood_array.hpp   copy + the two populate_on_host declarations (and so that its `#include "haplotype_likelihood_model.hpp"` finds the header below)
 Second seam, src/core/tools/read_assigner.cpp:145-287:
   read_assigner_seam_ref.inc                   the reference's own functions estimate_max_indel_size* ... calculate_likelihoods(genotype, reads, model, workers),
                                                cut out of a copy of the file as they are
@@ -71,10 +72,21 @@ a0, a1 = function_span(cpp, "void HaplotypeLikelihoodArray::populate(const ReadM
 b0, b1 = function_span(cpp, "void HaplotypeLikelihoodArray::populate(const TemplateMap& reads", a1)
 assert a0 < a1 <= b0 < b1 and cpp[a1:b0].strip() == "", "the two populate definitions are expected to be adjacent"
 inc = (HERE / "integration" / "populate_on_device.inc").resolve()
-# the patch file carries its own `namespace octopus { ... }`: close the file's namespace around it
-patched = (cpp[:a0] + "} // namespace octopus\n\n#include \"" + str(inc) + "\"\n\nnamespace octopus {\n" + cpp[b1:])
+# The reference's own two bodies stay in the file under another name, populate_on_host: what the patched populate() falls back to for a region the device path
+# does not take (OCT_PHMM_EUNSUPPORTED: a read of 32 k bases, a 40 k-base haplotype) - the patched class must answer every call the unpatched one answers.
+# The patch file carries its own `namespace octopus { ... }`: close the file's namespace around it.
+HOST = "void HaplotypeLikelihoodArray::populate_on_host("
+own_bodies = cpp[a0:b1].replace("void HaplotypeLikelihoodArray::populate(", HOST)
+assert own_bodies.count(HOST) == 2
+patched = (cpp[:a0] + own_bodies + "\n\n} // namespace octopus\n\n#include \"" + str(inc) + "\"\n\nnamespace octopus {\n" + cpp[b1:])
 (dst / "haplotype_likelihood_array.cpp").write_text(patched)
-(dst / "haplotype_likelihood_array.hpp").write_text((src / "haplotype_likelihood_array.hpp").read_text())
+# ... and the header declares them (the two populate declarations once more, renamed, without their default arguments)
+ahpp = (src / "haplotype_likelihood_array.hpp").read_text()
+decls = list(re.finditer(r"\n    void populate\((const (?:ReadMap|TemplateMap)& reads,[^;]*?)\);", ahpp))
+assert len(decls) == 2, "the two populate declarations of haplotype_likelihood_array.hpp"
+extra = "".join("\n    void populate_on_host(" + re.sub(r"\s*=\s*boost::none", "", d.group(1)) + ");   // INTEGRATION patch: the reference's own body, the fallback" for d in decls)
+ahpp = ahpp[:decls[1].end()] + extra + ahpp[decls[1].end():]
+(dst / "haplotype_likelihood_array.hpp").write_text(ahpp)
 
 # ---- second seam
 asg = (ref / "src" / "core" / "tools" / "read_assigner.cpp").read_text()

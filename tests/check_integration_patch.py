@@ -55,4 +55,31 @@ def check(backend, tol=0.0):
     a = oracle.ref_array_exercise(cfg, batch, rows, [0], 1, lib="sse2")
     b = oracle.ref_array_exercise(cfg, batch, rows, [0], 1, lib=lib)
     assert a[0] == 1 and b[0] == 1 and a[3:] == b[3:], (a[0], b[0], a[3:], b[3:])
+    n += check_unsupported_regions_fall_back(lib)
+    return n
+
+
+def check_unsupported_regions_fall_back(lib):
+    """A region the device path refuses (OCT_PHMM_EUNSUPPORTED: a read with T + 2 B >= 32,768) is answered by the reference's own body, kept in the patched class as
+    populate_on_host: the patched class answers every call the unpatched one answers - same matrix, same read-backs; and the next region runs on the device again."""
+    rng = np.random.default_rng(77)
+    n = 0
+    for tmpl in (False, True):
+        g = synth.make_region(rng, 4, 2, T=32760, Lh=33100, B=8, flank=(30, 30), positions="none")
+        batch = synth.batch_from_regions([g])
+        cfg = abi.Config.default(max_indel_error=8)
+        from backends import make_engine
+        eng = make_engine(lib.split("_")[1], max_indel_error=8)                 # the product itself refuses this batch: that is what the patch falls back from
+        _, st = eng.populate(batch, raise_on_error=False)
+        eng.close()
+        assert st.code == abi.EUNSUPPORTED, st.code
+        rows = np.asarray([0, 2, 4], np.uint32) if not tmpl else np.asarray([0, 1, 2], np.uint32)
+        if tmpl:
+            batch.row_offsets = np.asarray([0, 2, 4], np.uint32)
+        a = oracle.ref_array_exercise(cfg, batch, rows, [1], 1, lib="sse2")
+        b = oracle.ref_array_exercise(cfg, batch, rows, [1], 1, lib=lib)
+        assert a[0] == 0 and b[0] == 0, (a[0], b[0])
+        used = ~np.isnan(a[1])
+        assert np.array_equal(used, ~np.isnan(b[1])) and np.array_equal(a[1][used], b[1][used]) and np.array_equal(a[2], b[2])     # the SAME code ran: equal to the last bit
+        n += int(used.sum())
     return n
