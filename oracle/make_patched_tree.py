@@ -12,8 +12,8 @@ First seam (INTEGRATION.md section 2), HaplotypeLikelihoodArray::populate:
 Second seam, src/core/tools/read_assigner.cpp:145-287:
   read_assigner_seam_ref.inc                   the reference's own functions estimate_max_indel_size* ... calculate_likelihoods(genotype, reads, model, workers),
                                                cut out of a copy of the file as they are
-  read_assigner_seam_patched.inc               the same helpers, with the LAST function (:251-287) replaced by
-                                               #include "oracle/integration/read_assigner_on_device.inc" (expand -> reset -> pack -> ONE oct_phmm_populate)
+  read_assigner_seam_patched.inc               the same helpers, with the LAST function (:251-287) renamed calculate_likelihoods_on_host (the fallback) and followed by
+                                               #include "oracle/integration/read_assigner_on_device.inc" (the new last function: expand -> reset -> pack -> ONE oct_phmm_populate)
 Third seam, src/core/tools/read_realigner.cpp:83-155:
   read_realigner_seam_ref.inc                  the reference's own compute_read_hashes, the two realign(read, haplotype, ...) helpers and
                                                realign(reads, haplotype, model, log_likelihoods, workers), cut out of a copy of the file as they are
@@ -96,7 +96,10 @@ last0, last1 = function_span(asg, sig, first)
 assert first < last0 < last1
 (out / "read_assigner_seam_ref.inc").write_text(asg[first:last1] + "\n")
 asg_inc = (HERE / "integration" / "read_assigner_on_device.inc").resolve()
-(out / "read_assigner_seam_patched.inc").write_text(asg[first:last0] + '#include "' + str(asg_inc) + '"\n')
+# (the reference's own last function stays, renamed calculate_likelihoods_on_host: the fallback for a genotype / read set the device path refuses, OCT_PHMM_EUNSUPPORTED)
+own_last = asg[last0:last1].replace("auto calculate_likelihoods(const Genotype<Haplotype>& genotype,", "auto calculate_likelihoods_on_host(const Genotype<Haplotype>& genotype,")
+assert own_last != asg[last0:last1]
+(out / "read_assigner_seam_patched.inc").write_text(asg[first:last0] + own_last + '\n\n#include "' + str(asg_inc) + '"\n')
 
 # ---- third seam: src/core/tools/read_realigner.cpp:83-155
 rea = (ref / "src" / "core" / "tools" / "read_realigner.cpp").read_text()
