@@ -75,6 +75,9 @@ assert batches < calls
 check_server.check_server("sim", n_threads=4, per_thread=5, seed=23, devices=[0, 0])               # ... and two "devices" with two workers each
 check_server.check_server_rejects_malformed_calls("sim")
 check_server.check_server_contract_violation_reaches_only_its_caller("sim")
+import check_error_model as ce
+ce.check_align_and_server_generate_the_vectors("sim")            # error models installed while callers are being served (the workers pick them up between batches)
+ce.check_custom_model_in_calls("sim")                            # ... and a model read from a file, shared by reference between the server's handles
 print("TSAN-OK")
 """
 
