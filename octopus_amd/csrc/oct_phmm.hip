@@ -45,7 +45,8 @@ struct DevPool {
     static std::atomic<size_t>& device_cached(int dev) { static std::atomic<size_t> c[64]; return c[(unsigned)dev & 63u]; }
     static std::mutex& registry_mu() { static std::mutex m; return m; }
     static std::vector<DevPool*>& registry() { static std::vector<DevPool*> r; return r; }
-    int device = 0;
+    int device = 0;                                      // written once, under registry_mu (set_device), before the handle's first allocation; trim_device reads it under the same lock
+    void set_device(int dev) { std::lock_guard<std::mutex> lk(registry_mu()); device = dev; }
     static constexpr size_t kDeviceCacheCap = (size_t)128 << 30;
     static constexpr size_t kCacheCap = (size_t)64 << 30;       // (288 GB of HBM: a handle that streams 6,250-region batches - 20 GB resident each - paid a 20 GB hipMalloc + hipFree, 0.4 s, per call with the cap at 16 GB)
     DevPool() { std::lock_guard<std::mutex> lk(registry_mu()); registry().push_back(this); }
@@ -1133,7 +1134,7 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     std::unique_ptr<oct_phmm_handle> h(new (std::nothrow) oct_phmm_handle());
     if (!h) return OCT_PHMM_EHIP;
     h->cfg = *cfg; h->band = band; h->wide = cfg->use_int_scores != 0; h->lanes_c = band > 64 ? band / 64 : 1;
-    h->pool.device = cfg->device_id;
+    h->pool.set_device(cfg->device_id);
     if (h->cfg.mapping_quality_cap_trigger >= 0 && h->cfg.mapping_quality_cap_trigger >= h->cfg.mapping_quality_cap)
         h->cfg.mapping_quality_cap_trigger = -1;                                     // model.cpp:50-52
     h->timing = tune::timing();
@@ -1429,7 +1430,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     pk.upload(reg_lhs.data(), reg_lhs.size(), &d.reg_lhs);
     pk.upload(reg_rhs.data(), reg_rhs.size(), &d.reg_rhs);
     pk.dalloc(&d.pos, (size_t)b->n_pairs * S + 1); pk.dalloc(&d.npos, (size_t)b->n_pairs + 1);
-    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr; d.hhash = nullptr; d.map_count_only = 0; d.map_stats = 0; d.pair_mm = nullptr; d.rhash_rows = nullptr; d.rhash_stride = 0;
+    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr; d.hhash = nullptr; d.map_count_only = 0; d.map_stats = 0; d.pair_mm = nullptr; d.rhash_rows = nullptr; d.rhash_stride = 0; d.rcode = nullptr; d.rcode_words = 0;
     if (!positions) {
         if (b->map_big) pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1);      // the u16 table of k_kmer_map_big only
         pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
@@ -1443,7 +1444,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         {
             long long want = -1; tune::number("OCT_PHMM_LANE_MAPPER", &want);
             const uint32_t nq_cap = b->t_cap >= kKmer ? b->t_cap - kKmer + 1 : 0;
-            const bool can = !b->map_big && nq_cap >= 1 && nq_cap <= kLaneMapMaxKmers && kmer_map_lds_bytes(b->lh_cap) <= rt::kMaxLdsBytes;
+            const bool can = !b->map_big && nq_cap >= 1 && nq_cap <= kLaneMapMaxKmers && kmer_map_lanes_lds_bytes(b->lh_cap) <= rt::kMaxLdsBytes;
             if (can && (want >= 0 ? want != 0 : b->n_pairs >= kLaneMapMinPairs)) b->map_lanes = (int)kLaneMapThreads;
         }
         if (!b->map_lanes) pk.dalloc(&d.rhash, (size_t)n_read_bases + 1);        // (the lane mapper reads rhash_rows instead)
@@ -1451,6 +1452,8 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
             b->map_reads_per_block = (uint32_t)b->map_lanes;
             d.rhash_stride = rhash_row_stride(b->t_cap);
             pk.dalloc(&d.rhash_rows, (size_t)R->n_reads * d.rhash_stride + 64);
+            d.rcode_words = rcode_row_words(b->t_cap);                                  // the reads' 2-bit codes in tiles of 64 reads (the bit-parallel pass)
+            pk.dalloc(&d.rcode, (size_t)((R->n_reads + 63) / 64) * d.rcode_words * 64 + 64);
             if (tune::map_mismatches()) pk.dalloc(&d.pair_mm, (size_t)b->n_pairs + 2);   // k_kmer_map_lanes tells k_classify what it saw along the mapped position
         }
         std::vector<uint32_t> blk_hap, blk_read0;           // one k_kmer_map workgroup per (haplotype, read chunk of its region)
@@ -1506,11 +1509,23 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         pk.dalloc(&b->d_totals, (size_t)n_slices);
         if (b->late_ok) pk.dalloc(&b->d_totals_late, (size_t)n_slices);
         b->slices.reserve((size_t)n_slices);                   // the packer keeps addresses of the slices' pointers
-        uint32_t hap = 0;
+        // Slice sizes ramp up and down (round 6; profiles/r06_s03_slice_overlap.txt): nothing of a step's DP can start before the FIRST slice's mapper, classifier, scan and the
+        // host's read of its task counts are through (1.3 ms of the 29 ms step with eight equal slices), and behind the LAST slice's DP launches its walks run with nothing beside
+        // them. A small first slice starts the DP early, every later slice's front end hides behind the DP of the one before it (DP time is ~3 x front-end time, so a slice may be
+        // up to ~3 x its predecessor), a small last slice leaves a short tail.
+        static const uint32_t kRamp[oct_phmm_handle::kMaxSlices] = {1, 2, 4, 8, 8, 5, 3, 1};
+        uint32_t weight[oct_phmm_handle::kMaxSlices]; uint64_t weight_sum = 0;
+        for (int i = 0; i < n_slices; ++i) weight[i] = n_slices == oct_phmm_handle::kMaxSlices ? kRamp[i] : 1u;
+        if (const char* e = tune::get("OCT_PHMM_SLICE_RAMP")) {     // A/B: comma-separated weights, e.g. "1,1,1,1,1,1,1,1" = equal slices
+            int i = 0; for (const char* q = e; *q && i < n_slices; ++i) { weight[i] = (uint32_t)std::max(1l, strtol(q, (char**)&q, 10)); if (*q == ',') ++q; }
+        }
+        for (int i = 0; i < n_slices; ++i) weight_sum += weight[i];
+        uint32_t hap = 0; uint64_t weight_run = 0;
         for (int i = 0; i < n_slices; ++i) {
             oct_phmm_batch::Slice sl;
             sl.hap0 = hap;
-            const uint64_t target = b->n_pairs * (uint64_t)(i + 1) / (uint64_t)n_slices;
+            weight_run += weight[i];
+            const uint64_t target = (uint64_t)((unsigned __int128)b->n_pairs * weight_run / weight_sum);
             while (hap < H->n_haps && (i == n_slices - 1 || hap_pair_off[hap + 1] <= target || hap == sl.hap0)) ++hap;
             if (i == n_slices - 1) hap = H->n_haps;
             sl.hap1 = hap;
@@ -1815,7 +1830,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_big, lds));
                 OCT_LAUNCH(k_kmer_map_big, (uint32_t)np, 256, lds, s, d, sl.pair0); RT(rt::launch_ok());
             } else if (sl.blk1 > sl.blk0 && b->map_lanes) {
-                const size_t lds = kmer_map_lds_bytes(b->lh_cap);
+                const size_t lds = kmer_map_lanes_lds_bytes(b->lh_cap);
                 if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_lanes, lds));
                 OCT_LAUNCH(k_kmer_map_lanes, sl.blk1 - sl.blk0, kLaneMapThreads, lds, s, d, (const uint32_t*)b->d_blk_hap + sl.blk0, (const uint32_t*)b->d_blk_read0 + sl.blk0, b->lh_cap);
                 RT(rt::launch_ok());
@@ -1849,7 +1864,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         }
         if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one
         if (sl.scan_fused) {                                  // any size: tile prefixes, haplotype bases and totals of both count arrays in ONE single-workgroup launch
-            OCT_LAUNCH(k_scan_finish, 1, kHapBaseThreads, 16 * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, (const uint4*)sl.cnt_late, sl.pair0, pair_blocks,
+            OCT_LAUNCH(k_scan_finish, sl.cnt_late ? 2 : 1, kHapBaseThreads, 16 * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, (const uint4*)sl.cnt_late, sl.pair0, pair_blocks,
                        sl.tile_sums, sl.tile_sums_late, b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G); RT(rt::launch_ok());
             sl.totals_late = make_uint4(0, 0, 0, 0);
             if (!b->dsl) { RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s)); if (sl.cnt_late) RT(rt::d2h(&sl.totals_late, sl.d_totals_late, sizeof(uint4), s)); }
@@ -2573,6 +2588,10 @@ struct oct_phmm_server {
                         const size_t want = std::max<size_t>(1, std::min<size_t>(max_regions, last_batch));
                         while (!stop && queue.size() < want && flying() > 0)
                             cv_work.wait_for(lk, std::chrono::microseconds(50), [&] { return stop || queue.size() >= want; });
+                    } else {
+                        // OCT_PHMM_SERVER_GATHER=0 (the A/B setting): take whatever has arrived - but sleep while nothing has, instead of spinning on mu and W.m until the batch lands
+                        while (!stop && queue.empty() && flying() > 0)
+                            cv_work.wait_for(lk, std::chrono::microseconds(50), [&] { return stop || !queue.empty(); });
                     }
                     if (profile) ns_idle += now_ns() - t_idle;
                     if (queue.empty() && stop) { lk.unlock(); wait_all_landed(); return; }
@@ -2667,7 +2686,10 @@ extern "C" int oct_phmm_server_create_multi(const oct_phmm_config* cfg, const in
             // hipMalloc in the middle of a run stalled every caller for up to a second, once per worker and growth step
             { long long gb = 4; tune::number("OCT_PHMM_SERVER_BP_BUDGET_GB", &gb); if (gb >= 1) h->bp_budget = std::min<size_t>(h->bp_budget, (size_t)gb << 30); }
 #if !defined(OCTPHMM_SIM)
-            (void)ensure_bp(h, 0, h->bp_budget);            // (all of it: device-sized batches provision two traceback tasks per pair, and a worker's biggest batch comes late in a run)
+            // (all of it: device-sized batches provision two traceback tasks per pair, and a worker's biggest batch comes late in a run. A device that other processes - or this
+            // process's own per-thread handles - have filled gives what it has: the budget is halved until the reservation succeeds, and the handle then lives within that, its
+            // bigger batches running their traceback lists in chunks, instead of failing or trimming its neighbours' caches at the first big call)
+            while (!ensure_bp(h, 0, h->bp_budget) && h->bp_budget > ((size_t)256 << 20)) h->bp_budget >>= 1;
 #endif
             s->hs.push_back(h); if (w % oct_phmm_server::kSlots == 0) s->device_of.push_back((int)dv);
         }
@@ -2739,7 +2761,7 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
         std::lock_guard<std::mutex> lk(s->mu);
         if (s->stop) return fail(status, OCT_PHMM_EINVAL, "server is shutting down");
         s->queue.push_back(&q);
-        s->cv_work.notify_one();
+        s->cv_work.notify_all();                                // (all: one notification could land on a gatherer whose predicate is "as many calls as my last batch" and be lost on it while an idle worker - of another GPU, say - sleeps on)
     }
     { std::unique_lock<std::mutex> lk(q.m); q.cv.wait(lk, [&] { return q.done; }); }      // (the call's own lock: a batch's callers do not queue for the server's to return)
     if (status) *status = q.st;

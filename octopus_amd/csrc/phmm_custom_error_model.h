@@ -10,7 +10,8 @@
 //     the last entry for longer repeats); a motif that ends in '+' (the '+' is dropped) gives gap-EXTENSION penalties instead;
 //   * the motif is whatever stands between the line's start and the NEXT ':' of the file (not of the line); a line that starts with ':' , a motif
 //     that is only "+", a missing ':' before the end of the file, a row without numbers, and any entry that is not [+-]?digits (a blank, a '\r',
-//     an empty entry after a trailing comma) or does not fit int8 refuse the whole file;
+//     an empty entry - a trailing comma FOLLOWED BY A NEWLINE, or two commas; a row whose last character, at the very end of the file, is a comma parses like the reference's
+//     make_penalty_map, which stops at the end of input before it asks for another entry: "A:1," is read, "A:1,\n" is refused) or does not fit int8 refuse the whole file;
 //   * the first row of a motif wins (unordered_map::emplace);
 //   * a file without any open row is malformed (MalformedErrorModelFile, error_model_factory.cpp:577-579).
 // Look-ups (:68-103): the repeat's own motif as it stands at the repeat's start; else the row of min(period, 10) letters 'N'; else the default:

@@ -13,6 +13,7 @@ constexpr int      kBlockWaves = 4;            // waves per DP workgroup
 constexpr int      kGroupsPerWave = 4;         // task groups each wave works through per workgroup
 constexpr uint32_t kStatSlots  = 256;          // statistics counters are striped over this many lines
 constexpr uint32_t kStatStride = 16;           // counters per stripe (128 bytes)
+constexpr uint32_t kScanMeetSlot = 12;         // stripe 0, a counter no statistic uses: where k_scan_finish's two workgroups add up their traceback totals
 constexpr uint32_t kNoPair     = 0xffffffffu;  // DevBatch::pair_rep of a pair that is computed itself
 constexpr uint32_t kDedupReps  = 48;           // distinct pairs a read remembers per haplotype segment (k_dedup_match)
 
@@ -67,6 +68,10 @@ struct DevBatch {
     int map_count_only;                               // test / A-B switch: every pair takes the counting path
     int map_stats;                                    // OCT_PHMM_MAP_STATS: count the pairs the shortcut decides (diagnostics)
     uint16_t* rhash_rows; uint32_t rhash_stride;     // k_kmer_map_lanes: the same hashes as rhash in one 16-byte aligned row per read, 4096 behind a read's last k-mer; null when unused
+    // k_kmer_map_lanes' bit-parallel pass: every read's bases as 2-bit kmer_code()s, 16 per dword (base i of a dword in bits 2i, 2i + 1: twelve consecutive bits ARE a 6-mer hash),
+    // transposed in tiles of 64 reads - dword j of read r at rcode[((r >> 6) * rcode_words + j) * 64 + (r & 63)], so that a wave's 64 reads load one dword each from 256
+    // consecutive bytes; zero behind a read's last base. Null when unused.
+    uint32_t* rcode; uint32_t rcode_words;
     uint16_t* bin_start; uint16_t* bin_idx; uint16_t* rhash;   // rhash[roff[r] + q]: 6-mer hash of read r at q (written by the trailing workgroups of k_kmer_tables)
     // per pair
     uint64_t  n_pairs;

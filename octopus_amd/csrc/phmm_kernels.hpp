@@ -127,6 +127,10 @@ OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks, ui
 constexpr uint32_t kKmer = 6, kKmerBins = 4096;                 // mapperKmerSize (haplotype_likelihood_array.hpp:103), num_kmers(6)
 
 OCT_DEVICE uint32_t kmer_code(uint32_t c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }   // perfect_hash :25-39 (everything else 0)
+OCT_DEVICE uint32_t spread16(uint32_t x)                       // bit i of the low 16 -> bit 2i
+{
+    x = (x | x << 8) & 0x00ff00ffu; x = (x | x << 4) & 0x0f0f0f0fu; x = (x | x << 2) & 0x33333333u; return (x | x << 1) & 0x55555555u;
+}
 OCT_DEVICE uint32_t kmer_hash6(const uint8_t* s)               // perfect_kmer_hash<6> :43-53: sum of 4^j * code(base j)
 {
     uint32_t h = 0;
@@ -147,6 +151,15 @@ OCT_DEVICE void read_hash_wave(const DevBatch& b, uint32_t r, uint32_t lane)   /
         const uint32_t nq = T >= kKmer ? T - kKmer + 1 : 0;
         uint16_t* row = b.rhash_rows + (size_t)r * b.rhash_stride;
         for (uint32_t q = lane; q < b.rhash_stride; q += 64) row[q] = q < nq ? (uint16_t)kmer_hash6(b.rbases + ro + q) : (uint16_t)kKmerBins;
+    }
+    if (b.rcode) {      // the read's 2-bit codes, 16 per dword (DevBatch::rcode): 64 bases per round, two ballots, lanes 0-3 store a dword each
+        uint32_t* tile = b.rcode + ((size_t)(r >> 6) * b.rcode_words) * 64 + (r & 63u);
+        for (uint32_t t0 = 0; t0 < b.rcode_words * 16; t0 += 64) {
+            const uint32_t t = t0 + lane, c = t < T ? kmer_code(b.rbases[ro + t]) : 0u;
+            const uint64_t b0 = hw::ballot((c & 1u) != 0), b1 = hw::ballot((c & 2u) != 0);
+            const uint32_t j = (t0 >> 4) + lane;
+            if (lane < 4 && j < b.rcode_words) tile[(size_t)j * 64] = spread16((uint32_t)(b0 >> (16 * lane)) & 0xffffu) | spread16((uint32_t)(b1 >> (16 * lane)) & 0xffffu) << 1;
+        }
     }
 }
 
@@ -428,18 +441,31 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
 // The pairs a lane cannot decide (a few percent: both probes miss, repeats, near-even indel splits) are counted afterwards by the whole wave, one after the
 // other (kmer_count_votes_wave). Same votes, same output: tests/check_populate.py::assert_device_positions.
 constexpr uint32_t kLaneMapThreads = 256;
-// entries per row of DevBatch::rhash_rows: the kernel's loop takes three 16-byte chunks (24 k-mers) per trip and has the next trip's first chunk in flight
+// entries per row of DevBatch::rhash_rows (the probes and the counting path read them; 16-byte chunks of eight hashes)
 OCT_HD uint32_t rhash_row_stride(uint32_t t_cap) { const uint32_t nq = t_cap >= kKmer ? t_cap - kKmer + 1 : 0; return 8u * (3u * (((nq + 7) / 8 + 2) / 3) + 1u); }
-constexpr uint32_t kLaneMapMaxKmers = 496;       // lane form up to here (500-base chunks of long reads: 495 k-mers): q < 504 in the last trip, so q + d stays inside the kMapPad sentinels
+constexpr uint32_t kLaneMapMaxKmers = 496;       // lane form up to here (500-base chunks of long reads: 495 k-mers)
+// dwords per read of DevBatch::rcode: the pass takes 16 k-mers (one dword of codes and the next one's first five bases) per step and has the step after in flight
+OCT_HD uint32_t rcode_row_words(uint32_t t_cap) { const uint32_t nq = t_cap >= kKmer ? t_cap - kKmer + 1 : 0; return (nq + 15) / 16 + 3; }
+// dwords of the haplotype's packed codes / its repeated-k-mer bits in LDS: a diagonal's words start anywhere below nk / 16 and run on for a read's steps + 2
+OCT_HD uint32_t lane_map_hap_words(uint32_t lh_cap) { return lh_cap / 16 + (kLaneMapMaxKmers + 15) / 16 + 8; }
+inline uint32_t kmer_map_lanes_lds_bytes(uint32_t lh_cap)
+{
+    return (kKmerBins + 2) * 2 + ((lh_cap + 1) & ~1u) * 2 + kKmerBins + 4 + 2 * lane_map_hap_words(lh_cap) * 4 + kBlockWaves * (lh_cap + 64) * 4;
+}
+
+// bits 2i, i < n (n clamped to 0 ... 16): the k-mers (or bases) of one 16-entry step that lie before a limit
+OCT_DEVICE uint32_t low_pairs_mask(int32_t n) { n = n < 0 ? 0 : n > 16 ? 16 : n; return n ? 0x55555555u >> (32 - 2 * n) : 0u; }
+OCT_DEVICE uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }   // v_alignbit_b32, sh < 32
 
 OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_read0, uint32_t lh_cap)
 {
     OCT_DYN_SMEM(smem);
     uint16_t* bins = (uint16_t*)smem;                                  // [4097]
     uint16_t* idx = bins + kKmerBins + 2;                              // [lh_cap rounded to even]
-    uint16_t* hh = idx + ((lh_cap + 1) & ~1u);                         // [lh_cap rounded to even + kMapPad] the haplotype's hash at every position, then 0xffff
-    uint8_t* occ = (uint8_t*)(hh + ((lh_cap + 1) & ~1u) + kMapPad);    // [4096 + 1] bin occupancy capped at 255; entry 4096 = 0
-    uint32_t* counts_all = (uint32_t*)(occ + kKmerBins + 4);           // [waves][lh_cap + 64] (the counting path of undecided pairs)
+    uint8_t* occ = (uint8_t*)(idx + ((lh_cap + 1) & ~1u));             // [4096 + 1] bin occupancy capped at 255; entry 4096 = 0
+    uint32_t* hc = (uint32_t*)(occ + kKmerBins + 4);                   // [lane_map_hap_words] the haplotype's 2-bit codes, 16 per dword, zero behind its last base
+    uint32_t* mu = hc + lane_map_hap_words(lh_cap);                    // [lane_map_hap_words] bit 2(p & 15) of word p / 16: the k-mer at haplotype position p occurs more than once in the haplotype
+    uint32_t* counts_all = mu + lane_map_hap_words(lh_cap);            // [waves][lh_cap + 64] (the counting path of undecided pairs)
     const uint32_t tid = hw::thread_idx(), lane = tid & 63;
     const uint32_t wave = hw::readfirstlane(tid >> 6);
     const uint32_t h = blk_hap[hw::block_idx()], r_first = blk_read0[hw::block_idx()];
@@ -456,34 +482,47 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
         }
         if (tid == 0) { bins[kKmerBins] = (uint16_t)nk; *(uint32_t*)(occ + kKmerBins) = 0; }
     }
-    for (uint32_t i = tid; i < nk; i += kLaneMapThreads) { idx[i] = b.bin_idx[ho + i]; hh[i] = b.hhash[ho + i]; }
-    for (uint32_t i = nk + tid; i < ((lh_cap + 1) & ~1u) + kMapPad; i += kLaneMapThreads) hh[i] = 0xffffu;   // no read hash equals it
+    for (uint32_t i = tid; i < nk; i += kLaneMapThreads) idx[i] = b.bin_idx[ho + i];
+    const uint32_t hap_words = lane_map_hap_words(lh_cap);
+    // the haplotype's codes: 64 bases per wave and round, two ballots, lanes 0-3 store a dword each
+    for (uint32_t p0 = wave * 64; p0 < hap_words * 16; p0 += kLaneMapThreads) {
+        const uint32_t p = p0 + lane, c = p < Lh ? kmer_code(b.hbases[ho + p]) : 0u;
+        const uint64_t b0 = hw::ballot((c & 1u) != 0), b1 = hw::ballot((c & 2u) != 0);
+        if (lane < 4) hc[(p0 >> 4) + lane] = spread16((uint32_t)(b0 >> (16 * lane)) & 0xffffu) | spread16((uint32_t)(b1 >> (16 * lane)) & 0xffffu) << 1;
+    }
     uint32_t* counts = counts_all + wave * (lh_cap + 64);
     for (uint32_t d = lane; d < nk + 64; d += 64) counts[d] = 0;
+    hw::block_sync();
+    for (uint32_t p0 = wave * 64; p0 < hap_words * 16; p0 += kLaneMapThreads) {       // (after the barrier: occ is complete)
+        const uint32_t p = p0 + lane;
+        const uint64_t m = hw::ballot(p < nk && occ[b.hhash[ho + (p < nk ? p : 0)]] >= 2);
+        if (lane < 4) mu[(p0 >> 4) + lane] = spread16((uint32_t)(m >> (16 * lane)) & 0xffffu);
+    }
     hw::block_sync();
     const uint32_t max_pos = (uint32_t)b.max_pos, none = 0xffffffffu;
     const uint32_t r = r_first + tid;
     const bool live = r < reg_r1;
     const uint64_t e = b.hap_pair_off[h] + (uint64_t)((live ? r : reg_r0) - reg_r0);
-    uint32_t nq = 0;
-    if (live) { const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro; nq = T >= kKmer ? T - kKmer + 1 : 0; }
+    uint32_t nq = 0, T = 0;
+    if (live) { const uint32_t ro = b.roff[r]; T = b.roff[r + 1] - ro; nq = T >= kKmer ? T - kKmer + 1 : 0; }
     const bool eligible = live && nq > 0 && nq <= kLaneMapMaxKmers && !b.map_count_only;
-    const uint4* row = (const uint4*)(b.rhash_rows + (size_t)(live ? r : reg_r0) * b.rhash_stride);
-    auto hash_of = [](const uint4& v, int j) -> uint32_t { const uint32_t w = j < 2 ? v.x : j < 4 ? v.y : j < 6 ? v.z : v.w; return (j & 1) ? w >> 16 : w & 0xffffu; };
+    const uint32_t rr = live ? r : reg_r0;
+    const uint32_t* rc = b.rcode + ((size_t)(rr >> 6) * b.rcode_words) * 64 + (rr & 63u);     // this lane's column of its 64-read tile: dword j at rc[j * 64]
     // Three probes - the read's first, its middle and its last k-mer that occur exactly ONCE in the haplotype (a k-mer of a homopolymer or repeat names the
     // diagonal of its first copy, mostly the wrong one), each naming the diagonal of its bin's one entry - give the two candidates. A diagonal can only beat the bound below with more than half of the read's k-mers on it, and such a stretch of the read holds the middle
     // k-mer: dA = the middle probe's diagonal (a read whose two ends lie across two indels from each other is decided by it), dB = the first probe's where that
-    // differs, else the last one's (a read split by one indel: both of its diagonals, as k_kmer_map's first attempt takes them). Eight k-mers per step (one
-    // 16-byte load), until every lane of the wave has found its own: mostly one step per probe (a read's tail is where its errors sit).
+    // differs, else the last one's (a read split by one indel: both of its diagonals, as k_kmer_map's first attempt takes them). Eight k-mers per step (the 26 bits
+    // behind base 8c of the read's codes: two coalesced dword loads and a funnel shift), until every lane of the wave has found its own: mostly one step per probe (a read's tail is where its errors sit).
     uint32_t dA = none, dB = none;
     {
         const uint32_t nq_e = eligible ? nq : 0u;
-        auto scan_up = [&](uint32_t c0, uint32_t& q_found, uint32_t& h_found) {                   // the first k-mer from chunk c0 on that occurs in the haplotype
+        auto chunk_bits = [&](uint32_t c) -> uint32_t { return funnel(rc[(size_t)((c >> 1) + 1) * 64], rc[(size_t)(c >> 1) * 64], (c & 1u) * 16u); };   // bases 8c ... 8c + 15
+        auto scan_up = [&](uint32_t c0, uint32_t& q_found, uint32_t& h_found) {                   // the first k-mer from chunk c0 on that occurs once in the haplotype
             for (uint32_t c = c0; hw::ballot(q_found == none && c * 8 < nq_e) != 0; ++c) {
-                const uint4 v = row[c];
+                const uint32_t v = chunk_bits(c);
                 uint32_t qj = none, hj = 0;
 #pragma unroll
-                for (int j = 7; j >= 0; --j) { const uint32_t hq = hash_of(v, j); if (occ[hq] == 1) { qj = c * 8 + (uint32_t)j; hj = hq; } }   // (behind the read: 4096, occupancy 0)
+                for (int j = 7; j >= 0; --j) { const uint32_t q = c * 8 + (uint32_t)j, hq = (v >> (2 * j)) & 0xfffu; if (q < nq_e && occ[hq] == 1) { qj = q; hj = hq; } }
                 if (q_found == none && qj != none) { q_found = qj; h_found = hj; }
             }
         };
@@ -492,10 +531,10 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
         scan_up((nq_e >> 1) >> 3, qm, hqm);
         const uint32_t c_last = hw::wave_max_u32(nq_e ? (nq_e - 1) >> 3 : 0u);
         for (uint32_t c = c_last + 1; c-- > 0 && hw::ballot(ql == none && c * 8 < nq_e) != 0; ) {
-            const uint4 v = row[c];
+            const uint32_t v = chunk_bits(c);
             uint32_t qj = none, hj = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const uint32_t hq = hash_of(v, j); if (occ[hq] == 1) { qj = c * 8 + (uint32_t)j; hj = hq; } }
+            for (int j = 0; j < 8; ++j) { const uint32_t q = c * 8 + (uint32_t)j, hq = (v >> (2 * j)) & 0xfffu; if (q < nq_e && occ[hq] == 1) { qj = q; hj = hq; } }
             if (ql == none && qj != none) { ql = qj; hql = hj; }
         }
         uint32_t dF = none, dM = none, dL = none;
@@ -509,43 +548,51 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
         // pass 25 % more LDS gathers: k_kmer_map_lanes 2.29 -> 2.51 ms per launch, stream-hq 3.28 -> 3.84. Measured, not kept: those pairs are counted by the wave below.)
         if (!eligible) { dA = none; dB = none; }
     }
-    // one pass over the hashes. A diagonal that is "none" points at the sentinels behind the haplotype's hashes (0xffff: never a vote).
-    const uint16_t* hA = hh + (dA != none ? dA : nk);
-    const uint16_t* hB = hh + (dB != none ? dB : nk);
+    // ONE pass over the read, bit-parallel (round 6): 16 k-mers per step and diagonal. With read and haplotype as 2-bit codes, 16 per dword, the bases of a step against a
+    // diagonal are one funnel shift of two haplotype words and one XOR; a k-mer's six bases agree where none of six neighbouring base bits is set (five funnel shifts and ORs
+    // over this step's and the next one's bits); the votes of a diagonal are a population count. What any OTHER diagonal can collect is bounded from above without a look-up per
+    // k-mer: a read k-mer that sits on neither candidate may vote elsewhere (counted, whether or not the haplotype holds it at all), one that sits on a candidate votes elsewhere
+    // only if the haplotype holds it more than once - a bit per haplotype position (mu). The bound is never below the exact one the first form counted with a gather per k-mer
+    // (occ[hash] > onA + onB), so "best beats it" still proves the answer; the few pairs it no longer decides are counted by the wave below like every undecided pair. Per pair:
+    // 4 LDS gathers and ~55 vector instructions per 16 k-mers (first form: 3 gathers and ~20 instructions per k-mer, 2.8 bank-conflict cycles per gather).
+    const uint32_t limA = (eligible && dA != none && nk > dA) ? (nq < nk - dA ? nq : nk - dA) : 0u;     // k-mers q < lim have a haplotype k-mer beside them on the diagonal
+    const uint32_t limB = (eligible && dB != none && nk > dB) ? (nq < nk - dB ? nq : nk - dB) : 0u;
+    const uint32_t wA = limA ? dA >> 4 : 0u, shA = limA ? 2u * (dA & 15u) : 0u, wB = limB ? dB >> 4 : 0u, shB = limB ? 2u * (dB & 15u) : 0u;
     uint32_t cntA = 0, cntB = 0, others = 0, mm = 0, mm_pos = 0;
-    const uint32_t nq_wave = hw::wave_max_u32(eligible && dA != none ? nq : 0u);          // (lanes with fewer k-mers read sentinels)
-    uint4 hv = row[0];
-    for (uint32_t c = 0; c * 8 < nq_wave; c += 3) {                                       // 24 k-mers per trip: q % 6 is then a compile-time constant
-        uint4 chunk[3];
-        chunk[0] = hv; chunk[1] = row[c + 1]; chunk[2] = row[c + 2];                      // (reads of up to kLaneMapMaxKmers k-mers: the row's slack covers c + 3)
-        hv = row[c + 3];
-#pragma unroll
-        for (int jj = 0; jj < 24; ++jj) {
-            const uint32_t q = c * 8 + (uint32_t)jj;
-            const uint32_t hq = hash_of(chunk[jj >> 3], jj & 7);
-            const uint32_t a = hA[q], bb = hB[q], n = occ[hq];
-            const uint32_t onA = a == hq ? 1u : 0u, onB = bb == hq ? 1u : 0u;
-            cntA += onA; cntB += onB;
-            others += n > onA + onB ? 1u : 0u;
-            if (jj % 6 == 0) {                                                            // six fresh bases: bit 2j + 1 of t = base j of this k-mer differs
-                const uint32_t x = a ^ hq;
-                uint32_t t = hw_lshl_or(x, 1, x) & 0xaaau;
-                t = q + 1 < nq ? t : 0u;                                                  // (the read's LAST k-mer is taken below, whatever its q)
-                mm += (uint32_t)__builtin_popcount(t);
-                mm_pos = t ? q + ((uint32_t)__builtin_ctz(t) >> 1) : mm_pos;
-            }
+    const uint32_t nq_wave = hw::wave_max_u32(limA ? nq : 0u);
+    {
+        auto mism = [](uint32_t x) -> uint32_t { return (x | x >> 1) & 0x55555555u; };                 // bit 2i: base i differs
+        auto kmer_bad = [](uint32_t m0, uint32_t m1) -> uint32_t {                                        // bit 2i: some base of the k-mer at i differs (m1: the next 16 bases)
+            const uint32_t a_lo = m0 | funnel(m1, m0, 2), a_hi = m1 | m1 >> 2;
+            return a_lo | funnel(a_hi, a_lo, 4) | funnel(a_hi, a_lo, 8);
+        };
+        uint32_t r0 = rc[0], r1 = rc[64];
+        uint32_t hAl = hc[wA + 1], hBl = hc[wB + 1], uAl = mu[wA], uBl = mu[wB];
+        uint32_t mA0 = mism(r0 ^ funnel(hAl, hc[wA], shA)), mB0 = mism(r0 ^ funnel(hBl, hc[wB], shB));
+        for (uint32_t j = 0; j * 16 < nq_wave; ++j) {
+            const uint32_t r2 = rc[(size_t)(j + 2) * 64];                                               // (the row's slack covers it)
+            const uint32_t hAh = hc[wA + j + 2], hBh = hc[wB + j + 2], uAh = mu[wA + j + 1], uBh = mu[wB + j + 1];
+            const uint32_t mA1 = mism(r1 ^ funnel(hAh, hAl, shA)), mB1 = mism(r1 ^ funnel(hBh, hBl, shB));
+            const int32_t q0 = (int32_t)(j * 16);
+            const uint32_t okA = ~kmer_bad(mA0, mA1) & low_pairs_mask((int32_t)limA - q0), okB = ~kmer_bad(mB0, mB1) & low_pairs_mask((int32_t)limB - q0);
+            cntA += (uint32_t)__builtin_popcount(okA); cntB += (uint32_t)__builtin_popcount(okB);
+            const uint32_t rep = (okA & funnel(uAh, uAl, shA)) | (okB & funnel(uBh, uBl, shB));      // on a candidate, and the haplotype holds the k-mer elsewhere too
+            others += (uint32_t)__builtin_popcount(rep | (low_pairs_mask((int32_t)nq - q0) & ~(okA | okB)));
+            const uint32_t t = mA0 & low_pairs_mask((int32_t)T - q0);                                  // base mismatches along the first candidate (DevBatch::pair_mm)
+            mm += (uint32_t)__builtin_popcount(t);
+            mm_pos = t ? (uint32_t)q0 + ((uint32_t)__builtin_ctz(t) >> 1) : mm_pos;
+            mA0 = mA1; mB0 = mB1; hAl = hAh; hBl = hBh; uAl = uAh; uBl = uBh; r1 = r2;
+        }
+        {   // the bases behind the last step's sixteen (a read's last five bases belong to no k-mer of their own)
+            const int32_t q0 = (int32_t)(((nq_wave + 15) / 16) * 16);
+            const uint32_t t = mA0 & low_pairs_mask((int32_t)T - q0);
+            mm += (uint32_t)__builtin_popcount(t);
+            mm_pos = t ? (uint32_t)q0 + ((uint32_t)__builtin_ctz(t) >> 1) : mm_pos;
         }
     }
     bool decided = false;
     uint32_t w0 = none, w1 = none, mm_word = 0;
     if (eligible && dA != none) {
-        {   // the bases only the read's last k-mer covers (all six when nq - 1 is a multiple of six)
-            const uint32_t tailq = nq - 1, tr = tailq % 6u, tailmask = tr ? (0xaaau & ~((1u << (2u * (6u - tr))) - 1u)) : 0xaaau;
-            const uint32_t hq = (uint32_t)((const uint16_t*)row)[tailq];
-            const uint32_t x = (uint32_t)hA[tailq] ^ hq, t = hw_lshl_or(x, 1, x) & tailmask;
-            mm += (uint32_t)__builtin_popcount(t);
-            mm_pos = t ? tailq + ((uint32_t)__builtin_ctz(t) >> 1) : mm_pos;
-        }
         const uint32_t best = cntA > cntB ? cntA : cntB;
         if (best != 0 && best > others) {
             decided = true;
@@ -558,6 +605,9 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
             b.npos[e] = (uint8_t)n_w;
         }
     }
+#if defined(OCTPHMM_SIM) && defined(OCT_DEBUG_MAP)
+    if (live && !decided) fprintf(stderr, "undecided: nq %u dA %d dB %d cntA %u cntB %u others %u nk %u\n", nq, (int)dA, (int)dB, cntA, cntB, others, nk);
+#endif
     if (live && b.pair_mm) b.pair_mm[e] = (uint16_t)mm_word;
     // the undecided pairs of this wave, one after the other, by the whole wave
     uint64_t todo = hw::ballot(live && !decided);
@@ -751,6 +801,9 @@ OCT_DEVICE void store_scanned_local(uint4 mine, uint64_t e, uint64_t pair0, uint
 // best fast-path penalty in pair_best, classifies every remaining candidate as score-only or traceback DP.
 // A batch is processed in slices of whole haplotypes (pairs [pair0, pair1)); `cnt` is the slice's own scan array (pair1 - pair0 + 1 entries).
 // tile_sums != null: the counts are stored scanned across the workgroup (store_scanned_local; the grid then covers pair1 itself, the scan's extra entry)
+#if defined(OCT_CLASSIFY_WAVES) && !defined(OCTPHMM_SIM)
+__attribute__((amdgpu_waves_per_eu(OCT_CLASSIFY_WAVES, OCT_CLASSIFY_WAVES)))      // (A/B builds: tools/build_variant.sh)
+#endif
 OCT_KERNEL(k_classify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cnt, uint4* cnt_late, uint4* tile_sums, uint4* tile_sums_late)
 {
     __shared__ uint4 sh_scan[4];
@@ -1392,9 +1445,9 @@ OCT_KERNEL(k_scan_finish)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4*
     OCT_DYN_SMEM(smem);
     uint4* sh = (uint4*)smem;                                   // [16]
     const uint32_t tid = hw::thread_idx();
-    const uint32_t n_arr = cnt1 ? 2u : 1u;
-    uint4 all0 = make_uint4(0, 0, 0, 0), all1 = make_uint4(0, 0, 0, 0);          // (two names, not an array indexed by the loop: that lived in scratch memory)
-    for (uint32_t a = 0; a < n_arr; ++a) {
+    // one workgroup per count array (round 6: the two arrays' rounds of dependent loads ran one after the other in ONE workgroup - 0.73 ms on the 2,000-region stream in one slice)
+    const uint32_t n_arr = hw::grid_dim(), a = hw::block_idx();
+    {
         const uint4* cnt = a ? cnt1 : cnt0; uint4* tsum = a ? tile_sums1 : tile_sums0; uint4* hap_base = a ? hap_base1 : hap_base0;
         uint4 all_a;
         // tile totals -> exclusive tile prefixes, in place: eight consecutive tiles per thread and round (coalesced runs, one workgroup scan per 8,192 tiles = 2 M pairs)
@@ -1438,10 +1491,17 @@ OCT_KERNEL(k_scan_finish)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4*
         }
         all_a = carry_h;
         if (tid == 0) *(a ? totals1 : totals0) = all_a;
-        if (a) all1 = all_a; else all0 = all_a;
+        // one traceback launch may take a flavour's traceback list AND its late-start list: together they must fit the scratch the host provisioned. The two workgroups
+        // meet in one counter word (a spare slot of the statistics block, cleared with it): arrivals << 60 | generic tasks << 28 | fast tasks; whoever arrives last compares.
+        if (tid == 0 && b.dsl_trace_cap) {
+            const uint32_t lim = (1u << 28) - 1u;
+            const uint32_t fast = a ? all_a.x : all_a.y, gen = a ? all_a.y : all_a.w;
+            const unsigned long long mine = 1ull << 60 | (unsigned long long)(gen < lim ? gen : lim) << 28 | (unsigned long long)(fast < lim ? fast : lim);
+            unsigned long long sum = mine;
+            if (n_arr > 1) { const unsigned long long old = hw::atomic_add_u64(b.stats + kScanMeetSlot, mine); sum = (old >> 60) ? old + mine : 0ull; }
+            if ((sum >> 60) == n_arr && ((uint32_t)(sum & lim) > b.dsl_trace_cap || (uint32_t)((sum >> 28) & lim) > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
+        }
     }
-    // one traceback launch may take a flavour's traceback list AND its late-start list: together they must fit the scratch the host provisioned
-    if (tid == 0 && b.dsl_trace_cap && (all0.y + all1.x > b.dsl_trace_cap || all0.w + all1.y > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
 }
 
 struct TaskArrays { DevTask* t[kNumKinds]; };

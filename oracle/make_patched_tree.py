@@ -7,18 +7,18 @@ rules depend on.
 First seam (INTEGRATION.md section 2), HaplotypeLikelihoodArray::populate:
   core/models/haplotype_likelihood_array.cpp   src/core/models/haplotype_likelihood_array.cpp with the two populate() definitions (:51-103, :105-199)
                                                RENAMED populate_on_host (the fallback for regions the device path does not take) and followed by
-                                               #include "oracle/integration/populate_on_device.inc": the new populate() bodies (pack -> oct_phmm_populate -> scatter)
+                                               #include "integration/populate_on_device.inc": the new populate() bodies (pack -> oct_phmm_populate -> scatter)
   core/models/haplotype_likelihood_array.hpp   copy + the two populate_on_host declarations (and so that its `#include "haplotype_likelihood_model.hpp"` finds the header below)
 Second seam, src/core/tools/read_assigner.cpp:145-287:
   read_assigner_seam_ref.inc                   the reference's own functions estimate_max_indel_size* ... calculate_likelihoods(genotype, reads, model, workers),
                                                cut out of a copy of the file as they are
   read_assigner_seam_patched.inc               the same helpers, with the LAST function (:251-287) renamed calculate_likelihoods_on_host (the fallback) and followed by
-                                               #include "oracle/integration/read_assigner_on_device.inc" (the new last function: expand -> reset -> pack -> ONE oct_phmm_populate)
+                                               #include "integration/read_assigner_on_device.inc" (the new last function: expand -> reset -> pack -> ONE oct_phmm_populate)
 Third seam, src/core/tools/read_realigner.cpp:83-155:
   read_realigner_seam_ref.inc                  the reference's own compute_read_hashes, the two realign(read, haplotype, ...) helpers and
                                                realign(reads, haplotype, model, log_likelihoods, workers), cut out of a copy of the file as they are
   read_realigner_seam_patched.inc              the same helpers, with the LAST function (:114-155) replaced by
-                                               #include "oracle/integration/read_realigner_on_device.inc" (reset -> pack -> ONE oct_phmm_align -> AlignedRead::realign)
+                                               #include "integration/read_realigner_on_device.inc" (reset -> pack -> ONE oct_phmm_align -> AlignedRead::realign)
 All seams:
   core/models/haplotype_likelihood_model.hpp   src/core/models/haplotype_likelihood_model.hpp + one `friend` line per seam (FRIENDS below): the seams hand the six
                                                penalty vectors reset() prepares to the device
@@ -71,7 +71,7 @@ cpp = (src / "haplotype_likelihood_array.cpp").read_text()
 a0, a1 = function_span(cpp, "void HaplotypeLikelihoodArray::populate(const ReadMap& reads")
 b0, b1 = function_span(cpp, "void HaplotypeLikelihoodArray::populate(const TemplateMap& reads", a1)
 assert a0 < a1 <= b0 < b1 and cpp[a1:b0].strip() == "", "the two populate definitions are expected to be adjacent"
-inc = (HERE / "integration" / "populate_on_device.inc").resolve()
+inc = (HERE.parent / "integration" / "populate_on_device.inc").resolve()
 # The reference's own two bodies stay in the file under another name, populate_on_host: what the patched populate() falls back to for a region the device path
 # does not take (OCT_PHMM_EUNSUPPORTED: a read of 32 k bases, a 40 k-base haplotype) - the patched class must answer every call the unpatched one answers.
 # The patch file carries its own `namespace octopus { ... }`: close the file's namespace around it.
@@ -95,7 +95,7 @@ sig = "template <typename Container>\nauto calculate_likelihoods(const Genotype<
 last0, last1 = function_span(asg, sig, first)
 assert first < last0 < last1
 (out / "read_assigner_seam_ref.inc").write_text(asg[first:last1] + "\n")
-asg_inc = (HERE / "integration" / "read_assigner_on_device.inc").resolve()
+asg_inc = (HERE.parent / "integration" / "read_assigner_on_device.inc").resolve()
 # (the reference's own last function stays, renamed calculate_likelihoods_on_host: the fallback for a genotype / read set the device path refuses, OCT_PHMM_EUNSUPPORTED)
 own_last = asg[last0:last1].replace("auto calculate_likelihoods(const Genotype<Haplotype>& genotype,", "auto calculate_likelihoods_on_host(const Genotype<Haplotype>& genotype,")
 assert own_last != asg[last0:last1]
@@ -109,7 +109,7 @@ r_sig = ("void realign(std::vector<AlignedRead>& reads, const Haplotype& haploty
 r_last0, r_last1 = function_span(rea, r_sig, r_first)
 assert r_first < r_last0 < r_last1
 (out / "read_realigner_seam_ref.inc").write_text(rea[r_first:r_last1] + "\n")
-rea_inc = (HERE / "integration" / "read_realigner_on_device.inc").resolve()
+rea_inc = (HERE.parent / "integration" / "read_realigner_on_device.inc").resolve()
 (out / "read_realigner_seam_patched.inc").write_text(rea[r_first:r_last0] + '#include "' + str(rea_inc) + '"\n')
 
 # ---- the model's header, with every seam's friend line

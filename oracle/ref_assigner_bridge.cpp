@@ -3,7 +3,7 @@
 // extern "C" bridge over the second seam of INTEGRATION.md: the REFERENCE's own functions of src/core/tools/read_assigner.cpp:145-287
 // (estimate_max_indel_size, compute_read_hashes, expand_for_alignment, calculate_likelihoods: ploidy haplotypes x reads), cut out of a copy of that file by
 // oracle/make_patched_tree.py and compiled HERE between stand-in types — once as they are (SEAM_INC = read_assigner_seam_ref.inc ->
-// _ref/libref_assigner.so), once with the last function replaced by oracle/integration/read_assigner_on_device.inc (-> _ref/libref_assigner_patched_*.so,
+// _ref/libref_assigner.so), once with the last function replaced by integration/read_assigner_on_device.inc (-> _ref/libref_assigner_patched_*.so,
 // linked against the product's C ABI). Around them, compiled in place from /root/reference/src: core/models/haplotype_likelihood_model.cpp (reset,
 // evaluate, pad_requirement), the repeat-based indel / SNV error models with the tandem library, utils/kmer_mapper.hpp, utils/parallel_transform.hpp,
 // utils/thread_pool.cpp. Stand-ins (oracle/ref_shim + below): Haplotype, AlignedRead, Genotype, and the handful of region functions the seam calls; a

@@ -4,7 +4,7 @@
 // src/core/tools/read_realigner.cpp:83-155 (compute_read_hashes, the two realign(read, haplotype, ...) helpers and
 // realign(reads, haplotype, model, log_likelihoods, workers): k-mer table, model.reset, model.align read by read, AlignedRead::realign), cut out of a copy of
 // that file by oracle/make_patched_tree.py and compiled HERE between stand-in types - once as they are (SEAM_INC = read_realigner_seam_ref.inc ->
-// _ref/libref_realigner.so), once with the last function replaced by oracle/integration/read_realigner_on_device.inc (-> _ref/libref_realigner_patched_*.so, linked
+// _ref/libref_realigner.so), once with the last function replaced by integration/read_realigner_on_device.inc (-> _ref/libref_realigner_patched_*.so, linked
 // against the product's C ABI). Around them, compiled in place from /root/reference/src: core/models/haplotype_likelihood_model.cpp (reset, align), the
 // repeat-based indel / SNV error models with the tandem library, utils/kmer_mapper.hpp, utils/parallel_transform.hpp, utils/thread_pool.cpp, basics/cigar_string.cpp.
 // Stand-ins (oracle/ref_shim + below): Haplotype, AlignedRead (its realign() records region and CIGAR), GenomicRegion.

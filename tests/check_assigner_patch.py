@@ -1,7 +1,7 @@
 """INTEGRATION.md's second seam, compiled: the reference's OWN read-assignment likelihood functions (src/core/tools/read_assigner.cpp:145-287 - expand every
 haplotype of the genotype, k-mer table, model.reset, model.evaluate read by read; cut out of a copy of the file by oracle/make_patched_tree.py and
 compiled between stand-in types in oracle/ref_assigner_bridge.cpp) against the same functions with the last one replaced by
-oracle/integration/read_assigner_on_device.inc (expand -> reset -> pack -> ONE oct_phmm_populate with the device's k-mer mapper). Both sides run the
+integration/read_assigner_on_device.inc (expand -> reset -> pack -> ONE oct_phmm_populate with the device's k-mer mapper). Both sides run the
 reference's real repeat-based error models on the expanded haplotypes; reads and templates, ploidies 2 - 4, haplotypes with indels against the reference
 (so that the expansion's indel factor is not zero), and reads so far outside the haplotypes that both give up the same way. The reference runs its SERIAL branch
 here: its thread-pool branch (:260-270) hands ONE mutable lambda - and with it one HaplotypeLikelihoodModel - to all pool threads (utils/parallel_transform.hpp:116-118

@@ -1,6 +1,6 @@
 """INTEGRATION.md's patch, compiled: the reference's OWN HaplotypeLikelihoodArray class (haplotype_likelihood_array.hpp:65-134 on the
 oracle/ref_shim stand-in containers) with the bodies of its two populate() overloads (cpp:51-103, :105-199) replaced by
-pack -> oct_phmm_populate -> scatter (oracle/integration/populate_on_device.inc, spliced in by oracle/make_patched_tree.py), against the
+pack -> oct_phmm_populate -> scatter (integration/populate_on_device.inc, spliced in by oracle/make_patched_tree.py), against the
 same class unpatched — through the class's own read-back methods: operator()(sample, Haplotype / IndexedHaplotype), extract_sample,
 prime + operator[], num_likelihoods, merge_samples (both overloads), reset(kept haplotypes), contains, clear, and the ShortHaplotypeError
 it throws (same haplotype, same required extension)."""

@@ -1,6 +1,6 @@
 """INTEGRATION.md's third seam, compiled: the reference's OWN realignment of the reads assigned to a haplotype (src/core/tools/read_realigner.cpp:83-155 - k-mer
 table, model.reset, model.align read by read, AlignedRead::realign; cut out of a copy of the file by oracle/make_patched_tree.py and compiled between stand-in
-types in oracle/ref_realigner_bridge.cpp) against the same functions with the last one replaced by oracle/integration/read_realigner_on_device.inc
+types in oracle/ref_realigner_bridge.cpp) against the same functions with the last one replaced by integration/read_realigner_on_device.inc
 (reset -> pack -> ONE oct_phmm_align with the device's k-mer mapper -> AlignedRead::realign). Both sides run the reference's real repeat-based error models on
 the haplotype. Compared per read: the new region (begin, end), the CIGAR operation by operation, the log-likelihood. Reads with substitutions, insertions and
 deletions against the haplotype, with and without the log-likelihood vector, mapping quality on / capped / off, bands 8 - 32; a haplotype too short for its reads

@@ -20,7 +20,7 @@ def test_patched_reference_class_equals_the_unpatched_one_through_its_own_access
 
 def test_patched_read_assigner_seam_equals_the_reference_functions():
     """The second seam: read_assigner.cpp:145-287 compiled as it is and with its last function replaced by ONE oct_phmm_populate call
-    (oracle/integration/read_assigner_on_device.inc), on the simulator's build of the C ABI. See tests/check_assigner_patch.py."""
+    (integration/read_assigner_on_device.inc), on the simulator's build of the C ABI. See tests/check_assigner_patch.py."""
     if not oracle.have_ref_array():
         pytest.skip("oracle/_ref not built (no /root/reference here)")
     build_sim()
@@ -32,7 +32,7 @@ def test_patched_read_assigner_seam_equals_the_reference_functions():
 
 def test_patched_read_realigner_seam_equals_the_reference_functions():
     """The third seam: read_realigner.cpp:83-155 compiled as it is and with its last function replaced by ONE oct_phmm_align call
-    (oracle/integration/read_realigner_on_device.inc), on the simulator's build of the C ABI: new region, CIGAR and log-likelihood of every read.
+    (integration/read_realigner_on_device.inc), on the simulator's build of the C ABI: new region, CIGAR and log-likelihood of every read.
     See tests/check_realigner_patch.py."""
     if not oracle.have_ref_array():
         pytest.skip("oracle/_ref not built (no /root/reference here)")
