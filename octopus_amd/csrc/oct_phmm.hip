@@ -125,7 +125,10 @@ struct oct_phmm_handle {
     int band = 0;
     bool wide = false;                                   // int32 lanes (Config::use_int_scores)
     int  lanes_c = 1;                                    // band diagonals per lane on the streaming path (band / 64) for bands 128, 256
-    static constexpr int kMaxSlices = 8;
+#ifndef OCT_MAX_SLICES
+#define OCT_MAX_SLICES 8                                 // (a build-time knob for A/B libraries: tools/build_variant.sh)
+#endif
+    static constexpr int kMaxSlices = OCT_MAX_SLICES;
     rt::Stream stream {};                                 // slice 0 / uploads / downloads
     rt::Stream extra_streams[kMaxSlices] {};              // further slices run on their own streams so that latency-bound and VALU-bound kernels overlap
     bool main_stream_high_priority = false;
@@ -164,6 +167,7 @@ struct oct_phmm_batch {
         bool scan_fused = false;      // this run scanned the counts tile-locally (k_scan_fused): k_emit adds the tile prefixes, a flavour's traceback and late-start lists share one launch
         uint4* cnt_late = nullptr; uint4* tile_sums_late = nullptr; uint4* d_totals_late = nullptr; uint4 totals_late {};   // right-flank-only traceback tasks (x fast, y generic)
         DevTask* d_tasks = nullptr; size_t tasks_cap = 0; TraceEnd* d_ends = nullptr; size_t ends_cap = 0;
+        DevTask* d_tasks_sorted = nullptr; size_t sorted_cap = 0;    // the fast-cost lists after k_pair_sort (window pairing)
         unsigned long long* d_keys = nullptr; size_t keys_cap = 0;   // align mode: per traceback task
         uint32_t seg0 = 0, n_segs = 0, n_seg_tiles = 0;              // k_dedup_match: this slice's (region, haplotype range) segments and their 64-read tiles
         bool resumes = false; rt::Event matched {};                  // its first region began in the previous slice: its matcher waits for that slice's, its epilogue for the earlier slices' results
@@ -197,6 +201,8 @@ struct oct_phmm_batch {
     bool map_big = false;         // haplotypes too long for the LDS-resident k-mer mapper
     int  map_lanes = 0;           // > 0: k_kmer_map_lanes with this many lanes (= reads) per workgroup
     bool fast_adds = false;       // no int16 lane of this batch can wrap (bounds below): k_dp may add with v_add_u32
+    bool pair_ok = false;         // window pairing (k_pair_sort + the PAIRED segments of k_dp): big host-sized batches on the packed int16 fast-cost kernels
+    uint32_t* d_paired_end[3] = {nullptr, nullptr, nullptr};   // per haplotype: score-only fast, traceback fast, late-start fast
     uint32_t* d_blk_hap = nullptr; uint32_t* d_blk_read0 = nullptr; uint32_t n_map_blocks = 0;
     uint32_t map_reads_per_block = 64;   // reads one k_kmer_map workgroup walks with the haplotype's bins staged once; fewer for small batches (latency)
     double dp_ms = 0; uint32_t dp_launches = 0;
@@ -727,7 +733,8 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
                 int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false,
                 TaskListRef ref = TaskListRef {nullptr, nullptr, 0, nullptr}, const rt::Event* after_first_dp = nullptr,
                 int paired_score_list = -1, uint32_t paired_score_bound = 0,     // device-sized traceback launch: the score-only list of the same flavour rides along (k_dp_pair)
-                uint32_t joined_late_from = 0xffffffffu)                         // host-sized traceback launch: the flavour's late-start list lies behind the list proper (this many tasks) and is part of `n_tasks`
+                uint32_t joined_late_from = 0xffffffffu,                         // host-sized traceback launch: the flavour's late-start list lies behind the list proper (this many tasks) and is part of `n_tasks`
+                const uint32_t* paired_end = nullptr)                            // `tasks` went through k_pair_sort: per haplotype, the list index up to which tasks 2i and 2i + 1 share a window
 {
     if (!n_tasks) return OCT_PHMM_OK;
     const bool dsl = ref.totals != nullptr;
@@ -738,7 +745,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     const bool tr = kind == kTraceFast || kind == kTraceGen, gen = kind == kScoreGen || kind == kTraceGen;
     const bool dense = b->n_pairs > 20000 && b->n_pairs <= kDslMaxPairs;        // (a region-sized call is one round of workgroups: nothing to gain from a restage every 64 iterations)
     const uint32_t rec_chunk = (b->stream || h->wide) ? 0u : dp_rec_chunk(b->t_cap, b->lh_cap, (uint32_t)B, tr, dense);
-    const size_t lds = b->stream ? 0 : dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr, rec_chunk);
+    const size_t lds = b->stream ? 0 : dp_lds_bytes(b->t_cap, b->lh_cap, (uint32_t)B, tr, rec_chunk, paired_end != nullptr);
     if (lds > rt::kMaxLdsBytes) return fail(status, OCT_PHMM_EUNSUPPORTED, "read/haplotype too long for the LDS-resident DP kernel");
     DpParams p {};
     p.rec_chunk = rec_chunk;
@@ -761,6 +768,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     p.late = (may_start_late && (late || ref.join_late || joined_late_from != 0xffffffffu)) ? 1 : 0;
     p.late_from = late ? 0u : joined_late_from;
     p.hap_region = b->d.hap_region; p.reg_rhs = b->d.reg_rhs; p.reg_lhs = b->d.reg_lhs;
+    p.paired_end = paired_end; p.task0 = 0;
     uint32_t chunk_groups = n_groups;
     if (tr) {
         const size_t per_group = (size_t)p.k_cap * 4096 * (b->stream ? C : 1);
@@ -775,7 +783,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
     }
     for (uint32_t g0 = 0; g0 < n_groups; g0 += chunk_groups) {
         const uint32_t ng = std::min(chunk_groups, n_groups - g0);
-        p.tasks = tasks + (size_t)g0 * G; p.n_tasks = ng * G;
+        p.tasks = tasks + (size_t)g0 * G; p.n_tasks = ng * G; p.task0 = g0 * G;
         if (!late && joined_late_from != 0xffffffffu) p.late_from = joined_late_from > g0 * G ? joined_late_from - g0 * G : 0u;      // (relative to this chunk's first task)
         p.bp = h->bp[slice]; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
         uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
@@ -1195,7 +1203,7 @@ extern "C" void oct_phmm_batch_free(oct_phmm_handle* h, oct_phmm_batch* b)
     if (b->stat_stage) h->stat_stage_free.push_back(b->stat_stage);
     for (auto& t : b->timers) { h->put_event(t.first); h->put_event(t.second); }
     for (void* p : b->allocs) h->pool.release(p);
-    for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_ends); h->pool.release(sl.d_keys); h->put_event(sl.done); if (b->dedup) h->put_event(sl.matched); }
+    for (auto& sl : b->slices) { h->pool.release(sl.d_tasks); h->pool.release(sl.d_tasks_sorted); h->pool.release(sl.d_ends); h->pool.release(sl.d_keys); h->put_event(sl.done); if (b->dedup) h->put_event(sl.matched); }
     if (b->ev_fork) { h->put_event(b->ev_fork); h->put_event(b->ev_join); h->put_event(b->ev_hashes); }
     delete b;
 }
@@ -1364,8 +1372,9 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         // grow by at most one insertion step (gap extend + nuc_prior) per iteration. An uninitialised lane runs its insertion chain
         // (gap extend + nuc_prior per step) and its deletion chain for up to 2 B steps before the rolling initialiser reaches it.
         const uint64_t tail = R->n_reads ? (uint64_t)(b->t_cap - std::min(b->t_cap, t_min)) * (gemax + nuc) : 0;
-        const uint64_t finite = 4 * (sum_q_max + 2 * 64 * B64 + gomax + gemax + nuc + tail) + 1024;
-        const uint64_t garbage = 4 * (2 * B64 * (gemax + nuc) + 64 + gomax + gemax + nuc) + 64;
+        // (+ nuc once more: window-paired segments add nuc_prior to BOTH candidates of an insertion's minimum before they compare, not to the winner after it)
+        const uint64_t finite = 4 * (sum_q_max + 2 * 64 * B64 + gomax + gemax + 2 * nuc + tail) + 1024;
+        const uint64_t garbage = 4 * (2 * B64 * (gemax + nuc) + 64 + gomax + gemax + 2 * nuc) + 64;
         b->fast_adds = finite < 0xF800u && garbage < 0x7FFu && h->cfg.nuc_prior >= 0 && !tune::exact_adds();
     }
     if (any_empty) return fail(status, OCT_PHMM_EINVAL, "empty read");
@@ -1497,35 +1506,35 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     uint64_t late_min_pairs = 100000;
     { long long v; if (tune::number("OCT_PHMM_LATE_MIN_PAIRS", &v)) late_min_pairs = (uint64_t)v; }   // test hook (0 = always, a huge value = never)
     b->late_ok = b->fast_adds && !align_mode && !b->stream && !h->wide && b->n_pairs >= late_min_pairs;
+    {
+        // Window pairing: host-sized multi-slice batches (a haplotype's task runs are thousands long there: 100 k reads over ~240 (offset, strand) classes), packed int16 lanes with
+        // plain adds, fast-cost flavour; the 20-byte columns must leave the traceback form its three workgroups per CU. OCT_PHMM_PAIRED=0 / 1: off / forced (tests: small batches).
+        long long want = -1; tune::number("OCT_PHMM_PAIRED", &want);
+        const uint32_t Bw = (uint32_t)h->band;
+        const size_t lds_tr = dp_lds_bytes(b->t_cap, b->lh_cap, Bw, true, dp_rec_chunk(b->t_cap, b->lh_cap, Bw, true), true);
+        const bool can = !h->wide && !b->stream && b->fast_adds && !align_mode && b->lh_cap <= kPairSortMaxLh && b->n_pairs > 0 && lds_tr <= rt::kMaxLdsBytes;
+        b->pair_ok = can && (want >= 0 ? want != 0 : (b->n_pairs >= 4000000 && lds_tr * 3 <= rt::kMaxLdsBytes));
+        if (b->pair_ok) for (int k = 0; k < 3; ++k) pk.dalloc(&b->d_paired_end[k], (size_t)H->n_haps + 1);
+    }
     if (b->late_ok) {
         pk.dalloc(&b->d_pair_cnt_late, (size_t)b->n_pairs + oct_phmm_handle::kMaxSlices + 1); pk.dalloc(&b->d_hap_base_late, (size_t)H->n_haps + 1);
     }
     {
         // Slices of whole haplotypes, each on its own stream: while slice i is in its VALU-bound DP kernels, slice i+1 runs its
         // latency-bound mapper/classifier and slice i-1 its latency-bound walk. Small batches stay in one slice.
-        int n_slices = (int)std::min<uint64_t>(oct_phmm_handle::kMaxSlices, std::max<uint64_t>(1, b->n_pairs / 1000000));
+        // (at most four by default: every slice costs a front-end chain and a host read-back of its task counts, and round 6's sweep on the 12.8 M-pair step and the 2,000-region
+        // stream put 4 ahead of 2, 3, 5, 6, 8, 10, 12 and 16 - 28.5 against 29.0 ms at 8; profiles/r06_slice_count_sweep.txt. OCT_PHMM_SLICES asks for up to kMaxSlices.)
+        int n_slices = (int)std::min<uint64_t>(4, std::max<uint64_t>(1, b->n_pairs / 1000000));
         { long long v; if (tune::number("OCT_PHMM_SLICES", &v)) n_slices = std::max(1, std::min(oct_phmm_handle::kMaxSlices, (int)v)); }
         n_slices = (int)std::min<uint32_t>((uint32_t)n_slices, std::max<uint32_t>(1, H->n_haps));
         pk.dalloc(&b->d_totals, (size_t)n_slices);
         if (b->late_ok) pk.dalloc(&b->d_totals_late, (size_t)n_slices);
         b->slices.reserve((size_t)n_slices);                   // the packer keeps addresses of the slices' pointers
-        // Slice sizes ramp up and down (round 6; profiles/r06_s03_slice_overlap.txt): nothing of a step's DP can start before the FIRST slice's mapper, classifier, scan and the
-        // host's read of its task counts are through (1.3 ms of the 29 ms step with eight equal slices), and behind the LAST slice's DP launches its walks run with nothing beside
-        // them. A small first slice starts the DP early, every later slice's front end hides behind the DP of the one before it (DP time is ~3 x front-end time, so a slice may be
-        // up to ~3 x its predecessor), a small last slice leaves a short tail.
-        static const uint32_t kRamp[oct_phmm_handle::kMaxSlices] = {1, 2, 4, 8, 8, 5, 3, 1};
-        uint32_t weight[oct_phmm_handle::kMaxSlices]; uint64_t weight_sum = 0;
-        for (int i = 0; i < n_slices; ++i) weight[i] = n_slices == oct_phmm_handle::kMaxSlices ? kRamp[i] : 1u;
-        if (const char* e = tune::get("OCT_PHMM_SLICE_RAMP")) {     // A/B: comma-separated weights, e.g. "1,1,1,1,1,1,1,1" = equal slices
-            int i = 0; for (const char* q = e; *q && i < n_slices; ++i) { weight[i] = (uint32_t)std::max(1l, strtol(q, (char**)&q, 10)); if (*q == ',') ++q; }
-        }
-        for (int i = 0; i < n_slices; ++i) weight_sum += weight[i];
-        uint32_t hap = 0; uint64_t weight_run = 0;
+        uint32_t hap = 0;
         for (int i = 0; i < n_slices; ++i) {
             oct_phmm_batch::Slice sl;
             sl.hap0 = hap;
-            weight_run += weight[i];
-            const uint64_t target = (uint64_t)((unsigned __int128)b->n_pairs * weight_run / weight_sum);
+            const uint64_t target = b->n_pairs * (uint64_t)(i + 1) / (uint64_t)n_slices;
             while (hap < H->n_haps && (i == n_slices - 1 || hap_pair_off[hap + 1] <= target || hap == sl.hap0)) ++hap;
             if (i == n_slices - 1) hap = H->n_haps;
             sl.hap1 = hap;
@@ -1982,7 +1991,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         // a flavour's traceback list and its late-start list (which lies right behind it) in ONE DP launch and ONE walk: one-slice batches, where the step is a chain of
         // dependent launches (a region server's device batch; 16 regions: the second traceback launch and its walk were 233 of 868 us). Batches of several slices keep
         // the two launches: the 12.8 M-pair step lost 6 % of its traceback DP with them joined (17.8 against 2 x 8.36 ms per launch; profiles/EXPERIMENTS.md)
-        const bool join = sl.scan_fused && (tune::join_late() >= 0 ? tune::join_late() != 0 : (S == 1 && np <= 2000000));
+        const bool join = sl.scan_fused && !b->pair_ok && (tune::join_late() >= 0 ? tune::join_late() != 0 : (S == 1 && np <= 2000000));   // (window pairing keeps the lists apart: a haplotype's run is per list)
         const size_t n_trace = join ? (size_t)std::max(totals.y + late.x, totals.w + late.y) : (size_t)std::max(std::max(totals.y, totals.w), std::max(late.x, late.y));
         if (n_trace > sl.ends_cap) {
             h->pool.release(sl.d_ends); sl.d_ends = nullptr; sl.ends_cap = 0;
@@ -2000,6 +2009,22 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             OCT_LAUNCH(k_emit, (uint32_t)((np + 255) / 256), 256, 0, s, d, sl.pair0, sl.pair1, (const uint4*)sl.cnt, (const uint4*)b->d_hap_base, ta,
                        (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, TaskListRef {nullptr, nullptr, 0, nullptr}, G,
                        sl.scan_fused ? (const uint4*)sl.tile_sums : nullptr, sl.scan_fused ? (const uint4*)sl.tile_sums_late : nullptr); RT(rt::launch_ok());
+            // window pairing: the three fast-cost lists re-ordered per haplotype, out of place (k_pair_sort); the DP and the walk then read the sorted copy
+            const bool pairing = b->pair_ok && !join && !b->dsl && (totals.x + totals.y + late.x) > 0;
+            TaskArrays ts = ta, tsl = tl;
+            if (pairing) {
+                if (total > sl.sorted_cap) {
+                    h->pool.release(sl.d_tasks_sorted); sl.d_tasks_sorted = nullptr; sl.sorted_cap = 0;
+                    void* q = nullptr; RT(h->pool.alloc(&q, (total + total / 8) * sizeof(DevTask))); sl.d_tasks_sorted = (DevTask*)q; sl.sorted_cap = total + total / 8;
+                }
+                ts.t[0] = sl.d_tasks_sorted; ts.t[1] = ts.t[0] + totals.x; tsl.t[0] = ts.t[1] + totals.y;
+                const PairSortList none {nullptr, nullptr, nullptr, nullptr, 0, 0};
+                const PairSortList l0 = totals.x ? PairSortList {ta.t[0], ts.t[0], b->d_paired_end[0], (const uint4*)b->d_hap_base, 0u, totals.x} : none;
+                const PairSortList l1 = totals.y ? PairSortList {ta.t[1], ts.t[1], b->d_paired_end[1], (const uint4*)b->d_hap_base, 1u, totals.y} : none;
+                const PairSortList l2 = late.x ? PairSortList {tl.t[0], tsl.t[0], b->d_paired_end[2], (const uint4*)b->d_hap_base_late, 0u, late.x} : none;
+                OCT_LAUNCH(k_pair_sort, 3 * (sl.hap1 - sl.hap0), kPairSortThreads, pair_sort_lds_bytes(b->lh_cap), s, l0, l1, l2, d.rrev, sl.hap0, sl.hap1 - sl.hap0, pair_sort_keys(b->lh_cap));
+                RT(rt::launch_ok());
+            }
             static const int order[kNumKinds] = {kTraceFast, kTraceGen, kScoreFast, kScoreGen};   // traceback first: its walk then overlaps the score-only DP of the next slice
             // A single-slice (region-sized) batch is latency-bound: its score-only DP runs beside the traceback DP + walk on a second stream.
             const bool side = S == 1 && total < 200000 && (totals.x + totals.z) > 0 && (totals.y + totals.w + late.x + late.y) > 0;   // big launches fill the chip on their own
@@ -2011,8 +2036,9 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             if (side && (b->stream || tune::dsl_fork_early())) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
             for (int lk = 0; lk < 2 && !join; ++lk) {            // late-start traceback launches first (the longest walks of the slice start earliest)
                 const uint32_t n = lk ? late.y : late.x;
-                const int rc = run_dp_kind(h, b, i, lk ? kTraceGen : kTraceFast, tl.t[lk], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, nullptr, true,
-                                           TaskListRef {nullptr, nullptr, 0, nullptr}, side && !forked && n ? &b->ev_fork : nullptr);
+                const int rc = run_dp_kind(h, b, i, lk ? kTraceGen : kTraceFast, tsl.t[lk], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, nullptr, true,
+                                           TaskListRef {nullptr, nullptr, 0, nullptr}, side && !forked && n ? &b->ev_fork : nullptr, -1, 0, 0xffffffffu,
+                                           pairing && lk == 0 ? b->d_paired_end[2] : nullptr);
                 if (rc != OCT_PHMM_OK) return rc;
                 forked = forked || (side && n);
             }
@@ -2021,9 +2047,10 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                 const uint32_t n = k == 0 ? totals.x : k == 1 ? totals.y + (join ? late.x : 0u) : k == 2 ? totals.z : totals.w + (join ? late.y : 0u);   // (join: the late-start list lies right behind)
                 if (side && score_kind && !forked) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
                 if (side && score_kind && n) RT(rt::stream_wait_event(aux, b->ev_fork));
-                const int rc = run_dp_kind(h, b, i, k, ta.t[k], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, side && score_kind ? &aux : nullptr, false,
+                const int rc = run_dp_kind(h, b, i, k, ts.t[k], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, side && score_kind ? &aux : nullptr, false,
                                            TaskListRef {nullptr, nullptr, 0, nullptr}, side && !score_kind && !forked && n ? &b->ev_fork : nullptr, -1, 0,
-                                           join && !score_kind ? (k == kTraceFast ? totals.y : totals.w) : 0xffffffffu);
+                                           join && !score_kind ? (k == kTraceFast ? totals.y : totals.w) : 0xffffffffu,
+                                           pairing && k == kScoreFast ? b->d_paired_end[0] : pairing && k == kTraceFast ? b->d_paired_end[1] : nullptr);
                 if (rc != OCT_PHMM_OK) return rc;
                 forked = forked || (side && !score_kind && n);
             }

@@ -137,6 +137,10 @@ struct DpParams {
     // whose tasks ALL start at or behind the left flank's end (off >= reg_lhs: k_classify's class 3, pure geometry) starts late - the groups of a late-start list
     // by construction, and whichever other group happens to qualify.
     int late; const uint32_t* hap_region; const uint32_t* reg_rhs; const uint32_t* reg_lhs;
+    // window-paired task lists (k_pair_sort; packed int16 fast-cost kernels with plain adds only): paired_end[hap] = the list index up to which the tasks of haplotype `hap`
+    // lie two by two on ONE haplotype window (same offset, same strand) - task 2i and 2i + 1 of the list share it; null = the list is as k_emit wrote it. task0 = list index of tasks[0]
+    // (a traceback list that runs in several launches).
+    const uint32_t* paired_end; uint32_t task0;
     uint32_t late_from;                               // the launch's first task that belongs to a late-start list (0: the launch IS one; a joined launch: the length of the traceback list proper) -
                                                       // the groups before it skip the question (three dependent loads per group: 4 % of a 10 M-task traceback launch)
 };

@@ -499,6 +499,10 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
         if (lane < 4) mu[(p0 >> 4) + lane] = spread16((uint32_t)(m >> (16 * lane)) & 0xffffu);
     }
     hw::block_sync();
+#if defined(OCT_MAP_PROBE) && OCT_MAP_PROBE == 3
+    { const uint32_t rp_ = r_first + tid; if (rp_ < reg_r1) b.npos[b.hap_pair_off[h] + (rp_ - reg_r0)] = 0; }
+    return;                                                            // TIMING PROBE (tools/sessions_r06): the workgroup's staging alone (no candidates: every pair keeps its original position only)
+#endif
     const uint32_t max_pos = (uint32_t)b.max_pos, none = 0xffffffffu;
     const uint32_t r = r_first + tid;
     const bool live = r < reg_r1;
@@ -559,7 +563,11 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
     const uint32_t limB = (eligible && dB != none && nk > dB) ? (nq < nk - dB ? nq : nk - dB) : 0u;
     const uint32_t wA = limA ? dA >> 4 : 0u, shA = limA ? 2u * (dA & 15u) : 0u, wB = limB ? dB >> 4 : 0u, shB = limB ? 2u * (dB & 15u) : 0u;
     uint32_t cntA = 0, cntB = 0, others = 0, mm = 0, mm_pos = 0;
+#if defined(OCT_MAP_PROBE) && OCT_MAP_PROBE == 2
+    const uint32_t nq_wave = 0;                                        // TIMING PROBE: staging + probes, no pass
+#else
     const uint32_t nq_wave = hw::wave_max_u32(limA ? nq : 0u);
+#endif
     {
         auto mism = [](uint32_t x) -> uint32_t { return (x | x >> 1) & 0x55555555u; };                 // bit 2i: base i differs
         auto kmer_bad = [](uint32_t m0, uint32_t m1) -> uint32_t {                                        // bit 2i: some base of the k-mer at i differs (m1: the next 16 bases)
@@ -577,7 +585,7 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
             const uint32_t okA = ~kmer_bad(mA0, mA1) & low_pairs_mask((int32_t)limA - q0), okB = ~kmer_bad(mB0, mB1) & low_pairs_mask((int32_t)limB - q0);
             cntA += (uint32_t)__builtin_popcount(okA); cntB += (uint32_t)__builtin_popcount(okB);
             const uint32_t rep = (okA & funnel(uAh, uAl, shA)) | (okB & funnel(uBh, uBl, shB));      // on a candidate, and the haplotype holds the k-mer elsewhere too
-            others += (uint32_t)__builtin_popcount(rep | (low_pairs_mask((int32_t)nq - q0) & ~(okA | okB)));
+            others += (uint32_t)__builtin_popcount(rep | (low_pairs_mask((int32_t)nq - q0) & ~(okA | okB)));   // ... or on neither candidate: may vote anywhere, if the haplotype holds the k-mer at all
             const uint32_t t = mA0 & low_pairs_mask((int32_t)T - q0);                                  // base mismatches along the first candidate (DevBatch::pair_mm)
             mm += (uint32_t)__builtin_popcount(t);
             mm_pos = t ? (uint32_t)q0 + ((uint32_t)__builtin_ctz(t) >> 1) : mm_pos;
@@ -592,8 +600,8 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
     }
     bool decided = false;
     uint32_t w0 = none, w1 = none, mm_word = 0;
+    const uint32_t best = cntA > cntB ? cntA : cntB;
     if (eligible && dA != none) {
-        const uint32_t best = cntA > cntB ? cntA : cntB;
         if (best != 0 && best > others) {
             decided = true;
             if (cntA == cntB) { w0 = dA < dB ? dA : dB; w1 = dA < dB ? dB : dA; }       // only possible with two diagonals
@@ -611,6 +619,10 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
     if (live && b.pair_mm) b.pair_mm[e] = (uint16_t)mm_word;
     // the undecided pairs of this wave, one after the other, by the whole wave
     uint64_t todo = hw::ballot(live && !decided);
+#if defined(OCT_MAP_PROBE)
+    if (live && !decided) b.npos[e] = 0;
+    todo = 0;                                                          // TIMING PROBE: no counting path (undecided pairs keep their original position only)
+#endif
     const uint64_t all = hw::ballot(live);
     if (b.map_stats && lane == 0) {
         unsigned long long* st = b.stats + (size_t)(hw::block_idx() % kStatSlots) * kStatStride;
@@ -1591,6 +1603,75 @@ OCT_KERNEL(k_emit)(DevBatch b, uint64_t pair0, uint64_t pair1, const uint4* cnt,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Window pairing (round 6). k_dp packs two tasks into the halves of every lane; when both read the SAME haplotype window (same haplotype, offset and strand) the
+// per-column gap words arrive packed for both halves and two v_perm per iteration go (dp_groups, PAIRED). Big batches offer such pairs in plenty - 100 k reads over
+// ~240 (offset, strand) classes per haplotype - but k_emit writes a haplotype's tasks in read order. This kernel re-orders one haplotype's run of one task list
+// (out of place): a counting sort by key = offset * 2 + strand in LDS; every class gives its even part to the front of the run, class after class (tasks 2i, 2i + 1
+// of the run then share a window), its odd one out goes behind them; paired_end[hap] = list index where the front part ends. Which task of a class meets which is
+// decided by the order the LDS atomics land in - every task's result is its own, so the matrix does not depend on it.
+// Grid: one workgroup per (haplotype of the slice, list); runs = {first task, one past the last} of every such run in its list.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kPairSortThreads = 1024, kPairSortMaxLh = 2040;       // keys = 2 x (longest haplotype) + 2: three arrays of them stay below 64 KB of LDS
+OCT_HD uint32_t pair_sort_keys(uint32_t lh_cap) { return (2 * lh_cap + 2 + 3) & ~3u; }
+inline uint32_t pair_sort_lds_bytes(uint32_t lh_cap) { return 3 * pair_sort_keys(lh_cap) * 4 + 16 * 16; }
+// one task list of a slice: `comp` picks the list's component (0 x .. 3 w) of the per-haplotype bases k_scan_finish left (list index of a haplotype's first task); total = the list's length
+struct PairSortList { const DevTask* in; DevTask* out; uint32_t* paired_end; const uint4* hap_base; uint32_t comp, total; };
+OCT_DEVICE uint32_t comp4(const uint4& v, uint32_t c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+OCT_MAX_THREADS(1024) OCT_KERNEL(k_pair_sort)(PairSortList l0, PairSortList l1, PairSortList l2, const uint8_t* rrev, uint32_t hap0, uint32_t n_haps_slice, uint32_t n_keys)
+{
+    OCT_DYN_SMEM(smem);
+    uint32_t* cnt = (uint32_t*)smem;                 // [n_keys] class sizes, then the classes' cursors
+    uint32_t* front = cnt + n_keys;                  // [n_keys] where a class's even part starts (relative to the run)
+    uint32_t* back = front + n_keys;                 // [n_keys] where its odd one out goes
+    uint4* sh = (uint4*)(back + n_keys);             // [16] scan scratch
+    const uint32_t which = hw::block_idx() / n_haps_slice, hs = hw::block_idx() % n_haps_slice, tid = hw::thread_idx();
+    const PairSortList l = which == 0 ? l0 : which == 1 ? l1 : l2;
+    if (!l.in) return;
+    const uint32_t t0 = comp4(l.hap_base[hap0 + hs], l.comp), t1 = hs + 1 < n_haps_slice ? comp4(l.hap_base[hap0 + hs + 1], l.comp) : l.total, n = t1 - t0;
+    for (uint32_t k = tid; k < n_keys; k += kPairSortThreads) cnt[k] = 0;
+    hw::block_sync();
+    auto key_of = [&](const DevTask& t) -> uint32_t { const uint32_t k = t.off * 2u + (rrev[t.read] ? 1u : 0u); return k < n_keys ? k : n_keys - 1; };
+    // (four tasks per thread and trip, loads first: the passes are chains of dependent round trips - task, its read's strand, the counter - and a run of 40 k tasks is 40 trips deep)
+    constexpr uint32_t U = 4;
+    for (uint32_t i0 = tid; i0 < n; i0 += U * kPairSortThreads) {
+        DevTask t[U]; uint32_t k[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) { const uint32_t i = i0 + u * kPairSortThreads; t[u] = l.in[t0 + (i < n ? i : 0)]; }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) k[u] = key_of(t[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) if (i0 + u * kPairSortThreads < n) hw::atomic_add_lds_u32(&cnt[k[u]], 1u);
+    }
+    hw::block_sync();
+    // exclusive scans of the even parts and of the odd ones out over the classes: a contiguous stretch of classes per thread, one workgroup scan
+    const uint32_t per = (n_keys + kPairSortThreads - 1) / kPairSortThreads, k0 = tid * per, k1 = k0 + per < n_keys ? k0 + per : n_keys;
+    uint4 mine = make_uint4(0, 0, 0, 0);
+    for (uint32_t k = k0; k < k1; ++k) { mine.x += cnt[k] & ~1u; mine.y += cnt[k] & 1u; }
+    uint4 total;
+    const uint4 before = block_scan_excl(mine, sh, &total);
+    uint32_t run_f = before.x, run_b = total.x + before.y;
+    for (uint32_t k = k0; k < k1; ++k) { const uint32_t c = cnt[k]; front[k] = run_f; back[k] = run_b; run_f += c & ~1u; run_b += c & 1u; }
+    hw::block_sync();
+    for (uint32_t k = tid; k < n_keys; k += kPairSortThreads) cnt[k] &= ~1u;                 // a class's even part: cursors count up from it ... (see below)
+    hw::block_sync();
+    // second pass: a task takes the next place of its class's even part while there is one (an LDS counter per class counts DOWN from the even size), else the odd place
+    for (uint32_t i0 = tid; i0 < n; i0 += U * kPairSortThreads) {
+        DevTask t[U]; uint32_t k[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) { const uint32_t i = i0 + u * kPairSortThreads; t[u] = l.in[t0 + (i < n ? i : 0)]; }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) k[u] = key_of(t[u]);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) if (i0 + u * kPairSortThreads < n) {
+            const uint32_t left = hw::atomic_add_lds_u32(&cnt[k[u]], 0xffffffffu);            // returns the value before the decrement
+            const uint32_t dst = (left != 0 && left <= 0x7fffffffu) ? front[k[u]] + (left - 1) : back[k[u]];
+            l.out[t0 + dst] = t[u];
+        }
+    }
+    if (tid == 0) l.paired_end[hap0 + hs] = t0 + total.x;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // the banded min-plus DP
 // ------------------------------------------------------------------------------------------------------------------
 // Both shifts are ONE v_or_b32_dpp (B = 16, 64) or v_and_b32_dpp + v_or_b32 (B = 8, 32): the DPP move zeroes the lane that has no source
@@ -1624,10 +1705,10 @@ constexpr uint32_t kTileStride = OCT_TILE_STRIDE;   // dwords per row of the 16 
 // worth at a time (n + 2B + 12 entries) and restages every n iterations. 500-base reads (the chunks the reference's PacBio configuration cuts long reads into)
 // against 1.8 kb haplotypes would otherwise take 115 KB of LDS per workgroup = one wave per SIMD.
 OCT_HD constexpr uint32_t dp_rec_rows_n(uint32_t t_cap, uint32_t B, uint32_t rec_chunk) { return rec_chunk ? dp_rec_n(rec_chunk, B) : dp_rec_n(t_cap, B); }
-inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool trace, uint32_t rec_chunk = 0)
+inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool trace, uint32_t rec_chunk = 0, bool paired = false)   // paired: room for the 24-byte columns of window-paired segments
 {
     const uint32_t rows = 64 / B;
-    return 2 * ((lh_cap + 8 + 1) & ~1u) * 8 + kBlockWaves * rows * dp_rec_rows_n(t_cap, B, rec_chunk) * 8 + (trace ? kBlockWaves * 16 * kTileStride * 4 : 0);
+    return ((lh_cap + 8 + 1) & ~1u) * (paired ? 24 : 16) + kBlockWaves * rows * dp_rec_rows_n(t_cap, B, rec_chunk) * 8 + (trace ? kBlockWaves * 16 * kTileStride * 4 : 0);
 }
 // traceback scratch: per task group, ceil(iterations / 16) tiles of 64 lanes x 16 iterations, each lane's 16 dwords contiguous
 OCT_HD constexpr uint32_t bp_tiles(uint32_t t_cap, uint32_t B) { return (t_cap + B + 15) / 16 + 1; }
@@ -1643,7 +1724,14 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
     const uint32_t lh_n = (p.lh_cap + 8 + 1) & ~1u, rec_n = dp_rec_rows_n(p.t_cap, B, p.rec_chunk);
     uint2* tabF = (uint2*)smem;                      // [lh_n] forward-strand table of the current haplotype
     uint2* tabR = tabF + lh_n;                       // [lh_n] reverse-strand table
-    uint2* recs = tabR + lh_n;                       // [kBlockWaves][ROWS][rec_n] read-side records (of the whole reads, or of p.rec_chunk iterations at a time)
+    // Window-paired segments (p.paired_end, round 6): the two tasks packed in a lane's halves read ONE haplotype window, so a column's gap words arrive packed for both
+    // halves - no v_perm per iteration to bring two windows' words together - and the insertion's words carry nuc_prior already: per column ONE 16-byte entry of gap
+    // words {gap open[x] x 2, gap extend[x] x 2, gap open[x - 1] x 2 + nuc, gap extend[x - 1] x 2 + nuc} (the same on both strands) and a 4-byte cap row per strand:
+    // 24 bytes against the 16 of the two 8-byte tables - the traceback form keeps its three workgroups per CU (with 20 bytes per column AND strand it had two: + 3 % instead of - 6 %).
+    constexpr bool CAN_PAIR = !GENERIC && FASTADD;
+    uint4* tab4 = (uint4*)smem;
+    uint32_t* tab1F = (uint32_t*)(tab4 + lh_n); uint32_t* tab1R = tab1F + lh_n;
+    uint2* recs = (CAN_PAIR && p.paired_end) ? (uint2*)(tab1R + lh_n) : tabR + lh_n;   // [kBlockWaves][ROWS][rec_n] read-side records (of the whole reads, or of p.rec_chunk iterations at a time)
     uint32_t* tiles = (uint32_t*)(recs + kBlockWaves * ROWS * rec_n);   // [kBlockWaves][16][kTileStride] backpointer transpose tiles (TRACE)
     uint2* rec_row = recs + (wave * ROWS + row) * rec_n;
     uint32_t* tile = tiles + wave * 16 * kTileStride;
@@ -1670,7 +1758,24 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
         uint32_t seg_end = seg + 1;
         while (seg_end < g_end && tasks[seg_end * G].hap == hap) ++seg_end;
         const uint32_t ho = p.hoff[hap], Lh = p.hoff[hap + 1] - ho;
+        bool paired = false;
+        if constexpr (CAN_PAIR) if (p.paired_end) {
+            // the tasks of this haplotype before list index paired_end[hap] lie two by two on one window (k_pair_sort); the segment ends where they do
+            const uint32_t pe = p.paired_end[hap], pg = pe > p.task0 ? (pe - p.task0) / G : 0u;
+            if (seg < pg) { paired = true; if (seg_end > pg) seg_end = pg; }
+        }
         hw::block_sync();
+        if (paired) {
+            for (uint32_t x = tid; x < lh_n; x += kBlockWaves * 64) {
+                const bool in = x < Lh, inp = x >= 1 && x - 1 < Lh;
+                const uint2 f = in ? p.tabF[ho + x] : make_uint2(0, 0), r = in ? p.tabR[ho + x] : make_uint2(0, 0);
+                const uint32_t gp = inp ? p.tabF[ho + x - 1].y : 0u;                          // (the gap words are the same on both strands)
+                const uint32_t god = (f.y & 0xffffu) * 0x10001u, ged = (f.y >> 16) * 0x10001u;
+                const uint32_t goi = (gp & 0xffffu) * 0x10001u + NUC, gei = (gp >> 16) * 0x10001u + NUC;
+                tab4[x] = make_uint4(god, ged, goi, gei);
+                tab1F[x] = f.x; tab1R[x] = r.x;
+            }
+        } else
         for (uint32_t x = tid; x < lh_n; x += kBlockWaves * 64) {
             const bool in = x < Lh;
             tabF[x] = in ? p.tabF[ho + x] : make_uint2(0, 0);
@@ -1678,7 +1783,8 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
         }
         hw::block_sync();
 
-        for (uint32_t g = seg + wave; g < seg_end; g += kBlockWaves) {
+        auto run_group = [&](auto paired_c, const uint32_t g) {
+            constexpr bool PAIRED = decltype(paired_c)::value;
             const DevTask tA = tasks[g * G + 2 * row], tB = tasks[g * G + 2 * row + 1];
             const uint32_t roA = p.roff[tA.read], TA = p.roff[tA.read + 1] - roA;
             const uint32_t roB = p.roff[tB.read], TB = p.roff[tB.read + 1] - roB;
@@ -1742,6 +1848,8 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
 
             const uint2* pA = (p.rrev[tA.read] ? tabR : tabF) + tA.off + li;
             const uint2* pB = (p.rrev[tB.read] ? tabR : tabF) + tB.off + li;
+            const uint4* q4 = tab4 + tA.off + li;                                      // PAIRED: the one window of both tasks - its gap words ...
+            const uint32_t* q1 = (p.rrev[tA.read] ? tab1R : tab1F) + tA.off + li;      // ... and its strand's cap rows
             const uint2* rp = rec_row + (B - li);                      // rp[k] = the record of iteration k; rebased when the row is restaged (p.rec_chunk)
             const uint32_t kendA = TA + li, kendB = TB + li;          // the iteration whose M cells are this lane's end cells (t == T)
             uint4* bpg = TRACE ? (uint4*)(p.bp + (size_t)g * p.k_cap * 1024) : nullptr;   // this group's tiles (k_cap tiles of 4 KB)
@@ -1751,13 +1859,21 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
             uint32_t bestE = INFB, bestO = INFB;                                            // minscore :269, per diagonal parity
             // software pipeline: operands of iteration k are in registers when it starts, those of k+1 are in flight
             uint2 rr = rp[0];
-            uint2 cA = pA[0], cB = pB[0], nA = pA[1], nB = pB[1];
-            uint32_t GO = hw::perm(cB.y, cA.y, 0x05040100u), GE = hw::perm(cB.y, cA.y, 0x07060302u);
-            uint32_t GOn = hw::perm(nB.y, nA.y, 0x05040100u), GEn = hw::perm(nB.y, nA.y, 0x07060302u);
+            uint2 cA = make_uint2(0, 0), cB = cA, nA = cA, nB = cA;
+            uint32_t GO = 0, GE = 0, GOn = 0, GEn = 0;
+            if constexpr (!PAIRED) {
+                cA = pA[0]; cB = pB[0]; nA = pA[1]; nB = pB[1];
+                GO = hw::perm(cB.y, cA.y, 0x05040100u); GE = hw::perm(cB.y, cA.y, 0x07060302u);
+                GOn = hw::perm(nB.y, nA.y, 0x05040100u); GEn = hw::perm(nB.y, nA.y, 0x07060302u);
+            } else {
+                // cA.x / nA.x = the cap rows of columns x and x + 1; GOn / GEn = the deletion's words of column x + 1; GO / GE = the insertion's words of column x (nuc_prior added)
+                const uint4 e1 = q4[1];
+                cA.x = q1[0]; nA.x = q1[1]; GOn = e1.x; GEn = e1.y; GO = e1.z; GE = e1.w;
+            }
 
             // returns the packed match cost; fsrc = a word that is non-zero per half exactly where the walk would charge a flank penalty
             auto cost = [&](const uint2 r2, const uint2 a2, const uint2 b2, uint32_t& fsrc) -> uint32_t {
-                const uint32_t a = a2.x, b = b2.x;                                          // cost words of the two packed tasks
+                const uint32_t a = a2.x, b = PAIRED ? a2.x : b2.x;                          // cost words of the two packed tasks (PAIRED: one window)
                 if constexpr (GENERIC) {
                     // update_match_state with the reference's equality tests on raw bytes (:121-132)
                     const uint32_t hh = hw::perm(b, a, 0x0c040c00u), mm = hw::perm(b, a, 0x0c050c01u);
@@ -1801,7 +1917,8 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t k = k0 + u;
                     const uint2 rr_nx = rp[k + 1];                                          // prefetch iteration k+1
-                    const uint2 nnA = pA[k + 2], nnB = pB[k + 2];
+                    uint2 nnA = make_uint2(0, 0), nnB = nnA; uint4 e4 = make_uint4(0, 0, 0, 0); uint32_t e1 = 0;
+                    if constexpr (PAIRED) { e4 = q4[k + 2]; e1 = q1[k + 2]; } else { nnA = pA[k + 2]; nnB = pB[k + 2]; }
                     uint32_t gate = 0;                                                      // 0 on an end cell, saturating +65535 elsewhere
                     if constexpr (CAP) gate = (k == kendA ? 0u : 0xffffu) | (k == kendB ? 0u : 0xffff0000u);
                     // ---- even diagonal s = 2k: lane li is cell (t = k-li, x = k+li) ----
@@ -1814,7 +1931,8 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                     const uint32_t x2 = hw::pk_min_u(M2, I2);
                     const uint32_t dsh = hw::pk_min_u(sadd(D2, GEn), sadd(x2, GOn));
                     D1 = shift_up<B>(INFB, dsh, li);                                        // :293-294
-                    I1 = sadd(hw::pk_min_u(sadd(I2, GE), sadd(M2, GO)), NUC);               // :295
+                    if constexpr (PAIRED) I1 = hw::pk_min_u(sadd(I2, GE), sadd(M2, GO));     // (nuc_prior rides in the words)
+                    else I1 = sadd(hw::pk_min_u(sadd(I2, GE), sadd(M2, GO)), NUC);           // :295
                     uint32_t bpe = 0;
                     if constexpr (TR) {                                                     // update_traceback :147-163
                         const uint32_t tm = M1 & 0x00030003u, ti = I1 & 0x00030003u, td = D1 & 0x00030003u;
@@ -1828,7 +1946,7 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                     M2 = add_cost(m2, co);                                                  // :316
                     y1 = hw::pk_min_u(M1, I1);
                     D2 = hw::pk_min_u(sadd(D1, GEn), sadd(y1, GOn));                        // :317
-                    const uint32_t ish = sadd(hw::pk_min_u(sadd(I1, GE), sadd(M1, GO)), NUC);
+                    const uint32_t ish = PAIRED ? hw::pk_min_u(sadd(I1, GE), sadd(M1, GO)) : sadd(hw::pk_min_u(sadd(I1, GE), sadd(M1, GO)), NUC);
                     I2 = shift_down<B>(INFB, ish, li);                                      // :318-319
                     if constexpr (TR) {
                         const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
@@ -1836,8 +1954,11 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                         const uint32_t bpo = hw_lshl_or(td, 4, hw_lshl_or(ti, 2, tm));
                         tile[(k & 15) * kTileStride + lane] = hw_lshl_or(bpo, 6, bpe | flag_of(fo, 14));
                     }
+                    if constexpr (PAIRED) { rr = rr_nx; cA.x = nA.x; nA.x = e1; GOn = e4.x; GEn = e4.y; GO = e4.z; GE = e4.w; }
+                    else {
                     rr = rr_nx; cA = nA; cB = nB; GO = GOn; GE = GEn; nA = nnA; nB = nnB;
                     GOn = hw::perm(nB.y, nA.y, 0x05040100u); GEn = hw::perm(nB.y, nA.y, 0x07060302u);
+                    }
                 }
                 if constexpr (TR) {
                     if (((k0 + 4) & 15) == 0) flush_tile(k0 >> 4);
@@ -1909,6 +2030,10 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                 }
             }
             hw::wave_lds_fence();
+        };
+        for (uint32_t g = seg + wave; g < seg_end; g += kBlockWaves) {
+            if constexpr (CAN_PAIR) { if (paired) run_group(BoolC<true>{}, g); else run_group(BoolC<false>{}, g); }
+            else run_group(BoolC<false>{}, g);
         }
         seg = seg_end;
     }

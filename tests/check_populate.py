@@ -390,6 +390,47 @@ def check_late_traceback_start(backend, tol=0.0):
     return out
 
 
+def check_window_pairing(backend, tol=0.0):
+    """Big host-sized batches re-order every haplotype's task runs so that the two tasks packed into a lane's halves read ONE haplotype window (k_pair_sort), and
+    k_dp runs those segments with pre-packed gap words (dp_groups, PAIRED). Forced on for small batches through the test hook - with the late
+    start on and off, one slice and three, ragged reads, several regions, bands 8 / 16 / 32, a traceback budget that cuts the lists into several launches - every case
+    must equal the oracle and the bytes of the same batch with pairing off."""
+    import os
+    rng = np.random.default_rng(4321)
+    keys = ("OCT_PHMM_PAIRED", "OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_SLICES", "OCT_PHMM_LATE_MIN_PAIRS", "OCT_PHMM_BP_BUDGET_KB")
+    old = {k: os.environ.get(k) for k in keys}
+    out = []
+    try:
+        for B, R, H, T, Lh, flank, slices, late, budget_kb in ((16, 420, 5, 150, 300, (40, 40), "1", "0", None), (16, 300, 7, 150, 330, (40, 40), "3", "0", None),
+                                                                (8, 260, 4, 70, 200, (15, 60), "1", "1000000000000", None), (32, 200, 4, 150, 400, (30, 120), "2", "0", None),
+                                                                (16, 350, 4, 120, 280, (0, 90), "1", "0", 3000)):
+            regs = [synth.make_region(rng, R, H, T=T, Lh=Lh + 13 * i, B=B, flank=flank, positions="none", indels_per_read=0.05) for i in range(2)]
+            regs.append(synth.make_region(rng, 9, 3, T=T, Lh=Lh, B=B, flank=flank, positions="none"))      # a region whose classes hold one task each: the odd ones out only
+            batch = synth.batch_from_regions(regs)
+            os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"; os.environ["OCT_PHMM_SLICES"] = slices; os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = late
+            if budget_kb:
+                os.environ["OCT_PHMM_BP_BUDGET_KB"] = str(budget_kb)
+            else:
+                os.environ.pop("OCT_PHMM_BP_BUDGET_KB", None)
+            os.environ["OCT_PHMM_PAIRED"] = "1"
+            stats = compare(backend, batch, tol, max_indel_error=B)
+            eng = make_engine(backend, max_indel_error=B)
+            paired, _ = eng.populate(batch)
+            os.environ["OCT_PHMM_PAIRED"] = "0"
+            plain, _ = eng.populate(batch)
+            eng.close()
+            assert np.array_equal(paired, plain)
+            out.append(stats)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert sum(s["n_dp_traceback"] for s in out) > 2000 and sum(s["n_dp_score_only"] for s in out) > 1000
+    return out
+
+
 def check_chunked_traceback(backend, tol=0.0):
     """When a slice's traceback tasks do not fit the scratch budget the DP + walk pair runs in chunks of whole workgroups over the same
     scratch. Forced here with a budget of a few task groups (test hook), with and without the late traceback start, populate and align."""

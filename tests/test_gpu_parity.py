@@ -412,6 +412,11 @@ def test_gpu_mapper_mismatch_account_feeds_the_fast_path():
     assert len(cp.check_mapper_mismatch_account("gpu", TOL)) == 5
 
 
+def test_gpu_window_paired_task_lists_equal_oracle_and_plain_path():
+    """k_pair_sort + the PAIRED segments of k_dp forced on small batches (the full-size 100k x 128 test runs them by default): oracle, and the bytes of the plain path."""
+    assert len(cp.check_window_pairing("gpu", TOL)) == 5
+
+
 def test_gpu_lane_per_pair_mapper(monkeypatch):
     """k_kmer_map_lanes forced on small batches (the full-size tests run it by default): positions pair by pair against the oracle's mapper, populate checks."""
     monkeypatch.setenv("OCT_PHMM_LANE_MAPPER", "1")

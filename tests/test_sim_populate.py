@@ -152,6 +152,10 @@ def test_sim_lane_per_pair_mapper(monkeypatch):
     cp.check_device_kmer_mapper("sim")
 
 
+def test_sim_window_paired_task_lists_equal_oracle_and_plain_path():
+    assert len(cp.check_window_pairing("sim")) == 5
+
+
 def test_sim_page_locked_caller_buffers_skip_the_staging_copies():
     assert cp.check_page_locked_caller_buffers("sim") == 10
 
