@@ -2010,7 +2010,11 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
                        (const uint4*)sl.cnt_late, (const uint4*)b->d_hap_base_late, tl, TaskListRef {nullptr, nullptr, 0, nullptr}, G,
                        sl.scan_fused ? (const uint4*)sl.tile_sums : nullptr, sl.scan_fused ? (const uint4*)sl.tile_sums_late : nullptr); RT(rt::launch_ok());
             // window pairing: the three fast-cost lists re-ordered per haplotype, out of place (k_pair_sort); the DP and the walk then read the sorted copy
-            const bool pairing = b->pair_ok && !join && !b->dsl && (totals.x + totals.y + late.x) > 0;
+            // ... where a haplotype's runs are long enough to hold pairs: ~240 (offset, strand) classes per 150-base read on a 300-base haplotype - from ~1,000 fast-cost tasks per
+            // haplotype of the slice on. (The 2,000-region stream has ~500 per haplotype over three lists: a sort workgroup per run would cost more than the few pairs give.)
+            long long min_run = 1024; tune::number("OCT_PHMM_PAIRED_MIN_RUN", &min_run);      // (test hook: 0 = every slice of a batch that may pair)
+            const bool pairing = b->pair_ok && !join && !b->dsl && (totals.x + totals.y + late.x) > 0 &&
+                                 (uint64_t)(totals.x + totals.y + late.x) >= (uint64_t)min_run * (sl.hap1 - sl.hap0);
             TaskArrays ts = ta, tsl = tl;
             if (pairing) {
                 if (total > sl.sorted_cap) {

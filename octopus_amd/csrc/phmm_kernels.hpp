@@ -517,7 +517,7 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
     // k-mer: dA = the middle probe's diagonal (a read whose two ends lie across two indels from each other is decided by it), dB = the first probe's where that
     // differs, else the last one's (a read split by one indel: both of its diagonals, as k_kmer_map's first attempt takes them). Eight k-mers per step (the 26 bits
     // behind base 8c of the read's codes: two coalesced dword loads and a funnel shift), until every lane of the wave has found its own: mostly one step per probe (a read's tail is where its errors sit).
-    uint32_t dA = none, dB = none;
+    uint32_t dA = none, dB = none, dC = none;
     {
         const uint32_t nq_e = eligible ? nq : 0u;
         auto chunk_bits = [&](uint32_t c) -> uint32_t { return funnel(rc[(size_t)((c >> 1) + 1) * 64], rc[(size_t)(c >> 1) * 64], (c & 1u) * 16u); };   // bases 8c ... 8c + 15
@@ -548,9 +548,11 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
         dA = dM != none ? dM : dF != none ? dF : dL;
         dB = (dF != none && dF != dA) ? dF : dL;
         if (dB == dA) dB = none;
-        // (a third stream for the last probe where all three disagree - a read across two indels - decided 3.3 % more of the headline batch's pairs and cost the
-        // pass 25 % more LDS gathers: k_kmer_map_lanes 2.29 -> 2.51 ms per launch, stream-hq 3.28 -> 3.84. Measured, not kept: those pairs are counted by the wave below.)
-        if (!eligible) { dA = none; dB = none; }
+        // a third candidate where all three probes disagree - a read across two indels. (With a gather per k-mer and candidate - the first form of this kernel - the third stream
+        // cost more than the pairs it decided saved, 2.29 -> 2.51 ms per launch; bit-parallel it is 14 instructions and two gathers per 16 k-mers, and the counting path it
+        // spares is two thirds of the kernel's time: profiles/r06_s06_mapper_phases.txt.)
+        dC = (dL != none && dL != dA && dL != dB && dB != none) ? dL : none;
+        if (!eligible) { dA = none; dB = none; dC = none; }
     }
     // ONE pass over the read, bit-parallel (round 6): 16 k-mers per step and diagonal. With read and haplotype as 2-bit codes, 16 per dword, the bases of a step against a
     // diagonal are one funnel shift of two haplotype words and one XOR; a k-mer's six bases agree where none of six neighbouring base bits is set (five funnel shifts and ORs
@@ -561,8 +563,10 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
     // 4 LDS gathers and ~55 vector instructions per 16 k-mers (first form: 3 gathers and ~20 instructions per k-mer, 2.8 bank-conflict cycles per gather).
     const uint32_t limA = (eligible && dA != none && nk > dA) ? (nq < nk - dA ? nq : nk - dA) : 0u;     // k-mers q < lim have a haplotype k-mer beside them on the diagonal
     const uint32_t limB = (eligible && dB != none && nk > dB) ? (nq < nk - dB ? nq : nk - dB) : 0u;
+    const uint32_t limC = (eligible && dC != none && nk > dC) ? (nq < nk - dC ? nq : nk - dC) : 0u;
     const uint32_t wA = limA ? dA >> 4 : 0u, shA = limA ? 2u * (dA & 15u) : 0u, wB = limB ? dB >> 4 : 0u, shB = limB ? 2u * (dB & 15u) : 0u;
-    uint32_t cntA = 0, cntB = 0, others = 0, mm = 0, mm_pos = 0;
+    const uint32_t wC = limC ? dC >> 4 : 0u, shC = limC ? 2u * (dC & 15u) : 0u;
+    uint32_t cntA = 0, cntB = 0, cntC = 0, others = 0, mm = 0, mm_pos = 0;
 #if defined(OCT_MAP_PROBE) && OCT_MAP_PROBE == 2
     const uint32_t nq_wave = 0;                                        // TIMING PROBE: staging + probes, no pass
 #else
@@ -575,8 +579,9 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
             return a_lo | funnel(a_hi, a_lo, 4) | funnel(a_hi, a_lo, 8);
         };
         uint32_t r0 = rc[0], r1 = rc[64];
-        uint32_t hAl = hc[wA + 1], hBl = hc[wB + 1], uAl = mu[wA], uBl = mu[wB];
-        uint32_t mA0 = mism(r0 ^ funnel(hAl, hc[wA], shA)), mB0 = mism(r0 ^ funnel(hBl, hc[wB], shB));
+        uint32_t hAl = hc[wA + 1], hBl = hc[wB + 1], uAl = mu[wA], uBl = mu[wB], hCl = hc[wC + 1], uCl = mu[wC];
+        uint32_t mA0 = mism(r0 ^ funnel(hAl, hc[wA], shA)), mB0 = mism(r0 ^ funnel(hBl, hc[wB], shB)), mC0 = mism(r0 ^ funnel(hCl, hc[wC], shC));
+        const bool any_c = hw::ballot(limC != 0) != 0;                                                 // (most waves have no lane with a third candidate: they skip its stream)
         for (uint32_t j = 0; j * 16 < nq_wave; ++j) {
             const uint32_t r2 = rc[(size_t)(j + 2) * 64];                                               // (the row's slack covers it)
             const uint32_t hAh = hc[wA + j + 2], hBh = hc[wB + j + 2], uAh = mu[wA + j + 1], uBh = mu[wB + j + 1];
@@ -584,8 +589,17 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
             const int32_t q0 = (int32_t)(j * 16);
             const uint32_t okA = ~kmer_bad(mA0, mA1) & low_pairs_mask((int32_t)limA - q0), okB = ~kmer_bad(mB0, mB1) & low_pairs_mask((int32_t)limB - q0);
             cntA += (uint32_t)__builtin_popcount(okA); cntB += (uint32_t)__builtin_popcount(okB);
-            const uint32_t rep = (okA & funnel(uAh, uAl, shA)) | (okB & funnel(uBh, uBl, shB));      // on a candidate, and the haplotype holds the k-mer elsewhere too
-            others += (uint32_t)__builtin_popcount(rep | (low_pairs_mask((int32_t)nq - q0) & ~(okA | okB)));   // ... or on neither candidate: may vote anywhere, if the haplotype holds the k-mer at all
+            uint32_t rep = (okA & funnel(uAh, uAl, shA)) | (okB & funnel(uBh, uBl, shB));            // on a candidate, and the haplotype holds the k-mer elsewhere too
+            uint32_t okC = 0;
+            if (any_c) {
+                const uint32_t hCh = hc[wC + j + 2], uCh = mu[wC + j + 1];
+                const uint32_t mC1 = mism(r1 ^ funnel(hCh, hCl, shC));
+                okC = ~kmer_bad(mC0, mC1) & low_pairs_mask((int32_t)limC - q0);
+                cntC += (uint32_t)__builtin_popcount(okC);
+                rep |= okC & funnel(uCh, uCl, shC);
+                mC0 = mC1; hCl = hCh; uCl = uCh;
+            }
+            others += (uint32_t)__builtin_popcount(rep | (low_pairs_mask((int32_t)nq - q0) & ~(okA | okB | okC)));   // ... or on no candidate: may vote anywhere, if the haplotype holds the k-mer at all
             const uint32_t t = mA0 & low_pairs_mask((int32_t)T - q0);                                  // base mismatches along the first candidate (DevBatch::pair_mm)
             mm += (uint32_t)__builtin_popcount(t);
             mm_pos = t ? (uint32_t)q0 + ((uint32_t)__builtin_ctz(t) >> 1) : mm_pos;
@@ -600,16 +614,21 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
     }
     bool decided = false;
     uint32_t w0 = none, w1 = none, mm_word = 0;
-    const uint32_t best = cntA > cntB ? cntA : cntB;
+    const uint32_t bestAB = cntA > cntB ? cntA : cntB, best = bestAB > cntC ? bestAB : cntC;
     if (eligible && dA != none) {
         if (best != 0 && best > others) {
             decided = true;
-            if (cntA == cntB) { w0 = dA < dB ? dA : dB; w1 = dA < dB ? dB : dA; }       // only possible with two diagonals
-            else { w0 = cntA > cntB ? dA : dB; }
+            // the candidates that reach the maximum, ascending (map_query_to_target's output order, :145-157); equal counts need distinct diagonals, which the candidates are
+            uint32_t w2 = none;
+            const uint32_t a = cntA == best ? dA : none, bb = cntB == best ? dB : none, c = cntC == best ? dC : none;
+            const uint32_t lo = a < bb ? a : bb, hi = a < bb ? bb : a;                 // ("none" = 0xffffffff sorts last)
+            w0 = lo < c ? lo : c; const uint32_t rest = lo < c ? c : lo;
+            w1 = hi < rest ? hi : rest; w2 = hi < rest ? rest : hi;
             if (w1 == none && w0 == dA) mm_word = mm == 0 ? 1u << 14 : mm == 1 ? (2u << 14 | mm_pos) : 3u << 14;
             uint32_t n_w = 0;
             if (max_pos >= 1) { b.pos[e * (uint64_t)max_pos] = w0; n_w = 1; }
             if (w1 != none && max_pos >= 2) { b.pos[e * (uint64_t)max_pos + 1] = w1; n_w = 2; }
+            if (w2 != none && max_pos >= 3) { b.pos[e * (uint64_t)max_pos + 2] = w2; n_w = 3; }
             b.npos[e] = (uint8_t)n_w;
         }
     }

@@ -397,7 +397,7 @@ def check_window_pairing(backend, tol=0.0):
     must equal the oracle and the bytes of the same batch with pairing off."""
     import os
     rng = np.random.default_rng(4321)
-    keys = ("OCT_PHMM_PAIRED", "OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_SLICES", "OCT_PHMM_LATE_MIN_PAIRS", "OCT_PHMM_BP_BUDGET_KB")
+    keys = ("OCT_PHMM_PAIRED", "OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_SLICES", "OCT_PHMM_LATE_MIN_PAIRS", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_PAIRED_MIN_RUN")
     old = {k: os.environ.get(k) for k in keys}
     out = []
     try:
@@ -407,7 +407,7 @@ def check_window_pairing(backend, tol=0.0):
             regs = [synth.make_region(rng, R, H, T=T, Lh=Lh + 13 * i, B=B, flank=flank, positions="none", indels_per_read=0.05) for i in range(2)]
             regs.append(synth.make_region(rng, 9, 3, T=T, Lh=Lh, B=B, flank=flank, positions="none"))      # a region whose classes hold one task each: the odd ones out only
             batch = synth.batch_from_regions(regs)
-            os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"; os.environ["OCT_PHMM_SLICES"] = slices; os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = late
+            os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"; os.environ["OCT_PHMM_SLICES"] = slices; os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = late; os.environ["OCT_PHMM_PAIRED_MIN_RUN"] = "0"
             if budget_kb:
                 os.environ["OCT_PHMM_BP_BUDGET_KB"] = str(budget_kb)
             else:

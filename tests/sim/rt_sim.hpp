@@ -14,8 +14,11 @@ typedef int Stream;
 typedef int Event;
 inline int last_error_code = 0;
 
-inline bool device_count(int* n) { *n = 1; return true; }
-inline bool set_device(int) { return true; }
+// OCTSIM_DEVICES=n (tests/test_sim_server.py): the simulator reports n "devices" - nothing but ordinals here, but the host code's per-device bookkeeping (a region server's
+// workers and handles per device, the pools' per-device cache accounting and trimming) then runs with DISTINCT device ids, which a one-GPU box cannot offer either
+inline int sim_devices() { const char* e = getenv("OCTSIM_DEVICES"); const int n = e ? atoi(e) : 1; return n >= 1 && n <= 64 ? n : 1; }
+inline bool device_count(int* n) { *n = sim_devices(); return true; }
+inline bool set_device(int d) { return d >= 0 && d < sim_devices(); }
 inline bool device_is_gfx950(int) { return true; }
 inline bool stream_create(Stream* s) { *s = 0; return true; }
 inline bool stream_create_priority(Stream* s, bool) { return stream_create(s); }

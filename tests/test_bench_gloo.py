@@ -57,6 +57,20 @@ def test_bench_stream_mode_shards_one_fixed_stream_over_the_ranks():
     assert abs(two["value"] * two["ms_per_step"] / (one["value"] * one["ms_per_step"]) - 1.0) < 1e-6
 
 
+def test_bench_read_axis_split_of_one_region_is_strong_scaling():
+    """--split reads (SURVEY.md 8e's fine split): ONE region for the whole job, rank r takes the reads [r R / N, (r + 1) R / N) against every haplotype; the job's pairs
+    do not depend on N, every rank's rows are verified against the reference, and at N > 1 the line carries the per-rank host-side figures."""
+    wl = ("--workload", "tiny", "--split", "reads")
+    one, two = _run(1, wl), _run(2, wl)
+    assert one["scaling"] == "weak" and two["scaling"] == "strong"                # (N = 1: nothing is split)
+    assert two["config"]["pairs_per_step"] == one["config"]["pairs_per_step"]
+    assert two["stats"]["n_pairs"] * 2 == one["stats"]["n_pairs"]                 # rank 0 of two holds half of the reads
+    for b in (one, two):
+        assert b["verified_rows"] >= 1 and b["verified_max_abs_diff"] <= 1e-9
+    assert two["split"] == "reads" and len(two["rank_e2e_ms_from_host"]) == 2 and all(x > 0 for x in two["rank_e2e_ms_from_host"]) and len(two["rank_host_threads"]) == 2
+    assert "rank_e2e_ms_from_host" not in one
+
+
 def test_bench_defaults_to_the_stream_split_on_more_than_one_rank():
     """Without --workload, N > 1 runs BASELINE configs[3] (one stream sharded round-robin, strong scaling), N = 1 the 100k x 128 headline batch.
     (--regions / --stream-cap only shrink the stream to simulator size; the default size is 50,000 regions.)"""

@@ -13,6 +13,14 @@ def test_sim_server_over_several_devices_gives_the_same_answers():
     assert calls == 40
 
 
+def test_sim_server_over_two_distinct_devices(monkeypatch):
+    """Two DIFFERENT device ordinals (OCTSIM_DEVICES=2: the simulator's devices are ordinals only): the server's per-device workers, handles and pools are told apart
+    by id - what a node with several MI355X runs and a one-GPU box cannot. Same answers; both devices take calls."""
+    monkeypatch.setenv("OCTSIM_DEVICES", "2")
+    calls, batches = check_server.check_server("sim", n_threads=6, per_thread=5, seed=29, devices=[0, 1])
+    assert calls == 60
+
+
 def test_sim_server_rejects_a_device_that_does_not_exist():
     import pytest
     from backends import build_sim
