@@ -691,12 +691,15 @@ def main():
                 # configs[4]: 64 x 10 kb reads, 8 x 20 kb haplotypes, band 256, int32 lanes (streaming DP kernels, traceback in HBM)
                 lcfg = abi.Config.default(max_indel_error=256, use_int_scores=1, device_id=local_rank)
                 leng = engine.Engine(lcfg)
-                lbat = synth.config_batch("long64x8", seed=42, B=256, positions="none")
-                lb = leng.upload(lbat)
+                lregs0 = [synth.config_region("long64x8", seed=42, B=256, positions="none")]
+                lb = leng.upload(synth.batch_from_regions(lregs0))
                 dt = timed_resident(lb, 3)
                 ls = lb.stats()
+                lgot0 = lb.download().copy()
                 lb.free(); leng.close()
+                lv0 = verify_against_reference(lgot0, lregs0, 256, frac=0.1, cfg=lcfg)
                 out["long_read"] = {"ms": dt * 1e3, "gcups": ls["band_cells"] / dt / 1e9, "dtype": "int32", "band": 256,
+                                    "verified_rows": lv0["verified_rows"], "verified_max_abs_diff": lv0["verified_max_abs_diff"],
                                     "workload": "long64x8: 64 x 10 kb reads x 8 x 20 kb haplotypes (BASELINE configs[4])", "dp_tasks": ls["n_dp_score_only"] + ls["n_dp_traceback"]}
                 # the same shape at throughput size (8 x the reads: several waves per SIMD instead of less than one)
                 leng = engine.Engine(lcfg)
@@ -752,6 +755,22 @@ def main():
                 out["ccs2048x12"] = {"ms": dt * 1e3, "gcups": ks["band_cells"] / dt / 1e9, "dtype": "int32", "band": 16, "dp_tasks": ks["n_dp_score_only"] + ks["n_dp_traceback"],
                                      "verified_rows": kv["verified_rows"], "verified_max_abs_diff": kv["verified_max_abs_diff"],
                                      "workload": "ccs2048x12: 2,048 unsplit HiFi-like reads of 10-14 kb x 12 haplotypes of 16 kb, band 16, int32 lanes"}
+                # The wrapper's other long-read instantiations (simd_pair_hmm_wrapper.hpp:207-241), which still run round 1's streaming kernel k_dp_wide + the lockstep walker (DESIGN section 6:
+                # only band 16 x int32 has k_dp_rows, only bands 128 / 256 x int32 have k_dp_mw): reported so that the gap is a number - unsplit 10-14 kb reads at band 32 with int32 lanes,
+                # and at band 16 with int16 lanes (whose scores wrap for reads this long exactly as the reference's do: the comparison is bit for bit all the same)
+                for tag, band, wide in (("ccs256x12_band32_int32", 32, 1), ("ccs256x12_band16_int16", 16, 0)):
+                    wcfg = abi.Config.default(max_indel_error=band, use_int_scores=wide, use_mapping_quality=0, device_id=local_rank)
+                    weng = engine.Engine(wcfg)
+                    wregs = [synth.config_region("ccs256x12", seed=42, B=band, positions="none")]
+                    wb = weng.upload(synth.batch_from_regions(wregs))
+                    dt = timed_resident(wb, 2)
+                    ws = wb.stats()
+                    wgot = wb.download().copy()
+                    wb.free(); weng.close()
+                    wv = verify_against_reference(wgot, wregs, band, frac=0.05, cfg=wcfg)
+                    out[tag] = {"ms": dt * 1e3, "gcups": ws["band_cells"] / dt / 1e9, "dtype": "int32" if wide else "int16", "band": band, "dp_tasks": ws["n_dp_score_only"] + ws["n_dp_traceback"],
+                                "verified_rows": wv["verified_rows"], "verified_max_abs_diff": wv["verified_max_abs_diff"], "kernel": "k_dp_wide (streaming, round 1's form)",
+                                "workload": f"ccs256x12 at band {band}, {'int32' if wide else 'int16'} lanes: 256 unsplit reads of 10-14 kb x 12 haplotypes of 16 kb"}
         if world == 1 and extras and not sim:
             out.update(region_call_legs(stream_regs_for_calls, stream_resident_for_calls, B))
         if world == 1 and not args.no_small_batch:

@@ -62,7 +62,7 @@ def test_oracle_builds_from_a_clean_checkout_and_fails_loudly(tmp_path):
     assert "friend struct octopus::ReadRealignerDevice;" in hpp
 
     # one statement less in a seam's patch: the build must RAISE (last round it reported success and left no patched libraries)
-    inc = tmp_path / "oracle" / "integration" / "read_assigner_on_device.inc"
+    inc = tmp_path / "integration" / "read_assigner_on_device.inc"
     lines = inc.read_text().split("\n")
     k = next(i for i, line in enumerate(lines) if line.strip().endswith(";") and "prior_r.insert" in line)
     inc.write_text("\n".join(lines[:k] + ["    this_is_not_declared_anywhere();"] + lines[k + 1:]))
