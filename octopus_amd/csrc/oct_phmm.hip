@@ -132,11 +132,10 @@ struct oct_phmm_handle {
     rt::Stream stream {};                                 // slice 0 / uploads / downloads
     rt::Stream extra_streams[kMaxSlices] {};              // further slices run on their own streams so that latency-bound and VALU-bound kernels overlap
     bool main_stream_high_priority = false;
-    bool all_slices_aside = false;                        // this run's slices ALL take extra streams (OCT_PHMM_SLICES_ASIDE=1, A/B: the main stream's priority favours slice 0 in the pipeline of a
                                                           // batch of several slices - 12.8 M-pair step 29.2 -> 29.5 ms, stream-hq 22.4 -> 22.8 - but two calls in flight lose more without it); set by oct_phmm_batch_run
     rt::Event ev_ready {};
     uint32_t* bp[kMaxSlices] {}; size_t bp_bytes[kMaxSlices] {};   // traceback scratch per slice, grown on demand
-    rt::Stream slice_stream(int i) const { return all_slices_aside ? extra_streams[i] : (i == 0 ? stream : extra_streams[i - 1]); }
+    rt::Stream slice_stream(int i) const { return i == 0 ? stream : extra_streams[i - 1]; }
     // traceback scratch budget: large, so that all traceback tasks of a batch run in ONE DP launch and ONE walk launch (the walk
     // is a latency-bound pointer chase that needs every task in flight to hide it); MI355X has 288 GB. OCT_PHMM_BP_BUDGET_GB overrides.
     size_t bp_budget = (size_t)96 << 30;
@@ -216,12 +215,9 @@ struct oct_phmm_batch {
 // Every environment switch of the library, in one place (documented for callers in INTEGRATION.md section 7). None is needed in
 // production. They are read when a handle is created or a batch is uploaded - never by a kernel - and fall in three groups:
 //   profiling    OCT_PHMM_TIMING, OCT_PHMM_ROCTX (phmm_rt.hpp), OCT_PHMM_SERVER_PROFILE, OCT_PHMM_MAP_STATS, OCT_PHMM_UPLOAD_PROFILE
-//   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PAGEABLE_H2D, OCT_PHMM_PENALTIES,
-//                OCT_PHMM_MAP_READS_PER_BLOCK, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB, OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED,
-//                OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES, OCT_PHMM_DSL_FORK_EARLY, OCT_PHMM_DSL_MERGE_DP, OCT_PHMM_HOST_MAPPED, OCT_PHMM_SERVER_WORKERS,
-//                round 5: OCT_PHMM_SCAN_FUSED (0: round 4's scan launches and separate late-start launches), OCT_PHMM_JOIN_LATE, OCT_PHMM_LATE_START, OCT_PHMM_REC_CHUNK,
-//                OCT_PHMM_DSL_MAX_BLOCKS, OCT_PHMM_STREAM_PRIORITY, OCT_PHMM_SLICES_ASIDE, OCT_PHMM_SERVER_PIPELINE (0: one handle per worker, a batch is answered before the next is taken),
-//                OCT_PHMM_SERVER_GATHER (0: a worker whose batch is on the device takes whatever has arrived at once), OCT_PHMM_SERVER_CALLER_FACTS, OCT_PHMM_SERVER_LINGER_US
+//   A/B choices between paths with identical results    OCT_PHMM_SLICES, OCT_PHMM_EXACT_ADDS, OCT_PHMM_PENALTIES, OCT_PHMM_MAP_COUNT_ONLY, OCT_PHMM_LANE_MAPPER, OCT_PHMM_BP_BUDGET_GB,
+//                OCT_PHMM_DEDUP, OCT_PHMM_DEVICE_SIZED, OCT_PHMM_WALK_STAGE, OCT_PHMM_MULTI_WAVE, OCT_PHMM_MW_PLANES, OCT_PHMM_DP_ROWS, OCT_PHMM_DSL_MERGE_DP, OCT_PHMM_HOST_MAPPED, OCT_PHMM_SERVER_WORKERS,
+//                OCT_PHMM_JOIN_LATE, OCT_PHMM_LATE_START, OCT_PHMM_REC_CHUNK, OCT_PHMM_PAIRED (round 6). Switches whose A/B is recorded as lost were retired in round 6 (DESIGN.md section 9 lists the survivors).
 //   test hooks that push SMALL batches through the code paths only large ones take    OCT_PHMM_LATE_MIN_PAIRS, OCT_PHMM_BP_BUDGET_KB,
 //                OCT_PHMM_STAGE_MAX_KB, OCT_PHMM_BIG_MAPPER, OCT_PHMM_DEDUP_HASH_BITS (both de-duplication hashes cut to a few bits: collisions),
 //                OCT_PHMM_DSL_TRACE_PER_PAIR, OCT_PHMM_TEST_FAIL_BP_ALLOCS (the first traceback-scratch allocations "fail"), OCT_PHMM_SCAN_ONE_LAUNCH_MAX
@@ -253,9 +249,7 @@ inline bool timing()          { return prof_flag("OCT_PHMM_TIMING"); }          
 inline bool server_profile()  { return prof_flag("OCT_PHMM_SERVER_PROFILE"); }     // region server: where the workers' time goes, printed at destroy
 inline bool map_stats()       { return prof_flag("OCT_PHMM_MAP_STATS"); }          // k-mer mapper: pairs decided by the shortcut / counted, printed per run
 inline bool exact_adds()      { return flag("OCT_PHMM_EXACT_ADDS"); }         // keep v_pk_add_u16 even where the host bound allows v_add_u32
-inline bool pinned_direct()   { const char* e = get("OCT_PHMM_PINNED_DIRECT"); return !e || atoi(e) != 0; }   // 0: page-locked caller arrays are staged like pageable ones (A/B)
 inline size_t pinned_min_bytes(size_t dflt) { long long kb; return number("OCT_PHMM_PINNED_MIN_KB", &kb) && kb >= 0 ? (size_t)kb << 10 : dflt; }   // test hook: arrays / results from this size on are asked whether they are page-locked
-inline bool pageable_h2d()    { return flag("OCT_PHMM_PAGEABLE_H2D"); }       // big batches: copy from the caller's arrays instead of the pinned staging halves
 inline bool map_count_only()  { return flag("OCT_PHMM_MAP_COUNT_ONLY"); }     // k-mer mapper without the exact shortcut
 inline bool big_mapper()      { return flag("OCT_PHMM_BIG_MAPPER"); }         // test hook: the long-haplotype mapper on short haplotypes
 inline bool window_lds()      { const char* e = get("OCT_PHMM_WINDOW_LDS"); return !e || atoi(e) != 0; }      // 0: canonical windows through per-region hash tables in global memory (k_window_insert x 2 + k_window_candidate) instead of k_window_region (A/B, tests)
@@ -266,15 +260,12 @@ inline uint32_t dedup_hash_mask() { long long n; return number("OCT_PHMM_DEDUP_H
 inline int  device_sized()    { const char* e = get("OCT_PHMM_DEVICE_SIZED"); return !e ? -1 : atoi(e); }                           // -1 by shape, 0 never (host-sized launches: the mid-step read-back), 1 wherever possible
 inline bool trace_per_pair(long long* v) { return number("OCT_PHMM_DSL_TRACE_PER_PAIR", v); }                                      // test hook: traceback tasks per pair the device-sized path provisions scratch for (-1: one task group, so that every batch overflows and is repeated host-sized)
 inline bool late_start()      { const char* e = get("OCT_PHMM_LATE_START"); return !e || atoi(e) != 0; }                          // 0: every traceback task writes all of its backpointer tiles (A/B)
-inline bool scan_fused()      { const char* e = get("OCT_PHMM_SCAN_FUSED"); return !e || atoi(e) != 0; }                          // 0: the task counts are scanned by k_scan_bases / k_scan_tiles x 3 + k_hap_bases per array, and the late-start lists get launches of their own (round 4's chain, A/B)
 inline int  join_late()       { const char* e = get("OCT_PHMM_JOIN_LATE"); return !e ? -1 : atoi(e); }                                // a flavour's traceback and late-start lists in one DP launch and one walk: -1 one-slice batches only, 0 never, 1 always
 inline bool dp_rows()         { const char* e = get("OCT_PHMM_DP_ROWS"); return !e || atoi(e) != 0; }                             // 0: long reads at band 16 with int32 lanes keep k_dp_wide (generic cost for every task, operands per lane) instead of k_dp_rows
 inline bool multi_wave()      { const char* e = get("OCT_PHMM_MULTI_WAVE"); return !e || atoi(e) != 0; }                          // 0: bands 128 / 256 with int32 lanes keep one wave per task (k_dp_wide) instead of k_dp_mw
 inline int  mw_planes()       { const char* e = get("OCT_PHMM_MW_PLANES"); return !e ? -1 : atoi(e); }                              // k_dp_mw: -1 by task count, 0 one plane per wave (B / 64 waves per task), 1 all planes in one wave
 inline bool host_mapped()     { const char* e = get("OCT_PHMM_HOST_MAPPED"); return !e || atoi(e) != 0; }                                    // region-sized one-shot calls: inputs read and results written through mapped pinned host memory by kernels (0: DMA copies)
 inline int  dsl_merge_dp()    { const char* e = get("OCT_PHMM_DSL_MERGE_DP"); return !e ? -1 : atoi(e); }                                         // device-sized step: traceback and score-only list of a flavour in one launch (k_dp_pair): -1 by batch size, 0 never (two launches on two streams), 1 always
-inline bool dsl_fork_early()  { const char* e = get("OCT_PHMM_DSL_FORK_EARLY"); return !e || atoi(e) != 0; }                                 // device-sized step with two DP launches: the score-only DP starts beside the traceback DP (default) or after it, beside the walk (0)
-inline uint32_t walk_rows_threads() { const char* e = get("OCT_PHMM_WALK_ROWS_THREADS"); const int v = e ? atoi(e) : 0; return v == 64 || v == 128 || v == 256 ? (uint32_t)v : 64u; }
 inline int  walk_stage()      { const char* e = get("OCT_PHMM_WALK_STAGE"); return !e ? -1 : atoi(e); }                             // -1 by launch size; 0 lockstep walker out of registers, 1 lockstep out of LDS-staged tiles, 2 one walk per 16-lane row (k_walk_rows; k_walk_long at bands 128 / 256 for 1 and 2)
 inline bool penalties_report() { return getenv("OCT_PHMM_PENALTIES_REPORT") != nullptr; }                                       // one stderr line per device generation
 inline bool penalties_lane_kernel() { const char* e = get("OCT_PHMM_PENALTIES"); return e && e[0] == 'l'; }               // "lanes": one lane per haplotype even where a wave's LDS would do
@@ -379,7 +370,7 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
     {   // Big batch with arrays in page-locked caller memory (oct_phmm_host_alloc, hipHostMalloc, hipHostRegister): the DMA engine reads those arrays themselves; the
         // others (the library's own small tables, pageable caller arrays) go through the staging halves one by one
         std::vector<char> direct(n_in, 0); bool any = false;
-        if (tune::pinned_direct()) for (size_t i = 0; i < n_in; ++i) if (items[i].bytes >= tune::pinned_min_bytes((size_t)1 << 20) && rt::host_is_pinned(items[i].src, items[i].bytes)) { direct[i] = 1; any = true; }
+        for (size_t i = 0; i < n_in; ++i) if (items[i].bytes >= tune::pinned_min_bytes((size_t)1 << 20) && rt::host_is_pinned(items[i].src, items[i].bytes)) { direct[i] = 1; any = true; }
         if (any) {
             if (h->stage_bytes < kStageMax) {
                 rt::host_pinned_free(h->stage); h->stage = nullptr; h->stage_bytes = 0;
@@ -413,14 +404,6 @@ bool Packer::commit(oct_phmm_handle* h, oct_phmm_batch* b, rt::Stream s)
             for (int i = 0; i < 2; ++i) { if (used[i]) ok = rt::event_sync(ev[i]) && ok; h->put_event(ev[i]); }
             return ok;
         }
-    }
-    if (tune::pageable_h2d()) {                 // A/B switch: straight from the caller's (pageable) arrays
-        for (auto& it : items) {
-            if (!it.src) break;
-            if (!rt::dev_memset((char*)base + it.off + it.bytes, 0, 16, s)) return false;
-            if (!rt::h2d((char*)base + it.off, it.src, it.bytes, s)) return false;
-        }
-        return true;
     }
     // Big batch: the device image [0, in_bytes) goes through the two halves of the pinned staging buffer. While the DMA drains one half
     // a few host threads fill the other (one thread copies at ~10 GB/s, a pageable hipMemcpy no faster; PCIe takes ~50 GB/s).
@@ -594,7 +577,7 @@ bool launch_walk_inst(const WalkParams& w, rt::Stream s, int stage)     // stage
     const size_t lds = 256 * kWalkEvents * sizeof(uint32_t);
     if constexpr (C == 1) {
         const size_t stage_lds = walk_stage_lds_bytes(B, TPR);
-        if (stage == 2) { const uint32_t th = tune::walk_rows_threads(); OCT_LAUNCH((k_walk_rows<B, TPR>), (w.n_tasks + th / 16 - 1) / (th / 16), th, walk_rows_lds_bytes(B, th), s, w); }   // region-sized launch: four walks per wave, runs of matches in one move
+        if (stage == 2) { const uint32_t th = 64; OCT_LAUNCH((k_walk_rows<B, TPR>), (w.n_tasks + th / 16 - 1) / (th / 16), th, walk_rows_lds_bytes(B, th), s, w); }   // region-sized launch: four walks per wave, runs of matches in one move
         else if (stage && stage_lds <= rt::kMaxLdsBytes) {          // one wave per workgroup, the tiles staged in LDS
             if (stage_lds > 64 * 1024 && !rt::allow_lds((k_walk<B, TPR, C, true>), stage_lds)) return false;
             OCT_LAUNCH((k_walk<B, TPR, C, true>), (w.n_tasks + 63) / 64, 64, stage_lds, s, w);
@@ -717,7 +700,6 @@ bool ensure_bp(oct_phmm_handle* h, int slice, size_t bytes)
 // from the totals in device memory.
 // One workgroup scans ~10 us per tile of 8,192 pairs (41 us at four regions, 82 at eight: profiles/r03_step7_multi_region_timelines.txt); the four launches of the tiled scan
 // cost ~20 us whatever the size
-constexpr uint32_t kScanBasesOneLaunchMax = 2 * 8192;
 constexpr size_t   kPinnedOutMinBytes = (size_t)8 << 20;  // results from here on: is the caller's `out` page-locked? (the question costs microseconds: not asked for region-sized calls)
 constexpr uint64_t kLaneMapMinPairs = 200000;          // k-mer mapper: one lane per pair from here on (k_kmer_map_lanes), one wave per pair below
 constexpr uint64_t kDslMaxPairs = 400000;              // device-sized launches (no read-back inside the step, grids sized by the host's bound) up to here. Round 4 stopped at 100 k: first 6 / 8 / 12 / 16 / 64
@@ -787,7 +769,7 @@ int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, cons
         if (!late && joined_late_from != 0xffffffffu) p.late_from = joined_late_from > g0 * G ? joined_late_from - g0 * G : 0u;      // (relative to this chunk's first task)
         p.bp = h->bp[slice]; p.ends = tr ? ends + (size_t)g0 * G : nullptr;
         uint32_t n_blocks = (ng + p.groups_per_block - 1) / p.groups_per_block;
-        long long dsl_blocks = kDslMaxBlocks; tune::number("OCT_PHMM_DSL_MAX_BLOCKS", &dsl_blocks);      // (A/B: more, shorter-lived workgroups let the streams' priorities act between them)
+        const long long dsl_blocks = kDslMaxBlocks;
         if (dsl) n_blocks = std::min<uint32_t>(n_blocks, (uint32_t)std::max<long long>(64, dsl_blocks));
         rt::Event e0 {}, e1 {};
         if (h->timing) { RT(h->get_event(&e0)); RT(h->get_event(&e1)); RT(rt::event_record(e0, st)); }
@@ -1155,10 +1137,9 @@ extern "C" int oct_phmm_create(const oct_phmm_config* cfg, oct_phmm_handle** out
     { long long v; if (tune::number("OCT_PHMM_TEST_FAIL_BP_ALLOCS", &v) && v > 0) h->fail_bp_allocs = (int)v; }
     // The handle's own stream carries the chain a caller waits for (mapper -> classifier -> traceback DP -> walk -> epilogue); the score-only DP of a region-sized or
     // mid-size batch runs beside it on the second stream and is off the critical path as long as the traceback DP gets its CUs first: stream 0 at the device's highest
-    // priority, the others normal (OCT_PHMM_STREAM_PRIORITY=0: all normal, A/B).
-    { long long v; const bool prio = !(tune::number("OCT_PHMM_STREAM_PRIORITY", &v) && v == 0);
-      if (!rt::stream_create_priority(&h->stream, prio)) return OCT_PHMM_EHIP;
-      h->main_stream_high_priority = prio; }
+    // priority, the others normal.
+    if (!rt::stream_create_priority(&h->stream, true)) return OCT_PHMM_EHIP;
+    h->main_stream_high_priority = true;
     for (auto& es : h->extra_streams) if (!rt::stream_create(&es)) return OCT_PHMM_EHIP;
     if (!rt::event_create(&h->ev_ready)) return OCT_PHMM_EHIP;
     *out = h.release();
@@ -1447,7 +1428,6 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         d.map_count_only = tune::map_count_only(); d.map_stats = tune::map_stats();
         b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 256;      // the haplotype's tables are staged once per workgroup: big batches amortise them over more reads
         pk.dalloc(&d.bin32, (size_t)H->n_haps * kKmerBins + 4);
-        { long long n; if (tune::number("OCT_PHMM_MAP_READS_PER_BLOCK", &n) && n >= 4 && n <= 4096) b->map_reads_per_block = (uint32_t)n; }
         // lane-per-pair mapper (k_kmer_map_lanes: 256 reads of one haplotype per workgroup, the exact shortcut per lane): batches big enough to fill the chip with
         // 256-pair workgroups; region-sized calls keep one wave per pair (more, shorter waves). OCT_PHMM_LANE_MAPPER=0 / 1 forces one or the other.
         {
@@ -1539,7 +1519,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
             if (i == n_slices - 1) hap = H->n_haps;
             sl.hap1 = hap;
             sl.pair0 = hap_pair_off[sl.hap0]; sl.pair1 = hap_pair_off[sl.hap1]; sl.out0 = hap_out_off[sl.hap0]; sl.out1 = hap_out_off[sl.hap1];
-            sl.n_tiles = (uint32_t)((sl.pair1 - sl.pair0 + 1 + kScanTile - 1) / kScanTile);
+            sl.n_tiles = (uint32_t)((sl.pair1 - sl.pair0 + 1 + kScanLocalTile - 1) / kScanLocalTile);
             RT(h->get_event(&sl.done));
             sl.blk0 = (uint32_t)(std::lower_bound(b->h_blk_hap.begin(), b->h_blk_hap.end(), sl.hap0) - b->h_blk_hap.begin());
             sl.blk1 = (uint32_t)(std::lower_bound(b->h_blk_hap.begin(), b->h_blk_hap.end(), sl.hap1) - b->h_blk_hap.begin());
@@ -1809,10 +1789,8 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
     if (b->align_mode) RT(rt::dev_memset(b->d_err_flags, 0, 16, s0));
     if (b->dedup) RT(rt::dev_memset(d.pair_rep, 0xff, (size_t)b->n_pairs * sizeof(uint32_t), s0));      // kNoPair: every pair is computed itself until k_dedup_verify says otherwise
     for (int k = 0; k < kNumKinds; ++k) b->n_tasks[k] = 0;
-    // (OCT_PHMM_SLICES_ASIDE=1; off by default: with slice 0 on the high-priority stream two populate calls in flight from host buffers reach 0.92-0.95 x the resident rate, with all
-    // slices aside 0.88-0.92 - at 0.2-0.3 ms of the 12.8 M-pair step, profiles/r05_priority_big_batches.md)
-    { long long v; h->all_slices_aside = S > 1 && h->main_stream_high_priority && tune::number("OCT_PHMM_SLICES_ASIDE", &v) && v != 0; }
-    const int first_aside = h->all_slices_aside ? 0 : 1;    // the first slice that runs on a stream other than the handle's own
+    // (slice 0 stays on the handle's high-priority stream: with ALL slices on normal-priority streams the single step is 0.2-0.3 ms faster and two calls in flight fall from 0.92-0.95 x to 0.88-0.92 x the resident rate, profiles/r05_priority_big_batches.md)
+    const int first_aside = 1;    // the first slice that runs on a stream other than the handle's own
     if (S > 1) {
         RT(rt::event_record(h->ev_ready, s0));
         for (int i = first_aside; i < S; ++i) RT(rt::stream_wait_event(h->slice_stream(i), h->ev_ready));
@@ -1861,7 +1839,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         // The scan of the task counts starts in the kernel that makes them: its workgroups store tile-local prefixes and tile totals (k_scan_finish does the rest in
         // one workgroup). The grid then covers pair1 itself, the scan's extra entry.
         const uint64_t n_scan = np + 1;
-        sl.scan_fused = tune::scan_fused() && n_scan < 0xffffffffull;
+        sl.scan_fused = true;                                 // (the scan that starts in the classifier; round 4's chain of scan launches was retired in round 6)
         const bool verify_runs = b->dedup && sl.n_seg_tiles;
         const uint32_t pair_blocks = (uint32_t)(((sl.scan_fused ? n_scan : np) + 255) / 256);
         uint4* const ts = sl.scan_fused ? sl.tile_sums : nullptr; uint4* const ts_late = sl.scan_fused ? sl.tile_sums_late : nullptr;
@@ -1872,41 +1850,13 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             OCT_LAUNCH(k_dedup_verify, pair_blocks, 256, 0, s, d, sl.pair0, sl.pair1, sl.cnt, sl.cnt_late, ts, ts_late); RT(rt::launch_ok());
         }
         if (b->dedup && S > 1) RT(rt::event_record(sl.matched, s));   // the next slice's matcher may resume a region of this one
-        if (sl.scan_fused) {                                  // any size: tile prefixes, haplotype bases and totals of both count arrays in ONE single-workgroup launch
+        {                                                     // any size: tile prefixes, haplotype bases and totals of both count arrays in ONE single-workgroup launch
             OCT_LAUNCH(k_scan_finish, sl.cnt_late ? 2 : 1, kHapBaseThreads, 16 * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, (const uint4*)sl.cnt_late, sl.pair0, pair_blocks,
                        sl.tile_sums, sl.tile_sums_late, b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G); RT(rt::launch_ok());
             sl.totals_late = make_uint4(0, 0, 0, 0);
             if (!b->dsl) { RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s)); if (sl.cnt_late) RT(rt::d2h(&sl.totals_late, sl.d_totals_late, sizeof(uint4), s)); }
             return OCT_PHMM_OK;
         }
-        long long one_launch_max = kScanBasesOneLaunchMax; tune::number("OCT_PHMM_SCAN_ONE_LAUNCH_MAX", &one_launch_max);      // (test hook: 0 = the tiled scan for every device-sized batch)
-        if (b->dsl && (long long)n_scan <= one_launch_max) {  // region-sized: scans and per-haplotype bases of both count arrays in one launch
-            OCT_LAUNCH(k_scan_bases, sl.cnt_late ? 2 : 1, kHapBaseThreads, 16 * sizeof(uint4), s, d, sl.hap0, sl.hap1, sl.cnt, sl.cnt_late, sl.pair0, (uint32_t)n_scan,
-                       b->d_hap_base, b->d_hap_base_late, sl.d_totals, sl.d_totals_late, G); RT(rt::launch_ok());
-            return OCT_PHMM_OK;
-        }
-        if (sl.n_tiles == 1) {
-            OCT_LAUNCH(k_scan_tiles, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 2); RT(rt::launch_ok());
-        } else {
-            OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 0); RT(rt::launch_ok());
-            OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.tile_sums, sl.n_tiles); RT(rt::launch_ok());
-            OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt, n_scan, sl.tile_sums, 1); RT(rt::launch_ok());
-        }
-        OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt, sl.pair0, b->d_hap_base, sl.d_totals, G, 0); RT(rt::launch_ok());
-        if (!b->dsl) RT(rt::d2h(&sl.totals, sl.d_totals, sizeof(uint4), s));
-        sl.totals_late = make_uint4(0, 0, 0, 0);
-        if (sl.cnt_late) {                                    // the same scan for the late-start traceback tasks
-            if (sl.n_tiles == 1) {
-                OCT_LAUNCH(k_scan_tiles, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt_late, n_scan, sl.tile_sums_late, 2); RT(rt::launch_ok());
-            } else {
-                OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt_late, n_scan, sl.tile_sums_late, 0); RT(rt::launch_ok());
-                OCT_LAUNCH(k_scan_tile_sums, 1, kScanThreads, kScanThreads * sizeof(uint4), s, sl.tile_sums_late, sl.n_tiles); RT(rt::launch_ok());
-                OCT_LAUNCH(k_scan_tiles, sl.n_tiles, kScanThreads, kScanThreads * sizeof(uint4), s, sl.cnt_late, n_scan, sl.tile_sums_late, 1); RT(rt::launch_ok());
-            }
-            OCT_LAUNCH(k_hap_bases, 1, kHapBaseThreads, kHapBaseThreads * sizeof(uint4), s, d, sl.hap0, sl.hap1, (const uint4*)sl.cnt_late, sl.pair0, b->d_hap_base_late, sl.d_totals_late, G, 1); RT(rt::launch_ok());
-            if (!b->dsl) RT(rt::d2h(&sl.totals_late, sl.d_totals_late, sizeof(uint4), s));
-        }
-        return OCT_PHMM_OK;
     };
     // phase 2 of the one slice of a device-sized batch: the same launches with grids from the host's bound; the kernels find their task lists through
     // the totals k_hap_bases left in device memory
@@ -1943,7 +1893,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             const int want_merge = tune::dsl_merge_dp();
             const bool merge = (want_merge >= 0 ? want_merge != 0 : np <= kDslMergeMaxPairs) && !h->wide && !b->stream && !b->multi_wave && !b->align_mode;
             bool forked = false, score_done[2] = {false, false};
-            if (!merge && (b->stream || tune::dsl_fork_early())) { RT(rt::event_record(b->ev_fork, s)); forked = true; }     // (long reads: see the host-sized path)
+            if (!merge) { RT(rt::event_record(b->ev_fork, s)); forked = true; }     // (long reads: see the host-sized path)
             for (int list : {4, 5, (int)kTraceFast, (int)kTraceGen}) {
                 if (list >= 4 && (!sl.cnt_late || join)) continue;
                 if (!flavour_live(list)) continue;
@@ -2037,7 +1987,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             // ... except for long reads: a traceback launch of ~10^2 tasks is a few hundred latency-bound waves that leave the chip's issue slots to the score-only DP
             // ... and (round 5) for every such batch: joined with its late-start list the first traceback launch is the whole traceback DP, and a score-only DP that
             // waits for it runs behind it instead of beside it (16 regions: 204 + 190 us one after the other). OCT_PHMM_DSL_FORK_EARLY=0: beside the first walk.
-            if (side && (b->stream || tune::dsl_fork_early())) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
+            if (side) { RT(rt::event_record(b->ev_fork, s)); forked = true; }
             for (int lk = 0; lk < 2 && !join; ++lk) {            // late-start traceback launches first (the longest walks of the slice start earliest)
                 const uint32_t n = lk ? late.y : late.x;
                 const int rc = run_dp_kind(h, b, i, lk ? kTraceGen : kTraceFast, tsl.t[lk], n, sl.d_ends, h->cfg.nuc_prior, nullptr, status, nullptr, true,
@@ -2369,7 +2319,7 @@ static int populate_begin(oct_phmm_handle* h, const oct_phmm_reads* reads, const
     bool early = false;
     if (rc == OCT_PHMM_OK && out && b->n_out) {                // results come back through a pinned landing zone: slice by slice while a big batch computes, behind the
         const size_t bytes = (size_t)b->n_out * sizeof(double);  // epilogue of a small one - one stream synchronisation per call, no staged copy into pageable memory
-        if (bytes >= tune::pinned_min_bytes(kPinnedOutMinBytes) && tune::pinned_direct() && rt::host_is_pinned(out, bytes)) { b->early_out = out; b->out_landing = out; early = true; }   // the caller's own page-locked buffer IS the landing zone
+        if (bytes >= tune::pinned_min_bytes(kPinnedOutMinBytes) && rt::host_is_pinned(out, bytes)) { b->early_out = out; b->out_landing = out; early = true; }   // the caller's own page-locked buffer IS the landing zone
         else if (h->out_stage_bytes < bytes) {
             const size_t roomy = std::max(bytes + bytes / 2, (size_t)1 << 20);     // (a region thread's calls differ in size: no regrowth per call)
             rt::host_pinned_free(h->out_stage); h->out_stage = nullptr; h->out_stage_bytes = 0;
@@ -2435,11 +2385,7 @@ struct oct_phmm_server {
     std::atomic<uint64_t> n_calls {0}, n_batches {0};    // counted when the calls are taken / the batch is enqueued: a caller that has its answer finds itself counted
     std::vector<uint64_t> n_calls_by_device;
     int busy_workers = 0;                                // workers between taking calls and answering them (under mu)
-    static constexpr int kLingerSteps = 6;
-    int linger_us = [] { long long v; return tune::number("OCT_PHMM_SERVER_LINGER_US", &v) && v >= 0 && v <= 10000 ? (int)v : 0; }();    // 0 (default): take what is there. Measured: 25 us x 6 steps doubles the regions per device batch (13 -> 22 at 128 callers) and LOSES 5 - 20 % throughput
                                                          // (profiles/r04_step3_server_sweep.log): a bigger device batch is not cheaper per region, the step is a chain of ~25 small launches either way
-    bool gather = [] { long long v; return !(tune::number("OCT_PHMM_SERVER_GATHER", &v) && v == 0); }();          // 0: a worker whose batch is on the device takes whatever has arrived at once (A/B)
-    bool pipelined = [] { long long v; return !(tune::number("OCT_PHMM_SERVER_PIPELINE", &v) && v == 0); }();      // 0: a worker answers a batch before it takes the next calls (round 4's loop, A/B)
     std::atomic<bool> has_model {false};                 // oct_phmm_server_set_error_model: calls may leave their penalty vectors NULL
     // the model travels to the handles through their own worker threads (under mu): a handle is only ever touched by its worker
     oct_phmm_error_model pending_model {}; bool pending_has_model = false; uint64_t model_version = 0; std::vector<uint64_t> worker_version;
@@ -2573,7 +2519,7 @@ struct oct_phmm_server {
     void finish_loop(int w)
     {
         Worker& W = *wk[(size_t)w];
-        const int n_slots = pipelined ? kSlots : 1;
+        const int n_slots = kSlots;
         for (int k = 0;; k = (k + 1) % n_slots) {          // slots fly in turn
             {
                 std::unique_lock<std::mutex> lk(W.m);
@@ -2595,7 +2541,7 @@ struct oct_phmm_server {
     void run(int w)
     {
         Worker& W = *wk[(size_t)w];
-        const int n_slots = pipelined ? kSlots : 1;
+        const int n_slots = kSlots;
         oct_phmm_handle* hslot[kSlots]; for (int k = 0; k < kSlots; ++k) hslot[k] = hs[(size_t)w * kSlots + k];
         std::deque<std::vector<Request*>> groups;          // batches taken from the queue that wait for a slot
         int next_slot = 0; size_t last_batch = 1;
@@ -2611,7 +2557,7 @@ struct oct_phmm_server {
                     if (flying() == 0) {
                         if (w_busy) { --busy_workers; w_busy = false; }
                         cv_work.wait(lk, [&] { return stop || !queue.empty(); });
-                    } else if (gather) {
+                    } else {
                         // A batch of this worker is on the device: the calls that have arrived since are the first of the next burst (its own callers come back when it
                         // lands, the other workers' when theirs do). A batch of two costs the device what one of ten does, so there is no hurry - but the next batch should
                         // be enqueued when this one ends. Wait until as many calls wait as the last batch held (two batches of a size, turn and turn about: what a steady
@@ -2619,10 +2565,6 @@ struct oct_phmm_server {
                         const size_t want = std::max<size_t>(1, std::min<size_t>(max_regions, last_batch));
                         while (!stop && queue.size() < want && flying() > 0)
                             cv_work.wait_for(lk, std::chrono::microseconds(50), [&] { return stop || queue.size() >= want; });
-                    } else {
-                        // OCT_PHMM_SERVER_GATHER=0 (the A/B setting): take whatever has arrived - but sleep while nothing has, instead of spinning on mu and W.m until the batch lands
-                        while (!stop && queue.empty() && flying() > 0)
-                            cv_work.wait_for(lk, std::chrono::microseconds(50), [&] { return stop || !queue.empty(); });
                     }
                     if (profile) ns_idle += now_ns() - t_idle;
                     if (queue.empty() && stop) { lk.unlock(); wait_all_landed(); return; }
@@ -2634,14 +2576,6 @@ struct oct_phmm_server {
                         }
                         worker_version[(size_t)w] = model_version;
                     }
-                    // Bounded linger (OCT_PHMM_SERVER_LINGER_US, off by default): with other workers' batches on the device, wait while calls keep arriving
-                    if (linger_us > 0 && busy_workers > 0 && queue.size() < max_regions) {
-                        for (int step = 0; step < kLingerSteps && !stop; ++step) {
-                            const size_t before = queue.size();
-                            cv_work.wait_for(lk, std::chrono::microseconds(linger_us), [&] { return stop || queue.size() >= max_regions; });
-                            if (queue.size() == before || busy_workers == 0) break;
-                        }
-                    }
                     while (!queue.empty() && take.size() < max_regions) { take.push_back(queue.front()); queue.pop_front(); }
                     if (!take.empty() && !w_busy) { ++busy_workers; w_busy = true; }
                     n_calls += take.size(); n_calls_by_device[(size_t)device_of[(size_t)w]] += take.size();
@@ -2649,10 +2583,6 @@ struct oct_phmm_server {
                 if (take.empty()) continue;
                 std::vector<Request*> batchable, batchable_gen, single;       // calls that leave their penalty vectors to the library batch among themselves
                 for (Request* q : take) (q->pos || !q->R || !q->H || !q->R->n_reads || !q->H->n_haps ? single : q->H->gap_open ? batchable : batchable_gen).push_back(q);
-                if (!pipelined) {                              // (a lone call skips the concatenation; a pipelined worker sends it through the asynchronous path like any batch)
-                    if (batchable.size() == 1) { single.push_back(batchable[0]); batchable.clear(); }
-                    if (batchable_gen.size() == 1) { single.push_back(batchable_gen[0]); batchable_gen.clear(); }
-                }
                 if (!single.empty()) {                         // calls with positions of their own, empty calls: one by one, on a slot that is on the ground
                     const uint64_t t_single = profile ? now_ns() : 0;
                     { std::unique_lock<std::mutex> lk(W.m); W.cv_free.wait(lk, [&] { return !W.slot[next_slot].flying; }); }
@@ -2781,8 +2711,7 @@ extern "C" int oct_phmm_server_populate(oct_phmm_server* s, const oct_phmm_reads
         if (!out && (size_t)rows * haps->n_haps) return fail(status, OCT_PHMM_EINVAL, "null output");
     }
     oct_phmm_server::Request q; q.R = reads; q.H = haps; q.flank = flank; q.pos = positions; q.out = out; memset(&q.st, 0, sizeof(q.st));
-    static const bool caller_facts = [] { long long v; return !(tune::number("OCT_PHMM_SERVER_CALLER_FACTS", &v) && v == 0); }();      // 0: the workers look at every byte themselves (A/B)
-    if (caller_facts && haps->gap_open && reads->n_reads && haps->n_haps) {      // everything an upload has to know about the call's bytes: looked up HERE, on the caller's thread (the workers are what a busy server waits for)
+    if (haps->gap_open && reads->n_reads && haps->n_haps) {      // everything an upload has to know about the call's bytes: looked up HERE, on the caller's thread (the workers are what a busy server waits for)
         q.facts.dirty = 0; q.facts.have_haps = true;
         facts_of_reads(reads, 0, reads->n_reads, true, &q.facts);
         facts_of_haps(haps, haps->offsets[0], haps->offsets[haps->n_haps], true, &q.facts);

@@ -1296,111 +1296,11 @@ OCT_KERNEL(k_dedup_verify)(DevBatch b, uint64_t pair0, uint64_t pair1, uint4* cn
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// exclusive scan of the per-pair task counts (uint4, one component per task kind), in place over n = n_pairs + 1 items
+// exclusive scan of the per-pair task counts (uint4, one component per task kind) over n = n_pairs + 1 items: tile-local in the kernel that makes the counts, finished by k_scan_finish
+// (rounds 1-4 scanned with k_scan_tiles x 3 + k_hap_bases per count array, or k_scan_bases for region-sized batches: retired in round 6, profiles/EXPERIMENTS.md)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kScanThreads = 256, kScanItems = 4, kScanTile = kScanThreads * kScanItems;
-
 OCT_DEVICE uint4 add4(uint4 a, uint4 b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-
-OCT_KERNEL(k_scan_tiles)(uint4* data, uint64_t n, uint4* tile_sums, int apply)
-{
-    OCT_DYN_SMEM(smem);
-    uint4* sh = (uint4*)smem;                                   // [kScanThreads]
-    const uint32_t tid = hw::thread_idx();
-    const uint64_t base = (uint64_t)hw::block_idx() * kScanTile + (uint64_t)tid * kScanItems;
-    uint4 v[kScanItems]; uint4 sum = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = 0; i < kScanItems; ++i) { v[i] = base + i < n ? data[base + i] : make_uint4(0, 0, 0, 0); sum = add4(sum, v[i]); }
-    sh[tid] = sum;
-    hw::block_sync();
-    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {           // inclusive Hillis-Steele over the thread sums
-        uint4 o = make_uint4(0, 0, 0, 0);
-        if (tid >= d) o = sh[tid - d];
-        hw::block_sync();
-        sh[tid] = add4(sh[tid], o);
-        hw::block_sync();
-    }
-    if (!apply) {
-        if (tid == kScanThreads - 1) tile_sums[hw::block_idx()] = sh[tid];
-        return;
-    }
-    // apply == 2: the whole array is this one tile (a region-sized batch): no tile offsets to add, one launch instead of three
-    uint4 run = add4(apply == 2 ? make_uint4(0, 0, 0, 0) : tile_sums[hw::block_idx()], tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0));
-    for (uint32_t i = 0; i < kScanItems; ++i) if (base + i < n) { data[base + i] = run; run = add4(run, v[i]); }
-}
-
-OCT_KERNEL(k_scan_tile_sums)(uint4* tile_sums, uint32_t n_tiles)   // one block of kScanThreads threads
-{
-    OCT_DYN_SMEM(smem);
-    uint4* sh = (uint4*)smem;
-    const uint32_t tid = hw::thread_idx();
-    const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads, lo = tid * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
-    uint4 sum = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = lo; i < hi; ++i) sum = add4(sum, tile_sums[i]);
-    sh[tid] = sum;
-    hw::block_sync();
-    for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
-        uint4 o = make_uint4(0, 0, 0, 0);
-        if (tid >= d) o = sh[tid - d];
-        hw::block_sync();
-        sh[tid] = add4(sh[tid], o);
-        hw::block_sync();
-    }
-    uint4 run = tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0);
-    for (uint32_t i = lo; i < hi; ++i) { const uint4 v = tile_sums[i]; tile_sums[i] = run; run = add4(run, v); }
-}
-
 constexpr uint32_t kHapBaseThreads = 1024;
-// Per haplotype and kind: first task slot, with every haplotype's task run padded to a multiple of the group size so
-// that a DP task group never straddles two haplotypes. hap_base[n_haps] = padded totals.
-OCT_KERNEL(k_hap_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* cnt, uint64_t pair0, uint4* hap_base, uint4* totals, uint32_t group, int late)
-{
-    // one block of kHapBaseThreads threads: each sums a contiguous run of haplotypes, the block scans the thread sums, each writes its run
-    // (a slice of the many-region workload holds tens of thousands of haplotypes: one serial thread took 4.6 ms per launch)
-    OCT_DYN_SMEM(smem);
-    uint4* sh = (uint4*)smem;                                   // [kHapBaseThreads]
-    const uint32_t tid = hw::thread_idx(), n = hap1 - hap0;
-    const uint32_t per = (n + kHapBaseThreads - 1) / kHapBaseThreads;
-    const uint32_t lo = hap0 + (tid * per < n ? tid * per : n), hi = hap0 + ((tid + 1) * per < n ? (tid + 1) * per : n);
-    auto up = [&](uint32_t c) { return (c + group - 1) / group * group; };
-    auto padded = [&](uint32_t h) {
-        const uint4 a = cnt[b.hap_pair_off[h] - pair0], z = cnt[b.hap_pair_off[h + 1] - pair0];
-        return make_uint4(up(z.x - a.x), up(z.y - a.y), up(z.z - a.z), up(z.w - a.w));
-    };
-    // (a thread's haplotypes four at a time: eight independent loads in flight instead of a chain of dependent ones - 49 k haplotypes on 1,024 threads were 0.36 ms of latency)
-    uint4 sum = make_uint4(0, 0, 0, 0);
-    for (uint32_t h = lo; h < hi; h += 4) {
-        uint4 v[4];
-        for (uint32_t u = 0; u < 4; ++u) v[u] = h + u < hi ? padded(h + u) : make_uint4(0, 0, 0, 0);
-        for (uint32_t u = 0; u < 4; ++u) sum = add4(sum, v[u]);
-    }
-    sh[tid] = sum;
-    hw::block_sync();
-    for (uint32_t d = 1; d < kHapBaseThreads; d <<= 1) {
-        uint4 o = make_uint4(0, 0, 0, 0);
-        if (tid >= d) o = sh[tid - d];
-        hw::block_sync();
-        sh[tid] = add4(sh[tid], o);
-        hw::block_sync();
-    }
-    uint4 run = tid ? sh[tid - 1] : make_uint4(0, 0, 0, 0);
-    for (uint32_t h = lo; h < hi; h += 4) {
-        uint4 v[4];
-        for (uint32_t u = 0; u < 4; ++u) v[u] = h + u < hi ? padded(h + u) : make_uint4(0, 0, 0, 0);
-        for (uint32_t u = 0; u < 4; ++u) if (h + u < hi) { hap_base[h + u] = run; run = add4(run, v[u]); }
-    }
-    if (tid == kHapBaseThreads - 1) {
-        const uint4 all = sh[tid];
-        *totals = all;
-        const uint32_t t0 = late ? all.x : all.y, t1 = late ? all.y : all.w;          // the traceback lists (see k_scan_bases)
-        if (b.dsl_trace_cap && (t0 > b.dsl_trace_cap || t1 > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
-    }
-}
-
-// Region-sized batches: the scan of the per-pair counts and the per-haplotype bases in ONE single-workgroup launch instead of four (three scan
-// launches + k_hap_bases), for both count arrays at once (workgroup 0: cnt, workgroup 1: cnt_late). A call is a chain of dependent launches and each
-// link costs ~5 us however little it does. Tiles of 8192 items (eight consecutive per thread), the thread sums
-// scanned with shuffles inside a wave and through 16 LDS words across the waves: two workgroup barriers per tile.
-constexpr uint32_t kScanBasesMaxItems = 64 * 1024;
 OCT_DEVICE uint4 shfl4(uint4 v, uint32_t src) { return make_uint4(hw::shfl(v.x, (int)src), hw::shfl(v.y, (int)src), hw::shfl(v.z, (int)src), hw::shfl(v.w, (int)src)); }
 OCT_DEVICE uint4 sub4(uint4 a, uint4 b) { return make_uint4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 // exclusive prefix of `v` over the kHapBaseThreads threads of the workgroup; *total = the sum over all of them. sh: 16 words of LDS.
@@ -1417,57 +1317,15 @@ OCT_DEVICE uint4 block_scan_excl(uint4 v, uint4* sh, uint4* total)
     *total = all;
     return add4(before, sub4(inc, v));
 }
-OCT_KERNEL(k_scan_bases)(DevBatch b, uint32_t hap0, uint32_t hap1, uint4* cnt0, uint4* cnt1, uint64_t pair0, uint32_t n_scan,
-                         uint4* hap_base0, uint4* hap_base1, uint4* totals0, uint4* totals1, uint32_t group)
-{
-    OCT_DYN_SMEM(smem);
-    uint4* sh = (uint4*)smem;                                   // [16]
-    uint4* cnt = hw::block_idx() ? cnt1 : cnt0; uint4* hap_base = hw::block_idx() ? hap_base1 : hap_base0; uint4* totals = hw::block_idx() ? totals1 : totals0;
-    const uint32_t tid = hw::thread_idx();
-    uint4 carry = make_uint4(0, 0, 0, 0);
-    constexpr uint32_t PER = 8;                                 // items per thread and tile: a 300 x 24 region (7,201 items) is ONE tile, i.e. one round of loads, scan, stores
-    for (uint32_t base = 0; base < n_scan; base += kHapBaseThreads * PER) {    // exclusive scan of cnt[0, n_scan), in place
-        const uint32_t i0 = base + tid * PER;
-        uint4 v[PER], sum = make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) { v[j] = i0 + j < n_scan ? cnt[i0 + j] : make_uint4(0, 0, 0, 0); sum = add4(sum, v[j]); }
-        uint4 tile_total;
-        uint4 run = add4(carry, block_scan_excl(sum, sh, &tile_total));
-#pragma unroll
-        for (uint32_t j = 0; j < PER; ++j) if (i0 + j < n_scan) { cnt[i0 + j] = run; run = add4(run, v[j]); }
-        carry = add4(carry, tile_total);
-    }
-    hw::block_sync();                                           // the scanned counts are read across threads below
-    const uint32_t n = hap1 - hap0;
-    const uint32_t per = (n + kHapBaseThreads - 1) / kHapBaseThreads;
-    const uint32_t lo = hap0 + (tid * per < n ? tid * per : n), hi = hap0 + ((tid + 1) * per < n ? (tid + 1) * per : n);
-    auto up = [&](uint32_t c) { return (c + group - 1) / group * group; };
-    auto padded = [&](uint32_t h) {
-        const uint4 a = cnt[b.hap_pair_off[h] - pair0], z = cnt[b.hap_pair_off[h + 1] - pair0];
-        return make_uint4(up(z.x - a.x), up(z.y - a.y), up(z.z - a.z), up(z.w - a.w));
-    };
-    uint4 sum = make_uint4(0, 0, 0, 0);
-    for (uint32_t h = lo; h < hi; ++h) sum = add4(sum, padded(h));
-    uint4 all;
-    uint4 run = block_scan_excl(sum, sh, &all);
-    for (uint32_t h = lo; h < hi; ++h) { hap_base[h] = run; run = add4(run, padded(h)); }
-    if (tid == 0) {
-        *totals = all;
-        // the traceback lists (y, w of the main counts; x, y of the late-start ones) must fit the scratch the host provisioned
-        const uint32_t t0 = hw::block_idx() ? all.x : all.y, t1 = hw::block_idx() ? all.y : all.w;
-        if (b.dsl_trace_cap && (t0 > b.dsl_trace_cap || t1 > b.dsl_trace_cap)) *b.dsl_overflow = 1ull;
-    }
-}
 
-// Any size, TWO launches (round 5) instead of k_scan_tiles x 3 + k_hap_bases per count array (eight launches and their gaps with late-start lists: a region
-// server's device batch is a chain of dependent launches):
+// Any size, TWO launches (a region server's device batch is a chain of dependent launches):
 //   * the kernel that makes the counts - k_classify, or k_dedup_verify where pairs are shared - scans them across its own workgroup (a "tile" of 256 pairs) and
 //     stores every pair's tile-local exclusive prefix and the tile's total (block_scan_local);
-//   * k_scan_finish, ONE workgroup: tile totals -> tile prefixes (in place), per-haplotype bases and totals of both count arrays from local prefix + tile prefix.
+//   * k_scan_finish, one workgroup per count array: tile totals -> tile prefixes (in place), per-haplotype bases and totals of both count arrays from local prefix + tile prefix.
 // Readers of the counts (k_emit) add the tile prefix themselves: ScanView. (First form of the round: one launch whose last workgroup did the second step behind a
 // device-scope counter - 55 us for 150 k pairs against 48 us for the eight launches it replaced, and 10 % on the 12.8 M-pair step: every workgroup's release fence is a
 // write-back of its XCD's L2 on this chip, 392 of them per slice beside other slices' backpointer stores. profiles/EXPERIMENTS.md.)
-struct ScanView { const uint4* cnt; const uint4* tile_pref; };       // tile_pref null: cnt is scanned globally (k_scan_tiles, k_scan_bases)
+struct ScanView { const uint4* cnt; const uint4* tile_pref; };       // tile_pref null: cnt is scanned globally
 constexpr uint32_t kScanLocalShift = 8, kScanLocalTile = 1u << kScanLocalShift;      // = the 256 threads of k_classify / k_dedup_verify
 OCT_DEVICE uint4 scanned(const ScanView& v, uint64_t i) { const uint4 c = v.cnt[i]; return v.tile_pref ? add4(c, v.tile_pref[i >> kScanLocalShift]) : c; }
 OCT_KERNEL(k_scan_finish)(DevBatch b, uint32_t hap0, uint32_t hap1, const uint4* cnt0, const uint4* cnt1, uint64_t pair0, uint32_t n_tiles,
@@ -1732,6 +1590,11 @@ inline uint32_t dp_lds_bytes(uint32_t t_cap, uint32_t lh_cap, uint32_t B, bool t
 // traceback scratch: per task group, ceil(iterations / 16) tiles of 64 lanes x 16 iterations, each lane's 16 dwords contiguous
 OCT_HD constexpr uint32_t bp_tiles(uint32_t t_cap, uint32_t B) { return (t_cap + B + 15) / 16 + 1; }
 
+// OCT_DP_ABLATE=n (A/B builds only, tools/build_variant.sh; results are NOT the product's): the kernel without one of its phases, to price that phase by difference -
+// 1 haplotype-table staging, 2 read-record staging, 3 end-cell capture + the final reduction, 4 the tile flush to HBM (traceback), 5 tile writes and flush (traceback)
+#ifndef OCT_DP_ABLATE
+#define OCT_DP_ABLATE 0
+#endif
 // (the body of k_dp: workgroup `blk` of `nblk` - a launch may hold the workgroups of two task lists, see k_dp_pair)
 template <int B, bool TRACE, bool GENERIC, bool FASTADD>
 OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t nblk)
@@ -1784,7 +1647,8 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
             if (seg < pg) { paired = true; if (seg_end > pg) seg_end = pg; }
         }
         hw::block_sync();
-        if (paired) {
+        if (OCT_DP_ABLATE == 1) {}
+        else if (paired) {
             for (uint32_t x = tid; x < lh_n; x += kBlockWaves * 64) {
                 const bool in = x < Lh, inp = x >= 1 && x - 1 < Lh;
                 const uint2 f = in ? p.tabF[ho + x] : make_uint2(0, 0), r = in ? p.tabR[ho + x] : make_uint2(0, 0);
@@ -1819,6 +1683,7 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
             // holds the entries of the next rec_chunk iterations only (iteration k reads entries k - k_base + B - li and one beyond) and is restaged at every chunk border ----
             const uint32_t n_entries_all = K4 + B + 1;
             auto stage = [&](const uint32_t k_base) {
+            if (OCT_DP_ABLATE == 2) return;
             const uint32_t n_need = p.rec_chunk && k_base + p.rec_chunk + B + 2 < n_entries_all ? p.rec_chunk + B + 2 : n_entries_all - k_base;
             hw::wave_lds_fence();                                                            // (a restage: every lane has read what it needed of the old entries)
             if constexpr (!GENERIC) {
@@ -1919,6 +1784,7 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
             // every 16 iterations: transpose the 16 x 64 tile through LDS so that each lane's 16 words become one 64-byte line and
             // the wave stores 4 fully coalesced 1 KB pieces (k_walk then fetches one line per 16 walk steps)
             auto flush_tile = [&](uint32_t kt) {
+                if (OCT_DP_ABLATE >= 4) return;
                 hw::wave_lds_fence();
                 uint4* dst = bpg + (size_t)kt * 256;
 #pragma unroll
@@ -1931,7 +1797,7 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
             };
 
             auto quad = [&](uint32_t k0, auto init_c, auto cap_c, auto tr_c) {
-                constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value, TR = TRACE && decltype(tr_c)::value;
+                constexpr bool INIT = decltype(init_c)::value, CAP = decltype(cap_c)::value && OCT_DP_ABLATE != 3, TR = TRACE && decltype(tr_c)::value;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t k = k0 + u;
@@ -1971,7 +1837,10 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
                         const uint32_t tm = M2 & 0x00030003u, ti = I2 & 0x00030003u, td = D2 & 0x00030003u;
                         M2 ^= tm; I2 |= 0x00010001u; D2 |= 0x00030003u;
                         const uint32_t bpo = hw_lshl_or(td, 4, hw_lshl_or(ti, 2, tm));
-                        tile[(k & 15) * kTileStride + lane] = hw_lshl_or(bpo, 6, bpe | flag_of(fo, 14));
+                        if (OCT_DP_ABLATE != 5) tile[(k & 15) * kTileStride + lane] = hw_lshl_or(bpo, 6, bpe | flag_of(fo, 14));
+#if !defined(OCTPHMM_SIM)
+                        else asm volatile("" :: "v"(bpo | bpe));
+#endif
                     }
                     if constexpr (PAIRED) { rr = rr_nx; cA.x = nA.x; nA.x = e1; GOn = e4.x; GEn = e4.y; GO = e4.z; GE = e4.w; }
                     else {
@@ -2030,7 +1899,8 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
             if constexpr (TRACE) { if (K4 & 15) flush_tile(K4 >> 4); }
 
             // ---- first minimum over the row's end cells, per packed task (:285-291,309-315,323) ----
-            for (uint32_t half = 0; half < 2; ++half) {
+            if (OCT_DP_ABLATE == 3 && TRACE && li == 0) { TraceEnd e; e.score = 0; e.sidx = -1; p.ends[g * G + 2 * row] = e; p.ends[g * G + 2 * row + 1] = e; }   // (no walk)
+            for (uint32_t half = 0; half < (OCT_DP_ABLATE == 3 ? 0u : 2u); ++half) {
                 const uint32_t Th = half ? TB : TA;
                 const uint32_t vE = (bestE >> (16 * half)) & 0xffffu, vO = (bestO >> (16 * half)) & 0xffffu;   // biased: unsigned order
                 const uint32_t sE = 2 * (Th + li);

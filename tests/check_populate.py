@@ -404,7 +404,9 @@ def check_window_pairing(backend, tol=0.0):
         for B, R, H, T, Lh, flank, slices, late, budget_kb in ((16, 420, 5, 150, 300, (40, 40), "1", "0", None), (16, 300, 7, 150, 330, (40, 40), "3", "0", None),
                                                                 (8, 260, 4, 70, 200, (15, 60), "1", "1000000000000", None), (32, 200, 4, 150, 400, (30, 120), "2", "0", None),
                                                                 (16, 350, 4, 120, 280, (0, 90), "1", "0", 3000)):
-            regs = [synth.make_region(rng, R, H, T=T, Lh=Lh + 13 * i, B=B, flank=flank, positions="none", indels_per_read=0.05) for i in range(2)]
+            if backend == "sim":                                    # (the wave simulator runs ~10^4 x slower than the device: a third of the reads, one such region)
+                R = R // 3
+            regs = [synth.make_region(rng, R, H, T=T, Lh=Lh + 13 * i, B=B, flank=flank, positions="none", indels_per_read=0.05) for i in range(1 if backend == "sim" else 2)]
             regs.append(synth.make_region(rng, 9, 3, T=T, Lh=Lh, B=B, flank=flank, positions="none"))      # a region whose classes hold one task each: the odd ones out only
             batch = synth.batch_from_regions(regs)
             os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"; os.environ["OCT_PHMM_SLICES"] = slices; os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = late; os.environ["OCT_PHMM_PAIRED_MIN_RUN"] = "0"
@@ -427,7 +429,8 @@ def check_window_pairing(backend, tol=0.0):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    assert sum(s["n_dp_traceback"] for s in out) > 2000 and sum(s["n_dp_score_only"] for s in out) > 1000
+    floor = 1 if backend == "sim" else 6
+    assert sum(s["n_dp_traceback"] for s in out) > 330 * floor and sum(s["n_dp_score_only"] for s in out) > 160 * floor
     return out
 
 
@@ -651,8 +654,8 @@ def check_launch_modes(backend, tol=0.0):
     must give the same bytes, and both must equal the oracle: packed int16, int32 lanes, the streaming kernels, generic bytes, several regions
     with templates, and the late traceback start."""
     import os
-    SW = ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP", "OCT_PHMM_SCAN_ONE_LAUNCH_MAX", "OCT_PHMM_HOST_MAPPED",
-          "OCT_PHMM_SCAN_FUSED", "OCT_PHMM_LATE_START")
+    SW = ("OCT_PHMM_DEVICE_SIZED", "OCT_PHMM_BP_BUDGET_KB", "OCT_PHMM_DSL_TRACE_PER_PAIR", "OCT_PHMM_DSL_MERGE_DP", "OCT_PHMM_HOST_MAPPED",
+          "OCT_PHMM_LATE_START")
     keep = {k: os.environ.get(k) for k in SW + ("OCT_PHMM_LATE_MIN_PAIRS",)}
     rng = np.random.default_rng(4711)
     n = repeated = 0
@@ -673,22 +676,19 @@ def check_launch_modes(backend, tol=0.0):
         for case_no, (B, kw, late, batch) in enumerate(cases):
             os.environ["OCT_PHMM_LATE_MIN_PAIRS"] = "0" if late else "1000000000000"
             outs = []
-            # old_chain / old_chain_host (round 5): the round-4 launch chain - k_scan_bases or the tiled scans per count array, late-start lists in launches of their own -
+            # (round 4's chain of scan launches - "old_chain" - was retired in round 6)
             # against the default (k_scan_fused, a flavour's traceback and late-start lists in one DP launch and one walk); no_late_start: every task writes all its tiles
-            modes = ("default", "host", "budget", "overflow", "two_launches", "old_chain", "old_chain_host", "no_late_start")
+            modes = ("default", "host", "budget", "overflow", "two_launches", "no_late_start")
             if backend == "sim" and case_no >= 3:                   # (every lane is a coroutine there: the chunked and the multi-region forms on the first three shapes only)
-                modes = ("default", "host", "overflow", "old_chain")
+                modes = ("default", "host", "overflow")
             for mode in modes:
                 for k in SW:
                     os.environ.pop(k, None)
                 if mode == "two_launches":                          # what batches of several regions take: traceback and score-only DP as two launches on two streams instead of one
                     os.environ["OCT_PHMM_DSL_MERGE_DP"] = "0"       # k_dp_pair launch, the tiled scan instead of the one-workgroup one, DMA copies instead of mapped pinned memory
-                    os.environ["OCT_PHMM_SCAN_ONE_LAUNCH_MAX"] = "0"
                     os.environ["OCT_PHMM_HOST_MAPPED"] = "0"
-                if mode in ("host", "old_chain_host"):
+                if mode == "host":
                     os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"
-                if mode in ("old_chain", "old_chain_host"):
-                    os.environ["OCT_PHMM_SCAN_FUSED"] = "0"
                 if mode == "no_late_start":
                     os.environ["OCT_PHMM_LATE_START"] = "0"
                 if mode == "budget":
@@ -697,7 +697,7 @@ def check_launch_modes(backend, tol=0.0):
                     os.environ["OCT_PHMM_DSL_TRACE_PER_PAIR"] = "-1"
                 eng = make_engine(backend, max_indel_error=B, **kw)
                 rb = eng.upload(batch)
-                assert rb.device_sized() == (mode in ("default", "overflow", "two_launches", "old_chain", "no_late_start")), (mode, B)
+                assert rb.device_sized() == (mode in ("default", "overflow", "two_launches", "no_late_start")), (mode, B)
                 rb.run(); outs.append(rb.download().copy())
                 if mode == "overflow":
                     repeated += 0 if rb.device_sized() else 1

@@ -30,20 +30,17 @@ SWITCH_SETS = [
     {"OCT_PHMM_WALK_STAGE": "0"},
     {"OCT_PHMM_WALK_STAGE": "2"},
     {"OCT_PHMM_MAP_MISMATCHES": "0"},
-    {"OCT_PHMM_SCAN_ONE_LAUNCH_MAX": "0"},
     {"OCT_PHMM_LANE_MAPPER": "1", "OCT_PHMM_DEDUP": "1", "OCT_PHMM_SLICES": "3"},
-    {"OCT_PHMM_SCAN_FUSED": "0"},                                   # round 4's launch chain (scans per count array, late-start lists in launches of their own)
     {"OCT_PHMM_LATE_MIN_PAIRS": "0"},                               # late-start lists for every batch
     {"OCT_PHMM_LATE_MIN_PAIRS": "0", "OCT_PHMM_DEVICE_SIZED": "0"},
     {"OCT_PHMM_PAIRED": "1", "OCT_PHMM_DEVICE_SIZED": "0", "OCT_PHMM_PAIRED_MIN_RUN": "0"},          # round 6: window-paired task lists (k_pair_sort, PAIRED segments of k_dp)
     {"OCT_PHMM_PAIRED": "1", "OCT_PHMM_DEVICE_SIZED": "0", "OCT_PHMM_PAIRED_MIN_RUN": "0", "OCT_PHMM_LATE_MIN_PAIRS": "0", "OCT_PHMM_SLICES": "3"},
-    {"OCT_PHMM_LATE_MIN_PAIRS": "0", "OCT_PHMM_SCAN_FUSED": "0"},
     {"OCT_PHMM_LATE_START": "0"},
     {"OCT_PHMM_SLICES": "4", "OCT_PHMM_LATE_MIN_PAIRS": "0"},
     {"OCT_PHMM_JOIN_LATE": "0", "OCT_PHMM_LATE_MIN_PAIRS": "0"},     # late-start lists in launches of their own behind the new scan
     {"OCT_PHMM_JOIN_LATE": "1", "OCT_PHMM_LATE_MIN_PAIRS": "0", "OCT_PHMM_SLICES": "2"},
     {"OCT_PHMM_REC_CHUNK": "64"},
-    {"OCT_PHMM_DSL_MAX_BLOCKS": "64", "OCT_PHMM_LATE_MIN_PAIRS": "0"},
+
     {"OCT_PHMM_DP_ROWS": "0"},
 ]
 
