@@ -124,6 +124,9 @@ OCT_DEVICE unsigned long long lds_load_u64(const unsigned long long* p) { return
 OCT_DEVICE unsigned long long load_device_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 OCT_DEVICE uint32_t load_device_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 OCT_DEVICE void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+// a 16-byte store that will not be read again before it has left every cache (the DP's backpointer tiles: written once, fetched by the walk kernel a launch later): non-temporal
+typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
+OCT_DEVICE void store_streaming_u4(uint4* p, uint4 v) { u32x4_native w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (u32x4_native*)p); }
 OCT_DEVICE uint32_t thread_idx() { return threadIdx.x; }
 OCT_DEVICE uint32_t block_idx() { return blockIdx.x; }
 OCT_DEVICE uint32_t block_dim() { return blockDim.x; }

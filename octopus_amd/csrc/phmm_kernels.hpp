@@ -1790,8 +1790,10 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t src = 16 * j + (lane >> 2), kq = (lane & 3) * 4;
-                    dst[j * 64 + lane] = make_uint4(tile[(kq + 0) * kTileStride + src], tile[(kq + 1) * kTileStride + src],
-                                                    tile[(kq + 2) * kTileStride + src], tile[(kq + 3) * kTileStride + src]);
+                    // (streaming stores: the tiles are read once, by the walk kernel, a launch later - 17 GB per launch that need not displace what the other slices' kernels keep in L2;
+                    // 12.8 M-pair step 26.0 -> 25.3 ms, traceback launch 7.59 -> 7.40 ms: profiles/r06_s12_streaming_tile_stores.txt)
+                    hw::store_streaming_u4(dst + j * 64 + lane, make_uint4(tile[(kq + 0) * kTileStride + src], tile[(kq + 1) * kTileStride + src],
+                                                                             tile[(kq + 2) * kTileStride + src], tile[(kq + 3) * kTileStride + src]));
                 }
                 hw::wave_lds_fence();
             };
@@ -2876,7 +2878,7 @@ OCT_MAX_THREADS(STAGE ? 64 : 256) OCT_KERNEL(k_walk)(WalkParams w)
         auto load_line = [&]() {
             const size_t line = C == 1 ? (size_t)kt * 64 + row * B + (uint32_t)i : ((size_t)kt * C + (uint32_t)i % C) * 64 + (uint32_t)i / C;
             const uint4* l = bpg + line * 4;
-            const uint4 q0 = l[0], q1 = l[1], q2 = l[2], q3 = l[3];
+            const uint4 q0 = l[0], q1 = l[1], q2 = l[2], q3 = l[3];      // (plain loads: the two tasks of a word pair share these lines - non-temporal loads cost the walk 1.00 -> 1.29 ms, profiles/r06_s12b)
             c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y; c[6] = q1.z; c[7] = q1.w;
             c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w; c[12] = q3.x; c[13] = q3.y; c[14] = q3.z; c[15] = q3.w;
             line_i = i;
