@@ -39,8 +39,10 @@ SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
 CHEAP_CYCLES, DEAR_CYCLES = 2.40, 4.25
 # Fallback instruction budget (main-loop ISA count of the shipped build, VALU wave-instructions per DP iteration per wave = 8 tasks at
 # B = 16, and the share of cheap ones) for when no committed counter summary matches the kernels being timed.
-VALU_PER_ITER = {"score": 29.25, "trace": 51.75}
-CHEAP_SHARE = {"score": 45 / 117, "trace": 111 / 207}     # round 2: the two I-state relabels per iteration are v_or_b32 (cheap) instead of v_and_or_b32 (dear)
+# Round 6: the 100k x 128 step runs the window-PAIRED loops - score-only 104 VALU per four iterations (64 dear + 40 cheap), traceback 198 (92 + 106); the general
+# loops (batches that do not pair: the streams, region-sized calls) are 117 (72 + 45) and 207 (96 + 111).
+VALU_PER_ITER = {"score": 26.0, "trace": 49.5}
+CHEAP_SHARE = {"score": 40 / 104, "trace": 106 / 198}
 
 
 def issue_cycles_per_instr(kind: str) -> float:

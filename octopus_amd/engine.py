@@ -49,7 +49,8 @@ def stamp(artefact: Path, digest: str) -> None:
 def build(force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 the kernels + host API into octopus_amd/liboct_phmm.so (in-tree). Rebuilt whenever the sources' digest differs from
     the one the library was stamped with."""
-    srcs = [PKG_DIR / "csrc" / "oct_phmm.hip"] + sorted((PKG_DIR / "csrc").glob("*.hpp"))      # every header the one translation unit includes
+    srcs = [PKG_DIR / "csrc" / "oct_phmm.hip"] + sorted((PKG_DIR / "csrc").glob("*.hpp")) + sorted((PKG_DIR / "csrc").glob("*.hh")) + sorted((PKG_DIR / "csrc").glob("*.h"))
+    # (every file the one translation unit includes: *.hpp = device code and its data model, host_*.hh = the host side by subsystem, *.h = the model-file reader)
     srcs.append(PKG_DIR.parent / "include" / "oct_phmm.h")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
     digest = source_digest(srcs, flags)

@@ -25,7 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only
 def device_asm(src: Path, cache_dir: Path = Path("/tmp/oct_phmm_isa")) -> str:
     """hipcc -S --cuda-device-only of one translation unit; cached by the digest of everything it can include from the tree."""
     src = Path(src)
-    deps = [src] + sorted(src.parent.glob("*.hpp")) + sorted((ROOT / "include").glob("*.h"))
+    deps = [src] + sorted(src.parent.glob("*.hpp")) + sorted(src.parent.glob("*.hh")) + sorted((ROOT / "include").glob("*.h"))
     m = hashlib.sha256()
     for f in deps:
         m.update(f.name.encode()); m.update(f.read_bytes())
