@@ -67,12 +67,11 @@ struct DevBatch {
     uint16_t* hhash;                                  // hhash[hoff[h] + p]: 6-mer hash of haplotype h at p (k_kmer_tables); k_kmer_map's exact-count shortcut
     int map_count_only;                               // test / A-B switch: every pair takes the counting path
     int map_stats;                                    // OCT_PHMM_MAP_STATS: count the pairs the shortcut decides (diagnostics)
-    uint16_t* rhash_rows; uint32_t rhash_stride;     // k_kmer_map_lanes: the same hashes as rhash in one 16-byte aligned row per read, 4096 behind a read's last k-mer; null when unused
     // k_kmer_map_lanes' bit-parallel pass: every read's bases as 2-bit kmer_code()s, 16 per dword (base i of a dword in bits 2i, 2i + 1: twelve consecutive bits ARE a 6-mer hash),
     // transposed in tiles of 64 reads - dword j of read r at rcode[((r >> 6) * rcode_words + j) * 64 + (r & 63)], so that a wave's 64 reads load one dword each from 256
     // consecutive bytes; zero behind a read's last base. Null when unused.
     uint32_t* rcode; uint32_t rcode_words;
-    uint16_t* bin_start; uint16_t* bin_idx; uint16_t* rhash;   // rhash[roff[r] + q]: 6-mer hash of read r at q (written by the trailing workgroups of k_kmer_tables)
+    uint16_t* bin_start; uint16_t* bin_idx; uint16_t* rhash;   // rhash[roff[r] + q]: 6-mer hash of read r at q (written by the trailing workgroups of k_kmer_tables; null where the lane mapper runs: it reads rcode)
     // per pair
     uint64_t  n_pairs;
     int32_t*  pair_best;      // min phred penalty over candidates, kNoScore = none

@@ -146,12 +146,7 @@ OCT_DEVICE void read_hash_wave(const DevBatch& b, uint32_t r, uint32_t lane)   /
     const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro;
     // k_kmer_map_lanes reads a read's hashes eight at a time, one lane per read: a row per read, 16-byte aligned, the entries behind the last k-mer = 4096
     // ("no k-mer": occupancy 0, equals no haplotype hash), so that its loop needs neither bounds tests nor unaligned loads. The other mappers read rhash.
-    if (!b.rhash_rows) { for (uint32_t q = lane; q + kKmer <= T; q += 64) b.rhash[ro + q] = (uint16_t)kmer_hash6(b.rbases + ro + q); }
-    else {
-        const uint32_t nq = T >= kKmer ? T - kKmer + 1 : 0;
-        uint16_t* row = b.rhash_rows + (size_t)r * b.rhash_stride;
-        for (uint32_t q = lane; q < b.rhash_stride; q += 64) row[q] = q < nq ? (uint16_t)kmer_hash6(b.rbases + ro + q) : (uint16_t)kKmerBins;
-    }
+    if (b.rhash) { for (uint32_t q = lane; q + kKmer <= T; q += 64) b.rhash[ro + q] = (uint16_t)kmer_hash6(b.rbases + ro + q); }     // (the wave-per-pair mappers; the lane mapper reads the code rows below)
     if (b.rcode) {      // the read's 2-bit codes, 16 per dword (DevBatch::rcode): 64 bases per round, two ballots, lanes 0-3 store a dword each
         uint32_t* tile = b.rcode + ((size_t)(r >> 6) * b.rcode_words) * 64 + (r & 63u);
         for (uint32_t t0 = 0; t0 < b.rcode_words * 16; t0 += 64) {
@@ -221,15 +216,16 @@ inline uint32_t kmer_map_lds_bytes(uint32_t lh_cap) { return (kKmerBins + 1) * 2
 
 // map_query_to_target's vote (:128-144) and its output (:145-157) for ONE (haplotype, read) pair by a whole wave: the path of the pairs the exact shortcuts of
 // k_kmer_map / k_kmer_map_lanes cannot decide. `rh` = the read's hashes, `counts` = the wave's nk + 64 diagonal counters in LDS (zero on entry and on return).
-OCT_DEVICE void kmer_count_votes_wave(const DevBatch& b, uint64_t e, const uint16_t* rh, uint32_t nq, uint32_t nk, const uint16_t* bins, const uint16_t* idx,
+template <class HashAt>      // hash_at(q) = the read's 6-mer hash at q (q < nq): from its hash row (k_kmer_map, k_kmer_map_big's callers) or cut out of its 2-bit code words (k_kmer_map_lanes)
+OCT_DEVICE void kmer_count_votes_wave(const DevBatch& b, uint64_t e, HashAt hash_at, uint32_t nq, uint32_t nk, const uint16_t* bins, const uint16_t* idx,
                                       uint32_t* counts, uint32_t lane, uint32_t max_pos)
 {
-        uint32_t hq_next = lane < nq ? rh[lane] : 0;                        // software pipeline: next batch's hashes are in flight
+        uint32_t hq_next = lane < nq ? hash_at(lane) : 0;                   // software pipeline: next batch's hashes are in flight
         for (uint32_t q0 = 0; q0 < nq; q0 += 64) {
             const uint32_t q = q0 + lane;
             const bool valid = q < nq;
             const uint32_t hq = hq_next;
-            if (q0 + 64 < nq) hq_next = q + 64 < nq ? rh[q + 64] : 0;
+            if (q0 + 64 < nq) hq_next = q + 64 < nq ? hash_at(q + 64) : 0;
             const uint32_t b0 = bins[hq], n = valid ? (uint32_t)bins[hq + 1] - b0 : 0;
             for (uint32_t j = 0; hw::ballot(j < n) != 0; ++j) {
                 const uint32_t ti = j < n ? idx[b0 + j] : 0;
@@ -425,7 +421,7 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
             }
         }
         if (b.map_stats && lane == 0) hw::atomic_add_u64(b.stats + (size_t)(hw::block_idx() % kStatSlots) * kStatStride + (decided ? 6 : 7), 1ull);   // OCT_PHMM_MAP_STATS: pairs decided by the shortcut / counted
-        if (!decided) kmer_count_votes_wave(b, e, b.rhash + ro, nq, nk, bins, idx, counts, lane, max_pos);
+        if (!decided) { const uint16_t* rh = b.rhash + ro; kmer_count_votes_wave(b, e, [rh](uint32_t q) -> uint32_t { return rh[q]; }, nq, nk, bins, idx, counts, lane, max_pos); }
         ro = ro_n; nq = nq_n; ro_n = ro_nn; nq_n = nq_nn;
 #pragma unroll
         for (int k = 0; k < ROUNDS; ++k) hq4[k] = hq4_n[k];
@@ -441,8 +437,6 @@ OCT_KERNEL(k_kmer_map)(DevBatch b, const uint32_t* blk_hap, const uint32_t* blk_
 // The pairs a lane cannot decide (a few percent: both probes miss, repeats, near-even indel splits) are counted afterwards by the whole wave, one after the
 // other (kmer_count_votes_wave). Same votes, same output: tests/check_populate.py::assert_device_positions.
 constexpr uint32_t kLaneMapThreads = 256;
-// entries per row of DevBatch::rhash_rows (the probes and the counting path read them; 16-byte chunks of eight hashes)
-OCT_HD uint32_t rhash_row_stride(uint32_t t_cap) { const uint32_t nq = t_cap >= kKmer ? t_cap - kKmer + 1 : 0; return 8u * (3u * (((nq + 7) / 8 + 2) / 3) + 1u); }
 constexpr uint32_t kLaneMapMaxKmers = 496;       // lane form up to here (500-base chunks of long reads: 495 k-mers)
 // dwords per read of DevBatch::rcode: the pass takes 16 k-mers (one dword of codes and the next one's first five bases) per step and has the step after in flight
 OCT_HD uint32_t rcode_row_words(uint32_t t_cap) { const uint32_t nq = t_cap >= kKmer ? t_cap - kKmer + 1 : 0; return (nq + 15) / 16 + 3; }
@@ -652,7 +646,10 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
         todo &= todo - 1;
         const uint32_t r_u = hw::readlane(r, src), nq_u = hw::readlane(nq, src);
         const uint64_t e_u = b.hap_pair_off[h] + (uint64_t)(r_u - reg_r0);
-        kmer_count_votes_wave(b, e_u, b.rhash_rows + (size_t)r_u * b.rhash_stride, nq_u, nk, bins, idx, counts, lane, max_pos);
+        // (the read's hashes cut out of its code words: lane q's twelve bits lie in dwords q / 16 and q / 16 + 1 of the read's column - a round of 64 k-mers touches five dwords)
+        const uint32_t* rc_u = b.rcode + ((size_t)(r_u >> 6) * b.rcode_words) * 64 + (r_u & 63u);
+        kmer_count_votes_wave(b, e_u, [rc_u](uint32_t q) -> uint32_t { const uint32_t j = q >> 4; return funnel(rc_u[(size_t)(j + 1) * 64], rc_u[(size_t)j * 64], 2u * (q & 15u)) & 0xfffu; },
+                              nq_u, nk, bins, idx, counts, lane, max_pos);
     }
 }
 
