@@ -231,6 +231,10 @@ def cpu_baseline(B: int, seed: int, seconds_budget: float = 20.0):
             ns = sorted(int(k) for k in curve if int(k) >= 4)
             if len(ns) >= 2:
                 out["per_thread_gcups_parallel_slope"] = (curve[str(ns[-1])] - curve[str(ns[-2])]) / (ns[-1] - ns[-2])
+    if kind == "reference":
+        out["reference_build_note"] = ("oracle/_ref = the reference's own sources compiled where they lie (oracle/Makefile), on few-line stand-ins for the headers this image lacks "
+                                       "(boost::alignment allocator, the generated system.hpp, Boost optional / variant / lexical_cast, Haplotype / AlignedRead value types: oracle/ref_shim, "
+                                       "no arithmetic of the path in any of them) - DESIGN.md section 7")
     out.update(host_topology())
     if out.get("host_cores_per_socket") and out.get("per_thread_gcups"):
         cps = out["host_cores_per_socket"]

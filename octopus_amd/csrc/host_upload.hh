@@ -311,13 +311,13 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     { long long v; if (tune::number("OCT_PHMM_LATE_MIN_PAIRS", &v)) late_min_pairs = (uint64_t)v; }   // test hook (0 = always, a huge value = never)
     b->late_ok = b->fast_adds && !align_mode && !b->stream && !h->wide && b->n_pairs >= late_min_pairs;
     {
-        // Window pairing: host-sized multi-slice batches (a haplotype's task runs are thousands long there: 100 k reads over ~240 (offset, strand) classes), packed int16 lanes with
+        // Window pairing: host-sized batches with >= 2,048 pairs per haplotype (a haplotype's task runs are thousands long there: 100 k reads over ~240 (offset, strand) classes), packed int16 lanes with
         // plain adds, fast-cost flavour; the 20-byte columns must leave the traceback form its three workgroups per CU. OCT_PHMM_PAIRED=0 / 1: off / forced (tests: small batches).
         long long want = -1; tune::number("OCT_PHMM_PAIRED", &want);
         const uint32_t Bw = (uint32_t)h->band;
         const size_t lds_tr = dp_lds_bytes(b->t_cap, b->lh_cap, Bw, true, dp_rec_chunk(b->t_cap, b->lh_cap, Bw, true), true);
         const bool can = !h->wide && !b->stream && b->fast_adds && !align_mode && b->lh_cap <= kPairSortMaxLh && b->n_pairs > 0 && lds_tr <= rt::kMaxLdsBytes;
-        b->pair_ok = can && (want >= 0 ? want != 0 : (b->n_pairs >= 4000000 && lds_tr * 3 <= rt::kMaxLdsBytes));
+        b->pair_ok = can && (want >= 0 ? want != 0 : (b->n_pairs > kDslMaxPairs && b->n_pairs / std::max<uint32_t>(1, H->n_haps) >= 2048 && lds_tr * 3 <= rt::kMaxLdsBytes));
         if (b->pair_ok) for (int k = 0; k < 3; ++k) pk.dalloc(&b->d_paired_end[k], (size_t)H->n_haps + 1);
     }
     if (b->late_ok) {

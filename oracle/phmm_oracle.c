@@ -5,6 +5,11 @@
  * function cites the reference lines it follows (paths relative to /root/reference/src). Arithmetic is
  * carried in int32 and wrapped to the reference's lane type (int16 or int32) after every add, so that
  * even overflowing inputs follow the SIMD lanes bit for bit.
+ *
+ * PINNED (tests/test_oracle_*.py): to all 24 records of the reference's own unit tests (test/unit/core/models/pair_hmm_tests.cpp ->
+ * tests/golden/pair_hmm_tests.json, needs nothing but the fixture), and - exact equality on thousands of seeded cases per layer - to the
+ * reference's own sources compiled where they lie (oracle/Makefile -> oracle/_ref; that build stands on few-line stand-ins for the headers this
+ * image lacks, oracle/ref_shim: disclosed in DESIGN.md section 7).
  */
 #define _GNU_SOURCE
 #include "phmm_oracle.h"
