@@ -438,10 +438,7 @@ constexpr uint64_t kDslMaxPairs = 400000;              // device-sized launches 
                                                        // server's workers - is that oct_phmm_batch_run never waits.
 constexpr uint64_t kWalkRowsMaxPairs = 49152;          // traceback walks of batches up to here: one walk per 16-lane row (k_walk_rows)
 constexpr uint64_t kDslMergeMaxPairs = 12000;          // device-sized step: up to here the traceback and the score-only list of a flavour share one launch (k_dp_pair)
-#ifndef OCT_DSL_MAX_BLOCKS
-#define OCT_DSL_MAX_BLOCKS 1024                        // (a build-time knob for A/B libraries: tools/build_variant.sh)
-#endif
-constexpr uint32_t kDslMaxBlocks = OCT_DSL_MAX_BLOCKS;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups)
+constexpr uint32_t kDslMaxBlocks = 1024;               // grid of a device-sized DP launch: the bound, at most this (workgroups stride over the groups; 4,096 / 16,384 one-unit workgroups: the same populate times, profiles/r06_s14_dsl_grid.txt)
 int run_dp_kind(oct_phmm_handle* h, oct_phmm_batch* b, int slice, int kind, const DevTask* tasks, uint32_t n_tasks, TraceEnd* ends,
                 int nuc_prior, const WalkParams* seam_walk, oct_phmm_status* status, const rt::Stream* on_stream = nullptr, bool late = false,
                 TaskListRef ref = TaskListRef {nullptr, nullptr, 0, nullptr}, const rt::Event* after_first_dp = nullptr,
