@@ -55,7 +55,7 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
             if (hashes_here) { hash_slice = i; if (S > 1) RT(rt::event_record(b->ev_hashes, s)); }
             else RT(rt::stream_wait_event(s, b->ev_hashes));
             if (b->map_big) {
-                const size_t lds = (size_t)b->lh_cap * 4 + 64;
+                const size_t lds = kmer_map_big_lds_bytes(b->lh_cap);
                 if (lds > 64 * 1024) RT(rt::allow_lds(k_kmer_map_big, lds));
                 OCT_LAUNCH(k_kmer_map_big, (uint32_t)np, 256, lds, s, d, sl.pair0); RT(rt::launch_ok());
             } else if (sl.blk1 > sl.blk0 && b->map_lanes) {

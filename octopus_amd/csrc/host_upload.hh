@@ -199,8 +199,8 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     } else {
         b->device_map = true;
         b->map_big = kmer_map_lds_bytes(b->lh_cap) > rt::kMaxLdsBytes || tune::big_mapper();
-        if (b->lh_cap >= 65536 || (size_t)b->lh_cap * 4 + 64 > rt::kMaxLdsBytes)
-            return fail(status, OCT_PHMM_EUNSUPPORTED, "haplotype too long for the k-mer mapper (>= 40k bases)");
+        if (b->lh_cap >= 65536 || kmer_map_big_lds_bytes(b->lh_cap) > rt::kMaxLdsBytes)      // (16-bit bin tables; k_kmer_map_big's counters are 16-bit halves since round 6: 40 k bases were the limit before)
+            return fail(status, OCT_PHMM_EUNSUPPORTED, "haplotype too long for the k-mer mapper (>= 65,536 bases)");
     }
     b->h_roff.assign(R->offsets, R->offsets + R->n_reads + 1); b->h_hoff.assign(H->offsets, H->offsets + H->n_haps + 1);
     b->h_rbegin.assign(R->ref_begin, R->ref_begin + R->n_reads); b->h_hbegin.assign(H->ref_begin, H->ref_begin + H->n_haps);

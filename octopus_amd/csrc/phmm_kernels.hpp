@@ -653,12 +653,17 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
     }
 }
 
-// Long haplotypes (bins + per-wave counters no longer fit LDS beside each other): one workgroup per (haplotype, read) pair, the
-// diagonal counters alone in LDS, bins read from global memory. Same votes, same result as k_kmer_map; for the long-read configuration.
+// Long haplotypes (bins + per-wave counters no longer fit LDS beside each other): one workgroup per (haplotype, read) pair, the diagonal counters alone in LDS, bins read from
+// global memory. Same votes, same result as k_kmer_map; for the long-read configuration. Round 6: the counters are 16-bit halves of LDS words (a diagonal collects at most one
+// vote per read k-mer, and reads are shorter than 32,768 bases): twice the workgroups per CU (ccs2048x12: 5.4 -> 4.9 ms per launch), and haplotypes up to the 16-bit bin tables' own
+// limit of 65,535 bases (40 k before). Measured and not kept (profiles/r06_s17_*): the bin starts and entries staged in LDS beside the counters (4.9 ms as well: 40 KB of staging per
+// pair), and staging + merging a wave's votes where its 64 k-mers agree on a diagonal as kmer_count_votes_wave does (6.2 ms: every 6-mer of a 16 kb haplotype has ~4 bin entries,
+// the lanes' j-th entries never agree).
+OCT_HD uint32_t kmer_map_big_lds_bytes(uint32_t lh_cap) { return ((lh_cap + 2) / 2) * 4 + 64; }
 OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
 {
     OCT_DYN_SMEM(smem);
-    uint32_t* counts = (uint32_t*)smem;                                // [nk]
+    uint32_t* counts = (uint32_t*)smem;                                // [(lh_cap + 2) / 2] two 16-bit counters per word: diagonal d in half d & 1 of word d / 2
     __shared__ uint32_t s_max, s_nout;
     const uint64_t e = pair0 + hw::block_idx();
     const uint32_t tid = hw::thread_idx(), nt = hw::block_dim();
@@ -668,19 +673,21 @@ OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
     const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;
     const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;
     const uint16_t* bins = b.bin_start + (size_t)h * (kKmerBins + 1);
-    for (uint32_t d = tid; d < nk; d += nt) counts[d] = 0;
+    const uint16_t* idx = b.bin_idx + ho;
+    for (uint32_t w = tid; w < (nk + 1) / 2 + 1; w += nt) counts[w] = 0;
     if (tid == 0) { s_max = 0; s_nout = 0; }
     hw::block_sync();
     for (uint32_t q = tid; q < nq; q += nt) {
         const uint32_t hq = b.rhash[ro + q];
         for (uint32_t j = bins[hq]; j < bins[hq + 1]; ++j) {
-            const uint32_t ti = b.bin_idx[ho + j];
-            if (ti >= q) hw::atomic_add_lds_u32(&counts[ti - q], 1u);   // :130-132
+            const uint32_t ti = idx[j];
+            if (ti >= q) { const uint32_t d = ti - q; hw::atomic_add_lds_u32(&counts[d >> 1], 1u << (16 * (d & 1u))); }   // :130-132
         }
     }
     hw::block_sync();
+    auto cnt_of = [&](uint32_t d) -> uint32_t { return (counts[d >> 1] >> (16 * (d & 1u))) & 0xffffu; };
     uint32_t mx = 0;
-    for (uint32_t d = tid; d < nk; d += nt) mx = counts[d] > mx ? counts[d] : mx;
+    for (uint32_t w = tid; w < (nk + 1) / 2; w += nt) { const uint32_t c = counts[w], lo = c & 0xffffu, hi = c >> 16; mx = lo > mx ? lo : mx; mx = hi > mx ? hi : mx; }
     if (mx) hw::atomic_max_lds_u32(&s_max, mx);
     hw::block_sync();
     mx = s_max;
@@ -689,13 +696,13 @@ OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
     __shared__ uint32_t s_cnt[256];
     const uint32_t per = (nk + nt - 1) / nt, d0 = tid * per, d1 = d0 + per < nk ? d0 + per : nk;
     uint32_t mine = 0;
-    if (mx > 0) for (uint32_t d = d0; d < d1; ++d) mine += counts[d] == mx ? 1u : 0u;
+    if (mx > 0) for (uint32_t d = d0; d < d1; ++d) mine += cnt_of(d) == mx ? 1u : 0u;
     s_cnt[tid] = mine;
     hw::block_sync();
     if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < nt; ++i) { const uint32_t c = s_cnt[i]; s_cnt[i] = run; run += c; } s_nout = run; }
     hw::block_sync();
     uint32_t rank = s_cnt[tid];
-    if (mine) for (uint32_t d = d0; d < d1 && rank < (uint32_t)b.max_pos; ++d) if (counts[d] == mx) b.pos[e * (uint64_t)b.max_pos + rank++] = d;
+    if (mine) for (uint32_t d = d0; d < d1 && rank < (uint32_t)b.max_pos; ++d) if (cnt_of(d) == mx) b.pos[e * (uint64_t)b.max_pos + rank++] = d;
     if (tid == 0) b.npos[e] = (uint8_t)(s_nout < (uint32_t)b.max_pos ? s_nout : (uint32_t)b.max_pos);
 }
 

@@ -390,6 +390,23 @@ def check_late_traceback_start(backend, tol=0.0):
     return out
 
 
+def check_haplotype_beyond_40k_bases(backend, tol=0.0, Lh=45_000, R=6):
+    """Haplotypes of 40 k bases and more with the DEVICE k-mer mapper: refused until round 5 (k_kmer_map_big kept a 32-bit counter per diagonal in LDS), served since round 6
+    (16-bit counters: a diagonal collects at most one vote per read k-mer and reads are shorter than 32,768 bases) up to the 16-bit bin tables' own limit of 65,535 bases - where
+    the library still answers OCT_PHMM_EUNSUPPORTED. Positions pair by pair and the matrix against the oracle."""
+    rng = np.random.default_rng(77)
+    g = synth.make_region(rng, R, 2, T=150, Lh=Lh, B=16, flank=(40, 40), positions="none")
+    batch = synth.batch_from_regions([g])
+    stats = compare(backend, batch, tol, max_indel_error=16)
+    # 65,536 bases: refused as before
+    big = synth.make_region(rng, 2, 1, T=150, Lh=65_600, B=16, flank=(40, 40), positions="none")
+    eng = make_engine(backend, max_indel_error=16)
+    out, st = eng.populate(synth.batch_from_regions([big]), raise_on_error=False)
+    eng.close()
+    assert st.code == abi.EUNSUPPORTED, st.code
+    return stats
+
+
 def check_window_pairing(backend, tol=0.0):
     """Big host-sized batches re-order every haplotype's task runs so that the two tasks packed into a lane's halves read ONE haplotype window (k_pair_sort), and
     k_dp runs those segments with pre-packed gap words (dp_groups, PAIRED). Forced on for small batches through the test hook - with the late

@@ -412,6 +412,11 @@ def test_gpu_mapper_mismatch_account_feeds_the_fast_path():
     assert len(cp.check_mapper_mismatch_account("gpu", TOL)) == 5
 
 
+def test_gpu_haplotypes_of_40k_bases_and_more_map_on_the_device():
+    """k_kmer_map_big with 16-bit counters: a 60 k-base haplotype (refused until round 5), 64 reads; 65,536 bases still refused."""
+    cp.check_haplotype_beyond_40k_bases("gpu", TOL, Lh=60_000, R=64)
+
+
 def test_gpu_window_paired_task_lists_equal_oracle_and_plain_path():
     """k_pair_sort + the PAIRED segments of k_dp forced on small batches (the full-size 100k x 128 test runs them by default): oracle, and the bytes of the plain path."""
     assert len(cp.check_window_pairing("gpu", TOL)) == 5

@@ -50,6 +50,10 @@ def test_sim_big_haplotype_mapper_matches_reference_mapper(monkeypatch):
     cp.check_device_kmer_mapper("sim")
 
 
+def test_sim_haplotypes_of_40k_bases_and_more_map_on_the_device():
+    cp.check_haplotype_beyond_40k_bases("sim")
+
+
 def test_sim_populate_in_slices(monkeypatch):
     """Large batches are cut into slices of whole haplotypes that run on separate streams; force 3 slices on small batches."""
     monkeypatch.setenv("OCT_PHMM_SLICES", "3")
