@@ -38,15 +38,62 @@ extern "C" { void* __tsan_get_current_fiber(void); void* __tsan_create_fiber(uns
 #define HIPSIM_TO_FIBER(f) ((void)0)
 #endif
 
+// Lane switches: glibc's swapcontext saves and restores the signal mask with a system call on every switch, and a simulated cross-lane operation is four switches per lane -
+// the CPU suite spent most of its time there. Plain builds on x86-64 switch with a dozen instructions instead (callee-saved registers and the stack pointer; nothing here
+// changes the signal mask or the floating-point control words between lanes); sanitizer builds keep ucontext, which their fibre annotations know.
+#if defined(__x86_64__) && !defined(HIPSIM_TSAN) && !defined(HIPSIM_UCONTEXT)
+#if defined(__has_feature)
+#if !__has_feature(address_sanitizer)
+#define HIPSIM_FAST_SWITCH 1
+#endif
+#else
+#define HIPSIM_FAST_SWITCH 1
+#endif
+#endif
+#ifdef HIPSIM_FAST_SWITCH
+extern "C" void hipsim_switch(void** save_sp, void* const* load_sp);
+asm(R"(
+    .text
+    .p2align 4
+    .globl hipsim_switch
+    .type hipsim_switch,@function
+hipsim_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipsim_switch, .-hipsim_switch
+)");
+#endif
+
 namespace hipsim {
 
 enum Wait { kRun = 0, kWave = 1, kBlock = 2, kDone = 3 };
 
+#ifdef HIPSIM_FAST_SWITCH
+struct Lane { void* sp = nullptr; char* stack = nullptr; int wait = kRun; void* fiber = nullptr; };
+#else
 struct Lane { ucontext_t ctx; char* stack = nullptr; int wait = kRun; void* fiber = nullptr; };
+#endif
 
 struct State {
     std::vector<Lane> lanes;
+#ifdef HIPSIM_FAST_SWITCH
+    void* sched_sp = nullptr;
+#else
     ucontext_t sched;
+#endif
     void* sched_fiber = nullptr;
     uint32_t cur = 0, bid = 0, bdim = 0, gdim = 0;
     unsigned char* smem = nullptr;
@@ -55,11 +102,19 @@ struct State {
 };
 inline State& S() { static State s; return s; }
 
+#ifdef HIPSIM_FAST_SWITCH
+inline void yield_to_sched(int why) { State& s = S(); Lane& l = s.lanes[s.cur]; l.wait = why; hipsim_switch(&l.sp, &s.sched_sp); }
+#else
 inline void yield_to_sched(int why) { State& s = S(); s.lanes[s.cur].wait = why; HIPSIM_TO_FIBER(s.sched_fiber); swapcontext(&s.lanes[s.cur].ctx, &s.sched); }
+#endif
 inline void wave_sync() { yield_to_sched(kWave); }
 inline void block_sync_impl() { yield_to_sched(kBlock); }
 
+#ifdef HIPSIM_FAST_SWITCH
+inline void lane_entry() { State& s = S(); s.body(); Lane& l = s.lanes[s.cur]; l.wait = kDone; hipsim_switch(&l.sp, &s.sched_sp); abort(); }      // (a finished lane is never resumed)
+#else
 inline void lane_entry() { State& s = S(); s.body(); s.lanes[s.cur].wait = kDone; HIPSIM_TO_FIBER(s.sched_fiber); swapcontext(&s.lanes[s.cur].ctx, &s.sched); }
+#endif
 
 // run one workgroup of `bdim` threads
 inline void run_block(uint32_t bid, uint32_t bdim, uint32_t gdim, size_t smem_bytes)
@@ -73,9 +128,19 @@ inline void run_block(uint32_t bid, uint32_t bdim, uint32_t gdim, size_t smem_by
     for (uint32_t t = 0; t < bdim; ++t) {
         Lane& l = s.lanes[t];
         if (!l.stack) l.stack = (char*)malloc(kStack);
+#ifdef HIPSIM_FAST_SWITCH
+        {   // a fresh lane's stack as hipsim_switch expects to find it: six zeroed callee-saved registers, then lane_entry as the return address; at its entry
+            // the stack pointer is 8 below a 16-byte boundary, as after a call
+            void** top = (void**)(((uintptr_t)l.stack + kStack) & ~(uintptr_t)15);
+            top[-1] = nullptr; top[-2] = (void*)lane_entry;
+            for (int k = 3; k <= 8; ++k) top[-k] = nullptr;
+            l.sp = (void*)(top - 8);
+        }
+#else
         getcontext(&l.ctx);
         l.ctx.uc_stack.ss_sp = l.stack; l.ctx.uc_stack.ss_size = kStack; l.ctx.uc_link = &s.sched;
         makecontext(&l.ctx, (void (*)())lane_entry, 0);
+#endif
         l.wait = kRun;
 #ifdef HIPSIM_TSAN
         l.fiber = __tsan_create_fiber(0);
@@ -87,7 +152,11 @@ inline void run_block(uint32_t bid, uint32_t bdim, uint32_t gdim, size_t smem_by
     for (;;) {
         bool progressed = false, all_done = true;
         for (uint32_t t = 0; t < bdim; ++t) {
+#ifdef HIPSIM_FAST_SWITCH
+            if (s.lanes[t].wait == kRun) { s.cur = t; hipsim_switch(&s.sched_sp, &s.lanes[t].sp); progressed = true; }
+#else
             if (s.lanes[t].wait == kRun) { s.cur = t; HIPSIM_TO_FIBER(s.lanes[t].fiber); swapcontext(&s.sched, &s.lanes[t].ctx); progressed = true; }
+#endif
             if (s.lanes[t].wait != kDone) all_done = false;
         }
         if (all_done) break;
