@@ -155,6 +155,8 @@ struct oct_phmm_batch {
     unsigned long long* stat_stage = nullptr;                   // pinned landing block of the counters' copy (the handle's; pageable destinations cost a staged copy per call)
     bool synced = false;                                        // oct_phmm_batch_wait has seen the handle's streams idle since the last run
     unsigned long long h_err_key = ~0ull;
+    // tables_pending: a device-sized batch's per-base DP tables, read flags and read records are made by the FIRST step's table launch (k_tables: one launch with the k-mer tables), not by the upload
+    bool tables_pending = false; uint32_t tp_n_bases = 0, tp_table_blocks = 0, tp_flag_blocks = 0, tp_rec_blocks = 0;
     bool ran = false, device_map = false, stats_clear = false;       // stats_clear: the upload's table kernel left the counters zeroed (the first run skips its memset)
     // device-sized launches (one slice, scratch for the host-known task bound fits): no host read-back of the task counts in the middle of a step
     bool dsl = false; uint32_t dsl_list_bound = 0; size_t dsl_total_bound = 0; int dsl_flavours = 3;

@@ -253,6 +253,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         pk.dalloc(&d.hhash, (size_t)n_hap_bases + 1);
         d.map_count_only = tune::map_count_only(); d.map_stats = tune::map_stats();
         b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 256;      // the haplotype's tables are staged once per workgroup: big batches amortise them over more reads
+        { long long v; if (tune::number("OCT_PHMM_MAP_READS_PER_BLOCK", &v) && v >= 4 && v <= 1024) b->map_reads_per_block = (uint32_t)v / 4 * 4; }
         pk.dalloc(&d.bin32, (size_t)H->n_haps * kKmerBins + 4);
         // lane-per-pair mapper (k_kmer_map_lanes: 256 reads of one haplotype per workgroup, the exact shortcut per lane): batches big enough to fill the chip with
         // 256-pair workgroups; region-sized calls keep one wave per pair (more, shorter waves). OCT_PHMM_LANE_MAPPER=0 / 1 forces one or the other.
@@ -481,8 +482,12 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         if (table_blocks + flag_blocks + rec_blocks64 >= 0x7fffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "batch too large for one table launch");
         const uint32_t rec_blocks = (uint32_t)rec_blocks64;
         if (table_blocks + flag_blocks + rec_blocks) {
-            OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok());
-            b->stats_clear = true;                             // (the kernel's last workgroup cleared the counters)
+            // a device-sized batch that maps on the device: the first step's k-mer table launch makes these too (k_tables; OCT_PHMM_FUSE_TABLES=0: two launches)
+            long long fuse = 1; tune::number("OCT_PHMM_FUSE_TABLES", &fuse);
+            if (b->dsl && b->device_map && !b->dedup && fuse) {
+                b->tables_pending = true; b->tp_n_bases = n_hap_bases; b->tp_table_blocks = table_blocks; b->tp_flag_blocks = flag_blocks; b->tp_rec_blocks = rec_blocks;
+            } else { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok()); }
+            b->stats_clear = true;                             // (the kernel's last workgroup clears the counters)
         }
     }
     if (b->dedup) {

@@ -127,6 +127,8 @@ OCT_DEVICE void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 // a 16-byte store that will not be read again before it has left every cache (the DP's backpointer tiles: written once, fetched by the walk kernel a launch later): non-temporal
 typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
 OCT_DEVICE void store_streaming_u4(uint4* p, uint4 v) { u32x4_native w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (u32x4_native*)p); }
+// issue priority of this wave among the waves of its SIMD (0 lowest ... 3): a launch that heads a chain of dependent launches (traceback DP -> walk) beside one that does not
+template <int P> OCT_DEVICE void wave_priority() { __builtin_amdgcn_s_setprio(P); }
 OCT_DEVICE uint32_t thread_idx() { return threadIdx.x; }
 OCT_DEVICE uint32_t block_idx() { return blockIdx.x; }
 OCT_DEVICE uint32_t block_dim() { return blockDim.x; }

@@ -98,13 +98,13 @@ OCT_DEVICE void read_record_thread(const DevBatch& b, uint64_t g)
 
 // Once per batch (HaplotypeLikelihoodModel::reset analogue): the per-base DP tables; the workgroups past `table_blocks` set the per-read
 // "pure ACGT" flags, those past `table_blocks + flag_blocks` build the read record rows, in the same launch.
-OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks, uint32_t flag_blocks)
+OCT_DEVICE void hap_tables_block(const DevBatch& b, uint32_t n_bases, uint32_t table_blocks, uint32_t flag_blocks, uint32_t blk, uint32_t n_blk)   // workgroup `blk` of `n_blk`
 {
     // the last workgroup also clears the step's counters (+ error key + overflow flag behind them), so that the first run after an upload needs no memset launch
-    if (hw::block_idx() + 1 == hw::grid_dim()) for (uint32_t i = hw::thread_idx(); i < kStatSlots * kStatStride + 2; i += hw::block_dim()) b.stats[i] = 0ull;
-    if (hw::block_idx() >= table_blocks + flag_blocks) { read_record_thread(b, (uint64_t)(hw::block_idx() - table_blocks - flag_blocks) * hw::block_dim() + hw::thread_idx()); return; }
-    if (hw::block_idx() >= table_blocks) { read_flags_wave(b, (hw::block_idx() - table_blocks) * (hw::block_dim() / 64) + (hw::thread_idx() >> 6), hw::thread_idx() & 63u); return; }
-    const uint32_t g = hw::block_idx() * hw::block_dim() + hw::thread_idx();
+    if (blk + 1 == n_blk) for (uint32_t i = hw::thread_idx(); i < kStatSlots * kStatStride + 2; i += hw::block_dim()) b.stats[i] = 0ull;
+    if (blk >= table_blocks + flag_blocks) { read_record_thread(b, (uint64_t)(blk - table_blocks - flag_blocks) * hw::block_dim() + hw::thread_idx()); return; }
+    if (blk >= table_blocks) { read_flags_wave(b, (blk - table_blocks) * (hw::block_dim() / 64) + (hw::thread_idx() >> 6), hw::thread_idx() & 63u); return; }
+    const uint32_t g = blk * hw::block_dim() + hw::thread_idx();
     if (g >= n_bases) return;
     const uint32_t h = b.hbases[g], mf = b.maskF[g], mr = b.maskR[g];
     const uint32_t pf = (uint8_t)b.priorF[g], pr = (uint8_t)b.priorR[g];
@@ -120,6 +120,7 @@ OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks, ui
         hw::atomic_and_u32(&b.hclean[hap], 0u);
     }
 }
+OCT_KERNEL(k_hap_tables)(DevBatch b, uint32_t n_bases, uint32_t table_blocks, uint32_t flag_blocks) { hap_tables_block(b, n_bases, table_blocks, flag_blocks, hw::block_idx(), hw::grid_dim()); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // candidate mapping positions: 6-mer voting (utils/kmer_mapper.hpp)
@@ -159,13 +160,12 @@ OCT_DEVICE void read_hash_wave(const DevBatch& b, uint32_t r, uint32_t lane)   /
 }
 
 // The workgroups past `n_hap_blocks` (one slice only) compute the read hashes of the whole batch in the same launch, four reads each.
-OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks)
+OCT_DEVICE void kmer_tables_block(const DevBatch& b, uint32_t hap0, uint32_t n_hap_blocks, uint32_t blk, uint32_t* smem_words)
 {
-    if (hw::block_idx() >= n_hap_blocks) { read_hash_wave(b, (hw::block_idx() - n_hap_blocks) * (hw::block_dim() / 64) + (hw::thread_idx() >> 6), hw::thread_idx() & 63u); return; }
-    OCT_DYN_SMEM(smem);
-    uint32_t* hist = (uint32_t*)smem;            // [4096]
+    if (blk >= n_hap_blocks) { read_hash_wave(b, (blk - n_hap_blocks) * (hw::block_dim() / 64) + (hw::thread_idx() >> 6), hw::thread_idx() & 63u); return; }
+    uint32_t* hist = smem_words;                 // [4096]
     uint32_t* part = hist + kKmerBins;           // [256]
-    const uint32_t h = hap0 + hw::block_idx(), tid = hw::thread_idx(), nt = hw::block_dim();
+    const uint32_t h = hap0 + blk, tid = hw::thread_idx(), nt = hw::block_dim();
     const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;
     for (uint32_t i = tid; i < kKmerBins; i += nt) hist[i] = 0;
     hw::block_sync();
@@ -204,6 +204,15 @@ OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks)
         const uint32_t slot = hw::atomic_add_lds_u32(&hist[kmer_hash6(b.hbases + ho + p)], 1u) & 0xffffu;   // the start field counts up; it cannot reach the occupancy above it
         b.bin_idx[ho + slot] = (uint16_t)p;
     }
+}
+OCT_KERNEL(k_kmer_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks) { OCT_DYN_SMEM(smem); kmer_tables_block(b, hap0, n_hap_blocks, hw::block_idx(), (uint32_t*)smem); }
+// A one-shot call's first step: the batch's per-base DP tables, read flags and read records (k_hap_tables, otherwise part of the upload) in the SAME launch as the k-mer tables and
+// read hashes - a region server's device batch is a chain of dependent launches, and these two do not depend on each other. Workgroups [0, n_kmer_blocks): k_kmer_tables' roles.
+OCT_KERNEL(k_tables)(DevBatch b, uint32_t hap0, uint32_t n_hap_blocks, uint32_t n_kmer_blocks, uint32_t n_bases, uint32_t table_blocks, uint32_t flag_blocks)
+{
+    OCT_DYN_SMEM(smem);
+    if (hw::block_idx() < n_kmer_blocks) kmer_tables_block(b, hap0, n_hap_blocks, hw::block_idx(), (uint32_t*)smem);
+    else hap_tables_block(b, n_bases, table_blocks, flag_blocks, hw::block_idx() - n_kmer_blocks, hw::grid_dim() - n_kmer_blocks);
 }
 
 // compute_kmer_hashes<6> (:57-69) for every read, once per batch like the reference (haplotype_likelihood_array.cpp:118-131):
@@ -660,6 +669,10 @@ OCT_KERNEL(k_kmer_map_lanes)(DevBatch b, const uint32_t* blk_hap, const uint32_t
 // pair), and staging + merging a wave's votes where its 64 k-mers agree on a diagonal as kmer_count_votes_wave does (6.2 ms: every 6-mer of a 16 kb haplotype has ~4 bin entries,
 // the lanes' j-th entries never agree).
 OCT_HD uint32_t kmer_map_big_lds_bytes(uint32_t lh_cap) { return ((lh_cap + 2) / 2) * 4 + 64; }
+#ifndef OCT_BIG_MAP_U
+#define OCT_BIG_MAP_U 4
+#endif
+constexpr uint32_t kBigMapU = OCT_BIG_MAP_U, kBigMapE = OCT_BIG_MAP_U > 1 ? 4 : 1;      // k-mers in flight per thread, bin entries fetched ahead per k-mer
 OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
 {
     OCT_DYN_SMEM(smem);
@@ -677,11 +690,26 @@ OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
     for (uint32_t w = tid; w < (nk + 1) / 2 + 1; w += nt) counts[w] = 0;
     if (tid == 0) { s_max = 0; s_nout = 0; }
     hw::block_sync();
-    for (uint32_t q = tid; q < nq; q += nt) {
-        const uint32_t hq = b.rhash[ro + q];
-        for (uint32_t j = bins[hq]; j < bins[hq + 1]; ++j) {
-            const uint32_t ti = idx[j];
-            if (ti >= q) { const uint32_t d = ti - q; hw::atomic_add_lds_u32(&counts[d >> 1], 1u << (16 * (d & 1u))); }   // :130-132
+    // A k-mer's votes are a chain of three dependent global loads (its hash -> its bin's bounds -> the bin's entries): a thread walks kBigMapU k-mers at a time, stage by stage, and
+    // fetches the first kBigMapE entries of every bin at once, so that the chain's latency is paid per kBigMapU k-mers (one k-mer after the other: ~110 us per 12 kb read, the whole
+    // launch 4.9 ms on ccs2048x12; OCT_BIG_MAP_U=1 builds that form).
+    auto vote = [&](uint32_t ti, uint32_t q) { if (ti >= q) { const uint32_t d = ti - q; hw::atomic_add_lds_u32(&counts[d >> 1], 1u << (16 * (d & 1u))); } };   // :130-132
+    for (uint32_t q0 = tid; q0 < nq; q0 += nt * kBigMapU) {
+        uint32_t hq[kBigMapU], j0[kBigMapU], j1[kBigMapU], ent[kBigMapU][kBigMapE];
+#pragma unroll
+        for (uint32_t u = 0; u < kBigMapU; ++u) { const uint32_t q = q0 + u * nt; hq[u] = q < nq ? (uint32_t)b.rhash[ro + q] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < kBigMapU; ++u) { j0[u] = bins[hq[u]]; j1[u] = q0 + u * nt < nq ? (uint32_t)bins[hq[u] + 1] : j0[u]; }
+#pragma unroll
+        for (uint32_t u = 0; u < kBigMapU; ++u)
+#pragma unroll
+            for (uint32_t k = 0; k < kBigMapE; ++k) ent[u][k] = j0[u] + k < j1[u] ? (uint32_t)idx[j0[u] + k] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < kBigMapU; ++u) {
+            const uint32_t q = q0 + u * nt;
+#pragma unroll
+            for (uint32_t k = 0; k < kBigMapE; ++k) if (j0[u] + k < j1[u]) vote(ent[u][k], q);
+            for (uint32_t j = j0[u] + kBigMapE; j < j1[u]; ++j) vote(idx[j], q);
         }
     }
     hw::block_sync();
@@ -1935,8 +1963,15 @@ OCT_DEVICE void dp_groups(const DpParams& p, const uint32_t blk, const uint32_t 
     }
 }
 
+// A traceback launch heads a chain (DP -> walk -> epilogue) while the score-only launch beside it has nobody waiting: where their waves share a SIMD the
+// traceback wave issues first (s_setprio; OCT_CHAIN_PRIO=0 builds without, for A/B).
+#ifndef OCT_CHAIN_PRIO
+#define OCT_CHAIN_PRIO 2
+#endif
+template <bool HEAD> OCT_DEVICE void chain_head_priority() { if constexpr (HEAD && OCT_CHAIN_PRIO > 0) hw::wave_priority<OCT_CHAIN_PRIO>(); }
+
 template <int B, bool TRACE, bool GENERIC, bool FASTADD>
-OCT_KERNEL(k_dp)(DpParams p) { dp_groups<B, TRACE, GENERIC, FASTADD>(p, hw::block_idx(), hw::grid_dim()); }
+OCT_KERNEL(k_dp)(DpParams p) { chain_head_priority<TRACE>(); dp_groups<B, TRACE, GENERIC, FASTADD>(p, hw::block_idx(), hw::grid_dim()); }
 
 // Region-sized (device-sized) steps: the traceback list and the score-only list of one cost flavour in ONE launch - the first n_blocks_t workgroups take the
 // traceback form, the rest the score-only form. Both are a few hundred latency-bound waves: side by side they fill the chip's SIMDs once, one after the other
@@ -1944,7 +1979,7 @@ OCT_KERNEL(k_dp)(DpParams p) { dp_groups<B, TRACE, GENERIC, FASTADD>(p, hw::bloc
 template <int B, bool GENERIC, bool FASTADD>
 OCT_KERNEL(k_dp_pair)(DpParams pt, DpParams ps, uint32_t n_blocks_t)
 {
-    if (hw::block_idx() < n_blocks_t) dp_groups<B, true, GENERIC, FASTADD>(pt, hw::block_idx(), n_blocks_t);
+    if (hw::block_idx() < n_blocks_t) { chain_head_priority<true>(); dp_groups<B, true, GENERIC, FASTADD>(pt, hw::block_idx(), n_blocks_t); }
     else dp_groups<B, false, GENERIC, FASTADD>(ps, hw::block_idx() - n_blocks_t, hw::grid_dim() - n_blocks_t);
 }
 
@@ -2104,6 +2139,7 @@ template <bool W16> OCT_DEVICE uint32_t wadd(uint32_t a, uint32_t b)
 template <int B, bool TRACE, bool W16>
 OCT_KERNEL(k_dp_wide)(DpParams p)
 {
+    chain_head_priority<TRACE>();
     // B >= 64: one task per wave, C = B / 64 adjacent diagonals per lane. B < 64 (long reads at a narrow band - the reference's PacBio
     // configuration runs band 16): 64 / B tasks per wave, one per row of B lanes, exactly the task-group layout of the LDS-resident kernels.
     constexpr int C = B > 64 ? B / 64 : 1, BL = B < 64 ? B : 64, ROWS = 64 / BL;
@@ -2268,6 +2304,7 @@ OCT_KERNEL(k_dp_wide)(DpParams p)
 template <bool TRACE, bool GENERIC>
 OCT_KERNEL(k_dp_rows)(DpParams p)
 {
+    chain_head_priority<TRACE>();
     constexpr int B = 16, ROWS = 4, CH = 8;
     const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
     const uint32_t row = lane / B, li = lane % B;
@@ -2743,6 +2780,7 @@ inline size_t walk_stage_lds_bytes(uint32_t B, uint32_t tpr) { return (64 * kWal
 template <int B, int TPR, int C, bool STAGE = false>
 OCT_MAX_THREADS(STAGE ? 64 : 256) OCT_KERNEL(k_walk)(WalkParams w)
 {
+    chain_head_priority<true>();
     constexpr uint32_t ROWS = 64 * C / B, G = TPR * ROWS;   // C > 1: band 64 x C on one wave, diagonal i lives in lane i / C, plane i % C
     static_assert(!STAGE || C == 1, "staged walk: bands up to 64");
     OCT_DYN_SMEM(smem);
@@ -2960,6 +2998,10 @@ OCT_MAX_THREADS(STAGE ? 64 : 256) OCT_KERNEL(k_walk)(WalkParams w)
 //    any cross-lane operation, until the next run starts.
 // Every cross-lane operation sits in wave-uniform control flow (rows that are done idle along). Same steps, same events, same result as k_walk.
 constexpr uint32_t kWalkRowEvents = 64;
+#ifndef OCT_WALK_PREFETCH
+#define OCT_WALK_PREFETCH 1
+#endif
+constexpr bool kPrefetch = OCT_WALK_PREFETCH != 0;
 constexpr uint32_t kWalkRowLine = 20;                                      // words per staged line: 16 + pad (16-byte aligned; the 16 lanes of a row write their lines with b128 stores, two-way conflicts at most)
 constexpr uint32_t walk_rows_tiles(uint32_t B) { return B <= 16 ? 4 : (B == 32 ? 2 : 1); }
 constexpr uint32_t walk_rows_row_words(uint32_t B) { return kWalkRowEvents + walk_rows_tiles(B) * B * kWalkRowLine + 8; }   // (+ 8: the four rows of a wave start in different banks)
@@ -2968,6 +3010,7 @@ inline size_t walk_rows_lds_bytes(uint32_t B, uint32_t threads) { return threads
 template <int B, int TPR>
 OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
 {
+    chain_head_priority<true>();
     constexpr uint32_t ROWS = 64 / B, G = TPR * ROWS;
     constexpr uint32_t K = walk_rows_tiles(B), LPL = B <= 16 ? 1 : B / 16, LS = kWalkRowLine;   // tiles staged at a time, band lines per lane and tile
     static_assert(B <= 64, "one band row per task group row");
@@ -3058,24 +3101,32 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
 
     const int32_t mid_lo = want_flank ? lhs : INT32_MIN, mid_hi = (want_flank || stop_below_x != INT32_MIN) ? rhs_begin : INT32_MAX;   // mid_lo < x < mid_hi: the next column lies outside both flanks
     int32_t st_top = INT32_MIN / 2;                                       // the staged window: tiles st_top, st_top - 1, ... st_top - K + 1 (nothing yet)
+    uint4 pf[K * LPL][4]; int32_t pf_top = INT32_MIN / 2;                 // the window after it, on its way: tiles pf_top ... pf_top - K + 1
+#pragma unroll
+    for (uint32_t a = 0; a < K * LPL; ++a)
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) pf[a][j] = make_uint4(0, 0, 0, 0);
     for (;;) {
         if (!fin && sidx < 0) { ok = false; fin = true; }                                       // ran off the first diagonal with target bases left (:195-199)
         if (hw::ballot(!fin) == 0) break;
         const int32_t k = sidx >> 1, kt = k >> 4, kk = k & 15, sidx_at_pass_start = sidx;
         const bool in_band = !fin && (uint32_t)i < (uint32_t)B;
         // ---- stage the next K tiles of this task row (lane l: the lines of band lane l, l + 16, ...) ----
+        // The window after this one is known (the walk's diagonal only falls: tiles kt - K ... kt - 2K + 1), so its lines are fetched while this one is walked and wait
+        // in registers (`pf`): a 13 kb read's walk was ~200 dependent fetches of a window each (round 6; OCT_WALK_PREFETCH=0 builds without).
         const bool need = in_band && (uint32_t)(st_top - kt) >= K;
         if (hw::ballot(need) != 0) {
+            const bool hit = kPrefetch && need && pf_top == kt;
             uint4 v[K * LPL][4];
 #pragma unroll
             for (uint32_t a = 0; a < K; ++a)
 #pragma unroll
                 for (uint32_t q = 0; q < LPL; ++q) {
                     const int32_t tile = kt - (int32_t)a; const uint32_t b = l16 + 16 * q;
-                    const bool in = need && tile >= 0 && b < (uint32_t)B;
+                    const bool in = need && !hit && tile >= 0 && b < (uint32_t)B;
                     const uint4* src = (const uint4*)(bpg + ((size_t)(in ? tile : 0) * 64 + (in ? b : 0)) * 16);
 #pragma unroll
-                    for (uint32_t j = 0; j < 4; ++j) v[a * LPL + q][j] = in ? src[j] : make_uint4(0, 0, 0, 0);
+                    for (uint32_t j = 0; j < 4; ++j) v[a * LPL + q][j] = in ? src[j] : (hit ? pf[a * LPL + q][j] : make_uint4(0, 0, 0, 0));
                 }
             hw::wave_lds_fence();                                                               // the reads of the window before are done
 #pragma unroll
@@ -3091,6 +3142,20 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
                 }
             if (need) st_top = kt;
             hw::wave_lds_fence();
+            if constexpr (kPrefetch) {
+                const int32_t nt = kt - (int32_t)K;                                             // top tile of the window after this one
+                if (need) pf_top = nt;
+#pragma unroll
+                for (uint32_t a = 0; a < K; ++a)
+#pragma unroll
+                    for (uint32_t q = 0; q < LPL; ++q) {
+                        const int32_t tile = nt - (int32_t)a; const uint32_t b = l16 + 16 * q;
+                        const bool in = need && tile >= 0 && b < (uint32_t)B;
+                        const uint4* src = (const uint4*)(bpg + ((size_t)(in ? tile : 0) * 64 + (in ? b : 0)) * 16);
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j) if (need) pf[a * LPL + q][j] = in ? src[j] : make_uint4(0, 0, 0, 0);
+                    }
+            }
         }
         // ---- a run of match columns: words kk, kk - 1, ... of the walk's line, as far as their labels say "match" (the turn itself is a plain step) ----
         const uint32_t par = (uint32_t)sidx & 1u;
@@ -3264,6 +3329,7 @@ inline size_t walk_long_lds_bytes() { return (kWalkLongEvents + 2 * 64 * 16) * s
 template <int B, int C>
 OCT_MAX_THREADS(64) OCT_KERNEL(k_walk_long)(WalkParams w)
 {
+    chain_head_priority<true>();
     static_assert(C > 1 && B == 64 * C, "one task per band row of 64 x C diagonals");
     OCT_DYN_SMEM(smem);
     uint32_t* evbuf = (uint32_t*)smem;                                    // [kWalkLongEvents]

@@ -308,6 +308,7 @@ inline unsigned long long load_device_u64(const unsigned long long* p) { return 
 inline uint32_t load_device_u32(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 inline void spin_pause() { hipsim::yield_to_sched(hipsim::kRun); }      // a lane that waits for another wave's mailbox: let the other lanes run
 inline void store_streaming_u4(uint4* p, uint4 v) { *p = v; }
+template <int P> inline void wave_priority() {}
 inline uint32_t thread_idx() { return hipsim::S().cur; }
 inline uint32_t block_idx() { return hipsim::S().bid; }
 inline uint32_t block_dim() { return hipsim::S().bdim; }

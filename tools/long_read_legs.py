@@ -2,6 +2,7 @@
 """The long-read legs of bench.py on their own (resident timing only; bench.py and tests/test_gpu_fullsize.py verify them): long64x8 / long512x8 (configs[4] and 8 x its reads,
 band 256, int32), ccs-linked (PacBioCCS.config: 500-base linked chunks, band 16, int16), ccs256x12 (unsplit 10-14 kb reads at band 16, int32), ccs2048x12 (eight times its reads).   python tools/long_read_legs.py [leg ...]"""
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -24,6 +25,8 @@ for leg in legs:
     ts = []
     for _ in range(3):
         t0 = time.perf_counter(); rb.run(); rb.wait(); ts.append(time.perf_counter() - t0)
+    if os.environ.get("OCT_TRACE_MARK"):      # a last step on its own, for tools/timeline_tail.py
+        time.sleep(0.05); rb.run(); rb.wait()
     st = rb.stats()
     print(json.dumps({"leg": leg, "ms": min(ts) * 1e3, "gcups": (st["band_cells"] - st.get("band_cells_shared", 0)) / min(ts) / 1e9, "dp_kernel_ms_by_kind": rb.kernel_time_by_kind(),
                       "device_sized": rb.device_sized(), "stats": st}))
