@@ -342,9 +342,12 @@ bool launch_dp_wide_inst(bool w16, const DpParams& p, rt::Stream s)
 }
 bool launch_dp_rows(bool tr, bool gen, const DpParams& p, rt::Stream s)      // long reads at band 16, int32 lanes: one task per row of 16 lanes (k_dp_rows)
 {
-    const uint32_t waves = (p.n_tasks + 3) / 4, blocks = (waves + kBlockWaves - 1) / kBlockWaves;
-    if (tr) { if (gen) OCT_LAUNCH((k_dp_rows<true, true>), blocks, kBlockWaves * 64, 0, s, p); else OCT_LAUNCH((k_dp_rows<true, false>), blocks, kBlockWaves * 64, 0, s, p); }
-    else    { if (gen) OCT_LAUNCH((k_dp_rows<false, true>), blocks, kBlockWaves * 64, 0, s, p); else OCT_LAUNCH((k_dp_rows<false, false>), blocks, kBlockWaves * 64, 0, s, p); }
+    // a launch of about a wave per SIMD (ccs256x12: 1,340 waves of ~13,000 dependent iterations each): one wave per workgroup, so that the dispatcher spreads single waves, not fours
+    // (4.47-4.59 against 4.62-4.70 ms per step; a device-sized launch counts its bound, ~11 tasks per pair). Measured and not kept (profiles/EXPERIMENTS.md): unused LDS as a cap on the
+    // workgroups per CU, and a persistent grid of one workgroup per CU whose waves stride over the groups.
+    const uint32_t waves = (p.n_tasks + 3) / 4, wpb = waves <= 16384 ? 1u : (uint32_t)kBlockWaves, blocks = (waves + wpb - 1) / wpb;
+    if (tr) { if (gen) OCT_LAUNCH((k_dp_rows<true, true>), blocks, wpb * 64, 0, s, p); else OCT_LAUNCH((k_dp_rows<true, false>), blocks, wpb * 64, 0, s, p); }
+    else    { if (gen) OCT_LAUNCH((k_dp_rows<false, true>), blocks, wpb * 64, 0, s, p); else OCT_LAUNCH((k_dp_rows<false, false>), blocks, wpb * 64, 0, s, p); }
     return rt::launch_ok();
 }
 bool launch_dp_wide(int band, bool tr, bool w16, const DpParams& p, rt::Stream s)

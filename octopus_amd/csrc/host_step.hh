@@ -50,14 +50,16 @@ extern "C" int oct_phmm_batch_run(oct_phmm_handle* h, oct_phmm_batch* b, oct_phm
         if (b->device_map) {                              // HaplotypeLikelihoodArray::populate maps per haplotype (array.cpp:118-158)
             // the first slice that has pairs also hashes every read of the batch once (array.cpp:118-131); the later slices' mappers wait for it
             const bool hashes_here = hash_slice < 0;
-            const uint32_t hash_blocks = hashes_here ? (b->n_reads + 3) / 4 : 0;        // one wave per read
+            // a haplotype's table is one workgroup's work (one histogram in LDS): 1,024 threads from 4 k bases on (a 16 kb haplotype with 256: most of the 0.27 ms the launch took on ccs256x12)
+            const uint32_t kt_threads = (b->lh_cap >= 4096 && !b->tables_pending) ? 1024u : 256u, kt_waves = kt_threads / 64;
+            const uint32_t hash_blocks = hashes_here ? (uint32_t)(((uint64_t)b->n_reads * d.hash_segs + kt_waves - 1) / kt_waves) : 0;   // one wave per read and 1,024 bases
             if (b->tables_pending) {                        // first step of a device-sized batch: the upload left its table kernel to this launch
                 const uint32_t n_kmer_blocks = sl.hap1 - sl.hap0 + hash_blocks;
                 OCT_LAUNCH(k_tables, n_kmer_blocks + b->tp_table_blocks + b->tp_flag_blocks + b->tp_rec_blocks, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d, sl.hap0, sl.hap1 - sl.hap0,
                            n_kmer_blocks, b->tp_n_bases, b->tp_table_blocks, b->tp_flag_blocks); RT(rt::launch_ok());
                 b->tables_pending = false;
             } else {
-            OCT_LAUNCH(k_kmer_tables, sl.hap1 - sl.hap0 + hash_blocks, 256, (kKmerBins + 256) * sizeof(uint32_t), s, d, sl.hap0, sl.hap1 - sl.hap0); RT(rt::launch_ok());
+            OCT_LAUNCH(k_kmer_tables, sl.hap1 - sl.hap0 + hash_blocks, kt_threads, (kKmerBins + 256) * sizeof(uint32_t), s, d, sl.hap0, sl.hap1 - sl.hap0); RT(rt::launch_ok());
             }
             if (hashes_here) { hash_slice = i; if (S > 1) RT(rt::event_record(b->ev_hashes, s)); }
             else RT(rt::stream_wait_event(s, b->ev_hashes));

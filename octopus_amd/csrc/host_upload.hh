@@ -246,14 +246,13 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
     pk.upload(reg_lhs.data(), reg_lhs.size(), &d.reg_lhs);
     pk.upload(reg_rhs.data(), reg_rhs.size(), &d.reg_rhs);
     pk.dalloc(&d.pos, (size_t)b->n_pairs * S + 1); pk.dalloc(&d.npos, (size_t)b->n_pairs + 1);
-    d.bin_start = nullptr; d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr; d.hhash = nullptr; d.map_count_only = 0; d.map_stats = 0; d.pair_mm = nullptr; d.rcode = nullptr; d.rcode_words = 0;
+    d.hash_segs = std::max<uint32_t>(1u, (b->t_cap + kHashSegment - 1) / kHashSegment);
+    d.bin_idx = nullptr; d.rhash = nullptr; d.bin32 = nullptr; d.hhash = nullptr; d.map_count_only = 0; d.map_stats = 0; d.pair_mm = nullptr; d.rcode = nullptr; d.rcode_words = 0;
     if (!positions) {
-        if (b->map_big) pk.dalloc(&d.bin_start, (size_t)H->n_haps * (kKmerBins + 1) + 1);      // the u16 table of k_kmer_map_big only
-        pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 1);
+        pk.dalloc(&d.bin_idx, (size_t)n_hap_bases + 8);          // (+ 8: k_kmer_map_big fetches a bin's first four entries with one 8-byte load)
         pk.dalloc(&d.hhash, (size_t)n_hap_bases + 1);
         d.map_count_only = tune::map_count_only(); d.map_stats = tune::map_stats();
         b->map_reads_per_block = b->n_pairs < 500000 ? 16 : 256;      // the haplotype's tables are staged once per workgroup: big batches amortise them over more reads
-        { long long v; if (tune::number("OCT_PHMM_MAP_READS_PER_BLOCK", &v) && v >= 4 && v <= 1024) b->map_reads_per_block = (uint32_t)v / 4 * 4; }
         pk.dalloc(&d.bin32, (size_t)H->n_haps * kKmerBins + 4);
         // lane-per-pair mapper (k_kmer_map_lanes: 256 reads of one haplotype per workgroup, the exact shortcut per lane): batches big enough to fill the chip with
         // 256-pair workgroups; region-sized calls keep one wave per pair (more, shorter waves). OCT_PHMM_LANE_MAPPER=0 / 1 forces one or the other.
@@ -484,7 +483,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         if (table_blocks + flag_blocks + rec_blocks) {
             // a device-sized batch that maps on the device: the first step's k-mer table launch makes these too (k_tables; OCT_PHMM_FUSE_TABLES=0: two launches)
             long long fuse = 1; tune::number("OCT_PHMM_FUSE_TABLES", &fuse);
-            if (b->dsl && b->device_map && !b->dedup && fuse) {
+            if (b->dsl && b->device_map && !b->dedup && fuse && b->lh_cap < 4096) {      // (long haplotypes: k_kmer_tables runs 1,024 threads per haplotype)
                 b->tables_pending = true; b->tp_n_bases = n_hap_bases; b->tp_table_blocks = table_blocks; b->tp_flag_blocks = flag_blocks; b->tp_rec_blocks = rec_blocks;
             } else { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok()); }
             b->stats_clear = true;                             // (the kernel's last workgroup clears the counters)

@@ -62,7 +62,7 @@ struct DevBatch {
     // two 6-mer hash sequences there anyway; a hash is two bits per base): state << 14 | i1, state 0 = nothing known, 1 = no mismatch, 2 = exactly one, at read
     // position i1, 3 = two or more. Holds for pure-ACGT reads on pure-ACGT haplotypes (k_classify checks); null when another mapper or the caller made the positions.
     uint16_t* pair_mm;
-    // 6-mer tables per haplotype (k_kmer_tables): bin_start[h * 4097 + hash], bin_idx[hoff[h] + slot]
+    // 6-mer tables per haplotype (k_kmer_tables): bin32[h * 4096 + hash] = start | occupancy << 16, bin_idx[hoff[h] + slot]
     uint32_t* bin32;                                  // bin32[h * 4096 + hash] = start | occupancy << 16 (k_kmer_map, k_kmer_map_lanes); null when unused
     uint16_t* hhash;                                  // hhash[hoff[h] + p]: 6-mer hash of haplotype h at p (k_kmer_tables); k_kmer_map's exact-count shortcut
     int map_count_only;                               // test / A-B switch: every pair takes the counting path
@@ -71,7 +71,8 @@ struct DevBatch {
     // transposed in tiles of 64 reads - dword j of read r at rcode[((r >> 6) * rcode_words + j) * 64 + (r & 63)], so that a wave's 64 reads load one dword each from 256
     // consecutive bytes; zero behind a read's last base. Null when unused.
     uint32_t* rcode; uint32_t rcode_words;
-    uint16_t* bin_start; uint16_t* bin_idx; uint16_t* rhash;   // rhash[roff[r] + q]: 6-mer hash of read r at q (written by the trailing workgroups of k_kmer_tables; null where the lane mapper runs: it reads rcode)
+    uint32_t hash_segs;                               // waves per read in k_kmer_tables' read-hash role: ceil(longest read / 1024 bases), at least 1
+    uint16_t* bin_idx; uint16_t* rhash;   // rhash[roff[r] + q]: 6-mer hash of read r at q (written by the trailing workgroups of k_kmer_tables; null where the lane mapper runs: it reads rcode)
     // per pair
     uint64_t  n_pairs;
     int32_t*  pair_best;      // min phred penalty over candidates, kNoScore = none

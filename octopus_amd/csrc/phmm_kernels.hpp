@@ -141,16 +141,19 @@ OCT_DEVICE uint32_t kmer_hash6(const uint8_t* s)               // perfect_kmer_h
 
 // make_kmer_hash_table (:85-106) for every haplotype: one workgroup per haplotype, CSR bins (order inside a bin does not
 // affect the vote counts). LDS: 4096 counters + 256 scan slots.
-OCT_DEVICE void read_hash_wave(const DevBatch& b, uint32_t r, uint32_t lane)   // compute_kmer_hashes<6> (:57-69): one wave per read (no search for the read a base belongs to)
+constexpr uint32_t kHashSegment = 1024;                                       // bases per wave: a long read is hashed by several waves (DevBatch::hash_segs each; a 13 kb read was ~200 dependent trips of one wave)
+OCT_DEVICE void read_hash_wave(const DevBatch& b, uint32_t w, uint32_t lane)   // compute_kmer_hashes<6> (:57-69): wave w = segment w % hash_segs of read w / hash_segs (no search for the read a base belongs to)
 {
+    const uint32_t r = w / b.hash_segs, seg = w % b.hash_segs;
     if (r >= b.n_reads) return;
     const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro;
+    const uint32_t s0 = seg * kHashSegment, s1 = s0 + kHashSegment;             // this wave's positions [s0, s1)
     // k_kmer_map_lanes reads a read's hashes eight at a time, one lane per read: a row per read, 16-byte aligned, the entries behind the last k-mer = 4096
     // ("no k-mer": occupancy 0, equals no haplotype hash), so that its loop needs neither bounds tests nor unaligned loads. The other mappers read rhash.
-    if (b.rhash) { for (uint32_t q = lane; q + kKmer <= T; q += 64) b.rhash[ro + q] = (uint16_t)kmer_hash6(b.rbases + ro + q); }     // (the wave-per-pair mappers; the lane mapper reads the code rows below)
+    if (b.rhash) { for (uint32_t q = s0 + lane; q + kKmer <= T && q < s1; q += 64) b.rhash[ro + q] = (uint16_t)kmer_hash6(b.rbases + ro + q); }     // (the wave-per-pair mappers; the lane mapper reads the code rows below)
     if (b.rcode) {      // the read's 2-bit codes, 16 per dword (DevBatch::rcode): 64 bases per round, two ballots, lanes 0-3 store a dword each
         uint32_t* tile = b.rcode + ((size_t)(r >> 6) * b.rcode_words) * 64 + (r & 63u);
-        for (uint32_t t0 = 0; t0 < b.rcode_words * 16; t0 += 64) {
+        for (uint32_t t0 = s0; t0 < b.rcode_words * 16 && t0 < s1; t0 += 64) {
             const uint32_t t = t0 + lane, c = t < T ? kmer_code(b.rbases[ro + t]) : 0u;
             const uint64_t b0 = hw::ballot((c & 1u) != 0), b1 = hw::ballot((c & 2u) != 0);
             const uint32_t j = (t0 >> 4) + lane;
@@ -189,10 +192,8 @@ OCT_DEVICE void kmer_tables_block(const DevBatch& b, uint32_t hap0, uint32_t n_h
         for (uint32_t w = 0; w < wv; ++w) run += part[w];
         for (uint32_t i = 0; i < per; ++i) {
             const uint32_t c = cnt16[i]; hist[tid * per + i] = run | c << 16;                  // start and occupancy in one word (haplotypes are < 65,536 bases)
-            if (b.bin_start) b.bin_start[(size_t)h * (kKmerBins + 1) + tid * per + i] = (uint16_t)run;   // k_kmer_map_big's table (long haplotypes only)
             run += c;
         }
-        if (tid == 255 && b.bin_start) b.bin_start[(size_t)h * (kKmerBins + 1) + kKmerBins] = (uint16_t)run;
     }
     hw::block_sync();
     if (b.bin32) {                                                                              // the table of k_kmer_map / k_kmer_map_lanes, 16 bytes per thread per store: whole lines
@@ -201,7 +202,7 @@ OCT_DEVICE void kmer_tables_block(const DevBatch& b, uint32_t hap0, uint32_t n_h
     }
     hw::block_sync();
     for (uint32_t p = tid; p < nk; p += nt) {
-        const uint32_t slot = hw::atomic_add_lds_u32(&hist[kmer_hash6(b.hbases + ho + p)], 1u) & 0xffffu;   // the start field counts up; it cannot reach the occupancy above it
+        const uint32_t slot = hw::atomic_add_lds_u32(&hist[b.hhash[ho + p]], 1u) & 0xffffu;   // the start field counts up; it cannot reach the occupancy above it
         b.bin_idx[ho + slot] = (uint16_t)p;
     }
 }
@@ -672,7 +673,7 @@ OCT_HD uint32_t kmer_map_big_lds_bytes(uint32_t lh_cap) { return ((lh_cap + 2) /
 #ifndef OCT_BIG_MAP_U
 #define OCT_BIG_MAP_U 4
 #endif
-constexpr uint32_t kBigMapU = OCT_BIG_MAP_U, kBigMapE = OCT_BIG_MAP_U > 1 ? 4 : 1;      // k-mers in flight per thread, bin entries fetched ahead per k-mer
+constexpr uint32_t kBigMapU = OCT_BIG_MAP_U;      // k-mers in flight per thread
 OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
 {
     OCT_DYN_SMEM(smem);
@@ -685,31 +686,30 @@ OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
     const uint32_t r = b.reg_read0[g] + (uint32_t)(e - b.hap_pair_off[h]);
     const uint32_t ho = b.hoff[h], Lh = b.hoff[h + 1] - ho, nk = Lh >= kKmer ? Lh - kKmer + 1 : 0;
     const uint32_t ro = b.roff[r], T = b.roff[r + 1] - ro, nq = T >= kKmer ? T - kKmer + 1 : 0;
-    const uint16_t* bins = b.bin_start + (size_t)h * (kKmerBins + 1);
+    const uint32_t* bins = b.bin32 + (size_t)h * kKmerBins;             // start | occupancy << 16 per bin (k_kmer_tables)
     const uint16_t* idx = b.bin_idx + ho;
     for (uint32_t w = tid; w < (nk + 1) / 2 + 1; w += nt) counts[w] = 0;
     if (tid == 0) { s_max = 0; s_nout = 0; }
     hw::block_sync();
-    // A k-mer's votes are a chain of three dependent global loads (its hash -> its bin's bounds -> the bin's entries): a thread walks kBigMapU k-mers at a time, stage by stage, and
-    // fetches the first kBigMapE entries of every bin at once, so that the chain's latency is paid per kBigMapU k-mers (one k-mer after the other: ~110 us per 12 kb read, the whole
-    // launch 4.9 ms on ccs2048x12; OCT_BIG_MAP_U=1 builds that form).
-    auto vote = [&](uint32_t ti, uint32_t q) { if (ti >= q) { const uint32_t d = ti - q; hw::atomic_add_lds_u32(&counts[d >> 1], 1u << (16 * (d & 1u))); } };   // :130-132
+    // A k-mer's votes are a chain of three dependent gathers (its hash -> its bin -> the bin's entries): one word per bin (start | occupancy << 16), a bin's first four entries in ONE
+    // 8-byte load (they are neighbours in bin_idx; a 16 kb haplotype's bins hold ~4), kBigMapU k-mers per thread in flight, stage by stage. What the kernel runs out of, though, is the
+    // LDS: ~48,000 counter atomics per 12 kb read on random banks (SQ_LDS_IDX_ACTIVE = 0.93 x SQ_BUSY_CYCLES, 38 % of it bank conflicts: profiles/r06_s24_long_read_pmc.txt) - the
+    // loads' forms above moved the launch by 3 %, counting the diagonals a wave agrees on with ballots instead of atomics made it 17 % slower (profiles/EXPERIMENTS.md).
+    auto vote_d = [&](uint32_t d) { hw::atomic_add_lds_u32(&counts[d >> 1], 1u << (16 * (d & 1u))); };                                                               // :130-132
     for (uint32_t q0 = tid; q0 < nq; q0 += nt * kBigMapU) {
-        uint32_t hq[kBigMapU], j0[kBigMapU], j1[kBigMapU], ent[kBigMapU][kBigMapE];
+        uint32_t hq[kBigMapU], j0[kBigMapU], nj[kBigMapU]; uint64_t ent[kBigMapU];
 #pragma unroll
         for (uint32_t u = 0; u < kBigMapU; ++u) { const uint32_t q = q0 + u * nt; hq[u] = q < nq ? (uint32_t)b.rhash[ro + q] : 0u; }
 #pragma unroll
-        for (uint32_t u = 0; u < kBigMapU; ++u) { j0[u] = bins[hq[u]]; j1[u] = q0 + u * nt < nq ? (uint32_t)bins[hq[u] + 1] : j0[u]; }
+        for (uint32_t u = 0; u < kBigMapU; ++u) { const uint32_t w = bins[hq[u]]; j0[u] = w & 0xffffu; nj[u] = q0 + u * nt < nq ? w >> 16 : 0u; }
 #pragma unroll
-        for (uint32_t u = 0; u < kBigMapU; ++u)
-#pragma unroll
-            for (uint32_t k = 0; k < kBigMapE; ++k) ent[u][k] = j0[u] + k < j1[u] ? (uint32_t)idx[j0[u] + k] : 0u;
+        for (uint32_t u = 0; u < kBigMapU; ++u) ent[u] = ld64u((const uint8_t*)(idx + j0[u]));       // (bin_idx has eight spare entries behind the last haplotype's)
 #pragma unroll
         for (uint32_t u = 0; u < kBigMapU; ++u) {
             const uint32_t q = q0 + u * nt;
 #pragma unroll
-            for (uint32_t k = 0; k < kBigMapE; ++k) if (j0[u] + k < j1[u]) vote(ent[u][k], q);
-            for (uint32_t j = j0[u] + kBigMapE; j < j1[u]; ++j) vote(idx[j], q);
+            for (uint32_t k = 0; k < 4; ++k) { const uint32_t ti = (uint32_t)(ent[u] >> (16 * k)) & 0xffffu; if (k < nj[u] && ti >= q) vote_d(ti - q); }
+            for (uint32_t j = 4; j < nj[u]; ++j) { const uint32_t ti = idx[j0[u] + j]; if (ti >= q) vote_d(ti - q); }
         }
     }
     hw::block_sync();
@@ -721,15 +721,21 @@ OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
     mx = s_max;
     // the ascending offsets that reach the maximum, at most max_pos of them (:145-157): every thread owns a contiguous stretch of
     // diagonals, the stretches' match counts are prefix-summed, and a thread writes its matches while their rank is below max_pos
-    __shared__ uint32_t s_cnt[256];
-    const uint32_t per = (nk + nt - 1) / nt, d0 = tid * per, d1 = d0 + per < nk ? d0 + per : nk;
+    const uint32_t lane = tid & 63u;
+    __shared__ uint32_t s_part[16];                                    // per wave: its threads' matches (the workgroup has at most 16 waves)
+    // (an ODD number of counter words per thread: with 32 - a 16 kb haplotype over 256 threads - the 64 lanes of a wave read 64 words of ONE bank, pass after pass, and this tail
+    // was most of the kernel: 3.2 of ccs2048x12's 16.5 ms)
+    const uint32_t per = 2 * ((((nk + 1) / 2 + nt - 1) / nt) | 1u), d0 = tid * per < nk ? tid * per : nk, d1 = d0 + per < nk ? d0 + per : nk;
     uint32_t mine = 0;
     if (mx > 0) for (uint32_t d = d0; d < d1; ++d) mine += cnt_of(d) == mx ? 1u : 0u;
-    s_cnt[tid] = mine;
+    uint32_t inc = mine;                                               // inclusive prefix inside the wave by shuffles, across the waves through s_part (one thread walked all 256 counts before)
+    for (uint32_t dd = 1; dd < 64; dd <<= 1) { const uint32_t o = hw::shfl(inc, (int)(lane >= dd ? lane - dd : lane)); if (lane >= dd) inc += o; }
+    if (lane == 63) s_part[tid >> 6] = inc;
     hw::block_sync();
-    if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i < nt; ++i) { const uint32_t c = s_cnt[i]; s_cnt[i] = run; run += c; } s_nout = run; }
+    uint32_t rank = inc - mine, all = 0;
+    for (uint32_t w = 0; w < nt / 64; ++w) { const uint32_t c = s_part[w]; if (w < (tid >> 6)) rank += c; all += c; }
+    if (tid == 0) s_nout = all;
     hw::block_sync();
-    uint32_t rank = s_cnt[tid];
     if (mine) for (uint32_t d = d0; d < d1 && rank < (uint32_t)b.max_pos; ++d) if (cnt_of(d) == mx) b.pos[e * (uint64_t)b.max_pos + rank++] = d;
     if (tid == 0) b.npos[e] = (uint8_t)(s_nout < (uint32_t)b.max_pos ? s_nout : (uint32_t)b.max_pos);
 }
@@ -740,6 +746,12 @@ OCT_KERNEL(k_kmer_map_big)(DevBatch b, uint64_t pair0)
 OCT_DEVICE uint32_t first_mismatch(const uint8_t* a, const uint8_t* b, uint32_t from, uint32_t n)
 {
     uint32_t i = from;
+    // 16 bytes per step, four loads in flight: a thread's pass over a read is a chain of round trips to memory, one per step (32 bytes per step: two spilled registers in k_classify)
+    while (i + 16 <= n) {
+        const uint64_t x0 = ld64u(a + i) ^ ld64u(b + i), x1 = ld64u(a + i + 8) ^ ld64u(b + i + 8);
+        if (x0 | x1) return x0 ? i + (uint32_t)(__builtin_ctzll(x0) >> 3) : i + 8 + (uint32_t)(__builtin_ctzll(x1) >> 3);
+        i += 16;
+    }
     while (i + 8 <= n) {
         const uint64_t x = ld64u(a + i) ^ ld64u(b + i);
         if (x) return i + (uint32_t)(__builtin_ctzll(x) >> 3);
@@ -2308,9 +2320,9 @@ OCT_KERNEL(k_dp_rows)(DpParams p)
     constexpr int B = 16, ROWS = 4, CH = 8;
     const uint32_t tid = hw::thread_idx(), lane = tid & 63, wave = tid >> 6;
     const uint32_t row = lane / B, li = lane % B;
-    const uint32_t group = hw::block_idx() * kBlockWaves + wave;           // = the wave's task group (ROWS tasks)
     const DevTask* tasks = p.tasks; uint32_t n_tasks = p.n_tasks;
     if (p.ref.totals) { uint32_t first; task_list_range(p.ref, first, n_tasks); tasks += first; }   // device-sized launch: the grid is the host's bound
+    const uint32_t group = hw::block_idx() * (hw::block_dim() >> 6) + wave;   // = the wave's task group (ROWS tasks); the launcher picks the workgroup's waves
     if (group * ROWS >= n_tasks) return;                                   // whole waves only (n_tasks is a multiple of ROWS)
     const uint32_t task = group * ROWS + row;
     const DevTask t = tasks[task];
@@ -3143,17 +3155,19 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
             if (need) st_top = kt;
             hw::wave_lds_fence();
             if constexpr (kPrefetch) {
-                const int32_t nt = kt - (int32_t)K;                                             // top tile of the window after this one
-                if (need) pf_top = nt;
+                // every row of the wave fetches here, with nothing selected on the loaded values (a select would make the wave wait for them now): a row that staged, the window
+                // after its new one; a row that did not, the window it is still waiting for, again
+                const int32_t nt = need ? kt - (int32_t)K : pf_top;
+                pf_top = nt;
 #pragma unroll
                 for (uint32_t a = 0; a < K; ++a)
 #pragma unroll
                     for (uint32_t q = 0; q < LPL; ++q) {
                         const int32_t tile = nt - (int32_t)a; const uint32_t b = l16 + 16 * q;
-                        const bool in = need && tile >= 0 && b < (uint32_t)B;
+                        const bool in = tile >= 0 && nt <= (int32_t)w.k_cap && b < (uint32_t)B;          // (tiles below 0 are never walked: whatever tile 0 holds will do)
                         const uint4* src = (const uint4*)(bpg + ((size_t)(in ? tile : 0) * 64 + (in ? b : 0)) * 16);
 #pragma unroll
-                        for (uint32_t j = 0; j < 4; ++j) if (need) pf[a * LPL + q][j] = in ? src[j] : make_uint4(0, 0, 0, 0);
+                        for (uint32_t j = 0; j < 4; ++j) pf[a * LPL + q][j] = src[j];
                     }
             }
         }
