@@ -3059,7 +3059,9 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
     }
     const int32_t rhs_begin = L - rhs;
     const int32_t n_diag = 2 * (T + B) + 1; const int64_t n_flat = (int64_t)n_diag * B;
-    const uint32_t* bpg = w.bp + ((size_t)group * w.k_cap * 64 + row * B) * 16;   // this task row's lines: tile kt, band lane b at (kt * 64 + b) * 16 words
+    // this task row's lines: tile kt, band lane b at (kt * 64 + b) * 16 words. A row without a task (the tail of the last wave: its group lies behind the scratch of a host-sized launch)
+    // points at the scratch's first line: it walks nothing, but the next-window fetch below is issued by every row of the wave
+    const uint32_t* bpg = w.bp + (active ? ((size_t)group * w.k_cap * 64 + row * B) * 16 : (size_t)0);
     const uint32_t hshift = 16 * half;
 
     int32_t sidx = end.sidx, i = sidx / 2 - T, y = T, x = sidx - T;       // walker state (set_alignments :180-193), the same in all sixteen lanes of the row

@@ -43,6 +43,9 @@ cp.check_linked_chunks("sim")                      # templates of linked chunks,
 cp.check_page_locked_caller_buffers("sim")         # page-locked arrays / out: the direct upload path, results landing in the caller's buffer
 cp.check_window_tables("sim")                      # canonical windows: the table of a region in LDS (one and two key classes) and the tables in global memory
 cp.check_input_contract("sim")                     # what an upload refuses, single- and multi-threaded checks
+os.environ["OCT_PHMM_DEVICE_SIZED"] = "0"            # round 6: host-sized launches size the traceback scratch exactly - a row of k_walk_rows' last wave that has no task must not fetch from "its" group
+check_fuzz.check_fuzz("sim", seed=77, n=44)        # (scenario 42 of this seed faulted on the GPU: the next-window prefetch of a task-less row, band 64)
+os.environ.pop("OCT_PHMM_DEVICE_SIZED", None)
 print("SANITIZED-OK")
 """
 
