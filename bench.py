@@ -810,12 +810,21 @@ def main():
                         "note": "GPU reference-work rate / projected ONE socket of this host; projections as described in socket_projection - the clause is met only where these are >= 50"}
                 cb["ratio_note"] = (f"gpu_over_cpu_measured = value / cpu_baseline.value on {cb['cores']} host threads (the cgroup's quota, not a socket). value counts the cells the GPU kernels "
                                     "updated, the CPU figure every cell the reference evaluates: ..._reference_work compares the two on the same job")
-        print(json.dumps(out))
     rb.free()
     eng.close()
     if dist is not None:
         dist.barrier()                  # rank 0 reports (and runs its roofline leg) while the others wait: leave together
         dist.destroy_process_group()
+    if rank == 0:
+        # The ONE JSON line is the last thing on stdout: RCCL writes its version banner through C stdio, which is block-buffered when stdout is a pipe or a file and would
+        # otherwise land BEHIND the line at exit (seen on hardware with WORLD_SIZE=1 + OCT_BENCH_FORCE_DIST: profiles/r06_s28_*). Flush C's buffers first, then print and flush.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
