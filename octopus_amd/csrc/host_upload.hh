@@ -481,9 +481,9 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         if (table_blocks + flag_blocks + rec_blocks64 >= 0x7fffffffull) return fail(status, OCT_PHMM_EUNSUPPORTED, "batch too large for one table launch");
         const uint32_t rec_blocks = (uint32_t)rec_blocks64;
         if (table_blocks + flag_blocks + rec_blocks) {
-            // a device-sized batch that maps on the device: the first step's k-mer table launch makes these too (k_tables; OCT_PHMM_FUSE_TABLES=0: two launches)
-            long long fuse = 1; tune::number("OCT_PHMM_FUSE_TABLES", &fuse);
-            if (b->dsl && b->device_map && !b->dedup && fuse && b->lh_cap < 4096) {      // (long haplotypes: k_kmer_tables runs 1,024 threads per haplotype)
+            // a device-sized batch that maps on the device: the first step's k-mer table launch makes these too (k_tables: upload 0.355-0.375 -> 0.335 ms for 16 regions, one launch fewer;
+            // the A/B switch went with the measurement, profiles/EXPERIMENTS.md)
+            if (b->dsl && b->device_map && !b->dedup && b->lh_cap < 4096) {      // (long haplotypes: k_kmer_tables runs 1,024 threads per haplotype)
                 b->tables_pending = true; b->tp_n_bases = n_hap_bases; b->tp_table_blocks = table_blocks; b->tp_flag_blocks = flag_blocks; b->tp_rec_blocks = rec_blocks;
             } else { OCT_LAUNCH(k_hap_tables, table_blocks + flag_blocks + rec_blocks, 256, 0, s, d, n_hap_bases, table_blocks, flag_blocks); RT(rt::launch_ok()); }
             b->stats_clear = true;                             // (the kernel's last workgroup clears the counters)
