@@ -160,7 +160,8 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         b->stream = h->band > 64 || !fits;      // long reads at any band stream their operands (PacBioCCS.config: max-indel-errors=16 with 10-20 kb reads)
         b->multi_wave = h->band >= 128 && h->wide && tune::multi_wave();
         b->rows32 = b->stream && h->band == 16 && h->wide && tune::dp_rows();
-        if (b->t_cap + 2 * (uint32_t)h->band >= 32768) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long (walk events hold 15-bit coordinates)");
+        // a walk event holds a window coordinate in 20 bits (phmm_kernels.hpp: kMaxWindowBases; 15 bits, i.e. reads below 32 k bases, until round 6)
+        if ((uint64_t)b->t_cap + 2 * (uint32_t)h->band >= kMaxWindowBases) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long (T + 2B must stay below 2^20: walk events hold 20-bit coordinates)");
     }
     {
         // Can any biased int16 lane exceed 0xFFFF (= the reference's own lane wrapping)? Every finite cell is bounded by the pure-match
@@ -201,6 +202,7 @@ static int upload_impl_body(oct_phmm_handle* h, const oct_phmm_reads* R, const o
         b->map_big = kmer_map_lds_bytes(b->lh_cap) > rt::kMaxLdsBytes || tune::big_mapper();
         if (b->lh_cap >= 65536 || kmer_map_big_lds_bytes(b->lh_cap) > rt::kMaxLdsBytes)      // (16-bit bin tables; k_kmer_map_big's counters are 16-bit halves since round 6: 40 k bases were the limit before)
             return fail(status, OCT_PHMM_EUNSUPPORTED, "haplotype too long for the k-mer mapper (>= 65,536 bases)");
+        if (b->t_cap >= 65536) return fail(status, OCT_PHMM_EUNSUPPORTED, "read too long for the k-mer mapper (>= 65,536 bases: a diagonal's votes are counted in 16 bits)");
     }
     b->h_roff.assign(R->offsets, R->offsets + R->n_reads + 1); b->h_hoff.assign(H->offsets, H->offsets + H->n_haps + 1);
     b->h_rbegin.assign(R->ref_begin, R->ref_begin + R->n_reads); b->h_hbegin.assign(H->ref_begin, H->ref_begin + H->n_haps);

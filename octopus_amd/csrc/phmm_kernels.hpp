@@ -2759,9 +2759,22 @@ struct WalkPricing {
     const uint8_t* rbases; const int8_t* rquals; const uint8_t* hbases; const uint8_t* mask; const int8_t* prior;
     const int8_t* go; const int8_t* ge;       // rbases/rquals at the read's first base, the haplotype arrays at the window's first base
 };
-OCT_DEVICE_NOINLINE int32_t walk_price_event(WalkPricing p, uint32_t e)
+// A queued event is ONE word: kind << 30 | (x - y + 1) << 20 | x. A match column (kind 0) needs both coordinates, and inside the band x - y is the band diagonal,
+// 0 ... 2B - 1 (x + y = sidx + 2 and band lane i = (x - y) / 2 all along the walk): ten bits for it leave twenty for x, i.e. reads of up to a million bases (rounds 1-5 held
+// x and y in 15 bits each and refused reads from 32 k bases on). Gap columns (kinds 1, 2) are priced at x alone. A walk that has left the band through the reference's
+// flat-index rule can have any x - y: walk_event_fits() says no and the walker prices such a column at once instead of queueing it.
+constexpr uint32_t kWalkEventXBits = 20, kWalkEventDBits = 10;
+constexpr uint32_t kMaxWindowBases = 1u << kWalkEventXBits;              // T + 2B must stay below this (host_upload.hh)
+OCT_DEVICE bool walk_event_fits(uint32_t kind, int32_t ex, int32_t ey)
 {
-    const uint32_t kind = e >> 30, ex = e & 0x7fffu, ey = (e >> 15) & 0x7fffu;
+    return (uint32_t)ex < (1u << kWalkEventXBits) && (kind != 0 || (uint32_t)(ex - ey + 1) < (1u << kWalkEventDBits));
+}
+OCT_DEVICE uint32_t walk_event_word(uint32_t kind, int32_t ex, int32_t ey)
+{
+    return kind << 30 | (kind == 0 ? (uint32_t)(ex - ey + 1) : 0u) << kWalkEventXBits | (uint32_t)ex;
+}
+OCT_DEVICE_NOINLINE int32_t walk_price_column(WalkPricing p, uint32_t kind, int32_t ex, int32_t ey)
+{
     if (kind == 0) {
         const uint32_t hc = p.hbases[ex], rc = p.rbases[ey];
         if (hc == rc) return 0;
@@ -2772,6 +2785,11 @@ OCT_DEVICE_NOINLINE int32_t walk_price_event(WalkPricing p, uint32_t e)
         return q;
     }
     return (kind == 1 ? p.go : p.ge)[ex];
+}
+OCT_DEVICE int32_t walk_price_event(WalkPricing p, uint32_t e)
+{
+    const int32_t ex = (int32_t)(e & ((1u << kWalkEventXBits) - 1u));
+    return walk_price_column(p, e >> 30, ex, ex + 1 - (int32_t)((e >> kWalkEventXBits) & ((1u << kWalkEventDBits) - 1u)));
 }
 
 // Production walk: one thread per traceback task, all 64 tasks of a wave sweep the band iterations k from the top tile down IN
@@ -2849,8 +2867,7 @@ OCT_MAX_THREADS(STAGE ? 64 : 256) OCT_KERNEL(k_walk)(WalkParams w)
     }
     auto price_event = [&](uint32_t e) { flank += walk_price_event(pricing, e); };
     auto push_event = [&](uint32_t kind, int32_t ex, int32_t ey) {
-        const uint32_t e = kind << 30 | (uint32_t)ey << 15 | (uint32_t)ex;
-        if (nev < kWalkEvents) evbuf[nev++] = e; else price_event(e);
+        if (nev < kWalkEvents && walk_event_fits(kind, ex, ey)) evbuf[nev++] = walk_event_word(kind, ex, ey); else flank += walk_price_column(pricing, kind, ex, ey);
     };
     // one alignment column from backpointer word `wv` of cell (sidx, i). Written with selects instead of a three-way branch (the
     // unrolled sweep below instantiates it 32 times per tile; the branchy form overflowed the instruction cache); only the rare
@@ -3106,8 +3123,8 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
         if (inf && (!isM || mism)) {
             const bool ext = isI ? (y != 0 && new_state == 1) : new_state == 3;                 // first alignment column has prev_state = match (:369)
             const int32_t xi = x - 1 < 0 ? 0 : x - 1;                                           // x-1 == -1 is out of bounds in the reference (UB): clamp
-            const uint32_t e = (isM ? 0u : (ext ? 2u : 1u)) << 30 | (uint32_t)(isM ? y : 0) << 15 | (uint32_t)(isI ? xi : x);
-            if (nev < kWalkRowEvents) { if (l16 == 0) evbuf[nev] = e; ++nev; } else flank += walk_price_event(pricing, e);
+            const uint32_t kind = isM ? 0u : (ext ? 2u : 1u); const int32_t ex = isI ? xi : x, ey = isM ? y : 0;
+            if (nev < kWalkRowEvents && walk_event_fits(kind, ex, ey)) { if (l16 == 0) evbuf[nev] = walk_event_word(kind, ex, ey); ++nev; } else flank += walk_price_column(pricing, kind, ex, ey);
         }
         state = new_state;
         if (y <= 0 || x < stop_below_x) fin = true;                                             // :194 / early stop
@@ -3220,7 +3237,7 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
         }
         if (n > 0) {
             if ((ev_cols >> l16) & 1u)
-                evbuf[nev + (uint32_t)__builtin_popcount(ev_cols & ((1u << l16) - 1u))] = (uint32_t)(y - 1 - j) << 15 | (uint32_t)(x - 1 - j);   // (kind 0: a match column)
+                evbuf[nev + (uint32_t)__builtin_popcount(ev_cols & ((1u << l16) - 1u))] = walk_event_word(0u, x - 1 - j, y - 1 - j);   // (kind 0: a match column; inside the band, so the word holds it)
             nev += (uint32_t)__builtin_popcount(ev_cols); msz += __builtin_popcount(fl_cols);
             sidx -= 2 * n; x -= n; y -= n;
         }
@@ -3276,8 +3293,8 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
             if (!can || run_here || (ev && nev >= kWalkRowEvents)) break;                       // (no room in the queue: the general step below prices the event)
             const bool ext = isI ? (ny != 0 && new_state == 1) : new_state == 3;                // first alignment column has prev_state = match (:369)
             const int32_t xi = nx - 1 < 0 ? 0 : nx - 1;                                         // x-1 == -1 is out of bounds in the reference (UB): clamp
-            evbuf[ev ? nev : walk_rows_row_words(B) - 1u] =                                             // (all sixteen lanes store the same word; no event: a scratch word behind the queue)
-                (isM ? 0u : (ext ? 2u : 1u)) << 30 | (uint32_t)(isM ? ny : 0) << 15 | (uint32_t)(isI ? xi : nx);
+            evbuf[ev ? nev : walk_rows_row_words(B) - 1u] =                                             // (all sixteen lanes store the same word; no event: a scratch word behind the queue;
+                walk_event_word(isM ? 0u : (ext ? 2u : 1u), isI ? xi : nx, isM ? ny : 0);              //  `can`: the walk is inside the band, so the word holds a match column's coordinates)
             nev += ev ? 1u : 0u;
             msz += (inf && !isD) ? 1 : 0;
             flank += (inf && isI) ? w.nuc_prior : 0;
@@ -3390,8 +3407,7 @@ OCT_MAX_THREADS(64) OCT_KERNEL(k_walk_long)(WalkParams w)
         pricing.go = w.go + hb0; pricing.ge = w.ge + hb0;
     }
     auto push_event = [&](uint32_t kind, int32_t ex, int32_t ey) {
-        const uint32_t e = kind << 30 | (uint32_t)ey << 15 | (uint32_t)ex;
-        if (nev < kWalkLongEvents) { if (lane == 0) evbuf[nev] = e; ++nev; } else flank += walk_price_event(pricing, e);
+        if (nev < kWalkLongEvents && walk_event_fits(kind, ex, ey)) { if (lane == 0) evbuf[nev] = walk_event_word(kind, ex, ey); ++nev; } else flank += walk_price_column(pricing, kind, ex, ey);
     };
     auto in_flank = [&]() { return want_flank && (x < lhs || x >= rhs_begin); };   // calculate_flank_score_helper :383-424
     auto step = [&](uint32_t wv) {                                        // one alignment column from backpointer word `wv` of cell (sidx, i)

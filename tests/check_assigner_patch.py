@@ -126,8 +126,8 @@ def check(backend, tol=0.0, golden=False):
     a = likelihoods("ref", sc, 16)
     b = likelihoods(lib, sc, 16)
     assert a[0] == b[0] and a[0] in (1, 2) and (a[0] != 1 or a[2] == b[2]), (a[0], b[0], a[2], b[2])
-    # reads the device path refuses (OCT_PHMM_EUNSUPPORTED: T + 2 B >= 32,768): the reference's own function, kept as calculate_likelihoods_on_host, answers - identical to the last bit
-    sc = scenario(rng, 2, 4, 32760, 33000, False)
+    # haplotypes the device path refuses (OCT_PHMM_EUNSUPPORTED: 65,536 bases or more with device k-mer mapping): the reference's own function, kept as calculate_likelihoods_on_host, answers - identical to the last bit
+    sc = scenario(rng, 2, 4, 400, 65_900, False)
     a = likelihoods("ref", sc, 8)
     b = likelihoods(lib, sc, 8)
     assert a[0] == b[0] == 0 and np.array_equal(a[1], b[1]) and not np.isnan(a[1]).any(), (a[0], b[0])

@@ -60,12 +60,12 @@ def check(backend, tol=0.0):
 
 
 def check_unsupported_regions_fall_back(lib):
-    """A region the device path refuses (OCT_PHMM_EUNSUPPORTED: a read with T + 2 B >= 32,768) is answered by the reference's own body, kept in the patched class as
+    """A region the device path refuses (OCT_PHMM_EUNSUPPORTED: a haplotype of 65,536 bases or more with device k-mer mapping; until round 6 also reads from 32 k bases on) is answered by the reference's own body, kept in the patched class as
     populate_on_host: the patched class answers every call the unpatched one answers - same matrix, same read-backs; and the next region runs on the device again."""
     rng = np.random.default_rng(77)
     n = 0
     for tmpl in (False, True):
-        g = synth.make_region(rng, 4, 2, T=32760, Lh=33100, B=8, flank=(30, 30), positions="none")
+        g = synth.make_region(rng, 4, 2, T=400, Lh=65_900, B=8, flank=(30, 30), positions="none")
         batch = synth.batch_from_regions([g])
         cfg = abi.Config.default(max_indel_error=8)
         from backends import make_engine

@@ -407,6 +407,27 @@ def check_haplotype_beyond_40k_bases(backend, tol=0.0, Lh=45_000, R=6):
     return stats
 
 
+def check_reads_beyond_32k_bases(backend, tol=0.0, T=33_300, Lh=34_100, cases=((16, 1), (256, 1), (64, 0))):
+    """Reads of 32,768 bases and more: refused until round 6 (a queued walk event held both window coordinates in 15 bits each), served since (kind | band diagonal | x: 20 bits
+    of x - phmm_kernels.hpp, walk_event_word). Wide inactive flanks, so that nearly every candidate needs the traceback and the walks price columns at window coordinates on both
+    sides of 32,768; an indel-rich read, so that gap events are queued there too. All three long-read walkers: k_walk_rows (band 16, int32 lanes), k_walk_long (band 256, int32),
+    the lockstep walker behind the streaming kernel (band 64, int16 lanes). Device k-mer mapping (haplotypes stay below its 65,536 bases). T + 2B >= 2^20 is still refused."""
+    out = []
+    for (band, bits), seed in zip(cases, (91, 92, 93)):
+        rng = np.random.default_rng(seed)
+        g = synth.make_region(rng, 3, 2, T=T, Lh=Lh + 2 * band, B=band, flank=(Lh // 2 - 300, Lh // 2 - 300), positions="none", indels_per_read=6)
+        g["quals"][:] = np.clip(g["quals"], 5, 25)
+        g["read_len"] = np.asarray([T, T - 977, 32_768 - 2 * band], np.int64)          # (the last one: the old limit's first refused length)
+        out.append(compare(backend, synth.batch_from_regions([g]), tol, max_indel_error=band, use_int_scores=bits))
+    assert all(st["n_dp_traceback"] > 0 for st in out), out
+    big = synth.make_region(np.random.default_rng(94), 1, 1, T=(1 << 20) - 16, Lh=(1 << 20) + 600, B=8, flank=(40, 40), positions="true")
+    eng = make_engine(backend, max_indel_error=8)
+    _, st = eng.populate(synth.batch_from_regions([big]), raise_on_error=False)
+    eng.close()
+    assert st.code == abi.EUNSUPPORTED, st.code
+    return out
+
+
 def check_window_pairing(backend, tol=0.0):
     """Big host-sized batches re-order every haplotype's task runs so that the two tasks packed into a lane's halves read ONE haplotype window (k_pair_sort), and
     k_dp runs those segments with pre-packed gap words (dp_groups, PAIRED). Forced on for small batches through the test hook - with the late

@@ -152,8 +152,8 @@ def check(backend, tol=0.0, golden=False):
     sc = scenario(rng, 9, 80, 200, 16, short=True)
     a, b = realign("ref", sc, 16), realign(lib, sc, 16)
     assert a["rc"] == b["rc"] == 1 and a["ext"] == b["ext"] and a["ext"] > 0, (a["rc"], b["rc"], a["ext"], b["ext"])
-    # reads the device path refuses (OCT_PHMM_EUNSUPPORTED: T + 2 B >= 32,768): every read takes the reference's own lines - identical to the last bit
-    sc = scenario(rng, 3, 32760, 33100, 8)
+    # a haplotype the device path refuses (OCT_PHMM_EUNSUPPORTED: 65,536 bases or more with device k-mer mapping): every read takes the reference's own lines - identical to the last bit
+    sc = scenario(rng, 3, 3000, 65_900, 8)
     a, b = realign("ref", sc, 8, max_ops=8192), realign(lib, sc, 8, max_ops=8192)
     assert a["rc"] == b["rc"] == 0 and len(a["cigar"][0]) > 100 and a["begin"] == b["begin"] and a["end"] == b["end"] and a["cigar"] == b["cigar"] and a["loglik"] == b["loglik"]
     return n + 3

@@ -259,6 +259,12 @@ def test_gpu_late_traceback_start_equals_oracle_and_plain_path(monkeypatch):
     cp.compare("gpu", batch, TOL, max_indel_error=16)
 
 
+def test_gpu_reads_beyond_32k_bases():
+    """Round 6: reads of 32,768 bases and more (refused until then: walk events held 15-bit coordinates) through k_walk_rows (band 16, int32), k_walk_long (band 256, int32) and
+    the lockstep walker behind the streaming kernel (band 64, int16), device k-mer mapping, against the oracle; T + 2B >= 2^20 is still OCT_PHMM_EUNSUPPORTED."""
+    assert len(cp.check_reads_beyond_32k_bases("gpu", TOL)) == 3
+
+
 def test_gpu_device_sized_and_host_sized_launches_agree(monkeypatch):
     """Region-sized batches take the device-sized launches (no mid-step read-back); the host-sized single-slice path on the same inputs."""
     assert cp.check_launch_modes("gpu", TOL) == 6

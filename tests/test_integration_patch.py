@@ -40,5 +40,5 @@ def test_patched_read_realigner_seam_equals_the_reference_functions():
     subprocess.run(["make", "-C", str(ROOT / "oracle"), "all", "patched"], check=True, stdout=subprocess.DEVNULL)
     import check_realigner_patch as cr
     assert cr.have("ref") and cr.have("patched_sim")
-    assert cr.check("sim") == 101                    # 98 + the three 32,760-base reads the device path refuses (the seam's fallback)
+    assert cr.check("sim") == 101                    # 98 + three reads on a 65,900-base haplotype, which the device path refuses (the seam's fallback)
     assert cr.check("sim", golden=True) == 98        # (the committed goldens the GPU box compares with are the reference's answers of today)
