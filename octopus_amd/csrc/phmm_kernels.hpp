@@ -2759,22 +2759,16 @@ struct WalkPricing {
     const uint8_t* rbases; const int8_t* rquals; const uint8_t* hbases; const uint8_t* mask; const int8_t* prior;
     const int8_t* go; const int8_t* ge;       // rbases/rquals at the read's first base, the haplotype arrays at the window's first base
 };
-// A queued event is ONE word: kind << 30 | (x - y + 1) << 20 | x. A match column (kind 0) needs both coordinates, and inside the band x - y is the band diagonal,
+// A queued event is ONE word: kind << 30 | (x - y) << 20 | x. A match column (kind 0) needs both coordinates, and inside the band x - y is the band diagonal,
 // 0 ... 2B - 1 (x + y = sidx + 2 and band lane i = (x - y) / 2 all along the walk): ten bits for it leave twenty for x, i.e. reads of up to a million bases (rounds 1-5 held
-// x and y in 15 bits each and refused reads from 32 k bases on). Gap columns (kinds 1, 2) are priced at x alone. A walk that has left the band through the reference's
-// flat-index rule can have any x - y: walk_event_fits() says no and the walker prices such a column at once instead of queueing it.
+// x and y in 15 bits each and refused reads from 32 k bases on). Gap columns (kinds 1, 2) are priced at x alone: their callers pass y = x. A walk that has left the band through
+// the reference's flat-index rule can have any x - y: its column does not fit and is priced at once instead of queued (walk_price_lo, the one non-inlined pricing function;
+// two arguments and one call site per step - a third argument cost k_walk four registers and a wave per SIMD).
 constexpr uint32_t kWalkEventXBits = 20, kWalkEventDBits = 10;
 constexpr uint32_t kMaxWindowBases = 1u << kWalkEventXBits;              // T + 2B must stay below this (host_upload.hh)
-OCT_DEVICE bool walk_event_fits(uint32_t kind, int32_t ex, int32_t ey)
+OCT_DEVICE_NOINLINE int32_t walk_price_lo(WalkPricing p, uint32_t lo, int32_t ey)      // lo = kind << 30 | x
 {
-    return (uint32_t)ex < (1u << kWalkEventXBits) && (kind != 0 || (uint32_t)(ex - ey + 1) < (1u << kWalkEventDBits));
-}
-OCT_DEVICE uint32_t walk_event_word(uint32_t kind, int32_t ex, int32_t ey)
-{
-    return kind << 30 | (kind == 0 ? (uint32_t)(ex - ey + 1) : 0u) << kWalkEventXBits | (uint32_t)ex;
-}
-OCT_DEVICE_NOINLINE int32_t walk_price_column(WalkPricing p, uint32_t kind, int32_t ex, int32_t ey)
-{
+    const uint32_t kind = lo >> 30, ex = lo & 0x3fffffffu;
     if (kind == 0) {
         const uint32_t hc = p.hbases[ex], rc = p.rbases[ey];
         if (hc == rc) return 0;
@@ -2788,9 +2782,16 @@ OCT_DEVICE_NOINLINE int32_t walk_price_column(WalkPricing p, uint32_t kind, int3
 }
 OCT_DEVICE int32_t walk_price_event(WalkPricing p, uint32_t e)
 {
-    const int32_t ex = (int32_t)(e & ((1u << kWalkEventXBits) - 1u));
-    return walk_price_column(p, e >> 30, ex, ex + 1 - (int32_t)((e >> kWalkEventXBits) & ((1u << kWalkEventDBits) - 1u)));
+    const uint32_t ex = e & ((1u << kWalkEventXBits) - 1u);
+    return walk_price_lo(p, (e & 0xc0000000u) | ex, (int32_t)(ex - ((e >> kWalkEventXBits) & ((1u << kWalkEventDBits) - 1u))));
 }
+// queue the column (kind, x, y) - gap columns: y = x - or price it now: `room` = the queue has a free slot
+#define OCT_WALK_EVENT(kind, ex, ey, room, STORE)                                                                     \
+    do {                                                                                                            \
+        const uint32_t lo_ = (uint32_t)(kind) << 30 | (uint32_t)(ex), d_ = (uint32_t)((ex) - (ey));                 \
+        if ((room) && d_ < (1u << kWalkEventDBits)) { const uint32_t e_ = lo_ | d_ << kWalkEventXBits; STORE; }     \
+        else flank += walk_price_lo(pricing, lo_, (ey));                                                            \
+    } while (0)
 
 // Production walk: one thread per traceback task, all 64 tasks of a wave sweep the band iterations k from the top tile down IN
 // LOCKSTEP. Per 16-iteration tile every lane holds its own 64-byte backpointer line in registers (statically indexed in the
@@ -2867,7 +2868,7 @@ OCT_MAX_THREADS(STAGE ? 64 : 256) OCT_KERNEL(k_walk)(WalkParams w)
     }
     auto price_event = [&](uint32_t e) { flank += walk_price_event(pricing, e); };
     auto push_event = [&](uint32_t kind, int32_t ex, int32_t ey) {
-        if (nev < kWalkEvents && walk_event_fits(kind, ex, ey)) evbuf[nev++] = walk_event_word(kind, ex, ey); else flank += walk_price_column(pricing, kind, ex, ey);
+        OCT_WALK_EVENT(kind, ex, ey, nev < kWalkEvents, evbuf[nev++] = e_);
     };
     // one alignment column from backpointer word `wv` of cell (sidx, i). Written with selects instead of a three-way branch (the
     // unrolled sweep below instantiates it 32 times per tile; the branchy form overflowed the instruction cache); only the rare
@@ -2889,7 +2890,8 @@ OCT_MAX_THREADS(STAGE ? 64 : 256) OCT_KERNEL(k_walk)(WalkParams w)
         if (in_flank && (!isM || mism)) {
             const bool ext = isI ? (y != 0 && new_state == 1) : new_state == 3;                 // first alignment column has prev_state = match (:369)
             const int32_t xi = x - 1 < 0 ? 0 : x - 1;                                           // x-1 == -1 is out of bounds in the reference (UB): clamp
-            push_event(isM ? 0u : (ext ? 2u : 1u), isI ? xi : x, isM ? y : 0);
+            const int32_t ex = isI ? xi : x;
+            push_event(isM ? 0u : (ext ? 2u : 1u), ex, isM ? y : ex);                              // (a gap column is priced at x alone: y = x)
         }
         state = new_state;
         fl |= (y <= 0 || x < stop_below_x) ? kFin : 0u;                                         // :194 / early stop
@@ -3123,8 +3125,8 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
         if (inf && (!isM || mism)) {
             const bool ext = isI ? (y != 0 && new_state == 1) : new_state == 3;                 // first alignment column has prev_state = match (:369)
             const int32_t xi = x - 1 < 0 ? 0 : x - 1;                                           // x-1 == -1 is out of bounds in the reference (UB): clamp
-            const uint32_t kind = isM ? 0u : (ext ? 2u : 1u); const int32_t ex = isI ? xi : x, ey = isM ? y : 0;
-            if (nev < kWalkRowEvents && walk_event_fits(kind, ex, ey)) { if (l16 == 0) evbuf[nev] = walk_event_word(kind, ex, ey); ++nev; } else flank += walk_price_column(pricing, kind, ex, ey);
+            const uint32_t kind = isM ? 0u : (ext ? 2u : 1u); const int32_t ex = isI ? xi : x, ey = isM ? y : ex;
+            OCT_WALK_EVENT(kind, ex, ey, nev < kWalkRowEvents, { if (l16 == 0) evbuf[nev] = e_; ++nev; });
         }
         state = new_state;
         if (y <= 0 || x < stop_below_x) fin = true;                                             // :194 / early stop
@@ -3237,7 +3239,7 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
         }
         if (n > 0) {
             if ((ev_cols >> l16) & 1u)
-                evbuf[nev + (uint32_t)__builtin_popcount(ev_cols & ((1u << l16) - 1u))] = walk_event_word(0u, x - 1 - j, y - 1 - j);   // (kind 0: a match column; inside the band, so the word holds it)
+                evbuf[nev + (uint32_t)__builtin_popcount(ev_cols & ((1u << l16) - 1u))] = (uint32_t)(x - y) << kWalkEventXBits | (uint32_t)(x - 1 - j);   // (kind 0: a match column; inside the band, so the word holds it)
             nev += (uint32_t)__builtin_popcount(ev_cols); msz += __builtin_popcount(fl_cols);
             sidx -= 2 * n; x -= n; y -= n;
         }
@@ -3294,7 +3296,7 @@ OCT_MAX_THREADS(256) OCT_KERNEL(k_walk_rows)(WalkParams w)
             const bool ext = isI ? (ny != 0 && new_state == 1) : new_state == 3;                // first alignment column has prev_state = match (:369)
             const int32_t xi = nx - 1 < 0 ? 0 : nx - 1;                                         // x-1 == -1 is out of bounds in the reference (UB): clamp
             evbuf[ev ? nev : walk_rows_row_words(B) - 1u] =                                             // (all sixteen lanes store the same word; no event: a scratch word behind the queue;
-                walk_event_word(isM ? 0u : (ext ? 2u : 1u), isI ? xi : nx, isM ? ny : 0);              //  `can`: the walk is inside the band, so the word holds a match column's coordinates)
+                (isM ? 0u : (ext ? 2u : 1u)) << 30 | (isM ? (uint32_t)(nx - ny) : 0u) << kWalkEventXBits | (uint32_t)(isI ? xi : nx);   //  `can`: the walk is inside the band, so the word holds a match column's diagonal)
             nev += ev ? 1u : 0u;
             msz += (inf && !isD) ? 1 : 0;
             flank += (inf && isI) ? w.nuc_prior : 0;
@@ -3407,7 +3409,7 @@ OCT_MAX_THREADS(64) OCT_KERNEL(k_walk_long)(WalkParams w)
         pricing.go = w.go + hb0; pricing.ge = w.ge + hb0;
     }
     auto push_event = [&](uint32_t kind, int32_t ex, int32_t ey) {
-        if (nev < kWalkLongEvents && walk_event_fits(kind, ex, ey)) { if (lane == 0) evbuf[nev] = walk_event_word(kind, ex, ey); ++nev; } else flank += walk_price_column(pricing, kind, ex, ey);
+        OCT_WALK_EVENT(kind, ex, ey, nev < kWalkLongEvents, { if (lane == 0) evbuf[nev] = e_; ++nev; });
     };
     auto in_flank = [&]() { return want_flank && (x < lhs || x >= rhs_begin); };   // calculate_flank_score_helper :383-424
     auto step = [&](uint32_t wv) {                                        // one alignment column from backpointer word `wv` of cell (sidx, i)
@@ -3419,10 +3421,10 @@ OCT_MAX_THREADS(64) OCT_KERNEL(k_walk_long)(WalkParams w)
             if (in_flank()) { ++msz; if (mism) push_event(0u, x, y); }
         } else if (state == 1) {                                                                // insert :205-209
             i += sidx & 1; sidx -= 1; --y;
-            if (in_flank()) { ++msz; flank += w.nuc_prior; push_event((y != 0 && new_state == 1) ? 2u : 1u, x - 1 < 0 ? 0 : x - 1, 0); }   // (x - 1 == -1: UB in the reference, clamped)
+            if (in_flank()) { ++msz; flank += w.nuc_prior; const int32_t xi = x - 1 < 0 ? 0 : x - 1; push_event((y != 0 && new_state == 1) ? 2u : 1u, xi, xi); }   // (x - 1 == -1: UB in the reference, clamped)
         } else {                                                                                // delete :210-215
             sidx -= 1; i -= sidx & 1; --x;
-            if (in_flank()) push_event(new_state == 3 ? 2u : 1u, x, 0);
+            if (in_flank()) push_event(new_state == 3 ? 2u : 1u, x, x);
         }
         state = new_state;
         if (y <= 0) fin = true;                                                                 // :194

@@ -409,7 +409,7 @@ def check_haplotype_beyond_40k_bases(backend, tol=0.0, Lh=45_000, R=6):
 
 def check_reads_beyond_32k_bases(backend, tol=0.0, T=33_300, Lh=34_100, cases=((16, 1), (256, 1), (64, 0))):
     """Reads of 32,768 bases and more: refused until round 6 (a queued walk event held both window coordinates in 15 bits each), served since (kind | band diagonal | x: 20 bits
-    of x - phmm_kernels.hpp, walk_event_word). Wide inactive flanks, so that nearly every candidate needs the traceback and the walks price columns at window coordinates on both
+    of x - phmm_kernels.hpp, OCT_WALK_EVENT). Wide inactive flanks, so that nearly every candidate needs the traceback and the walks price columns at window coordinates on both
     sides of 32,768; an indel-rich read, so that gap events are queued there too. All three long-read walkers: k_walk_rows (band 16, int32 lanes), k_walk_long (band 256, int32),
     the lockstep walker behind the streaming kernel (band 64, int16 lanes). Device k-mer mapping (haplotypes stay below its 65,536 bases). T + 2B >= 2^20 is still refused."""
     out = []
