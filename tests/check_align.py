@@ -119,3 +119,15 @@ def check_align_candidate_counts(backend):
         assert eng.align_candidate_counts(b2.n_read_pairs())[1] == 0
         eng.close()
     return True
+
+
+def check_align_reads_beyond_32k_bases(backend, T=33_300, Lh=34_132):
+    """oct_phmm_align on reads of 32,768 bases and more (refused until round 6, see check_populate.check_reads_beyond_32k_bases): position, CIGAR and likelihood of every pair
+    against the oracle - band 16, int32 lanes (the reference's long-read configuration), device k-mer mapping."""
+    import numpy as np
+    from octopus_amd import synth
+    rng = np.random.default_rng(95)
+    g = synth.make_region(rng, 3, 2, T=T, Lh=Lh, B=16, flank=(300, 300), positions="none", indels_per_read=6)
+    g["quals"][:] = np.clip(g["quals"], 5, 25)
+    return compare_align(backend, synth.batch_from_regions([g]), max_cigar_ops=4096, max_indel_error=16, use_int_scores=1)
+

@@ -263,6 +263,8 @@ def test_gpu_reads_beyond_32k_bases():
     """Round 6: reads of 32,768 bases and more (refused until then: walk events held 15-bit coordinates) through k_walk_rows (band 16, int32), k_walk_long (band 256, int32) and
     the lockstep walker behind the streaming kernel (band 64, int16), device k-mer mapping, against the oracle; T + 2B >= 2^20 is still OCT_PHMM_EUNSUPPORTED."""
     assert len(cp.check_reads_beyond_32k_bases("gpu", TOL)) == 3
+    import check_align as ca
+    ca.check_align_reads_beyond_32k_bases("gpu")
 
 
 def test_gpu_device_sized_and_host_sized_launches_agree(monkeypatch):

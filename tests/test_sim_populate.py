@@ -110,6 +110,8 @@ def test_sim_pairs_with_equal_candidates_share_one_result():
 def test_sim_reads_beyond_32k_bases():
     """Round 6: reads of 32,768 bases and more through all three long-read walkers (20-bit window coordinates in the queued walk events); 2^20 is still refused."""
     assert len(cp.check_reads_beyond_32k_bases("sim")) == 3
+    import check_align as ca
+    ca.check_align_reads_beyond_32k_bases("sim")
 
 
 def test_sim_device_sized_and_host_sized_launches_agree():
